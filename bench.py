@@ -1,0 +1,193 @@
+#!/usr/bin/env python
+"""bench.py — issue-reports/sec of the MemVul predict_memory.py hot loop on MI355X.
+
+One "step" = one pass of the hot path (BERT issue-encoder forward + CWE anchor-memory match,
+model_memory.py:133-147) over one batch of synthetic issue reports.  Workload = BASELINE.json
+configs[1]: bert-base-uncased geometry, seq_len 256, batch 256, 124-anchor memory, fp16 MFMA operands /
+fp32 accumulate (the precision that meets the 1e-3 logit tolerance; same MFMA peak as bf16).  Inputs are
+resident in HBM when the timed region starts (mv_corpus_upload); weights are seeded random init.
+
+    python bench.py                              # 1 GPU
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (dominant kernel:
+algorithmic FLOPs per launch / HIP-event duration on the engine's stream) and `cpu_baseline` (the
+reference's CPU graph, oracle/hf_reference.py, timed on this box's host cores on a bounded sample).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from memvul_amd import synth  # noqa: E402
+from memvul_amd.binding import Engine  # noqa: E402
+from memvul_amd import distributed as mvdist  # noqa: E402
+
+MFMA_PEAK_TFLOPS = 2500.0  # MI355X dense fp16/bf16 MFMA peak (MI355X_MICROARCH.md)
+H, I, P = 768, 3072, 512
+
+
+def flops_per_ir(S: int, G: int, layers: int = 12) -> float:
+    """Algorithmic FLOPs of one issue report."""
+    per_layer = 24 * S * H * H + 4 * S * S * H
+    return layers * per_layer + 2 * H * H + 2 * H * P + G * 7680.0
+
+
+def gemm_flops(cls: str, M: int) -> float:
+    return {"gemm_qkv": 2.0 * M * H * 3 * H, "gemm_attn_out": 2.0 * M * H * H, "gemm_ffn1_gelu": 2.0 * M * H * I,
+            "gemm_ffn2": 2.0 * M * I * H}[cls]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=256)
+    ap.add_argument("--seq-len", type=int, default=256)
+    ap.add_argument("--anchors", type=int, default=124)
+    ap.add_argument("--anchor-len", type=int, default=512)
+    ap.add_argument("--layers", type=int, default=12)
+    ap.add_argument("--cpu-sample", type=int, default=96, help="IRs timed on the CPU baseline (0 disables)")
+    ap.add_argument("--no-profile", action="store_true", help="do not record per-kernel HIP events in the timed region")
+    args = ap.parse_args()
+
+    rank, local_rank, world = mvdist.env_world()
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    multi = world > 1
+    if multi:
+        mvdist.init_process_group("nccl")
+
+    B, S, G, K, W = args.batch, args.seq_len, args.anchors, args.steps, args.warmup
+    dims = synth.BertDims(layers=args.layers)
+    weights = synth.make_weights(dims)
+    eng = Engine(local_rank, vocab_size=dims.vocab_size, layers=dims.layers, max_tokens=max(B * S, 128 * 512),
+                 max_batch=max(B, 128), max_anchors=max(G, 128))
+    eng.load_state_dict(weights)
+
+    # anchor memory: G synthetic CWE descriptions of up to 512 tokens, built once per process (untimed;
+    # predict_memory.py:81-83 forwards them in chunks of 128)
+    aids, alens = synth.make_ids(G, args.anchor_len, dims.vocab_size, seed=synth.SEED + 1, ragged=True, min_len=32)
+    for s0 in range(0, G, 128):
+        LA = int(alens[s0:s0 + 128].max())
+        eng.anchor_append(aids[s0:s0 + 128, :LA], alens[s0:s0 + 128])
+
+    # this rank's shard of the synthetic corpus, resident in HBM before the clock starts
+    n_batches = min(K + W, 16)
+    ids, lens = synth.make_ids(n_batches * B, S, dims.vocab_size, seed=synth.SEED + 1000 * rank)
+    eng.corpus_upload(ids, lens)
+
+    def step(i):
+        eng.corpus_run((i % n_batches) * B, B, B, keep_probs=False)
+
+    for i in range(W):
+        step(i)
+    eng.sync()
+    if multi:
+        mvdist.all_gather_stats(np.zeros(4, np.float32), np.zeros(4, np.uint8))  # RCCL communicator warm-up
+        mvdist.barrier()
+    if not args.no_profile:
+        eng.profile_enable(True)
+        eng.profile_read()
+    lab = synth.make_labels(n_batches * B, seed=synth.SEED + rank)
+    if multi:
+        mvdist.barrier()
+    eng.sync()
+    t0 = time.perf_counter()
+    for i in range(K):
+        step(W + i)
+    # whole job: per-IR results of the resident sweep back to the host, then the single exchange step
+    best, idx, _ = eng.corpus_results(0, n_batches * B)  # synchronises the stream
+    t_gather0 = time.perf_counter()
+    all_s, all_l = mvdist.all_gather_stats(best[:, 0], lab) if multi else (best[:, 0], lab)
+    gather_ms = (time.perf_counter() - t_gather0) * 1e3
+    if multi:
+        mvdist.barrier()
+    t1 = time.perf_counter()
+    elapsed = mvdist.all_reduce_max(t1 - t0) if multi else (t1 - t0)
+    prof = {} if args.no_profile else eng.profile_read()
+    eng.profile_enable(False)
+
+    if rank != 0:
+        return
+    from memvul_amd.custom_metric import threshold_confusion_table
+
+    table = threshold_confusion_table(all_l, all_s)
+    total_irs = world * K * B
+    value = total_irs / elapsed
+    M = B * S
+    fpi = flops_per_ir(S, G, dims.layers)
+    out = {
+        "metric": "issue-reports/sec at seq_len=%d (BERT-base issue encoder + %d-anchor memory match)" % (S, G),
+        "value": round(value, 2), "unit": "issue-reports/s", "n_gpus": world, "steps": K, "warmup": W,
+        "ms_per_step": round(elapsed / K * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "fp16", "data": "synthetic",
+        "config": {"workload": "BASELINE.json configs[1]: 1xMI355X-per-rank, bert-base-uncased geometry (%d layers), "
+                               "seq_len=%d, batch=%d, %d-anchor CWE memory, fp16 MFMA operands + fp32 accumulate; "
+                               "seeded random-init weights, synthetic token ids resident in HBM" % (dims.layers, S, B, G),
+                   "global_batch": world * B, "seq_len": S, "anchors": G, "parallelism": "dp%d (corpus shards, one "
+                   "all-gather of (score,label) stats)" % world},
+        "e2e_tflops_per_gpu": round(value / world * fpi / 1e12, 2),
+        "e2e_mfma_frac": round(value / world * fpi / 1e12 / MFMA_PEAK_TFLOPS, 4),
+        "stats_allgather_ms": round(gather_ms, 3),
+        "stats_table_sum": int(table.sum()),
+    }
+    if prof:
+        kernels = {}
+        for name, (ms, n) in prof.items():
+            if n:
+                kernels[name] = {"ms_total": round(ms, 3), "launches": n, "avg_us": round(ms / n * 1e3, 2)}
+                if name.startswith("gemm_"):
+                    kernels[name]["tflops"] = round(gemm_flops(name, M) / (ms / n * 1e-3) / 1e12, 1)
+        gemms = {k: v for k, v in kernels.items() if k.startswith("gemm_")}
+        dom = max(gemms, key=lambda k: gemms[k]["ms_total"])
+        achieved = gemms[dom]["tflops"]
+        out["roofline"] = {"kernel": dom, "bound": "mfma", "achieved": achieved, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                           "frac": round(achieved / MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                           "flops_per_launch": gemm_flops(dom, M), "avg_launch_us": gemms[dom]["avg_us"]}
+        out["kernels"] = kernels
+    if args.cpu_sample > 0 and world == 1:
+        out["cpu_baseline"], out["logit_max_abs_err_vs_cpu"] = cpu_baseline(weights, dims, eng, ids, lens, S, args.cpu_sample)
+    print(json.dumps(out), flush=True)
+
+
+def cpu_baseline(weights, dims, eng, ids, lens, S, n):
+    """The reference's CPU graph (HF BertModel + pooler + header + matcher, fp32, all host cores) on the
+    first n IRs of the same synthetic corpus; also the GPU-vs-CPU logit error on those IRs."""
+    import torch
+
+    from oracle.hf_reference import HFReference
+
+    cores = os.cpu_count() or 1
+    ref = HFReference(weights, dims.as_dict(), threads=cores)
+    v = eng.anchor_get()
+    bs = 32
+    ref.predict(ids[:4].astype(np.int64), np.ones((4, S), bool), v)  # warm-up
+    t0 = time.perf_counter()
+    logits = []
+    for s0 in range(0, n, bs):
+        part = ids[s0:s0 + bs].astype(np.int64)
+        u, lg, p, best, idx = ref.predict(part, np.ones(part.shape, bool), v)
+        logits.append(lg)
+    dt = time.perf_counter() - t0
+    logits = np.concatenate(logits)
+    gpu = eng.forward(ids[:n], lens[:n])
+    err = float(np.abs(gpu["logits"] - logits).max())
+    return ({"value": round(n / dt, 3), "unit": "issue-reports/s", "cores": cores, "kind": "port",
+             "sample": f"{n} synthetic IRs x {S} tokens, batch {bs}, fp32 torch-CPU ({torch.get_num_threads()} threads): HF BertModel "
+                       "(eager attention) + tanh pooler + ReLU header + bias-free matcher = the reference's CPU path "
+                       "(AllenNLP itself is not installable here); anchor bank taken from the GPU engine"}, err)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,156 @@
+/*
+ * memvul_hip.h — C ABI of libmemvul_hip.so: the MI355X (gfx950) inference engine for MemVul's
+ * predict_memory.py hot loop (BERT issue-encoder forward + CWE golden-anchor memory matching).
+ *
+ * The reference is pure Python and has no FFI of its own; this header is the boundary a
+ * maintainer binds with ctypes from `MemVul/model_memory.py`.  Each entry
+ * point names the reference code it replaces (paths relative to the MemVul repository).
+ *
+ * Conventions
+ *   - every function returns MV_OK (0) or a negative mv_status; the message is available from
+ *     mv_last_error(); no C++ exception crosses the ABI; HIP errors are captured and translated.
+ *   - the caller owns every host buffer; the library owns all device memory (weights, anchor bank,
+ *     workspaces, resident corpus).  No device pointer is ever returned.
+ *   - one handle <-> one GPU <-> one HIP stream; a handle is not thread-safe; distinct handles are
+ *     independent (one process per GPU in multi-GPU runs).
+ *   - entry points that launch device work are asynchronous with respect to the host until
+ *     mv_sync(), except where they copy results back to host memory (they synchronise first).
+ *   - token ids are int32, sequences are 0-padded ([PAD]=0) to S columns, `lens[b]` is the number of
+ *     real tokens of row b (the reference's boolean `mask` is `arange(S) < lens[b]`,
+ *     custom_PTM_embedder.py:215-228).  S may be any value in [1, max_pos]; the engine pads
+ *     internally to a multiple of 64 with masked keys.
+ */
+#ifndef MEMVUL_HIP_H
+#define MEMVUL_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct mv_handle mv_handle;
+
+typedef enum mv_status {
+  MV_OK = 0,
+  MV_ERR_INVALID = -1,        /* bad argument / shape */
+  MV_ERR_HIP = -2,            /* a HIP runtime call or kernel launch failed */
+  MV_ERR_STATE = -3,          /* call order violated (e.g. forward before finalize / no anchors) */
+  MV_ERR_MISSING_WEIGHT = -4, /* mv_finalize_weights: a state-dict key was never loaded */
+  MV_ERR_CAPACITY = -5,       /* B*S, B or G exceeds what mv_create reserved */
+  MV_ERR_NOMEM = -6
+} mv_status;
+
+typedef enum mv_dtype { MV_F32 = 0, MV_F16 = 1, MV_BF16 = 2, MV_I32 = 3, MV_I64 = 4 } mv_dtype;
+
+/* Geometry + capacities.  The kernels are specialised to bert-base geometry (hidden 768, 12 heads
+ * of 64, intermediate 3072, header 512); `layers`, `vocab_size`, `max_pos` are free.
+ * (HF BertConfig defaults; model hyper-parameters MemVul/config_memory.json:31-49.) */
+typedef struct mv_config {
+  int32_t vocab_size;   /* 30522 */
+  int32_t hidden;       /* 768  (must be 768) */
+  int32_t layers;       /* 12 */
+  int32_t heads;        /* 12   (must be 12) */
+  int32_t intermediate; /* 3072 (must be 3072) */
+  int32_t max_pos;      /* 512 */
+  int32_t type_vocab;   /* 2 */
+  int32_t proj_dim;     /* 512  (must be 512; FeedForward(768,1,[512],ReLU), model_memory.py:70) */
+  float ln_eps;         /* 1e-12 */
+  int32_t max_tokens;   /* capacity of one forward in padded tokens, B * roundup(S,64) */
+  int32_t max_batch;    /* capacity of one forward in issue reports */
+  int32_t max_anchors;  /* capacity of the anchor bank (G) */
+  int32_t same_idx;     /* index of label "same" in the `labels` vocabulary (model_memory.py:61) */
+} mv_config;
+
+/* ---- lifetime ----------------------------------------------------------------------------- */
+
+/* Replaces Model.from_params + model.to(cuda_device) (predict_memory.py:62-70): binds `device`,
+ * creates the stream and reserves all workspaces. */
+int mv_create(int device, const mv_config* cfg, mv_handle** out);
+void mv_destroy(mv_handle* h);
+/* Last error message of this handle (or of a failed mv_create when h == NULL). */
+const char* mv_last_error(mv_handle* h);
+int mv_sync(mv_handle* h);
+
+/* ---- weights (replaces model.load_state_dict(weights.th), AllenNLP archival) ---------------- */
+
+/* `name` is a key of the reference model's state_dict:
+ *   _text_field_embedder.token_embedder_tokens.transformer_model.<HF BertModel key>
+ *   _bert_pooler.pooler.dense.{weight,bias}            (model_memory.py:64)
+ *   _projector_single._linear_layers.0.{weight,bias}   (model_memory.py:70)
+ *   _projector.weight                                  (model_memory.py:73)
+ * Unknown keys (e.g. ...embeddings.position_ids, custom_PTM_embedder.py:64) are accepted and
+ * ignored.  dtype MV_F32 / MV_F16 / MV_BF16; the data is copied, the caller may free it. */
+int mv_load_tensor(mv_handle* h, const char* name, const void* host_ptr, int dtype, const int64_t* shape, int ndim);
+/* Checks that every needed key is present and well-shaped, packs QKV, converts the GEMM weights to
+ * `compute_dtype` (MV_F16: fp16 MFMA operands, fp32 accumulation — the parity path; MV_BF16) and
+ * uploads.  Embeddings, LayerNorm, biases, pooler, header and matcher stay fp32. */
+int mv_finalize_weights(mv_handle* h, int compute_dtype);
+
+/* ---- anchor memory (replaces ModelMemory.forward_gold_instances, model_memory.py:105-115, as
+ *      driven by predict_memory.py:81-83 and callbacks.py:48-53) ------------------------------ */
+
+int mv_anchor_reset(mv_handle* h); /* _golden_instances_embeddings = None */
+/* Encodes n anchors (ids [n,S], lens [n]) and appends their 512-d embeddings to the bank. */
+int mv_anchor_append(mv_handle* h, const int32_t* ids, const int32_t* lens, int n, int S);
+int mv_anchor_count(mv_handle* h);
+/* Copies the bank to host: out fp32 [G,512]. */
+int mv_anchor_get(mv_handle* h, float* out);
+/* Installs a precomputed bank v fp32 [G,512] (BASELINE.json configs[4]: synthetic 1000-anchor bank). */
+int mv_anchor_set(mv_handle* h, const float* v, int G);
+
+/* ---- the hot loop (replaces ModelMemory.forward test/unlabel branch, model_memory.py:133-147,
+ *      including _instance_forward l.90-103 and the embedder forward custom_PTM_embedder.py:172-242)
+ * ids int32 [B,S] host, lens int32 [B] host.  Any output pointer may be NULL.
+ *   logits fp32 [B,G,2]   W_m [u; v; |u-v|]                       (l.141)
+ *   probs  fp32 [B,G,2]   softmax(logits, -1)                     (l.142; `output_dict['probs']`)
+ *   best   fp32 [B,2]     probs[b, argmax_g probs[b,g,same_idx]]  (l.144-147)
+ *   best_idx int32 [B]    that argmax (first maximal g)
+ *   embed  fp32 [B,512]   u = header(pooler(BERT(ids)[:,0]))      (l.133)
+ * Returns after the results are in host memory. */
+int mv_forward(mv_handle* h, const int32_t* ids, const int32_t* lens, int B, int S,
+               float* logits, float* probs, float* best, int32_t* best_idx, float* embed);
+/* Encoder only (ModelMemory._instance_forward, model_memory.py:90-103): embed fp32 [B,512]. */
+int mv_encode(mv_handle* h, const int32_t* ids, const int32_t* lens, int B, int S, float* embed);
+/* Matcher only on host embeddings u fp32 [B,512] against the resident bank (model_memory.py:135-147). */
+int mv_match(mv_handle* h, const float* u, int B, float* logits, float* probs, float* best, int32_t* best_idx);
+/* Fused match + top-k over the resident bank (BASELINE.json configs[4]): for each u[b] the k anchors
+ * with the largest P(same), ties to the lower anchor index; topk_p fp32 [B,k], topk_idx int32 [B,k]. */
+int mv_topk(mv_handle* h, const float* u, int B, int k, float* topk_p, int32_t* topk_idx);
+
+/* ---- HBM-resident corpus (the MI355X-native form of the AllenNLP `evaluate` loop,
+ *      predict_memory.py:103-110): the whole tokenised shard (1.2 M x 256 x int32 = 1.25 GB) and all
+ *      per-IR results live in HBM; the host launches batches back-to-back and downloads once. ---- */
+int mv_corpus_upload(mv_handle* h, const int32_t* ids, const int32_t* lens, int64_t n, int S);
+/* Runs IRs [first, first+count) in batches of `batch`; asynchronous. keep_probs != 0 also keeps
+ * P(same) for every (IR, anchor) pair (what make_output_human_readable serialises, l.169-191). */
+int mv_corpus_run(mv_handle* h, int64_t first, int64_t count, int batch, int keep_probs);
+/* best fp32 [count,2], best_idx int32 [count], p_same fp32 [count,G] (NULL unless kept). Synchronises. */
+int mv_corpus_results(mv_handle* h, int64_t first, int64_t count, float* best, int32_t* best_idx, float* p_same);
+
+/* ---- measurement / test hooks ---------------------------------------------------------------- */
+
+/* Per-kernel-class HIP-event timing on the engine's own stream. Classes: see mv_kernel_class_name. */
+#define MV_NUM_KERNEL_CLASSES 12
+int mv_profile_enable(mv_handle* h, int on);
+/* Synchronises, adds up the recorded launches since the last read: ms[c], launches[c]; then clears. */
+int mv_profile_read(mv_handle* h, double* ms, int64_t* launches, int n);
+const char* mv_kernel_class_name(int cls);
+
+/* Debug taps for per-kernel parity tests: run the encoder on (ids,lens) and stop after `n_layers`
+ * encoder layers (0 = embeddings only, <0 = all), then copy an internal buffer to host.
+ * buffer ids: 0 hidden fp32 [B*Sp,768]; 1 hidden fp16; 2 Q fp16 [B,12,Sp,64]; 3 K fp16 [B,12,Sp,64];
+ * 4 V^T fp16 [B,12,64,Sp]; 5 attention context fp16 [B*Sp,768]; 6 FFN intermediate fp16 [B*Sp,3072].
+ * (Sp = roundup(S,64); buffers hold the state of the LAST executed layer.) */
+int mv_debug_encode(mv_handle* h, const int32_t* ids, const int32_t* lens, int B, int S, int n_layers);
+int mv_debug_read(mv_handle* h, int buffer, void* dst, int64_t bytes);
+/* Stand-alone GEMM check/bench on caller data: C[M,N] = A[M,K] (fp16 bits) x W[N,K]^T (fp16 bits)
+ * + bias, fp32 out.  variant selects the kernel build (0 = default). iters > 1 repeats for timing;
+ * *ms receives the average milliseconds per launch. M,N multiples of 128 (256 for variant>=2), K of 64. */
+int mv_test_gemm(mv_handle* h, int variant, int M, int N, int K, const uint16_t* A, const uint16_t* W,
+                 const float* bias, float* C, int iters, float* ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MEMVUL_HIP_H */

@@ -1,0 +1,271 @@
+"""ctypes binding of libmemvul_hip.so (include/memvul_hip.h) and a thin ``Engine`` wrapper.
+
+The product path has no CPU fallback: if the library cannot be loaded, or a call fails, a
+``RuntimeError`` is raised.  Nothing here imports torch or anything under ``oracle/``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Dict, Iterable, Optional, Tuple
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libmemvul_hip.so")
+
+MV_F32, MV_F16, MV_BF16, MV_I32, MV_I64 = 0, 1, 2, 3, 4
+NUM_KERNEL_CLASSES = 12
+
+# every symbol include/memvul_hip.h declares (tests check the .so exports all of them)
+ABI_SYMBOLS = [
+    "mv_create", "mv_destroy", "mv_last_error", "mv_sync", "mv_load_tensor", "mv_finalize_weights",
+    "mv_anchor_reset", "mv_anchor_append", "mv_anchor_count", "mv_anchor_get", "mv_anchor_set",
+    "mv_forward", "mv_encode", "mv_match", "mv_topk", "mv_corpus_upload", "mv_corpus_run",
+    "mv_corpus_results", "mv_profile_enable", "mv_profile_read", "mv_kernel_class_name",
+    "mv_debug_encode", "mv_debug_read", "mv_test_gemm",
+]
+
+
+class MvConfig(C.Structure):
+    _fields_ = [
+        ("vocab_size", C.c_int32), ("hidden", C.c_int32), ("layers", C.c_int32), ("heads", C.c_int32),
+        ("intermediate", C.c_int32), ("max_pos", C.c_int32), ("type_vocab", C.c_int32), ("proj_dim", C.c_int32),
+        ("ln_eps", C.c_float), ("max_tokens", C.c_int32), ("max_batch", C.c_int32), ("max_anchors", C.c_int32),
+        ("same_idx", C.c_int32),
+    ]
+
+
+_lib = None
+
+
+def load_library(path: Optional[str] = None):
+    """dlopen the HIP library and declare the prototypes.  Raises RuntimeError if it is missing —
+    there is deliberately no other implementation to fall back to."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = path or os.environ.get("MEMVUL_HIP_LIB") or LIB_PATH
+    if not os.path.exists(path):
+        raise RuntimeError(
+            f"libmemvul_hip.so not found at {path}: build it with `python -m memvul_amd.build` "
+            "(hipcc --offload-arch=gfx950); the MemVul hot path has no CPU fallback"
+        )
+    try:
+        lib = C.CDLL(path, mode=C.RTLD_GLOBAL)
+    except OSError as e:  # pragma: no cover
+        raise RuntimeError(f"cannot load {path}: {e}") from e
+    vp, i32p, f32p = C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_float)
+    P = C.POINTER
+    sig = {
+        "mv_create": (C.c_int, [C.c_int, P(MvConfig), P(vp)]),
+        "mv_destroy": (None, [vp]),
+        "mv_last_error": (C.c_char_p, [vp]),
+        "mv_sync": (C.c_int, [vp]),
+        "mv_load_tensor": (C.c_int, [vp, C.c_char_p, vp, C.c_int, P(C.c_int64), C.c_int]),
+        "mv_finalize_weights": (C.c_int, [vp, C.c_int]),
+        "mv_anchor_reset": (C.c_int, [vp]),
+        "mv_anchor_append": (C.c_int, [vp, vp, vp, C.c_int, C.c_int]),
+        "mv_anchor_count": (C.c_int, [vp]),
+        "mv_anchor_get": (C.c_int, [vp, vp]),
+        "mv_anchor_set": (C.c_int, [vp, vp, C.c_int]),
+        "mv_forward": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, vp, vp, vp, vp, vp]),
+        "mv_encode": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, vp]),
+        "mv_match": (C.c_int, [vp, vp, C.c_int, vp, vp, vp, vp]),
+        "mv_topk": (C.c_int, [vp, vp, C.c_int, C.c_int, vp, vp]),
+        "mv_corpus_upload": (C.c_int, [vp, vp, vp, C.c_int64, C.c_int]),
+        "mv_corpus_run": (C.c_int, [vp, C.c_int64, C.c_int64, C.c_int, C.c_int]),
+        "mv_corpus_results": (C.c_int, [vp, C.c_int64, C.c_int64, vp, vp, vp]),
+        "mv_profile_enable": (C.c_int, [vp, C.c_int]),
+        "mv_profile_read": (C.c_int, [vp, P(C.c_double), P(C.c_int64), C.c_int]),
+        "mv_kernel_class_name": (C.c_char_p, [C.c_int]),
+        "mv_debug_encode": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, C.c_int]),
+        "mv_debug_read": (C.c_int, [vp, C.c_int, vp, C.c_int64]),
+        "mv_test_gemm": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, C.c_int, P(C.c_float)]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(lib, name)  # AttributeError if the .so does not export a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def _ptr(a: Optional[np.ndarray]):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def _as(a, dtype) -> np.ndarray:
+    return np.ascontiguousarray(a, dtype=dtype)
+
+
+class Engine:
+    """One handle <-> one GPU <-> one stream (see include/memvul_hip.h)."""
+
+    def __init__(self, device: int = 0, *, vocab_size: int = 30522, layers: int = 12, max_pos: int = 512,
+                 type_vocab: int = 2, ln_eps: float = 1e-12, max_tokens: int = 65536, max_batch: int = 512,
+                 max_anchors: int = 1024, same_idx: int = 0):
+        self._lib = load_library()
+        self.cfg = MvConfig(vocab_size, 768, layers, 12, 3072, max_pos, type_vocab, 512, ln_eps, max_tokens,
+                            max_batch, max_anchors, same_idx)
+        h = C.c_void_p()
+        rc = self._lib.mv_create(device, C.byref(self.cfg), C.byref(h))
+        if rc != 0:
+            msg = self._lib.mv_last_error(None)
+            raise RuntimeError(f"mv_create failed ({rc}): {msg.decode() if msg else ''}")
+        self._h = h
+        self.device = device
+
+    # -- plumbing
+    def _check(self, rc: int, what: str):
+        if rc != 0:
+            msg = self._lib.mv_last_error(self._h)
+            raise RuntimeError(f"{what} failed ({rc}): {msg.decode() if msg else ''}")
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.mv_destroy(self._h)
+            self._h = None
+
+    def __del__(self):  # pragma: no cover
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def sync(self):
+        self._check(self._lib.mv_sync(self._h), "mv_sync")
+
+    # -- weights
+    def load_tensor(self, name: str, arr: np.ndarray):
+        if arr.dtype == np.float16:
+            dt = MV_F16
+        elif arr.dtype in (np.int64, np.int32):
+            dt = MV_I64 if arr.dtype == np.int64 else MV_I32
+        else:
+            arr = _as(arr, np.float32)
+            dt = MV_F32
+        arr = np.ascontiguousarray(arr)
+        shape = (C.c_int64 * arr.ndim)(*arr.shape)
+        self._check(self._lib.mv_load_tensor(self._h, name.encode(), _ptr(arr), dt, shape, arr.ndim), f"mv_load_tensor({name})")
+
+    def load_state_dict(self, sd: Dict[str, np.ndarray], compute_dtype: int = MV_F16):
+        """``sd``: reference ``state_dict`` keys -> arrays (torch tensors are converted by the caller)."""
+        for k, v in sd.items():
+            a = np.asarray(v)
+            if a.ndim == 0:
+                continue
+            self.load_tensor(k, a)
+        self._check(self._lib.mv_finalize_weights(self._h, compute_dtype), "mv_finalize_weights")
+
+    # -- anchors
+    def anchor_reset(self):
+        self._check(self._lib.mv_anchor_reset(self._h), "mv_anchor_reset")
+
+    def anchor_append(self, ids: np.ndarray, lens: np.ndarray):
+        ids, lens = _as(ids, np.int32), _as(lens, np.int32)
+        self._check(self._lib.mv_anchor_append(self._h, _ptr(ids), _ptr(lens), ids.shape[0], ids.shape[1]), "mv_anchor_append")
+
+    @property
+    def n_anchors(self) -> int:
+        return int(self._lib.mv_anchor_count(self._h))
+
+    def anchor_get(self) -> np.ndarray:
+        out = np.empty((self.n_anchors, 512), np.float32)
+        self._check(self._lib.mv_anchor_get(self._h, _ptr(out)), "mv_anchor_get")
+        return out
+
+    def anchor_set(self, v: np.ndarray):
+        v = _as(v, np.float32)
+        self._check(self._lib.mv_anchor_set(self._h, _ptr(v), v.shape[0]), "mv_anchor_set")
+
+    # -- hot loop
+    def forward(self, ids: np.ndarray, lens: np.ndarray, want_logits=True, want_probs=True, want_embed=False):
+        ids, lens = _as(ids, np.int32), _as(lens, np.int32)
+        B, S = ids.shape
+        G = self.n_anchors
+        logits = np.empty((B, G, 2), np.float32) if want_logits else None
+        probs = np.empty((B, G, 2), np.float32) if want_probs else None
+        best = np.empty((B, 2), np.float32)
+        idx = np.empty((B,), np.int32)
+        embed = np.empty((B, 512), np.float32) if want_embed else None
+        self._check(self._lib.mv_forward(self._h, _ptr(ids), _ptr(lens), B, S, _ptr(logits), _ptr(probs), _ptr(best),
+                                         _ptr(idx), _ptr(embed)), "mv_forward")
+        return {"logits": logits, "probs": probs, "best": best, "best_idx": idx, "embed": embed}
+
+    def encode(self, ids: np.ndarray, lens: np.ndarray) -> np.ndarray:
+        ids, lens = _as(ids, np.int32), _as(lens, np.int32)
+        out = np.empty((ids.shape[0], 512), np.float32)
+        self._check(self._lib.mv_encode(self._h, _ptr(ids), _ptr(lens), ids.shape[0], ids.shape[1], _ptr(out)), "mv_encode")
+        return out
+
+    def match(self, u: np.ndarray):
+        u = _as(u, np.float32)
+        B, G = u.shape[0], self.n_anchors
+        logits = np.empty((B, G, 2), np.float32)
+        probs = np.empty((B, G, 2), np.float32)
+        best = np.empty((B, 2), np.float32)
+        idx = np.empty((B,), np.int32)
+        self._check(self._lib.mv_match(self._h, _ptr(u), B, _ptr(logits), _ptr(probs), _ptr(best), _ptr(idx)), "mv_match")
+        return {"logits": logits, "probs": probs, "best": best, "best_idx": idx}
+
+    def topk(self, u: np.ndarray, k: int):
+        u = _as(u, np.float32)
+        p = np.empty((u.shape[0], k), np.float32)
+        i = np.empty((u.shape[0], k), np.int32)
+        self._check(self._lib.mv_topk(self._h, _ptr(u), u.shape[0], k, _ptr(p), _ptr(i)), "mv_topk")
+        return p, i
+
+    # -- resident corpus
+    def corpus_upload(self, ids: np.ndarray, lens: np.ndarray):
+        ids, lens = _as(ids, np.int32), _as(lens, np.int32)
+        self._check(self._lib.mv_corpus_upload(self._h, _ptr(ids), _ptr(lens), ids.shape[0], ids.shape[1]), "mv_corpus_upload")
+        self._corpus_n = ids.shape[0]
+
+    def corpus_run(self, first: int, count: int, batch: int, keep_probs: bool = False):
+        self._check(self._lib.mv_corpus_run(self._h, first, count, batch, int(keep_probs)), "mv_corpus_run")
+
+    def corpus_results(self, first: int, count: int, with_probs: bool = False):
+        best = np.empty((count, 2), np.float32)
+        idx = np.empty((count,), np.int32)
+        ps = np.empty((count, self.n_anchors), np.float32) if with_probs else None
+        self._check(self._lib.mv_corpus_results(self._h, first, count, _ptr(best), _ptr(idx), _ptr(ps)), "mv_corpus_results")
+        return best, idx, ps
+
+    # -- measurement / debug
+    def profile_enable(self, on: bool = True):
+        self._check(self._lib.mv_profile_enable(self._h, int(on)), "mv_profile_enable")
+
+    def profile_read(self) -> Dict[str, Tuple[float, int]]:
+        ms = (C.c_double * NUM_KERNEL_CLASSES)()
+        n = (C.c_int64 * NUM_KERNEL_CLASSES)()
+        self._check(self._lib.mv_profile_read(self._h, ms, n, NUM_KERNEL_CLASSES), "mv_profile_read")
+        return {self._lib.mv_kernel_class_name(i).decode(): (float(ms[i]), int(n[i])) for i in range(NUM_KERNEL_CLASSES)}
+
+    def debug_encode(self, ids, lens, n_layers: int):
+        ids, lens = _as(ids, np.int32), _as(lens, np.int32)
+        self._check(self._lib.mv_debug_encode(self._h, _ptr(ids), _ptr(lens), ids.shape[0], ids.shape[1], n_layers), "mv_debug_encode")
+        self._dbg = (ids.shape[0], (ids.shape[1] + 63) // 64 * 64)
+
+    def debug_read(self, buffer: int) -> np.ndarray:
+        B, Sp = self._dbg
+        shapes = {
+            0: ((B, Sp, 768), np.float32), 1: ((B, Sp, 768), np.float16), 2: ((B, 12, Sp, 64), np.float16),
+            3: ((B, 12, Sp, 64), np.float16), 4: ((B, 12, 64, Sp), np.float16), 5: ((B, Sp, 768), np.float16),
+            6: ((B, Sp, 3072), np.float16), 7: ((B, 512), np.float32),
+        }
+        shape, dt = shapes[buffer]
+        out = np.empty(shape, dt)
+        self._check(self._lib.mv_debug_read(self._h, buffer, _ptr(out), out.nbytes), "mv_debug_read")
+        return out
+
+    def test_gemm(self, A16: np.ndarray, W16: np.ndarray, bias: Optional[np.ndarray], variant: int = 0, iters: int = 1):
+        A16, W16 = _as(A16, np.float16), _as(W16, np.float16)
+        M, K = A16.shape
+        N = W16.shape[0]
+        bias = None if bias is None else _as(bias, np.float32)
+        out = np.empty((M, N), np.float32)
+        ms = C.c_float(0)
+        self._check(self._lib.mv_test_gemm(self._h, variant, M, N, K, _ptr(A16), _ptr(W16), _ptr(bias), _ptr(out), iters,
+                                           C.byref(ms)), "mv_test_gemm")
+        return out, float(ms.value)

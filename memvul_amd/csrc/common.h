@@ -1,0 +1,46 @@
+// Shared device helpers for the gfx950 (CDNA4, wave64) kernels of libmemvul_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef _Float16 half_t;
+typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
+typedef _Float16 half4_t __attribute__((ext_vector_type(4)));
+typedef _Float16 half8_t __attribute__((ext_vector_type(8)));
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+
+#define MV_HIDDEN 768
+#define MV_HEADS 12
+#define MV_HEAD_DIM 64
+#define MV_INTER 3072
+#define MV_PROJ 512
+#define MV_WAVE 64
+
+// Sum / max over the 64 lanes of a wave (all lanes receive the result).
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
+  return v;
+}
+
+// Row of the 32x32 MFMA C/D fragment held in accumulator register r by a lane of half `hi`
+// (= lane >> 5); the column is lane & 31 (cdna_hip_programming.md §3).
+__device__ __forceinline__ int mfma32_row(int r, int hi) { return (r & 3) + 8 * (r >> 2) + 4 * hi; }
+
+// XCD-aware, bijective remap of a 1-D block id: the hardware dispatches block b to XCD b % 8, so give
+// each XCD one contiguous chunk of the logical tile sequence (neighbouring tiles share operand panels
+// in that XCD's private L2).  cdna_hip_programming.md §5 "XCD swizzle must be bijective".
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+  const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+  const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return base + (bid >> 3);
+}
+
+// exact-erf GELU (HF "gelu", BertIntermediate)
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }

@@ -1,0 +1,868 @@
+// libmemvul_hip.so — C ABI (include/memvul_hip.h) over the gfx950 kernels in this directory.
+// Host side: weight staging/packing, workspace ownership, launch sequencing on one HIP stream,
+// HIP-event profiling per kernel class, error translation.  No torch, no exceptions across the ABI.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/memvul_hip.h"
+#include "attention.h"
+#include "common.h"
+#include "gemm.h"
+#include "misc_kernels.h"
+
+namespace {
+
+enum KernelClass {
+  KC_EMBED_LN = 0, KC_GEMM_QKV, KC_ATTENTION, KC_GEMM_OUT, KC_LN, KC_GEMM_FFN1, KC_GEMM_FFN2,
+  KC_POOL_HEAD, KC_MATCH, KC_TOPK, KC_TEST_GEMM, KC_OTHER
+};
+const char* kKernelClassNames[MV_NUM_KERNEL_CLASSES] = {
+    "embed_ln", "gemm_qkv", "attention", "gemm_attn_out", "layernorm", "gemm_ffn1_gelu", "gemm_ffn2",
+    "pool_head", "match", "topk", "test_gemm", "other"};
+
+thread_local std::string g_create_error;
+
+struct HostTensor {
+  std::vector<float> data;
+  std::vector<int64_t> shape;
+};
+
+struct LayerW {
+  half_t *wqkv = nullptr, *wo = nullptr, *w1 = nullptr, *w2 = nullptr;
+  float *bqkv = nullptr, *bo = nullptr, *b1 = nullptr, *b2 = nullptr;
+  float *ln1g = nullptr, *ln1b = nullptr, *ln2g = nullptr, *ln2b = nullptr;
+};
+
+inline int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
+
+// fp32 -> fp16 bits, round-to-nearest-even (same result as numpy astype(float16))
+inline uint16_t f32_to_f16_bits(float f) {
+  uint32_t x;
+  std::memcpy(&x, &f, 4);
+  const uint32_t sign = (x >> 16) & 0x8000u;
+  x &= 0x7fffffffu;
+  if (x >= 0x7f800000u) return (uint16_t)(sign | 0x7c00u | ((x > 0x7f800000u) ? 0x200u : 0));
+  if (x >= 0x477ff000u) return (uint16_t)(sign | 0x7c00u);  // rounds to >= 65520 -> inf
+  if (x < 0x38800000u) {                                     // subnormal half or zero
+    if (x < 0x33000000u) return (uint16_t)sign;              // < 2^-25 -> 0
+    const int e = (int)(x >> 23);
+    uint32_t m = (x & 0x7fffffu) | 0x800000u;
+    const int shift = 126 - e;  // 14..24 -> bits to drop
+    const uint32_t half_m = m >> shift;
+    const uint32_t rem = m & ((1u << shift) - 1), halfway = 1u << (shift - 1);
+    uint32_t r = half_m;
+    if (rem > halfway || (rem == halfway && (half_m & 1))) r++;
+    return (uint16_t)(sign | r);
+  }
+  const uint32_t e = (x >> 23) - 112, m = x & 0x7fffffu;
+  uint32_t h = (e << 10) | (m >> 13);
+  const uint32_t rem = m & 0x1fffu;
+  if (rem > 0x1000u || (rem == 0x1000u && (h & 1))) h++;
+  return (uint16_t)(sign | h);
+}
+inline float f16_bits_to_f32(uint16_t h) {
+  const uint32_t sign = (uint32_t)(h & 0x8000u) << 16;
+  uint32_t e = (h >> 10) & 0x1f, m = h & 0x3ffu, x;
+  if (e == 0) {
+    if (m == 0) x = sign;
+    else {
+      int sh = 0;
+      while (!(m & 0x400u)) { m <<= 1; sh++; }
+      m &= 0x3ffu;
+      x = sign | ((uint32_t)(113 - sh) << 23) | (m << 13);
+    }
+  } else if (e == 31) x = sign | 0x7f800000u | (m << 13);
+  else x = sign | ((e + 112) << 23) | (m << 13);
+  float f;
+  std::memcpy(&f, &x, 4);
+  return f;
+}
+inline float bf16_bits_to_f32(uint16_t h) {
+  uint32_t x = (uint32_t)h << 16;
+  float f;
+  std::memcpy(&f, &x, 4);
+  return f;
+}
+
+struct ProfRec {
+  int cls;
+  hipEvent_t e0, e1;
+};
+
+}  // namespace
+
+struct mv_handle {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  mv_config cfg{};
+  std::string err;
+  bool finalized = false;
+  int compute_dtype = MV_F16;
+  std::map<std::string, HostTensor> staged;
+  std::vector<void*> allocs;
+
+  // weights
+  float *wemb = nullptr, *pemb = nullptr, *temb = nullptr, *embg = nullptr, *embb = nullptr;
+  std::vector<LayerW> L;
+  float *WpT = nullptr, *bp = nullptr, *WhT = nullptr, *bh = nullptr, *Wm = nullptr;
+
+  // workspaces
+  int64_t cap_tokens = 0;  // rows every activation buffer holds (multiple of 128, + slack)
+  int32_t *d_ids = nullptr, *d_lens = nullptr;
+  float* xres = nullptr;
+  half_t *x16 = nullptr, *q = nullptr, *k = nullptr, *vt = nullptr, *ctx = nullptr, *h16 = nullptr;
+  float *u = nullptr, *anchors = nullptr;
+  int n_anchors = 0;
+  float *logits = nullptr, *probs = nullptr, *psame = nullptr, *best = nullptr;
+  int32_t* best_idx = nullptr;
+  float* topk_p = nullptr;
+  int32_t* topk_idx = nullptr;
+  float* u_in = nullptr;  // host-provided embeddings for mv_match / mv_topk
+
+  // resident corpus
+  int32_t *c_ids = nullptr, *c_lens = nullptr;
+  int64_t c_n = 0;
+  int c_S = 0;
+  float* c_best = nullptr;
+  int32_t* c_idx = nullptr;
+  float* c_psame = nullptr;
+  int64_t c_psame_rows = 0;
+  int c_G = 0;
+
+  // profiling
+  bool prof = false;
+  std::vector<ProfRec> recs;
+  std::vector<hipEvent_t> free_events;
+
+  // debug
+  int dbg_B = 0, dbg_Sp = 0;
+};
+
+namespace {
+
+int fail(mv_handle* h, int code, const std::string& msg) {
+  if (h) h->err = msg; else g_create_error = msg;
+  return code;
+}
+
+#define HIPCHK(h, expr)                                                                             \
+  do {                                                                                              \
+    hipError_t _e = (expr);                                                                         \
+    if (_e != hipSuccess)                                                                           \
+      return fail(h, MV_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e));                \
+  } while (0)
+
+template <typename T>
+int dev_alloc(mv_handle* h, T** p, int64_t count, bool zero = true) {
+  void* d = nullptr;
+  const size_t bytes = (size_t)count * sizeof(T);
+  hipError_t e = hipMalloc(&d, bytes ? bytes : 16);
+  if (e != hipSuccess) return fail(h, MV_ERR_NOMEM, std::string("hipMalloc failed: ") + hipGetErrorString(e));
+  if (zero) {
+    e = hipMemsetAsync(d, 0, bytes ? bytes : 16, h->stream);
+    if (e != hipSuccess) return fail(h, MV_ERR_HIP, std::string("hipMemset failed: ") + hipGetErrorString(e));
+  }
+  h->allocs.push_back(d);
+  *p = (T*)d;
+  return MV_OK;
+}
+void dev_free(mv_handle* h, void* p) {
+  if (!p) return;
+  for (auto it = h->allocs.begin(); it != h->allocs.end(); ++it)
+    if (*it == p) { h->allocs.erase(it); break; }
+  hipFree(p);
+}
+
+hipEvent_t get_event(mv_handle* h) {
+  if (!h->free_events.empty()) {
+    hipEvent_t e = h->free_events.back();
+    h->free_events.pop_back();
+    return e;
+  }
+  hipEvent_t e;
+  hipEventCreate(&e);
+  return e;
+}
+
+struct ProfScope {
+  mv_handle* h;
+  ProfRec rec;
+  bool on;
+  ProfScope(mv_handle* h_, int cls) : h(h_), on(h_->prof) {
+    if (on) {
+      rec.cls = cls;
+      rec.e0 = get_event(h);
+      rec.e1 = get_event(h);
+      hipEventRecord(rec.e0, h->stream);
+    }
+  }
+  ~ProfScope() {
+    if (on) {
+      hipEventRecord(rec.e1, h->stream);
+      h->recs.push_back(rec);
+    }
+  }
+};
+
+int launch_check(mv_handle* h, const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(h, MV_ERR_HIP, std::string("launch ") + what + ": " + hipGetErrorString(e));
+  return MV_OK;
+}
+
+template <int EPI, bool GLDS>
+int launch_gemm128(mv_handle* h, int cls, const GemmArgs& a) {
+  if (a.M % 128 || a.N % 128 || a.K % 64) return fail(h, MV_ERR_INVALID, "gemm128: M,N % 128, K % 64 required");
+  const int grid = (a.M / 128) * (a.N / 128);
+  ProfScope ps(h, cls);
+  hipLaunchKernelGGL((gemm128_kernel<EPI, GLDS>), dim3(grid), dim3(256), G128_LDS_BYTES, h->stream, a);
+  return launch_check(h, "gemm128");
+}
+
+// ---- encoder: ids (device) -> u (device, [B][512]); stops after n_layers (<0: all) ------------
+int encode_dev(mv_handle* h, const int32_t* d_ids, const int32_t* d_lens, int B, int S_in, int n_layers, float* u_out) {
+  const mv_config& c = h->cfg;
+  const int Sp = (int)round_up(S_in, 64);
+  const int64_t M = (int64_t)B * Sp, Mpad = round_up(M, 128);
+  if (Sp > c.max_pos && S_in > c.max_pos) return fail(h, MV_ERR_INVALID, "sequence longer than max_pos");
+  if (Mpad > h->cap_tokens) return fail(h, MV_ERR_CAPACITY, "B*S exceeds mv_config.max_tokens");
+  if (n_layers < 0 || n_layers > c.layers) n_layers = c.layers;
+  h->dbg_B = B;
+  h->dbg_Sp = Sp;
+  {
+    ProfScope ps(h, KC_EMBED_LN);
+    hipLaunchKernelGGL(embed_ln_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, h->stream, d_ids, S_in, Sp, (int)M,
+                       c.vocab_size, h->wemb, h->pemb, h->temb, h->embg, h->embb, c.ln_eps, h->xres, h->x16);
+    if (int rc = launch_check(h, "embed_ln")) return rc;
+  }
+  for (int l = 0; l < n_layers; ++l) {
+    const LayerW& w = h->L[l];
+    GemmArgs g{};
+    g.M = (int)Mpad; g.Mreal = (int)M; g.S = Sp;
+    // K2: QKV projection
+    g.A = h->x16; g.W = w.wqkv; g.bias = w.bqkv; g.N = 3 * MV_HIDDEN; g.K = MV_HIDDEN;
+    g.q = h->q; g.k = h->k; g.vt = h->vt;
+    if (int rc = launch_gemm128<EPI_QKV, true>(h, KC_GEMM_QKV, g)) return rc;
+    // K3: attention
+    {
+      AttnArgs a{h->q, h->k, h->vt, d_lens, h->ctx, Sp, B};
+      ProfScope ps(h, KC_ATTENTION);
+      if (Sp <= 256) {
+        const int qblocks = (Sp + 127) / 128;
+        hipLaunchKernelGGL((attention_kernel<4>), dim3(B * MV_HEADS * qblocks), dim3(256), ATT_LDS_BYTES(Sp), h->stream, a);
+      } else {
+        const int qblocks = (Sp + 255) / 256;
+        hipLaunchKernelGGL((attention_kernel<8>), dim3(B * MV_HEADS * qblocks), dim3(512), ATT_LDS_BYTES(Sp), h->stream, a);
+      }
+      if (int rc = launch_check(h, "attention")) return rc;
+    }
+    // K4: attention output projection + bias + residual (in place), then LayerNorm
+    g.A = h->ctx; g.W = w.wo; g.bias = w.bo; g.N = MV_HIDDEN; g.K = MV_HIDDEN; g.xres = h->xres;
+    if (int rc = launch_gemm128<EPI_RES, true>(h, KC_GEMM_OUT, g)) return rc;
+    {
+      ProfScope ps(h, KC_LN);
+      hipLaunchKernelGGL(ln_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, h->stream, h->xres, h->x16, (int)M, w.ln1g, w.ln1b, c.ln_eps);
+      if (int rc = launch_check(h, "ln1")) return rc;
+    }
+    // K5: FFN-1 + exact-erf GELU
+    g.A = h->x16; g.W = w.w1; g.bias = w.b1; g.N = MV_INTER; g.K = MV_HIDDEN; g.out16 = h->h16;
+    if (int rc = launch_gemm128<EPI_GELU, true>(h, KC_GEMM_FFN1, g)) return rc;
+    // K6: FFN-2 + bias + residual, then LayerNorm
+    g.A = h->h16; g.W = w.w2; g.bias = w.b2; g.N = MV_HIDDEN; g.K = MV_INTER; g.xres = h->xres;
+    if (int rc = launch_gemm128<EPI_RES, true>(h, KC_GEMM_FFN2, g)) return rc;
+    {
+      ProfScope ps(h, KC_LN);
+      hipLaunchKernelGGL(ln_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, h->stream, h->xres, h->x16, (int)M, w.ln2g, w.ln2b, c.ln_eps);
+      if (int rc = launch_check(h, "ln2")) return rc;
+    }
+  }
+  if (u_out) {
+    ProfScope ps(h, KC_POOL_HEAD);
+    hipLaunchKernelGGL(pool_head_kernel, dim3((B + POOL_RB - 1) / POOL_RB), dim3(256), 0, h->stream, h->xres, Sp, B, h->WpT,
+                       h->bp, h->WhT, h->bh, u_out);
+    if (int rc = launch_check(h, "pool_head")) return rc;
+  }
+  return MV_OK;
+}
+
+// largest batch one encoder pass can take at padded length Sp
+int max_rows_for(mv_handle* h, int S_in) {
+  const int Sp = (int)round_up(S_in, 64);
+  int64_t r = (h->cap_tokens - 128) / Sp;
+  if (r > h->cfg.max_batch) r = h->cfg.max_batch;
+  return (int)r;
+}
+
+// ---- matcher on device embeddings ------------------------------------------------------------
+int match_dev(mv_handle* h, const float* u_dev, int B, float* psame_out, int k, float* best_out, int32_t* idx_out) {
+  const int G = h->n_anchors;
+  if (G <= 0) return fail(h, MV_ERR_STATE, "anchor bank is empty (call mv_anchor_append / mv_anchor_set first)");
+  {
+    ProfScope ps(h, KC_MATCH);
+    hipLaunchKernelGGL(match_kernel, dim3((G + MT_G - 1) / MT_G, (B + MT_B - 1) / MT_B), dim3(256), 0, h->stream, u_dev,
+                       h->anchors, h->Wm, B, G, h->cfg.same_idx, h->logits, h->probs, psame_out);
+    if (int rc = launch_check(h, "match")) return rc;
+  }
+  {
+    ProfScope ps(h, KC_TOPK);
+    hipLaunchKernelGGL(topk_kernel, dim3((B + 3) / 4), dim3(256), 0, h->stream, psame_out, h->probs, B, G, k, best_out,
+                       idx_out, k > 1 ? h->topk_p : nullptr, k > 1 ? h->topk_idx : nullptr);
+    if (int rc = launch_check(h, "topk")) return rc;
+  }
+  return MV_OK;
+}
+
+int check_ready(mv_handle* h) {
+  if (!h) return MV_ERR_INVALID;
+  if (!h->finalized) return fail(h, MV_ERR_STATE, "weights not finalized (mv_finalize_weights)");
+  return MV_OK;
+}
+
+const HostTensor* find(mv_handle* h, const std::string& k) {
+  auto it = h->staged.find(k);
+  return it == h->staged.end() ? nullptr : &it->second;
+}
+
+int need(mv_handle* h, const std::string& k, std::initializer_list<int64_t> shape, const HostTensor** out) {
+  const HostTensor* t = find(h, k);
+  if (!t) return fail(h, MV_ERR_MISSING_WEIGHT, "missing weight: " + k);
+  std::vector<int64_t> s(shape);
+  if (t->shape != s) {
+    std::string got;
+    for (auto d : t->shape) got += std::to_string(d) + ",";
+    return fail(h, MV_ERR_INVALID, "bad shape for " + k + ": got [" + got + "]");
+  }
+  *out = t;
+  return MV_OK;
+}
+
+int upload_f32(mv_handle* h, float** dst, const float* src, int64_t n) {
+  if (int rc = dev_alloc(h, dst, n, false)) return rc;
+  HIPCHK(h, hipMemcpyAsync(*dst, src, (size_t)n * 4, hipMemcpyHostToDevice, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  return MV_OK;
+}
+int upload_f16(mv_handle* h, half_t** dst, const float* src, int64_t n, float scale = 1.0f) {
+  std::vector<uint16_t> tmp((size_t)n);
+  for (int64_t i = 0; i < n; ++i) tmp[(size_t)i] = f32_to_f16_bits(src[i] * scale);
+  if (int rc = dev_alloc(h, dst, n, false)) return rc;
+  HIPCHK(h, hipMemcpyAsync(*dst, tmp.data(), (size_t)n * 2, hipMemcpyHostToDevice, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  return MV_OK;
+}
+
+}  // namespace
+
+// =================================================================================================
+extern "C" {
+
+const char* mv_last_error(mv_handle* h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+
+const char* mv_kernel_class_name(int cls) {
+  return (cls >= 0 && cls < MV_NUM_KERNEL_CLASSES) ? kKernelClassNames[cls] : "";
+}
+
+int mv_create(int device, const mv_config* cfg, mv_handle** out) {
+  if (!cfg || !out) return fail(nullptr, MV_ERR_INVALID, "null argument");
+  if (cfg->hidden != MV_HIDDEN || cfg->heads != MV_HEADS || cfg->intermediate != MV_INTER || cfg->proj_dim != MV_PROJ)
+    return fail(nullptr, MV_ERR_INVALID, "kernels are specialised to hidden=768, heads=12, intermediate=3072, proj_dim=512");
+  if (cfg->layers < 0 || cfg->vocab_size <= 0 || cfg->max_pos <= 0 || cfg->max_pos > 512 || cfg->max_tokens <= 0 ||
+      cfg->max_batch <= 0 || cfg->max_anchors <= 0 || cfg->type_vocab <= 0 || (cfg->same_idx != 0 && cfg->same_idx != 1))
+    return fail(nullptr, MV_ERR_INVALID, "bad mv_config field");
+  int ndev = 0;
+  hipError_t e = hipGetDeviceCount(&ndev);
+  if (e != hipSuccess || ndev <= 0)
+    return fail(nullptr, MV_ERR_HIP, std::string("no HIP device: ") + hipGetErrorString(e));
+  if (device < 0 || device >= ndev) return fail(nullptr, MV_ERR_INVALID, "device index out of range");
+  e = hipSetDevice(device);
+  if (e != hipSuccess) return fail(nullptr, MV_ERR_HIP, std::string("hipSetDevice: ") + hipGetErrorString(e));
+  mv_handle* h = new (std::nothrow) mv_handle();
+  if (!h) return fail(nullptr, MV_ERR_NOMEM, "out of host memory");
+  h->device = device;
+  h->cfg = *cfg;
+  e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
+  if (e != hipSuccess) {
+    g_create_error = std::string("hipStreamCreate: ") + hipGetErrorString(e);
+    delete h;
+    return MV_ERR_HIP;
+  }
+  // dynamic LDS above 64 KiB needs an explicit opt-in
+  hipFuncSetAttribute((const void*)attention_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  hipFuncSetAttribute((const void*)attention_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  (void)hipGetLastError();
+
+  h->cap_tokens = round_up(cfg->max_tokens, 128) + 128;
+  const int64_t T = h->cap_tokens;
+  int rc = MV_OK;
+  auto A = [&](int r) { if (rc == MV_OK) rc = r; };
+  A(dev_alloc(h, &h->d_ids, T));
+  A(dev_alloc(h, &h->d_lens, (int64_t)cfg->max_batch + 16));
+  A(dev_alloc(h, &h->xres, T * MV_HIDDEN));
+  A(dev_alloc(h, &h->x16, T * MV_HIDDEN));
+  A(dev_alloc(h, &h->q, T * MV_HIDDEN));
+  A(dev_alloc(h, &h->k, T * MV_HIDDEN));
+  A(dev_alloc(h, &h->vt, T * MV_HIDDEN));
+  A(dev_alloc(h, &h->ctx, T * MV_HIDDEN));
+  A(dev_alloc(h, &h->h16, T * MV_INTER));
+  A(dev_alloc(h, &h->u, (int64_t)cfg->max_batch * MV_PROJ));
+  A(dev_alloc(h, &h->u_in, (int64_t)cfg->max_batch * MV_PROJ));
+  A(dev_alloc(h, &h->anchors, (int64_t)cfg->max_anchors * MV_PROJ));
+  const int64_t BG = (int64_t)cfg->max_batch * cfg->max_anchors;
+  A(dev_alloc(h, &h->logits, BG * 2));
+  A(dev_alloc(h, &h->probs, BG * 2));
+  A(dev_alloc(h, &h->psame, BG));
+  A(dev_alloc(h, &h->best, (int64_t)cfg->max_batch * 2));
+  A(dev_alloc(h, &h->best_idx, cfg->max_batch));
+  A(dev_alloc(h, &h->topk_p, (int64_t)cfg->max_batch * 64));
+  A(dev_alloc(h, &h->topk_idx, (int64_t)cfg->max_batch * 64));
+  if (rc == MV_OK && hipStreamSynchronize(h->stream) != hipSuccess) rc = MV_ERR_HIP;
+  if (rc != MV_OK) {
+    g_create_error = h->err.empty() ? "workspace allocation failed" : h->err;
+    mv_destroy(h);
+    return rc;
+  }
+  *out = h;
+  return MV_OK;
+}
+
+void mv_destroy(mv_handle* h) {
+  if (!h) return;
+  hipSetDevice(h->device);
+  if (h->stream) hipStreamSynchronize(h->stream);
+  for (auto& r : h->recs) { hipEventDestroy(r.e0); hipEventDestroy(r.e1); }
+  for (auto e : h->free_events) hipEventDestroy(e);
+  for (void* p : h->allocs) hipFree(p);
+  if (h->stream) hipStreamDestroy(h->stream);
+  delete h;
+}
+
+int mv_sync(mv_handle* h) {
+  if (!h) return MV_ERR_INVALID;
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  return MV_OK;
+}
+
+int mv_load_tensor(mv_handle* h, const char* name, const void* host_ptr, int dtype, const int64_t* shape, int ndim) {
+  if (!h || !name || !host_ptr || !shape || ndim < 1 || ndim > 4) return fail(h, MV_ERR_INVALID, "mv_load_tensor: bad argument");
+  if (h->finalized) return fail(h, MV_ERR_STATE, "weights already finalized");
+  int64_t n = 1;
+  for (int i = 0; i < ndim; ++i) {
+    if (shape[i] < 0) return fail(h, MV_ERR_INVALID, "negative dimension");
+    n *= shape[i];
+  }
+  HostTensor t;
+  t.shape.assign(shape, shape + ndim);
+  t.data.resize((size_t)n);
+  if (dtype == MV_F32) std::memcpy(t.data.data(), host_ptr, (size_t)n * 4);
+  else if (dtype == MV_F16) { const uint16_t* s = (const uint16_t*)host_ptr; for (int64_t i = 0; i < n; ++i) t.data[(size_t)i] = f16_bits_to_f32(s[i]); }
+  else if (dtype == MV_BF16) { const uint16_t* s = (const uint16_t*)host_ptr; for (int64_t i = 0; i < n; ++i) t.data[(size_t)i] = bf16_bits_to_f32(s[i]); }
+  else if (dtype == MV_I64 || dtype == MV_I32) return MV_OK;  // e.g. embeddings.position_ids: accepted, unused
+  else return fail(h, MV_ERR_INVALID, "mv_load_tensor: unsupported dtype");
+  h->staged[name] = std::move(t);
+  return MV_OK;
+}
+
+int mv_finalize_weights(mv_handle* h, int compute_dtype) {
+  if (!h) return MV_ERR_INVALID;
+  if (h->finalized) return fail(h, MV_ERR_STATE, "weights already finalized");
+  if (compute_dtype != MV_F16)
+    return fail(h, MV_ERR_INVALID, "only MV_F16 (fp16 MFMA operands, fp32 accumulation) is built in this round");
+  HIPCHK(h, hipSetDevice(h->device));
+  const mv_config& c = h->cfg;
+  const std::string P = "_text_field_embedder.token_embedder_tokens.transformer_model.";
+  const int64_t H = MV_HIDDEN, I = MV_INTER;
+  const HostTensor *t = nullptr, *t2 = nullptr, *t3 = nullptr;
+  int rc;
+#define NEED(key, ...) if ((rc = need(h, key, {__VA_ARGS__}, &t)) != MV_OK) return rc
+  NEED(P + "embeddings.word_embeddings.weight", c.vocab_size, H);
+  if ((rc = upload_f32(h, &h->wemb, t->data.data(), (int64_t)c.vocab_size * H))) return rc;
+  {
+    const HostTensor* tp = find(h, P + "embeddings.position_embeddings.weight");
+    if (!tp) return fail(h, MV_ERR_MISSING_WEIGHT, "missing weight: " + P + "embeddings.position_embeddings.weight");
+    if (tp->shape.size() != 2 || tp->shape[1] != H || tp->shape[0] < c.max_pos)
+      return fail(h, MV_ERR_INVALID, "bad shape for position_embeddings");
+    if ((rc = upload_f32(h, &h->pemb, tp->data.data(), (int64_t)c.max_pos * H))) return rc;
+  }
+  NEED(P + "embeddings.token_type_embeddings.weight", c.type_vocab, H);
+  if ((rc = upload_f32(h, &h->temb, t->data.data(), H))) return rc;  // row 0 only: type ids are all zero on this path
+  NEED(P + "embeddings.LayerNorm.weight", H);
+  if ((rc = upload_f32(h, &h->embg, t->data.data(), H))) return rc;
+  NEED(P + "embeddings.LayerNorm.bias", H);
+  if ((rc = upload_f32(h, &h->embb, t->data.data(), H))) return rc;
+  h->L.resize(c.layers);
+  for (int l = 0; l < c.layers; ++l) {
+    const std::string q = P + "encoder.layer." + std::to_string(l) + ".";
+    LayerW& w = h->L[l];
+    // packed QKV [2304][768]; 1/sqrt(64) folded into W_q, b_q (exact: power of two)
+    if ((rc = need(h, q + "attention.self.query.weight", {H, H}, &t))) return rc;
+    if ((rc = need(h, q + "attention.self.key.weight", {H, H}, &t2))) return rc;
+    if ((rc = need(h, q + "attention.self.value.weight", {H, H}, &t3))) return rc;
+    {
+      std::vector<float> pack((size_t)(3 * H * H));
+      for (int64_t i = 0; i < H * H; ++i) {
+        pack[(size_t)i] = t->data[(size_t)i] * 0.125f;
+        pack[(size_t)(H * H + i)] = t2->data[(size_t)i];
+        pack[(size_t)(2 * H * H + i)] = t3->data[(size_t)i];
+      }
+      if ((rc = upload_f16(h, &w.wqkv, pack.data(), 3 * H * H))) return rc;
+    }
+    if ((rc = need(h, q + "attention.self.query.bias", {H}, &t))) return rc;
+    if ((rc = need(h, q + "attention.self.key.bias", {H}, &t2))) return rc;
+    if ((rc = need(h, q + "attention.self.value.bias", {H}, &t3))) return rc;
+    {
+      std::vector<float> pack((size_t)(3 * H));
+      for (int64_t i = 0; i < H; ++i) {
+        pack[(size_t)i] = t->data[(size_t)i] * 0.125f;
+        pack[(size_t)(H + i)] = t2->data[(size_t)i];
+        pack[(size_t)(2 * H + i)] = t3->data[(size_t)i];
+      }
+      if ((rc = upload_f32(h, &w.bqkv, pack.data(), 3 * H))) return rc;
+    }
+    NEED(q + "attention.output.dense.weight", H, H);
+    if ((rc = upload_f16(h, &w.wo, t->data.data(), H * H))) return rc;
+    NEED(q + "attention.output.dense.bias", H);
+    if ((rc = upload_f32(h, &w.bo, t->data.data(), H))) return rc;
+    NEED(q + "attention.output.LayerNorm.weight", H);
+    if ((rc = upload_f32(h, &w.ln1g, t->data.data(), H))) return rc;
+    NEED(q + "attention.output.LayerNorm.bias", H);
+    if ((rc = upload_f32(h, &w.ln1b, t->data.data(), H))) return rc;
+    NEED(q + "intermediate.dense.weight", I, H);
+    if ((rc = upload_f16(h, &w.w1, t->data.data(), I * H))) return rc;
+    NEED(q + "intermediate.dense.bias", I);
+    if ((rc = upload_f32(h, &w.b1, t->data.data(), I))) return rc;
+    NEED(q + "output.dense.weight", H, I);
+    if ((rc = upload_f16(h, &w.w2, t->data.data(), H * I))) return rc;
+    NEED(q + "output.dense.bias", H);
+    if ((rc = upload_f32(h, &w.b2, t->data.data(), H))) return rc;
+    NEED(q + "output.LayerNorm.weight", H);
+    if ((rc = upload_f32(h, &w.ln2g, t->data.data(), H))) return rc;
+    NEED(q + "output.LayerNorm.bias", H);
+    if ((rc = upload_f32(h, &w.ln2b, t->data.data(), H))) return rc;
+  }
+  // pooler / header: transposed to [k][n] (fp32)
+  NEED("_bert_pooler.pooler.dense.weight", H, H);
+  {
+    std::vector<float> tr((size_t)(H * H));
+    for (int64_t n = 0; n < H; ++n) for (int64_t k = 0; k < H; ++k) tr[(size_t)(k * H + n)] = t->data[(size_t)(n * H + k)];
+    if ((rc = upload_f32(h, &h->WpT, tr.data(), H * H))) return rc;
+  }
+  NEED("_bert_pooler.pooler.dense.bias", H);
+  if ((rc = upload_f32(h, &h->bp, t->data.data(), H))) return rc;
+  NEED("_projector_single._linear_layers.0.weight", MV_PROJ, H);
+  {
+    std::vector<float> tr((size_t)(H * MV_PROJ));
+    for (int64_t n = 0; n < MV_PROJ; ++n) for (int64_t k = 0; k < H; ++k) tr[(size_t)(k * MV_PROJ + n)] = t->data[(size_t)(n * H + k)];
+    if ((rc = upload_f32(h, &h->WhT, tr.data(), H * MV_PROJ))) return rc;
+  }
+  NEED("_projector_single._linear_layers.0.bias", MV_PROJ);
+  if ((rc = upload_f32(h, &h->bh, t->data.data(), MV_PROJ))) return rc;
+  NEED("_projector.weight", 2, 3 * MV_PROJ);
+  if ((rc = upload_f32(h, &h->Wm, t->data.data(), 2 * 3 * MV_PROJ))) return rc;
+#undef NEED
+  h->staged.clear();
+  h->compute_dtype = compute_dtype;
+  h->finalized = true;
+  return MV_OK;
+}
+
+int mv_anchor_reset(mv_handle* h) {
+  if (!h) return MV_ERR_INVALID;
+  h->n_anchors = 0;
+  return MV_OK;
+}
+int mv_anchor_count(mv_handle* h) { return h ? h->n_anchors : MV_ERR_INVALID; }
+
+int mv_anchor_append(mv_handle* h, const int32_t* ids, const int32_t* lens, int n, int S) {
+  if (int rc = check_ready(h)) return rc;
+  if (!ids || !lens || n <= 0 || S <= 0 || S > h->cfg.max_pos) return fail(h, MV_ERR_INVALID, "mv_anchor_append: bad argument");
+  if (h->n_anchors + n > h->cfg.max_anchors) return fail(h, MV_ERR_CAPACITY, "anchor bank capacity (mv_config.max_anchors) exceeded");
+  HIPCHK(h, hipSetDevice(h->device));
+  const int rows = max_rows_for(h, S);
+  if (rows <= 0) return fail(h, MV_ERR_CAPACITY, "mv_config.max_tokens too small for one anchor of this length");
+  for (int off = 0; off < n; off += rows) {
+    const int nb = (n - off < rows) ? (n - off) : rows;
+    HIPCHK(h, hipMemcpyAsync(h->d_ids, ids + (size_t)off * S, (size_t)nb * S * 4, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->d_lens, lens + off, (size_t)nb * 4, hipMemcpyHostToDevice, h->stream));
+    if (int rc = encode_dev(h, h->d_ids, h->d_lens, nb, S, -1, h->anchors + (size_t)(h->n_anchors + off) * MV_PROJ)) return rc;
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+  }
+  h->n_anchors += n;
+  return MV_OK;
+}
+
+int mv_anchor_get(mv_handle* h, float* out) {
+  if (!h || !out) return MV_ERR_INVALID;
+  HIPCHK(h, hipMemcpyAsync(out, h->anchors, (size_t)h->n_anchors * MV_PROJ * 4, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  return MV_OK;
+}
+
+int mv_anchor_set(mv_handle* h, const float* v, int G) {
+  if (!h || !v || G <= 0) return fail(h, MV_ERR_INVALID, "mv_anchor_set: bad argument");
+  if (G > h->cfg.max_anchors) return fail(h, MV_ERR_CAPACITY, "anchor bank capacity (mv_config.max_anchors) exceeded");
+  HIPCHK(h, hipMemcpyAsync(h->anchors, v, (size_t)G * MV_PROJ * 4, hipMemcpyHostToDevice, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  h->n_anchors = G;
+  return MV_OK;
+}
+
+int mv_encode(mv_handle* h, const int32_t* ids, const int32_t* lens, int B, int S, float* embed) {
+  if (int rc = check_ready(h)) return rc;
+  if (!ids || !lens || B <= 0 || S <= 0 || S > h->cfg.max_pos) return fail(h, MV_ERR_INVALID, "mv_encode: bad argument");
+  HIPCHK(h, hipSetDevice(h->device));
+  const int rows = max_rows_for(h, S);
+  if (rows <= 0) return fail(h, MV_ERR_CAPACITY, "mv_config.max_tokens too small for this sequence length");
+  for (int off = 0; off < B; off += rows) {
+    const int nb = (B - off < rows) ? (B - off) : rows;
+    HIPCHK(h, hipMemcpyAsync(h->d_ids, ids + (size_t)off * S, (size_t)nb * S * 4, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->d_lens, lens + off, (size_t)nb * 4, hipMemcpyHostToDevice, h->stream));
+    if (int rc = encode_dev(h, h->d_ids, h->d_lens, nb, S, -1, h->u)) return rc;
+    if (embed) HIPCHK(h, hipMemcpyAsync(embed + (size_t)off * MV_PROJ, h->u, (size_t)nb * MV_PROJ * 4, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+  }
+  return MV_OK;
+}
+
+int mv_forward(mv_handle* h, const int32_t* ids, const int32_t* lens, int B, int S, float* logits, float* probs, float* best,
+               int32_t* best_idx, float* embed) {
+  if (int rc = check_ready(h)) return rc;
+  if (!ids || !lens || B <= 0 || S <= 0 || S > h->cfg.max_pos) return fail(h, MV_ERR_INVALID, "mv_forward: bad argument");
+  if (h->n_anchors <= 0) return fail(h, MV_ERR_STATE, "anchor bank is empty (call mv_anchor_append / mv_anchor_set first)");
+  HIPCHK(h, hipSetDevice(h->device));
+  const int rows = max_rows_for(h, S);
+  if (rows <= 0) return fail(h, MV_ERR_CAPACITY, "mv_config.max_tokens too small for this sequence length");
+  const int G = h->n_anchors;
+  for (int off = 0; off < B; off += rows) {
+    const int nb = (B - off < rows) ? (B - off) : rows;
+    HIPCHK(h, hipMemcpyAsync(h->d_ids, ids + (size_t)off * S, (size_t)nb * S * 4, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->d_lens, lens + off, (size_t)nb * 4, hipMemcpyHostToDevice, h->stream));
+    if (int rc = encode_dev(h, h->d_ids, h->d_lens, nb, S, -1, h->u)) return rc;
+    if (int rc = match_dev(h, h->u, nb, h->psame, 1, h->best, h->best_idx)) return rc;
+    const size_t bg = (size_t)nb * G;
+    if (logits) HIPCHK(h, hipMemcpyAsync(logits + (size_t)off * G * 2, h->logits, bg * 8, hipMemcpyDeviceToHost, h->stream));
+    if (probs) HIPCHK(h, hipMemcpyAsync(probs + (size_t)off * G * 2, h->probs, bg * 8, hipMemcpyDeviceToHost, h->stream));
+    if (best) HIPCHK(h, hipMemcpyAsync(best + (size_t)off * 2, h->best, (size_t)nb * 8, hipMemcpyDeviceToHost, h->stream));
+    if (best_idx) HIPCHK(h, hipMemcpyAsync(best_idx + off, h->best_idx, (size_t)nb * 4, hipMemcpyDeviceToHost, h->stream));
+    if (embed) HIPCHK(h, hipMemcpyAsync(embed + (size_t)off * MV_PROJ, h->u, (size_t)nb * MV_PROJ * 4, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+  }
+  return MV_OK;
+}
+
+int mv_match(mv_handle* h, const float* u, int B, float* logits, float* probs, float* best, int32_t* best_idx) {
+  if (int rc = check_ready(h)) return rc;
+  if (!u || B <= 0) return fail(h, MV_ERR_INVALID, "mv_match: bad argument");
+  if (B > h->cfg.max_batch) return fail(h, MV_ERR_CAPACITY, "B exceeds mv_config.max_batch");
+  HIPCHK(h, hipSetDevice(h->device));
+  const int G = h->n_anchors;
+  HIPCHK(h, hipMemcpyAsync(h->u_in, u, (size_t)B * MV_PROJ * 4, hipMemcpyHostToDevice, h->stream));
+  if (int rc = match_dev(h, h->u_in, B, h->psame, 1, h->best, h->best_idx)) return rc;
+  const size_t bg = (size_t)B * G;
+  if (logits) HIPCHK(h, hipMemcpyAsync(logits, h->logits, bg * 8, hipMemcpyDeviceToHost, h->stream));
+  if (probs) HIPCHK(h, hipMemcpyAsync(probs, h->probs, bg * 8, hipMemcpyDeviceToHost, h->stream));
+  if (best) HIPCHK(h, hipMemcpyAsync(best, h->best, (size_t)B * 8, hipMemcpyDeviceToHost, h->stream));
+  if (best_idx) HIPCHK(h, hipMemcpyAsync(best_idx, h->best_idx, (size_t)B * 4, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  return MV_OK;
+}
+
+int mv_topk(mv_handle* h, const float* u, int B, int k, float* topk_p, int32_t* topk_idx) {
+  if (int rc = check_ready(h)) return rc;
+  if (!u || B <= 0 || k <= 0 || k > 64 || !topk_p || !topk_idx) return fail(h, MV_ERR_INVALID, "mv_topk: bad argument (1 <= k <= 64)");
+  if (B > h->cfg.max_batch) return fail(h, MV_ERR_CAPACITY, "B exceeds mv_config.max_batch");
+  if (k > h->n_anchors) return fail(h, MV_ERR_INVALID, "k exceeds the number of anchors");
+  HIPCHK(h, hipSetDevice(h->device));
+  HIPCHK(h, hipMemcpyAsync(h->u_in, u, (size_t)B * MV_PROJ * 4, hipMemcpyHostToDevice, h->stream));
+  // k == 1 goes through the same kernel; force the top-k outputs on
+  {
+    const int G = h->n_anchors;
+    {
+      ProfScope ps(h, KC_MATCH);
+      hipLaunchKernelGGL(match_kernel, dim3((G + MT_G - 1) / MT_G, (B + MT_B - 1) / MT_B), dim3(256), 0, h->stream, h->u_in,
+                         h->anchors, h->Wm, B, G, h->cfg.same_idx, (float*)nullptr, (float*)nullptr, h->psame);
+      if (int rc = launch_check(h, "match")) return rc;
+    }
+    {
+      ProfScope ps(h, KC_TOPK);
+      hipLaunchKernelGGL(topk_kernel, dim3((B + 3) / 4), dim3(256), 0, h->stream, h->psame, (const float*)nullptr, B, G, k,
+                         (float*)nullptr, (int32_t*)nullptr, h->topk_p, h->topk_idx);
+      if (int rc = launch_check(h, "topk")) return rc;
+    }
+  }
+  HIPCHK(h, hipMemcpyAsync(topk_p, h->topk_p, (size_t)B * k * 4, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipMemcpyAsync(topk_idx, h->topk_idx, (size_t)B * k * 4, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  return MV_OK;
+}
+
+// ---- resident corpus ---------------------------------------------------------------------------
+int mv_corpus_upload(mv_handle* h, const int32_t* ids, const int32_t* lens, int64_t n, int S) {
+  if (int rc = check_ready(h)) return rc;
+  if (!ids || !lens || n <= 0 || S <= 0 || S > h->cfg.max_pos) return fail(h, MV_ERR_INVALID, "mv_corpus_upload: bad argument");
+  HIPCHK(h, hipSetDevice(h->device));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  dev_free(h, h->c_ids); dev_free(h, h->c_lens); dev_free(h, h->c_best); dev_free(h, h->c_idx); dev_free(h, h->c_psame);
+  h->c_ids = nullptr; h->c_lens = nullptr; h->c_best = nullptr; h->c_idx = nullptr; h->c_psame = nullptr;
+  h->c_psame_rows = 0;
+  if (int rc = dev_alloc(h, &h->c_ids, n * S, false)) return rc;
+  if (int rc = dev_alloc(h, &h->c_lens, n, false)) return rc;
+  if (int rc = dev_alloc(h, &h->c_best, n * 2)) return rc;
+  if (int rc = dev_alloc(h, &h->c_idx, n)) return rc;
+  HIPCHK(h, hipMemcpyAsync(h->c_ids, ids, (size_t)n * S * 4, hipMemcpyHostToDevice, h->stream));
+  HIPCHK(h, hipMemcpyAsync(h->c_lens, lens, (size_t)n * 4, hipMemcpyHostToDevice, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  h->c_n = n;
+  h->c_S = S;
+  return MV_OK;
+}
+
+int mv_corpus_run(mv_handle* h, int64_t first, int64_t count, int batch, int keep_probs) {
+  if (int rc = check_ready(h)) return rc;
+  if (!h->c_ids) return fail(h, MV_ERR_STATE, "no resident corpus (mv_corpus_upload)");
+  if (first < 0 || count <= 0 || first + count > h->c_n || batch <= 0) return fail(h, MV_ERR_INVALID, "mv_corpus_run: bad range");
+  if (h->n_anchors <= 0) return fail(h, MV_ERR_STATE, "anchor bank is empty");
+  HIPCHK(h, hipSetDevice(h->device));
+  const int rows = max_rows_for(h, h->c_S);
+  if (batch > rows) return fail(h, MV_ERR_CAPACITY, "batch exceeds mv_config.max_batch / max_tokens");
+  const int G = h->n_anchors;
+  if (keep_probs && (h->c_psame_rows != h->c_n || h->c_G != G)) {
+    dev_free(h, h->c_psame);
+    h->c_psame = nullptr;
+    if (int rc = dev_alloc(h, &h->c_psame, h->c_n * G)) return rc;
+    h->c_psame_rows = h->c_n;
+    h->c_G = G;
+  }
+  for (int64_t off = first; off < first + count; off += batch) {
+    const int nb = (int)((first + count - off < batch) ? (first + count - off) : batch);
+    if (int rc = encode_dev(h, h->c_ids + (size_t)off * h->c_S, h->c_lens + off, nb, h->c_S, -1, h->u)) return rc;
+    float* ps = keep_probs ? h->c_psame + (size_t)off * G : h->psame;
+    if (int rc = match_dev(h, h->u, nb, ps, 1, h->c_best + (size_t)off * 2, h->c_idx + off)) return rc;
+  }
+  return MV_OK;
+}
+
+int mv_corpus_results(mv_handle* h, int64_t first, int64_t count, float* best, int32_t* best_idx, float* p_same) {
+  if (!h) return MV_ERR_INVALID;
+  if (!h->c_ids) return fail(h, MV_ERR_STATE, "no resident corpus (mv_corpus_upload)");
+  if (first < 0 || count <= 0 || first + count > h->c_n) return fail(h, MV_ERR_INVALID, "mv_corpus_results: bad range");
+  if (best) HIPCHK(h, hipMemcpyAsync(best, h->c_best + (size_t)first * 2, (size_t)count * 8, hipMemcpyDeviceToHost, h->stream));
+  if (best_idx) HIPCHK(h, hipMemcpyAsync(best_idx, h->c_idx + first, (size_t)count * 4, hipMemcpyDeviceToHost, h->stream));
+  if (p_same) {
+    if (!h->c_psame) return fail(h, MV_ERR_STATE, "P(same) was not kept (mv_corpus_run keep_probs=0)");
+    HIPCHK(h, hipMemcpyAsync(p_same, h->c_psame + (size_t)first * h->c_G, (size_t)count * h->c_G * 4, hipMemcpyDeviceToHost, h->stream));
+  }
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  return MV_OK;
+}
+
+// ---- measurement / debug -----------------------------------------------------------------------
+int mv_profile_enable(mv_handle* h, int on) {
+  if (!h) return MV_ERR_INVALID;
+  h->prof = on != 0;
+  return MV_OK;
+}
+
+int mv_profile_read(mv_handle* h, double* ms, int64_t* launches, int n) {
+  if (!h || !ms || !launches || n < MV_NUM_KERNEL_CLASSES) return fail(h, MV_ERR_INVALID, "mv_profile_read: bad argument");
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  for (int i = 0; i < n; ++i) { ms[i] = 0; launches[i] = 0; }
+  for (auto& r : h->recs) {
+    float t = 0.f;
+    if (hipEventElapsedTime(&t, r.e0, r.e1) == hipSuccess) { ms[r.cls] += t; launches[r.cls] += 1; }
+    h->free_events.push_back(r.e0);
+    h->free_events.push_back(r.e1);
+  }
+  h->recs.clear();
+  return MV_OK;
+}
+
+int mv_debug_encode(mv_handle* h, const int32_t* ids, const int32_t* lens, int B, int S, int n_layers) {
+  if (int rc = check_ready(h)) return rc;
+  if (!ids || !lens || B <= 0 || S <= 0 || S > h->cfg.max_pos) return fail(h, MV_ERR_INVALID, "mv_debug_encode: bad argument");
+  if (B > max_rows_for(h, S)) return fail(h, MV_ERR_CAPACITY, "mv_debug_encode: batch too large for one pass");
+  HIPCHK(h, hipSetDevice(h->device));
+  HIPCHK(h, hipMemcpyAsync(h->d_ids, ids, (size_t)B * S * 4, hipMemcpyHostToDevice, h->stream));
+  HIPCHK(h, hipMemcpyAsync(h->d_lens, lens, (size_t)B * 4, hipMemcpyHostToDevice, h->stream));
+  if (int rc = encode_dev(h, h->d_ids, h->d_lens, B, S, n_layers < 0 ? h->cfg.layers : n_layers, h->u)) return rc;
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  return MV_OK;
+}
+
+int mv_debug_read(mv_handle* h, int buffer, void* dst, int64_t bytes) {
+  if (!h || !dst || bytes <= 0) return MV_ERR_INVALID;
+  const int64_t T = (int64_t)h->dbg_B * h->dbg_Sp;
+  const void* src = nullptr;
+  int64_t avail = 0;
+  switch (buffer) {
+    case 0: src = h->xres; avail = T * MV_HIDDEN * 4; break;
+    case 1: src = h->x16; avail = T * MV_HIDDEN * 2; break;
+    case 2: src = h->q; avail = T * MV_HIDDEN * 2; break;
+    case 3: src = h->k; avail = T * MV_HIDDEN * 2; break;
+    case 4: src = h->vt; avail = T * MV_HIDDEN * 2; break;
+    case 5: src = h->ctx; avail = T * MV_HIDDEN * 2; break;
+    case 6: src = h->h16; avail = T * MV_INTER * 2; break;
+    case 7: src = h->u; avail = (int64_t)h->dbg_B * MV_PROJ * 4; break;
+    default: return fail(h, MV_ERR_INVALID, "mv_debug_read: unknown buffer");
+  }
+  if (bytes > avail) return fail(h, MV_ERR_INVALID, "mv_debug_read: more bytes requested than the buffer holds");
+  HIPCHK(h, hipMemcpyAsync(dst, src, (size_t)bytes, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  return MV_OK;
+}
+
+int mv_test_gemm(mv_handle* h, int variant, int M, int N, int K, const uint16_t* A, const uint16_t* W, const float* bias,
+                 float* C, int iters, float* ms) {
+  if (!h || !A || !W || M <= 0 || N <= 0 || K <= 0) return fail(h, MV_ERR_INVALID, "mv_test_gemm: bad argument");
+  if (M % 128 || N % 128 || K % 64) return fail(h, MV_ERR_INVALID, "mv_test_gemm: M,N % 128 and K % 64 required");
+  HIPCHK(h, hipSetDevice(h->device));
+  half_t *dA = nullptr, *dW = nullptr;
+  float *dB = nullptr, *dC = nullptr;
+  int rc;
+  if ((rc = dev_alloc(h, &dA, (int64_t)M * K, false))) return rc;
+  if ((rc = dev_alloc(h, &dW, (int64_t)N * K, false))) return rc;
+  if ((rc = dev_alloc(h, &dB, N))) return rc;
+  if ((rc = dev_alloc(h, &dC, (int64_t)M * N))) return rc;
+  HIPCHK(h, hipMemcpyAsync(dA, A, (size_t)M * K * 2, hipMemcpyHostToDevice, h->stream));
+  HIPCHK(h, hipMemcpyAsync(dW, W, (size_t)N * K * 2, hipMemcpyHostToDevice, h->stream));
+  if (bias) HIPCHK(h, hipMemcpyAsync(dB, bias, (size_t)N * 4, hipMemcpyHostToDevice, h->stream));
+  GemmArgs g{};
+  g.A = dA; g.W = dW; g.bias = dB; g.M = M; g.Mreal = M; g.N = N; g.K = K; g.outf = dC; g.S = 64;
+  if (iters < 1) iters = 1;
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0);
+  hipEventCreate(&e1);
+  auto run = [&]() -> int {
+    switch (variant) {
+      case 0: return launch_gemm128<EPI_F32, true>(h, KC_TEST_GEMM, g);
+      case 1: return launch_gemm128<EPI_F32, false>(h, KC_TEST_GEMM, g);
+      default: return fail(h, MV_ERR_INVALID, "mv_test_gemm: unknown variant");
+    }
+  };
+  rc = run();  // warm-up / correctness launch
+  if (rc == MV_OK) {
+    hipEventRecord(e0, h->stream);
+    for (int i = 0; i < iters && rc == MV_OK; ++i) rc = run();
+    hipEventRecord(e1, h->stream);
+  }
+  hipError_t se = hipStreamSynchronize(h->stream);
+  float t = 0.f;
+  hipEventElapsedTime(&t, e0, e1);
+  hipEventDestroy(e0);
+  hipEventDestroy(e1);
+  if (ms) *ms = t / (float)iters;
+  if (rc == MV_OK && se != hipSuccess) rc = fail(h, MV_ERR_HIP, std::string("test gemm: ") + hipGetErrorString(se));
+  if (rc == MV_OK && C) {
+    se = hipMemcpy(C, dC, (size_t)M * N * 4, hipMemcpyDeviceToHost);
+    if (se != hipSuccess) rc = fail(h, MV_ERR_HIP, std::string("test gemm copy: ") + hipGetErrorString(se));
+  }
+  dev_free(h, dA); dev_free(h, dW); dev_free(h, dB); dev_free(h, dC);
+  return rc;
+}
+
+}  // extern "C"

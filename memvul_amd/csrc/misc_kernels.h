@@ -1,0 +1,260 @@
+// Memory-bound and small fp32 kernels of the hot path: embeddings + LayerNorm (K1), LayerNorm of the
+// residual stream (the LN half of K4/K6), pooler + header (K7/K8), anchor match + best anchor / top-k
+// (K9/K10).  SURVEY.md §2a.
+#pragma once
+#include "common.h"
+
+// ---------------------------------------------------------------------------------------------
+// One wave per token row of 768 fp32: lane owns elements 4*lane + 256*i .. +3, i = 0..2
+// (three coalesced 1-KiB float4 sweeps per row).
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void ln_row_store(const float4 (&x)[3], const float* __restrict__ gamma,
+                                             const float* __restrict__ beta, float eps, int lane,
+                                             float* __restrict__ out32, half_t* __restrict__ out16) {
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) s += x[i].x + x[i].y + x[i].z + x[i].w;
+  const float mean = wave_sum(s) * (1.0f / MV_HIDDEN);
+  float v = 0.f;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const float a = x[i].x - mean, b = x[i].y - mean, c = x[i].z - mean, d = x[i].w - mean;
+    v += a * a + b * b + c * c + d * d;
+  }
+  const float rstd = 1.0f / sqrtf(wave_sum(v) * (1.0f / MV_HIDDEN) + eps);
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const int c = 4 * lane + 256 * i;
+    const float4 g = *(const float4*)(gamma + c);
+    const float4 bb = *(const float4*)(beta + c);
+    float4 y;
+    y.x = (x[i].x - mean) * rstd * g.x + bb.x;
+    y.y = (x[i].y - mean) * rstd * g.y + bb.y;
+    y.z = (x[i].z - mean) * rstd * g.z + bb.z;
+    y.w = (x[i].w - mean) * rstd * g.w + bb.w;
+    *(float4*)(out32 + c) = y;
+    half4_t h;
+    h[0] = (half_t)y.x; h[1] = (half_t)y.y; h[2] = (half_t)y.z; h[3] = (half_t)y.w;
+    *(half4_t*)(out16 + c) = h;
+  }
+}
+
+// K1: x = LN(word[id] + pos[s] + type[0])   (HF BertEmbeddings; token-type ids are all zero in this
+// path, custom_PTM_embedder.py:199-202).  ids are [B][S_in] (0-padded), the engine row pitch is Sp.
+__global__ __launch_bounds__(256) void embed_ln_kernel(const int32_t* __restrict__ ids, int S_in, int Sp, int n_tok,
+                                                       int vocab, const float* __restrict__ wemb,
+                                                       const float* __restrict__ pemb, const float* __restrict__ temb,
+                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                       float eps, float* __restrict__ x32, half_t* __restrict__ x16) {
+  const int lane = threadIdx.x & 63;
+  const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (t >= n_tok) return;
+  const int b = t / Sp, s = t - b * Sp;
+  int id = (s < S_in) ? ids[(size_t)b * S_in + s] : 0;
+  id = (id < 0 || id >= vocab) ? 0 : id;
+  const float* w = wemb + (size_t)id * MV_HIDDEN;
+  const float* p = pemb + (size_t)(s < S_in ? s : 0) * MV_HIDDEN;  // columns >= S_in are engine padding (always masked)
+  float4 x[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const int c = 4 * lane + 256 * i;
+    const float4 a = *(const float4*)(w + c), q = *(const float4*)(p + c), r = *(const float4*)(temb + c);
+    x[i].x = a.x + q.x + r.x; x[i].y = a.y + q.y + r.y; x[i].z = a.z + q.z + r.z; x[i].w = a.w + q.w + r.w;
+  }
+  ln_row_store(x, gamma, beta, eps, lane, x32 + (size_t)t * MV_HIDDEN, x16 + (size_t)t * MV_HIDDEN);
+}
+
+// LayerNorm of the residual stream in place (the GEMM epilogue already added bias + residual):
+// x32 <- LN(x32), x16 <- fp16(x32).
+__global__ __launch_bounds__(256) void ln_kernel(float* __restrict__ x32, half_t* __restrict__ x16, int n_tok,
+                                                 const float* __restrict__ gamma, const float* __restrict__ beta, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (t >= n_tok) return;
+  float* row = x32 + (size_t)t * MV_HIDDEN;
+  float4 x[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) x[i] = *(const float4*)(row + 4 * lane + 256 * i);
+  ln_row_store(x, gamma, beta, eps, lane, row, x16 + (size_t)t * MV_HIDDEN);
+}
+
+// K7+K8 (model_memory.py:99-102): u = relu(W_h tanh(W_p h[:,0] + b_p) + b_h), all fp32.
+// One workgroup handles POOL_RB issue reports; thread n owns output column n; the weights are stored
+// transposed ([k][n]) so a wave reads 256 contiguous bytes per k.
+#define POOL_RB 4
+__global__ __launch_bounds__(256) void pool_head_kernel(const float* __restrict__ x32, int Sp, int B,
+                                                        const float* __restrict__ WpT, const float* __restrict__ bp,
+                                                        const float* __restrict__ WhT, const float* __restrict__ bh,
+                                                        float* __restrict__ u) {
+  __shared__ float cls[POOL_RB][MV_HIDDEN];
+  __shared__ float pooled[POOL_RB][MV_HIDDEN];
+  const int b0 = blockIdx.x * POOL_RB;
+  const int tid = threadIdx.x;
+  for (int e = tid; e < POOL_RB * MV_HIDDEN; e += 256) {
+    const int r = e / MV_HIDDEN, c = e - r * MV_HIDDEN;
+    cls[r][c] = (b0 + r < B) ? x32[(size_t)(b0 + r) * Sp * MV_HIDDEN + c] : 0.f;
+  }
+  __syncthreads();
+  {
+    float acc[3][POOL_RB];
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+      for (int r = 0; r < POOL_RB; ++r) acc[j][r] = 0.f;
+    for (int k = 0; k < MV_HIDDEN; ++k) {
+      float w[3];
+#pragma unroll
+      for (int j = 0; j < 3; ++j) w[j] = WpT[(size_t)k * MV_HIDDEN + tid + 256 * j];
+#pragma unroll
+      for (int r = 0; r < POOL_RB; ++r) {
+        const float c = cls[r][k];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) acc[j][r] = fmaf(w[j], c, acc[j][r]);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+      for (int r = 0; r < POOL_RB; ++r) pooled[r][tid + 256 * j] = tanhf(acc[j][r] + bp[tid + 256 * j]);
+  }
+  __syncthreads();
+  {
+    float acc[2][POOL_RB];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < POOL_RB; ++r) acc[j][r] = 0.f;
+    for (int k = 0; k < MV_HIDDEN; ++k) {
+      float w[2];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) w[j] = WhT[(size_t)k * MV_PROJ + tid + 256 * j];
+#pragma unroll
+      for (int r = 0; r < POOL_RB; ++r) {
+        const float c = pooled[r][k];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[j][r] = fmaf(w[j], c, acc[j][r]);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < POOL_RB; ++r)
+        if (b0 + r < B) u[(size_t)(b0 + r) * MV_PROJ + tid + 256 * j] = fmaxf(acc[j][r] + bh[tid + 256 * j], 0.f);
+  }
+}
+
+// K9 (model_memory.py:135-142): logits[b,g,:] = W_m [u_b ; v_g ; |u_b - v_g|], p = softmax_2.
+// W_m is [2][1536] row-major: columns 0..511 multiply u, 512..1023 v, 1024..1535 |u-v|.
+// A workgroup covers MT_B issue reports x MT_G anchors; the 512-long feature axis is walked in chunks
+// of MT_I staged through LDS (u tile, anchor tile with a +1 pad => conflict-free column reads, and the
+// two |u-v| weight rows).  Thread (wave w, lane l) owns anchor l and issue reports 4w..4w+3.
+#define MT_B 16
+#define MT_G 64
+#define MT_I 128
+__global__ __launch_bounds__(256) void match_kernel(const float* __restrict__ u, const float* __restrict__ v,
+                                                    const float* __restrict__ Wm, int B, int G, int same_idx,
+                                                    float* __restrict__ logits, float* __restrict__ probs,
+                                                    float* __restrict__ psame) {
+  __shared__ float su[MT_B][MT_I];
+  __shared__ float sv[MT_G][MT_I + 1];
+  __shared__ float sw[4][MT_I];  // Wa0, Wa1 (u part) are folded below; rows: Wb0, Wb1, Wc0, Wc1
+  __shared__ float swa[2][MT_I];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int b0 = blockIdx.y * MT_B, g0 = blockIdx.x * MT_G;
+  float accc[4][2], accu[4][2], accv[2];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) { accc[r][0] = accc[r][1] = 0.f; accu[r][0] = accu[r][1] = 0.f; }
+  accv[0] = accv[1] = 0.f;
+  for (int i0 = 0; i0 < MV_PROJ; i0 += MT_I) {
+    __syncthreads();
+    for (int e = tid; e < MT_B * MT_I; e += 256) {
+      const int r = e / MT_I, c = e - r * MT_I;
+      su[r][c] = (b0 + r < B) ? u[(size_t)(b0 + r) * MV_PROJ + i0 + c] : 0.f;
+    }
+    for (int e = tid; e < MT_G * MT_I; e += 256) {
+      const int r = e / MT_I, c = e - r * MT_I;
+      sv[r][c] = (g0 + r < G) ? v[(size_t)(g0 + r) * MV_PROJ + i0 + c] : 0.f;
+    }
+    for (int e = tid; e < 2 * MT_I; e += 256) {
+      const int r = e / MT_I, c = e - r * MT_I;
+      swa[r][c] = Wm[(size_t)r * 3 * MV_PROJ + i0 + c];
+      sw[r][c] = Wm[(size_t)r * 3 * MV_PROJ + MV_PROJ + i0 + c];
+      sw[2 + r][c] = Wm[(size_t)r * 3 * MV_PROJ + 2 * MV_PROJ + i0 + c];
+    }
+    __syncthreads();
+    for (int i = 0; i < MT_I; ++i) {
+      const float vv = sv[lane][i];
+      const float wa0 = swa[0][i], wa1 = swa[1][i];
+      const float wc0 = sw[2][i], wc1 = sw[3][i];
+      accv[0] = fmaf(sw[0][i], vv, accv[0]);
+      accv[1] = fmaf(sw[1][i], vv, accv[1]);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float uu = su[4 * w + r][i];
+        const float dd = fabsf(uu - vv);
+        accu[r][0] = fmaf(wa0, uu, accu[r][0]);
+        accu[r][1] = fmaf(wa1, uu, accu[r][1]);
+        accc[r][0] = fmaf(wc0, dd, accc[r][0]);
+        accc[r][1] = fmaf(wc1, dd, accc[r][1]);
+      }
+    }
+  }
+  const int g = g0 + lane;
+  if (g >= G) return;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int b = b0 + 4 * w + r;
+    if (b >= B) continue;
+    const float l0 = accu[r][0] + accv[0] + accc[r][0];
+    const float l1 = accu[r][1] + accv[1] + accc[r][1];
+    const float m = fmaxf(l0, l1);
+    const float e0 = expf(l0 - m), e1 = expf(l1 - m);
+    const float inv = 1.0f / (e0 + e1);
+    const size_t o = ((size_t)b * G + g) * 2;
+    if (logits) { logits[o] = l0; logits[o + 1] = l1; }
+    const float p0 = e0 * inv, p1 = e1 * inv;
+    if (probs) { probs[o] = p0; probs[o + 1] = p1; }
+    psame[(size_t)b * G + g] = same_idx == 0 ? p0 : p1;
+  }
+}
+
+// K10 (model_memory.py:144-147) generalised to top-k (BASELINE configs[4]): one wave per issue report;
+// k rounds of (value, index) arg-max over the row of P(same), ties to the LOWER anchor index
+// (torch.argmax returns the first maximal element).  k = 1 is the reference's best-anchor pick.
+__global__ __launch_bounds__(256) void topk_kernel(const float* __restrict__ psame, const float* __restrict__ probs,
+                                                   int B, int G, int k, float* __restrict__ best,
+                                                   int32_t* __restrict__ best_idx, float* __restrict__ topk_p,
+                                                   int32_t* __restrict__ topk_idx) {
+  const int lane = threadIdx.x & 63;
+  const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (b >= B) return;
+  const float* row = psame + (size_t)b * G;
+  float prev_v = 3.0e38f;
+  int prev_i = -1;
+  for (int round = 0; round < k; ++round) {
+    float bv = -1.0f;
+    int bi = 0x7fffffff;
+    for (int g = lane; g < G; g += 64) {
+      const float x = row[g];
+      // candidates: strictly after (prev_v, prev_i) in (value desc, index asc) order
+      const bool after = (x < prev_v) || (x == prev_v && g > prev_i);
+      if (after && (x > bv || (x == bv && g < bi))) { bv = x; bi = g; }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      const float ov = __shfl_xor(bv, off, 64);
+      const int oi = __shfl_xor(bi, off, 64);
+      if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+    }
+    if (lane == 0) {
+      if (topk_p) { topk_p[(size_t)b * k + round] = bv; topk_idx[(size_t)b * k + round] = bi; }
+      if (round == 0 && best_idx) best_idx[b] = bi;
+      if (round == 0 && best && probs) {
+        best[2 * b] = probs[((size_t)b * G + bi) * 2];
+        best[2 * b + 1] = probs[((size_t)b * G + bi) * 2 + 1];
+      }
+    }
+    prev_v = bv;
+    prev_i = bi;
+  }
+}

@@ -1,0 +1,104 @@
+"""Corpus sharding and the one exchange step of the multi-GPU path.
+
+The reference's inference is single-process (predict_memory.py:103); each issue report is scored
+independently against a read-only anchor bank (model_memory.py:133-147) and the only cross-IR state is
+the metric accumulator (custom_metric.py:61,72).  So: one process per GPU, contiguous corpus shards (the
+reference's positives-first order is preserved inside the concatenation, reader_memory.py:150-152), no
+data-path collective, and ONE all-gather (RCCL over xGMI when the backend is "nccl") of the per-rank
+``(score fp32, label u8)`` sufficient statistics at the end, after which every rank can run
+``find_best_thres`` / ROC-AUC / AP on the concatenation (bit-identical to a single-GPU run).
+
+torch.distributed is used as plumbing only (process group + all_gather); it is imported lazily so that
+single-GPU runs never load torch.
+"""
+from __future__ import annotations
+
+import os
+from typing import Optional, Tuple
+
+import numpy as np
+
+
+def shard_range(n: int, rank: int, world: int) -> Tuple[int, int]:
+    """Contiguous shard [first, first+count) of an n-item corpus: ceil(n/world) per rank, the tail
+    ranks possibly shorter/empty."""
+    per = (n + world - 1) // world
+    first = min(n, rank * per)
+    return first, max(0, min(n, first + per) - first)
+
+
+def env_world() -> Tuple[int, int, int]:
+    return int(os.environ.get("RANK", 0)), int(os.environ.get("LOCAL_RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
+
+
+def init_process_group(backend: Optional[str] = None):
+    """Initialise torch.distributed from the torchrun environment (RANK/WORLD_SIZE/MASTER_*)."""
+    import torch.distributed as dist
+
+    if dist.is_initialized():
+        return dist
+    rank, local_rank, world = env_world()
+    if backend is None:
+        import torch
+
+        backend = "nccl" if torch.cuda.is_available() else "gloo"
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29531")
+    if backend == "nccl":
+        import torch
+
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend, rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    else:
+        dist.init_process_group(backend, rank=rank, world_size=world)
+    return dist
+
+
+def all_gather_stats(scores: np.ndarray, labels: np.ndarray, device=None) -> Tuple[np.ndarray, np.ndarray]:
+    """All-gather the per-rank ``(score, label)`` arrays; returns the rank-ordered concatenation, trimmed
+    to the true per-rank counts.  One collective on a padded ``[n_max, 2]`` fp32 block per rank (labels
+    ride along as 0.0/1.0) plus a tiny count gather."""
+    import torch
+    import torch.distributed as dist
+
+    scores = np.ascontiguousarray(scores, np.float32)
+    labels = np.ascontiguousarray(labels, np.uint8)
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return scores.copy(), labels.copy()
+    world = dist.get_world_size()
+    if device is None:
+        device = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
+    n = torch.tensor([scores.shape[0]], dtype=torch.int64, device=device)
+    counts = [torch.zeros_like(n) for _ in range(world)]
+    dist.all_gather(counts, n)
+    counts = [int(c.item()) for c in counts]
+    n_max = max(max(counts), 1)
+    block = torch.zeros((n_max, 2), dtype=torch.float32)
+    block[: scores.shape[0], 0] = torch.from_numpy(scores)
+    block[: scores.shape[0], 1] = torch.from_numpy(labels.astype(np.float32))
+    block = block.to(device)
+    out = torch.empty((world, n_max, 2), dtype=torch.float32, device=device)
+    dist.all_gather_into_tensor(out, block)
+    out = out.cpu().numpy()
+    s = np.concatenate([out[r, : counts[r], 0] for r in range(world)])
+    l = np.concatenate([out[r, : counts[r], 1] for r in range(world)]).astype(np.uint8)
+    return s, l
+
+
+def barrier():
+    import torch.distributed as dist
+
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        dist.barrier()
+
+
+def all_reduce_max(x: float) -> float:
+    import torch
+    import torch.distributed as dist
+
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return x
+    dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
+    t = torch.tensor([x], dtype=torch.float64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())

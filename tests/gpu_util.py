@@ -1,0 +1,47 @@
+"""Helpers shared by the GPU parity tests (the HIP path is reached only through the C-ABI binding)."""
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+
+from memvul_amd import synth  # noqa: E402
+from memvul_amd.binding import Engine  # noqa: E402
+
+DIAG_DIR = os.path.join(ROOT, "gpurun_out")
+_engines = {}
+_weights = {}
+
+
+def record(name, **kv):
+    """Append a diagnostics record (max errors, timings) to gpurun_out/diag.jsonl so one GPU call yields
+    numbers even for passing tests."""
+    os.makedirs(DIAG_DIR, exist_ok=True)
+    with open(os.path.join(DIAG_DIR, "diag.jsonl"), "a") as f:
+        f.write(json.dumps({"name": name, **{k: (float(v) if isinstance(v, (np.floating, float)) else v) for k, v in kv.items()}}) + "\n")
+
+
+def weights_for(dims_kw: dict, w_kw: dict):
+    key = (tuple(sorted(dims_kw.items())), tuple(sorted(w_kw.items())))
+    if key not in _weights:
+        dims = synth.BertDims(**dims_kw)
+        _weights[key] = (dims, synth.make_weights(dims, **w_kw))
+    return _weights[key]
+
+
+def engine_for(dims_kw: dict, w_kw: dict, **eng_kw) -> Engine:
+    key = (tuple(sorted(dims_kw.items())), tuple(sorted(w_kw.items())), tuple(sorted(eng_kw.items())))
+    if key not in _engines:
+        if len(_engines) >= 2:  # keep HBM use bounded: drop the oldest engine
+            k0 = next(iter(_engines))
+            _engines.pop(k0).close()
+        dims, w = weights_for(dims_kw, w_kw)
+        kw = dict(max_tokens=16384, max_batch=64, max_anchors=64)
+        kw.update(eng_kw)
+        e = Engine(0, vocab_size=dims.vocab_size, layers=dims.layers, max_pos=dims.max_pos, **kw)
+        e.load_state_dict(w)
+        _engines[key] = e
+    return _engines[key]

@@ -1,0 +1,114 @@
+"""Per-kernel parity of the HIP path against the oracle's intermediate tensors (all through the C ABI)."""
+import numpy as np
+import pytest
+
+from memvul_amd import synth
+from oracle import memvul_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+L2 = dict(layers=2, vocab_size=2048)
+WK = dict(qk_scale=4.0)
+
+
+@pytest.fixture(scope="module")
+def gu():
+    import gpu_util
+    return gpu_util
+
+
+@pytest.mark.parametrize("variant", [0, 1])
+@pytest.mark.parametrize("shape", [(128, 128, 64), (256, 384, 768), (384, 256, 3072)])
+def test_gemm_variants(gu, variant, shape):
+    M, N, K = shape
+    rng = np.random.default_rng(M + N + K)
+    A = rng.standard_normal((M, K)).astype(np.float16)
+    W = (rng.standard_normal((N, K)) * 0.05).astype(np.float16)
+    bias = rng.standard_normal(N).astype(np.float32)
+    eng = gu.engine_for(L2, WK)
+    out, ms = eng.test_gemm(A, W, bias, variant=variant, iters=1)
+    ref = A.astype(np.float32) @ W.astype(np.float32).T + bias
+    err = float(np.abs(out - ref).max())
+    gu.record("gemm", variant=variant, M=M, N=N, K=K, max_err=err)
+    assert err < 2e-4 * np.sqrt(K / 64.0), f"gemm variant {variant} {shape}: max err {err}"
+
+
+def _taps(gu, B, S, ragged):
+    dims, w = gu.weights_for(L2, WK)
+    ids, lens = synth.make_ids(B, S, dims.vocab_size, ragged=ragged)
+    taps = {}
+    mask = synth.mask_from_lens(lens, S)
+    u = orc.instance_forward(w, ids.astype(np.int64), mask, taps=taps)
+    return dims, w, ids, lens, mask, taps, u
+
+
+@pytest.mark.parametrize("B,S,ragged", [(3, 64, False), (2, 128, True), (2, 100, True)])
+def test_embeddings_layernorm(gu, B, S, ragged):
+    dims, w, ids, lens, mask, taps, _ = _taps(gu, B, S, ragged)
+    eng = gu.engine_for(L2, WK)
+    eng.debug_encode(ids, lens, 0)
+    x = eng.debug_read(0)[:, :S]
+    err = float(np.abs(x - taps["embed"]).max())
+    gu.record("embed_ln", B=B, S=S, max_err=err)
+    assert err < 2e-5
+    x16 = eng.debug_read(1)[:, :S].astype(np.float32)
+    assert np.abs(x16 - taps["embed"]).max() < 4e-3
+
+
+@pytest.mark.parametrize("B,S,ragged", [(2, 64, False), (3, 128, True), (2, 256, True), (1, 320, True), (2, 100, True)])
+def test_layer0_stages(gu, B, S, ragged):
+    """QKV projection, attention, FFN and both LayerNorms of encoder layer 0 against the oracle taps.
+    Tolerances are fp16-operand level (inputs rounded to fp16, fp32 accumulation)."""
+    dims, w, ids, lens, mask, taps, _ = _taps(gu, B, S, ragged)
+    eng = gu.engine_for(L2, WK)
+    eng.debug_encode(ids, lens, 1)
+    q = eng.debug_read(2)[:, :, :S].astype(np.float32) * 8.0  # engine folds 1/sqrt(64) into W_q
+    k = eng.debug_read(3)[:, :, :S].astype(np.float32)
+    vt = eng.debug_read(4)[:, :, :, :S].astype(np.float32)
+    ctx = eng.debug_read(5)[:, :S].astype(np.float32)
+    h16 = eng.debug_read(6)[:, :S].astype(np.float32)
+    x = eng.debug_read(0)[:, :S]
+    m = mask  # compare real tokens only (padded query rows are never consumed)
+    errs = dict(
+        q=np.abs(q - taps["l0_q"])[np.broadcast_to(m[:, None, :, None], q.shape)].max(),
+        k=np.abs(k - taps["l0_k"])[np.broadcast_to(m[:, None, :, None], k.shape)].max(),
+        v=np.abs(vt.transpose(0, 1, 3, 2) - taps["l0_v"])[np.broadcast_to(m[:, None, :, None], k.shape)].max(),
+        ctx=np.abs(ctx - taps["l0_ctx"])[m].max(),
+        gelu=np.abs(h16 - taps["l0_gelu"])[m].max(),
+        layer0=np.abs(x - taps["layer0"])[m].max(),
+    )
+    gu.record("layer0", B=B, S=S, **{k_: float(v_) for k_, v_ in errs.items()})
+    scale_q = float(np.abs(taps["l0_q"]).max())
+    assert errs["q"] < 3e-3 * max(1.0, scale_q), errs
+    assert errs["k"] < 3e-3 * max(1.0, float(np.abs(taps["l0_k"]).max())), errs
+    assert errs["v"] < 3e-3, errs
+    assert errs["ctx"] < 4e-3, errs
+    assert errs["gelu"] < 4e-3, errs
+    assert errs["layer0"] < 1e-2, errs
+
+
+def test_match_and_topk_vs_oracle(gu):
+    rng = np.random.default_rng(5)
+    dims, w = gu.weights_for(L2, WK)
+    eng = gu.engine_for(L2, WK)
+    for B, G in [(1, 1), (5, 7), (37, 124), (64, 64)]:
+        u = np.maximum(rng.standard_normal((B, 512)), 0).astype(np.float32)
+        v = np.maximum(rng.standard_normal((G, 512)), 0).astype(np.float32)
+        if G > 3:
+            v[3] = v[1]  # exact tie between anchors 1 and 3: the lower index must win
+        eng.anchor_set(v)
+        out = eng.match(u)
+        logits, p, best, idx = orc.match(u, v, w[synth.KEY_MATCH_W], same_idx=0)
+        e = float(np.abs(out["logits"] - logits).max())
+        gu.record("match", B=B, G=G, max_err=e)
+        assert e < 2e-5
+        assert np.abs(out["probs"] - p).max() < 1e-5
+        # GPU-side consistency (bit-exact): best is the row of probs at best_idx, best_idx the first arg-max
+        ps = out["probs"][:, :, 0]
+        assert np.array_equal(out["best_idx"], np.argmax(ps, axis=1).astype(np.int32))
+        assert np.array_equal(out["best"], out["probs"][np.arange(B), out["best_idx"]])
+        k = min(5, G)
+        tp, ti = eng.topk(u, k)
+        rp, ri = orc.topk_match(ps, k)
+        assert np.array_equal(ti, ri.astype(np.int32)) and np.array_equal(tp, rp)
+    eng.anchor_reset()

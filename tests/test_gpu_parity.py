@@ -1,0 +1,110 @@
+"""End-to-end parity of the HIP path (C ABI) with the committed golden vectors and the oracle, plus
+size-independent properties at BASELINE.json's full batch size."""
+import os
+
+import numpy as np
+import pytest
+
+from memvul_amd import synth
+from oracle import memvul_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+LOGIT_TOL = 1e-3  # north_star: logits within 1e-3 of the CPU reference
+
+
+@pytest.fixture(scope="module")
+def gu():
+    import gpu_util
+    return gpu_util
+
+
+@pytest.mark.parametrize("name", ["l2_peaky_full", "l2_ragged", "l12_base_ragged", "l12_base_s256"])
+def test_golden_logits(gu, golden_dir, name):
+    import make_golden
+    g = np.load(os.path.join(golden_dir, f"{name}.npz"))
+    dk, wk, B, S, ragged, G, SA = make_golden.CASES[name]
+    eng = gu.engine_for(dk, wk)
+    eng.anchor_reset()
+    LA = int(g["anchor_lens"].max())
+    eng.anchor_append(g["anchor_ids"][:, :LA], g["anchor_lens"])  # one chunk padded to its longest (predict_memory.py:81)
+    v = eng.anchor_get()
+    out = eng.forward(g["ids"], g["lens"], want_embed=True)
+    errs = dict(
+        v=float(np.abs(v - g["v"]).max()), u=float(np.abs(out["embed"] - g["u"]).max()),
+        logits=float(np.abs(out["logits"] - g["logits"]).max()), p=float(np.abs(out["probs"] - g["p"]).max()),
+        logit_scale=float(np.abs(g["logits"]).max()),
+    )
+    gu.record("golden", case=name, **errs)
+    assert errs["logits"] <= LOGIT_TOL, errs
+    assert errs["p"] <= LOGIT_TOL, errs
+    # decisions: best-anchor index agrees wherever the reference's top-2 margin exceeds the tolerance
+    ps = g["p"][:, :, 0]
+    srt = np.sort(ps, axis=1)
+    clear = (srt[:, -1] - srt[:, -2]) > 2 * LOGIT_TOL if ps.shape[1] > 1 else np.ones(len(ps), bool)
+    assert np.array_equal(out["best_idx"][clear], g["idx"][clear].astype(np.int32))
+    assert np.abs(out["best"] - g["best"])[clear].max() <= LOGIT_TOL if clear.any() else True
+    eng.anchor_reset()
+
+
+def test_anchor_chunking_and_padding_invariance(gu):
+    """Anchors appended in two chunks (128 + rest in the reference, predict_memory.py:81-83) equal one
+    append; extra zero padding columns do not change an embedding (masked keys)."""
+    dk, wk = dict(layers=2, vocab_size=2048), dict(qk_scale=3.0)
+    dims, w = gu.weights_for(dk, wk)
+    eng = gu.engine_for(dk, wk)
+    ids, lens = synth.make_ids(9, 96, dims.vocab_size, ragged=True, min_len=5)
+    eng.anchor_reset(); eng.anchor_append(ids, lens); v1 = eng.anchor_get()
+    eng.anchor_reset(); eng.anchor_append(ids[:4], lens[:4]); eng.anchor_append(ids[4:], lens[4:]); v2 = eng.anchor_get()
+    assert np.array_equal(v1, v2)
+    wide = np.zeros((9, 128), np.int32); wide[:, :96] = ids
+    u_wide = eng.encode(wide, lens)
+    assert np.array_equal(u_wide, v1)  # 96 -> Sp 128 either way: bit-identical
+    short_rows = lens <= 64
+    if short_rows.any():
+        u_short = eng.encode(ids[short_rows][:, :64], lens[short_rows])
+        assert np.abs(u_short - v1[short_rows]).max() < 5e-4  # different Sp: same maths, different tiling
+    ref = orc.build_anchor_bank(w, [ids[i, : lens[i]].astype(np.int64) for i in range(9)])
+    e = float(np.abs(v1 - ref).max())
+    gu.record("anchor_bank", max_err=e)
+    assert e < 2e-3
+    eng.anchor_reset()
+
+
+def test_full_batch_properties(gu):
+    """BASELINE.json configs[1] shape (B=256, S=256, G=124) on the 12-layer model: properties that need
+    no CPU reference at this size, plus agreement of the resident-corpus path with mv_forward and an
+    oracle spot-check of a few rows."""
+    dk, wk = dict(layers=12), dict()
+    dims, w = gu.weights_for(dk, wk)
+    eng = gu.engine_for(dk, wk, max_tokens=65536, max_batch=256, max_anchors=128)
+    B, S, G = 256, 256, 124
+    ids, lens = synth.make_ids(B, S, dims.vocab_size, ragged=False)
+    aids, alens = synth.make_ids(G, 64, dims.vocab_size, seed=synth.SEED + 1, ragged=True, min_len=8)
+    eng.anchor_reset(); eng.anchor_append(aids, alens)
+    out = eng.forward(ids, lens, want_embed=True)
+    p = out["probs"]
+    assert np.isfinite(out["logits"]).all() and np.isfinite(p).all()
+    assert np.abs(p.sum(-1) - 1.0).max() < 1e-6
+    assert np.array_equal(out["best_idx"], np.argmax(p[:, :, 0], axis=1).astype(np.int32))
+    # batch-composition independence: a permuted batch gives the permuted results bit-for-bit
+    perm = np.random.default_rng(1).permutation(B)
+    out2 = eng.forward(ids[perm], lens[perm], want_embed=True)
+    assert np.array_equal(out2["embed"], out["embed"][perm])
+    assert np.array_equal(out2["logits"], out["logits"][perm])
+    # resident-corpus path == host path (bit-exact), in two batches of 128
+    eng.corpus_upload(ids, lens)
+    eng.corpus_run(0, B, 128, keep_probs=True)
+    best, idx, ps = eng.corpus_results(0, B, with_probs=True)
+    out128 = eng.forward(ids[:128], lens[:128])
+    assert np.array_equal(ps[:128], out128["probs"][:, :, 0])
+    assert np.array_equal(idx[:128], out128["best_idx"]) and np.array_equal(best[:128], out128["best"])
+    # oracle spot-check: 2 rows of the full-size batch
+    v = eng.anchor_get()
+    rows = [0, 255]
+    u_ref = orc.instance_forward(w, ids[rows].astype(np.int64), np.ones((2, S), bool))
+    lg, pp, bb, ii = orc.match(u_ref, v, w[synth.KEY_MATCH_W])
+    e = float(np.abs(out["logits"][rows] - lg).max())
+    gu.record("full_batch", logits_err=e, u_err=float(np.abs(out["embed"][rows] - u_ref).max()))
+    assert e <= LOGIT_TOL
+    eng.anchor_reset()
