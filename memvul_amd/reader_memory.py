@@ -1,0 +1,148 @@
+"""``reader_memory`` — the DatasetReader of the hot path (reference: MemVul/reader_memory.py:35-245).
+
+Kept from the reference, by line:
+  * constructor arguments and defaults (l.38-45); ``sample_neg is None`` -> the "golden anchors only"
+    reader of ``custom_validation`` / ``validation_dataset_reader`` which never opens CVE_dict.json
+    (l.58-60); otherwise ``CVE_dict.json`` and the anchor file are loaded (l.62-68);
+  * ``read_dataset``: golden files are ``{cwe_id: description}`` (l.73-79); issue files are a list of
+    records tokenised as ``"{Issue_Title}. {Issue_Body}"`` (l.88), labelled pos/neg from
+    ``str(s[target]) == "1"`` (l.91), positives keyed by the CWE id of their CVE (l.93-108) and dropped when
+    that id is ``None`` (l.103-105); parsed files are cached per path (l.81-82,111);
+  * ``_read``: branch by path substring — ``"golden_"`` (l.138), ``"test_"`` -> type "unlabel" (l.146),
+    ``"validation_"`` -> type "test" (l.155); test/validation instances are emitted in REVERSED
+    concatenation order, i.e. positives first (l.150-152);
+  * ``text_to_instance`` for golden / test / unlabel (l.195-246): fields ``sample1``, ``label`` (same/diff)
+    and ``metadata = {"type", "instance": [{"label", "Issue_Url"}]}``.
+Out of scope: the online pair-sampling training branch (l.164-192, 205-229).
+The CVE-description normalisation (``replace_tokens_simple``, l.96-99) only feeds training pairs and is
+skipped: at test time a positive needs nothing but its CVE's ``CWE_ID``.
+"""
+from __future__ import annotations
+
+import json
+import logging
+import os
+from typing import Dict, Optional
+
+from .data import Instance, LabelField, MetadataField, TextField
+from .registry import DatasetReader, TokenIndexer, Tokenizer
+from . import tokenizer as _tok  # noqa: F401  (registers "pretrained_transformer")
+
+logger = logging.getLogger(__name__)
+
+# The reference hard-codes ``data_path = "xxx"`` (l.62); here it is an environment/module setting.
+DATA_PATH = os.environ.get("MEMVUL_DATA_PATH", "")
+
+
+@DatasetReader.register("reader_memory")
+class ReaderMemory(DatasetReader):
+    def __init__(self,
+                 tokenizer: Tokenizer = None,
+                 same_diff_ratio: Dict[str, int] = None,
+                 target: str = "Security_Issue_Full",
+                 anchor_path: str = "CWE_anchor_golden_project.json",
+                 sample_neg: float = None,
+                 train_iter: int = None,
+                 token_indexers: Dict[str, TokenIndexer] = None) -> None:
+        super().__init__()
+        self._token_indexers = token_indexers
+        self._tokenizer = tokenizer
+        self._same_diff_ratio = same_diff_ratio or {"diff": 6, "same": 2}
+        self._choice_neg = [True, False]
+        select_neg = sample_neg or 0.1
+        self._train_iter = train_iter or 1
+        self._select_neg = [select_neg, 1 - select_neg]
+        self._target = target
+        self._dataset = dict()
+        self._cve_info = None
+        self._anchor = None
+        if sample_neg is None:
+            return
+        cve_path = os.path.join(DATA_PATH, "CVE_dict.json") if DATA_PATH else "CVE_dict.json"
+        if os.path.exists(cve_path):
+            with open(cve_path, "r") as f:
+                self._cve_info = json.load(f)
+        if os.path.exists(anchor_path):
+            with open(anchor_path, "r") as f:
+                self._anchor = json.load(f)
+            for k, v in self._anchor.items():
+                self._anchor[k] = self._tokenizer.tokenize(v)
+
+    def read_dataset(self, file_path):
+        if "golden" in file_path:
+            dataset = dict()
+            with open(file_path, "r", encoding="utf-8") as f:
+                anchors = json.load(f)
+            for cwe_id, description in anchors.items():
+                dataset[cwe_id] = [{self._target: cwe_id, "description": self._tokenizer.tokenize(description)}]
+            return dataset
+
+        if self._dataset.get(file_path):
+            return self._dataset[file_path]
+
+        with open(file_path, "r", encoding="utf-8") as f:
+            samples = json.load(f)
+        dataset = {"neg": list()}
+        for s in samples:
+            s["description"] = self._tokenizer.tokenize(f"{s['Issue_Title']}. {s['Issue_Body']}")
+            label = "pos" if str(s[self._target]) == "1" else "neg"
+            s[self._target] = label
+            if label == "pos":
+                if "CWE_ID" not in s or self._cve_info is not None:
+                    if self._cve_info is None:
+                        raise FileNotFoundError("CVE_dict.json is needed to map a positive issue report to its CWE id "
+                                                "(reader_memory.py:62-64); set MEMVUL_DATA_PATH")
+                    s["CWE_ID"] = self._cve_info[s["CVE_ID"]]["CWE_ID"]
+                label = s["CWE_ID"]
+                if label is None:
+                    continue  # "2 dirty data" (l.103-105)
+                if label not in dataset:
+                    dataset[label] = list()
+            dataset[label].append(s)
+        self._dataset[file_path] = dataset
+        return dataset
+
+    def _read(self, file_path):
+        dataset = self.read_dataset(file_path)
+        all_data = list()
+        for ll in list(dataset.values()):
+            all_data.extend(ll)
+        dist = {"pos": sum(len(v) for k, v in dataset.items() if k != "neg"), "neg": len(dataset["neg"]) if "neg" in dataset else None}
+        logger.info(dist)
+
+        if "golden_" in file_path:
+            logger.info("Begin loading golden instances------")
+            for sample in all_data:
+                yield self.text_to_instance((sample, sample), type_="golden")
+            logger.info(f"Num of golden instances is {len(all_data)}")
+        elif "test_" in file_path:
+            logger.info("Begin predict------")
+            for sample in reversed(all_data):  # positives first, then the negatives
+                yield self.text_to_instance((sample, sample), type_="unlabel")
+            logger.info(f"Predict sample num is {len(all_data)}")
+        elif "validation_" in file_path:
+            logger.info("Begin testing------")
+            for sample in reversed(all_data):
+                yield self.text_to_instance((sample, sample), type_="test")
+            logger.info(f"Test sample num is {len(all_data)}")
+        else:
+            raise NotImplementedError(
+                "the online pair-sampling training branch (reader_memory.py:164-192) is outside the inference hot "
+                "path; file names select the branch by substring: 'golden_', 'test_', 'validation_'")
+
+    def text_to_instance(self, p, type_="train") -> Instance:
+        fields = dict()
+        ins1, ins2 = p
+        fields["sample1"] = TextField(ins1["description"], self._token_indexers)
+        if type_ == "train":
+            raise NotImplementedError("training pairs (reader_memory.py:205-229) are outside the inference hot path")
+        if type_ in ["test", "unlabel"]:
+            # pos == same (only CIRs make matched pairs), neg == diff
+            fields["label"] = LabelField("same" if ins1[self._target] == "pos" else "diff")
+        meta_ins1 = {"label": ins1[self._target]}
+        if type_ in ["test", "unlabel"]:
+            if ins1[self._target] == "pos":
+                meta_ins1["label"] = ins1["CWE_ID"]
+            meta_ins1["Issue_Url"] = ins1["Issue_Url"]
+        fields["metadata"] = MetadataField({"type": type_, "instance": [meta_ins1]})
+        return Instance(fields)

@@ -70,13 +70,19 @@ except Exception:
             elif cls in Registrable._registry and cls.default_implementation:
                 sub = cls.by_name(cls.default_implementation)
             sig = inspect.signature(sub.__init__)
+            try:  # resolve string annotations (`from __future__ import annotations`)
+                import typing
+
+                hints = typing.get_type_hints(sub.__init__)
+            except Exception:
+                hints = {}
             kwargs: Dict[str, Any] = {}
             accepts_kwargs = any(p.kind == p.VAR_KEYWORD for p in sig.parameters.values())
             for pname, p in sig.parameters.items():
                 if pname == "self" or p.kind in (p.VAR_KEYWORD, p.VAR_POSITIONAL):
                     continue
                 if pname in params:
-                    kwargs[pname] = _construct(p.annotation, params.pop(pname), extras)
+                    kwargs[pname] = _construct(hints.get(pname, p.annotation), params.pop(pname), extras)
                 elif pname in extras:
                     kwargs[pname] = extras[pname]
             if params and not accepts_kwargs:

@@ -1,0 +1,80 @@
+"""``pretrained_transformer`` tokenizer / indexer stand-ins (AllenNLP names used by the reference
+configs: test_config_memory.json:5-16, config_memory.json:15-27).
+
+Behaviour kept from AllenNLP's ``PretrainedTransformerTokenizer``: lower-cased WordPiece of
+``bert-base-uncased`` with ``[CLS] ... [SEP]`` added and truncation to ``max_length`` INCLUDING the two
+special tokens (256 for issue reports, 512 for anchors).  The real WordPiece vocabulary is used when a
+``vocab.txt`` is reachable (``model_name`` is a directory holding one, or ``$MEMVUL_BERT_VOCAB``); it is
+not on disk in this image and there is no network, so otherwise a deterministic hashing word tokenizer
+with the same id range / special ids is used — enough for plumbing and throughput runs on synthetic
+text, not for real accuracy numbers.
+"""
+from __future__ import annotations
+
+import os
+import re
+import zlib
+from typing import Dict, List, Optional
+
+from .data import Token
+from .registry import Tokenizer, TokenIndexer
+
+CLS_ID, SEP_ID, PAD_ID, UNK_ID = 101, 102, 0, 100
+_WORD_RE = re.compile(r"[a-z0-9]+|[^\sa-z0-9]")
+
+
+def _find_vocab(model_name: str) -> Optional[str]:
+    cands = [os.environ.get("MEMVUL_BERT_VOCAB")]
+    if model_name and os.path.isdir(model_name):
+        cands.append(os.path.join(model_name, "vocab.txt"))
+    for c in cands:
+        if c and os.path.isfile(c):
+            return c
+    return None
+
+
+@Tokenizer.register("pretrained_transformer")
+class PretrainedTransformerTokenizer(Tokenizer):
+    def __init__(self, model_name: str = "bert-base-uncased", add_special_tokens: bool = True, max_length: Optional[int] = None,
+                 tokenizer_kwargs: Optional[Dict] = None, vocab_size: int = 30522) -> None:
+        self.model_name, self._add_special, self._max_length = model_name, add_special_tokens, max_length
+        self.vocab_size = vocab_size
+        self._hf = None
+        vocab = _find_vocab(model_name)
+        if vocab is not None:
+            from transformers import BertTokenizerFast
+
+            self._hf = BertTokenizerFast(vocab_file=vocab, do_lower_case=True, **(tokenizer_kwargs or {}))
+            self.vocab_size = self._hf.vocab_size
+
+    def _hash_ids(self, text: str) -> List[int]:
+        lo = 1000 if self.vocab_size > 2000 else 3
+        return [lo + zlib.crc32(w.encode("utf-8")) % (self.vocab_size - lo) for w in _WORD_RE.findall(text.lower())]
+
+    def tokenize(self, text: str) -> List[Token]:
+        if self._hf is not None:
+            enc = self._hf(text, add_special_tokens=self._add_special, truncation=self._max_length is not None,
+                           max_length=self._max_length, return_attention_mask=False, return_token_type_ids=False)
+            ids = enc["input_ids"]
+            texts = self._hf.convert_ids_to_tokens(ids)
+            return [Token(t, i, 0) for t, i in zip(texts, ids)]
+        ids = self._hash_ids(text)
+        if self._add_special:
+            if self._max_length is not None:
+                ids = ids[: max(0, self._max_length - 2)]
+            ids = [CLS_ID] + ids + [SEP_ID]
+        elif self._max_length is not None:
+            ids = ids[: self._max_length]
+        return [Token(str(i), i, 0) for i in ids]
+
+
+@TokenIndexer.register("pretrained_transformer")
+class PretrainedTransformerIndexer(TokenIndexer):
+    """Tokens already carry their wordpiece ids; indexing is the identity (``namespace`` is only where
+    AllenNLP would mirror the HF vocabulary)."""
+
+    def __init__(self, model_name: str = "bert-base-uncased", namespace: str = "tags", max_length: Optional[int] = None, **_kw) -> None:
+        self.model_name, self._namespace, self._max_length = model_name, namespace, max_length
+
+    def tokens_to_indices(self, tokens: List[Token], vocabulary=None) -> Dict[str, List]:
+        return {"token_ids": [t.text_id for t in tokens], "mask": [True] * len(tokens), "type_ids": [t.type_id or 0 for t in tokens]}

@@ -1,0 +1,136 @@
+"""Host-side logic of the drop-in boundary (CPU only): metrics vs the scalar oracle, reader branches and
+emission order, config parsing of the reference's own files, registry construction."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from memvul_amd import custom_metric as cm
+from memvul_amd import params
+from memvul_amd.data import DataLoader, collate
+from memvul_amd.predict_memory import measure_arrays, model_measure
+from memvul_amd.reader_memory import ReaderMemory
+from memvul_amd.registry import DatasetReader, Vocabulary
+from memvul_amd.tokenizer import PretrainedTransformerIndexer, PretrainedTransformerTokenizer
+from oracle import stats_oracle as so
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.parametrize("seed,n,pos", [(0, 300, 0.3), (1, 1000, 0.01), (2, 64, 0.5)])
+def test_find_best_thres_matches_reference_loops(seed, n, pos):
+    rng = np.random.default_rng(seed)
+    y = (rng.random(n) < pos).astype(int)
+    y[0] = 1; y[1] = 0
+    s = np.clip(rng.normal(0.55 + 0.15 * y, 0.15), 0, 1).astype(np.float32)
+    s[5] = np.float32(0.6)  # a score exactly on a nominal threshold value
+    ref = so.find_best_thres(list(y), [float(v) for v in s])
+    got = cm.find_best_thres(y, s)
+    assert got == ref  # counts, precision/recall/f1 and the chosen threshold (float arange value) identical
+    full_ref = so.siamese_get_metric(list(y), [float(v) for v in s])
+    full = cm.siamese_metrics(y, s)
+    for k in full_ref:
+        assert full[k] == pytest.approx(full_ref[k], rel=0, abs=1e-12), k
+
+
+def test_find_best_thres_all_zero_f1_picks_last_threshold():
+    y = np.array([0, 0, 1, 1]); s = np.array([0.9, 0.95, 0.1, 0.2], np.float32)
+    ref = so.find_best_thres(list(y), [float(v) for v in s]); got = cm.find_best_thres(y, s)
+    assert got == ref and got["f1"] >= 0
+
+
+def test_threshold_table_is_additive_over_shards():
+    rng = np.random.default_rng(3)
+    y = (rng.random(500) < 0.2).astype(int); s = rng.random(500).astype(np.float32)
+    whole = cm.threshold_confusion_table(y, s)
+    parts = sum(cm.threshold_confusion_table(y[a:b], s[a:b]) for a, b in [(0, 100), (100, 333), (333, 500)])
+    assert np.array_equal(whole, parts)
+    assert cm.best_from_table(parts) == cm.find_best_thres(y, s)
+
+
+def test_cal_f1_and_model_measure_match_reference():
+    rng = np.random.default_rng(4)
+    y = (rng.random(200) < 0.3).astype(int); pred = (rng.random(200) < 0.4).astype(int); sc = rng.random(200)
+    assert cm.cal_f1(y, pred) == so.cal_f1(list(y), list(pred))
+    got, _, _ = model_measure(y, pred, sc)
+    ref = so.model_measure(list(y), list(pred), list(sc))
+    assert got == ref
+    m = measure_arrays(sc, y, thres=0.5)
+    assert m["TP"] == int(np.sum((sc >= 0.5) & (y == 1)))
+
+
+def test_siamese_measure_accumulates_like_reference():
+    m = cm.SiameseMeasureV1(same_idx=0)
+    probs = np.array([[0.7, 0.3], [0.2, 0.8], [0.55, 0.45]], np.float32)
+    meta = [{"instance": [{"label": "CWE-79"}]}, {"instance": [{"label": "neg"}]}, {"instance": [{"label": "neg"}]}]
+    m(probs, meta); m(probs[:1], meta[:1])
+    lab, sc = m.arrays()
+    assert lab.tolist() == [1, 0, 0, 1] and np.allclose(sc, [0.7, 0.2, 0.55, 0.7])
+    assert m.get_metric(reset=False)["f1"] == 0  # only computed when the whole evaluation is done (l.84)
+    out = m.get_metric(reset=True)
+    assert out == {**so.siamese_get_metric([1, 0, 0, 1], [float(np.float32(v)) for v in [0.7, 0.2, 0.55, 0.7]])}
+    assert m.arrays()[0].size == 0
+
+
+def test_reference_configs_parse_unchanged():
+    ref = "/root/reference"
+    if not os.path.isdir(ref):
+        pytest.skip("reference tree not mounted (GPU box)")
+    c = params.load_config(os.path.join(ref, "MemVul", "config_memory.json"))
+    t = params.load_config(os.path.join(ref, "test_config_memory.json"))
+    merged = params.with_overrides(c, t)
+    assert merged["model"]["type"] == "model_memory" and merged["model"]["text_field_embedder"]["token_embedders"]["tokens"]["type"] == "custom_pretrained_transformer"
+    assert merged["dataset_reader"]["tokenizer"]["max_length"] == 256
+    assert merged["validation_dataset_reader"]["tokenizer"]["max_length"] == 512
+    assert merged["validation_data_loader"] == {"batch_size": 512, "shuffle": False}
+    r = DatasetReader.from_params(merged["validation_dataset_reader"])
+    assert isinstance(r, ReaderMemory) and r._tokenizer._max_length == 512
+
+
+def test_jsonnet_subset():
+    txt = 'local a = "x";\nlocal n = 3;\n{ "k": a, "v": [n, 2,], "s": "a stays a", // c\n }'
+    assert params.parse_jsonnet_subset(txt) == {"k": "x", "v": [3, 2], "s": "a stays a"}
+
+
+def _reader(max_length=32):
+    tok = PretrainedTransformerTokenizer("bert-base-uncased", add_special_tokens=True, max_length=max_length)
+    return ReaderMemory(tokenizer=tok, token_indexers={"tokens": PretrainedTransformerIndexer("bert-base-uncased", namespace="tags")})
+
+
+def test_reader_branches_and_order():
+    import pathlib
+    import tempfile
+
+    # NOT pytest's tmp_path: its name contains "test_", and the reader dispatches on path substrings
+    # (reader_memory.py:138,146,155 — "path may accidentally contain the keywords")
+    tmp_path = pathlib.Path(tempfile.mkdtemp(prefix="mvreader"))
+    golden = tmp_path / "CWE_anchor_golden_project.json"
+    golden.write_text(json.dumps({"CWE-79": "cross site scripting in web pages", "CWE-89": "sql injection " * 40}))
+    r = _reader(max_length=16)
+    g = list(r.read(str(golden)))
+    assert [i["metadata"].metadata["instance"][0]["label"] for i in g] == ["CWE-79", "CWE-89"]
+    assert all(i["metadata"].metadata["type"] == "golden" and "label" not in i.fields for i in g)
+    assert len(g[1]["sample1"]) == 16 and g[1]["sample1"].tokens[0].text_id == 101 and g[1]["sample1"].tokens[-1].text_id == 102
+
+    recs = [{"Issue_Title": f"t{i}", "Issue_Body": f"body {i}", "Security_Issue_Full": "1" if i in (1, 3) else "0",
+             "Issue_Url": f"u{i}", "CVE_ID": f"CVE-{i}", "CWE_ID": "CWE-79" if i == 1 else "CWE-89"} for i in range(5)]
+    for name, typ in (("test_project.json", "unlabel"), ("validation_project.json", "test")):
+        p = tmp_path / name
+        p.write_text(json.dumps(recs))
+        ins = list(r.read(str(p)))
+        urls = [i["metadata"].metadata["instance"][0]["Issue_Url"] for i in ins]
+        assert urls == ["u3", "u1", "u4", "u2", "u0"]  # reversed concatenation: positives first (l.150-152)
+        assert [i["label"].label for i in ins] == ["same", "same", "diff", "diff", "diff"]
+        assert [i["metadata"].metadata["instance"][0]["label"] for i in ins] == ["CWE-89", "CWE-79", "neg", "neg", "neg"]
+        assert all(i["metadata"].metadata["type"] == typ for i in ins)
+    with pytest.raises(NotImplementedError):
+        p = tmp_path / "train_project.json"; p.write_text(json.dumps(recs)); list(r.read(str(p)))
+
+    vocab = Vocabulary({"labels": ["same", "diff"]})
+    batch = collate(ins[:3], vocab)
+    t = batch["sample1"]["tokens"]
+    assert t["token_ids"].dtype == np.int64 and t["mask"].dtype == bool and t["token_ids"].shape == t["mask"].shape
+    assert batch["label"].tolist() == [0, 0, 1] and len(batch["metadata"]) == 3
+    dl = DataLoader(reader=r, data_path=str(tmp_path / "test_project.json"), batch_size=2); dl.index_with(vocab)
+    assert len(dl) == 3 and [len(b["metadata"]) for b in dl] == [2, 2, 1]
