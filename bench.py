@@ -169,21 +169,39 @@ def cpu_baseline(weights, dims, eng, ids, lens, S, n):
     from oracle.hf_reference import HFReference
 
     cores = os.cpu_count() or 1
-    ref = HFReference(weights, dims.as_dict(), threads=cores)
+    ref = HFReference(weights, dims.as_dict(), threads=min(cores, 32))
     v = eng.anchor_get()
-    bs = 32
-    ref.predict(ids[:4].astype(np.int64), np.ones((4, S), bool), v)  # warm-up
+    bs = 16
+    ones = np.ones((bs, S), bool)
+    # pick the intra-op thread count that is fastest on this host (all cores is often slower on a
+    # many-core box), on one small batch each; then time the sample with it
+    best_t, best_dt = None, None
+    for t in sorted({c for c in (8, 16, 32, 64, 128) if c <= cores} | {min(cores, 8)}):
+        torch.set_num_threads(t)
+        ref.predict(ids[:bs].astype(np.int64), ones, v)
+        t0 = time.perf_counter()
+        ref.predict(ids[:bs].astype(np.int64), ones, v)
+        d = time.perf_counter() - t0
+        if best_dt is None or d < best_dt:
+            best_t, best_dt = t, d
+    torch.set_num_threads(best_t)
     t0 = time.perf_counter()
     logits = []
+    done = 0
     for s0 in range(0, n, bs):
         part = ids[s0:s0 + bs].astype(np.int64)
         u, lg, p, best, idx = ref.predict(part, np.ones(part.shape, bool), v)
         logits.append(lg)
+        done += part.shape[0]
+        if time.perf_counter() - t0 > 30.0:  # bounded sample
+            break
     dt = time.perf_counter() - t0
+    n = done
+    cores_used = best_t
     logits = np.concatenate(logits)
     gpu = eng.forward(ids[:n], lens[:n])
     err = float(np.abs(gpu["logits"] - logits).max())
-    return ({"value": round(n / dt, 3), "unit": "issue-reports/s", "cores": cores, "kind": "port",
+    return ({"value": round(n / dt, 3), "unit": "issue-reports/s", "cores": cores_used, "host_cores": cores, "kind": "port",
              "sample": f"{n} synthetic IRs x {S} tokens, batch {bs}, fp32 torch-CPU ({torch.get_num_threads()} threads): HF BertModel "
                        "(eager attention) + tanh pooler + ReLU header + bias-free matcher = the reference's CPU path "
                        "(AllenNLP itself is not installable here); anchor bank taken from the GPU engine"}, err)

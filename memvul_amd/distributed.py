@@ -77,9 +77,9 @@ def all_gather_stats(scores: np.ndarray, labels: np.ndarray, device=None) -> Tup
     block[: scores.shape[0], 0] = torch.from_numpy(scores)
     block[: scores.shape[0], 1] = torch.from_numpy(labels.astype(np.float32))
     block = block.to(device)
-    out = torch.empty((world, n_max, 2), dtype=torch.float32, device=device)
+    out = torch.empty((world * n_max, 2), dtype=torch.float32, device=device)  # rank-major concatenation
     dist.all_gather_into_tensor(out, block)
-    out = out.cpu().numpy()
+    out = out.cpu().numpy().reshape(world, n_max, 2)
     s = np.concatenate([out[r, : counts[r], 0] for r in range(world)])
     l = np.concatenate([out[r, : counts[r], 1] for r in range(world)]).astype(np.uint8)
     return s, l

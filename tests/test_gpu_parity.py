@@ -108,3 +108,39 @@ def test_full_batch_properties(gu):
     gu.record("full_batch", logits_err=e, u_err=float(np.abs(out["embed"][rows] - u_ref).max()))
     assert e <= LOGIT_TOL
     eng.anchor_reset()
+
+
+def test_engine_coexists_with_torch_hip_runtime():
+    """Multi-GPU runs import torch (torch.distributed / RCCL) in the same process as libmemvul_hip.so.
+    torch bundles its own libamdhip64 (same SONAME): whichever is loaded first serves both.  Check both
+    load orders in fresh processes, plus a world-size-1 RCCL process group around an engine call."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    body = (
+        "import numpy as np\n"
+        "from memvul_amd import synth\n"
+        "from memvul_amd.binding import Engine\n"
+        "dims = synth.BertDims(layers=1, vocab_size=1024)\n"
+        "e = Engine(0, vocab_size=1024, layers=1, max_tokens=2048, max_batch=8, max_anchors=8)\n"
+        "e.load_state_dict(synth.make_weights(dims))\n"
+        "ids, lens = synth.make_ids(4, 64, 1024)\n"
+        "e.anchor_set(synth.make_anchor_bank(3))\n"
+        "o = e.forward(ids, lens)\n"
+        "assert np.isfinite(o['logits']).all()\n"
+        "print('OK', float(o['logits'][0,0,0]))\n"
+    )
+    torch_first = "import torch\ntorch.cuda.init()\nx = torch.ones(4, device='cuda') * 2\n" + body + "assert float(x.sum()) == 8.0\n"
+    engine_first = body + "import torch\nx = torch.ones(4, device='cuda') * 2\nassert float(x.sum()) == 8.0\n"
+    nccl = (
+        "import os, torch\nos.environ.update(RANK='0', LOCAL_RANK='0', WORLD_SIZE='1', MASTER_ADDR='127.0.0.1', MASTER_PORT='29577')\n"
+        "from memvul_amd import distributed as d\ndist = d.init_process_group('nccl')\n" + body +
+        "t = torch.arange(6, dtype=torch.float32, device='cuda').reshape(3, 2)\nout = torch.empty_like(t)\n"
+        "dist.all_gather_into_tensor(out, t)\nassert torch.equal(out, t)\nassert d.all_reduce_max(3.0) == 3.0\nd.barrier()\ndist.destroy_process_group()\n"
+    )
+    outs = []
+    for name, code in (("torch_first", torch_first), ("engine_first", engine_first), ("nccl_world1", nccl)):
+        r = subprocess.run([sys.executable, "-c", code], cwd=root, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0 and "OK" in r.stdout, f"{name}: {r.stderr[-1500:]}"
+        outs.append(r.stdout.strip().splitlines()[-1])
+    assert outs[0] == outs[1] == outs[2]  # same numbers whichever HIP runtime copy serves the engine
