@@ -42,5 +42,21 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
   return base + (bid >> 3);
 }
 
-// exact-erf GELU (HF "gelu", BertIntermediate)
-__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+// exact-erf GELU (HF "gelu", BertIntermediate): gelu(x) = x Phi(x) = 0.5 x (1 + erf(x / sqrt 2)).
+// erfc(z), z = |x|/sqrt 2 >= 0, by Abramowitz & Stegun 7.1.26 (|abs error| <= 1.5e-7):
+//   erfc(z) = t (a1 + t (a2 + t (a3 + t (a4 + t a5)))) exp(-z^2),  t = 1 / (1 + p z)
+// and gelu(x) = 0.5 x erfc(z) for x < 0, x - 0.5 x erfc(z) for x >= 0: no cancellation, no branches, one
+// v_rcp + one v_exp (ocml erff costs ~45 VALU with two divergent branches per element, which made the FFN-1
+// epilogue as long as its main loop).  The result is stored as fp16 (rel. step 4.9e-4), so 1.5e-7 is noise.
+__device__ __forceinline__ float gelu_erf(float x) {
+  const float z = fabsf(x) * 0.70710678118654752440f;
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
+  float poly = fmaf(t, 1.061405429f, -1.453152027f);
+  poly = fmaf(t, poly, 1.421413741f);
+  poly = fmaf(t, poly, -0.284496736f);
+  poly = fmaf(t, poly, 0.254829592f);
+  poly *= t;
+  const float e = __builtin_amdgcn_exp2f(z * z * -1.44269504088896340736f);
+  const float q = 0.5f * x * poly * e;  // 0.5 x erfc(|x|/sqrt2)
+  return x >= 0.f ? x - q : q;
+}

@@ -5,6 +5,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -140,6 +141,8 @@ struct mv_handle {
   std::vector<ProfRec> recs;
   std::vector<hipEvent_t> free_events;
 
+  int gemm_tile = 0;  // 0 auto, 128 or 256 (env MEMVUL_GEMM_TILE; both give bit-identical results)
+
   // debug
   int dbg_B = 0, dbg_Sp = 0;
 };
@@ -216,20 +219,48 @@ int launch_check(mv_handle* h, const char* what) {
   return MV_OK;
 }
 
+int choose_gn(int tn, int gn_max) {
+  int g = 1;
+  for (int d = 1; d <= gn_max && d <= tn; ++d)
+    if (tn % d == 0) g = d;
+  return g;
+}
+
 template <int EPI, bool GLDS>
-int launch_gemm128(mv_handle* h, int cls, const GemmArgs& a) {
+int launch_gemm128(mv_handle* h, int cls, GemmArgs a) {
   if (a.M % 128 || a.N % 128 || a.K % 64) return fail(h, MV_ERR_INVALID, "gemm128: M,N % 128, K % 64 required");
+  a.GN = choose_gn(a.N / 128, 8);
   const int grid = (a.M / 128) * (a.N / 128);
   ProfScope ps(h, cls);
   hipLaunchKernelGGL((gemm128_kernel<EPI, GLDS>), dim3(grid), dim3(256), G128_LDS_BYTES, h->stream, a);
   return launch_check(h, "gemm128");
 }
 
+template <int EPI>
+int launch_gemm256(mv_handle* h, int cls, GemmArgs a) {
+  if (a.M % 256 || a.N % 256 || a.K % 64) return fail(h, MV_ERR_INVALID, "gemm256: M,N % 256, K % 64 required");
+  a.GN = choose_gn(a.N / 256, 4);
+  const int grid = (a.M / 256) * (a.N / 256);
+  ProfScope ps(h, cls);
+  hipLaunchKernelGGL((gemm256_kernel<EPI>), dim3(grid), dim3(512), G256_LDS_BYTES, h->stream, a);
+  return launch_check(h, "gemm256");
+}
+
+// tile choice: the 256^2 kernel needs enough tiles to fill 256 CUs (one workgroup each)
+template <int EPI>
+int launch_gemm(mv_handle* h, int cls, const GemmArgs& a) {
+  const bool big = (a.M % 256 == 0) && (a.N % 256 == 0) && ((int64_t)(a.M / 256) * (a.N / 256) >= 256);
+  if (h->gemm_tile == 256 || (h->gemm_tile == 0 && big)) {
+    if (a.M % 256 == 0 && a.N % 256 == 0) return launch_gemm256<EPI>(h, cls, a);
+  }
+  return launch_gemm128<EPI, true>(h, cls, a);
+}
+
 // ---- encoder: ids (device) -> u (device, [B][512]); stops after n_layers (<0: all) ------------
 int encode_dev(mv_handle* h, const int32_t* d_ids, const int32_t* d_lens, int B, int S_in, int n_layers, float* u_out) {
   const mv_config& c = h->cfg;
   const int Sp = (int)round_up(S_in, 64);
-  const int64_t M = (int64_t)B * Sp, Mpad = round_up(M, 128);
+  const int64_t M = (int64_t)B * Sp, Mpad = round_up(M, 256);
   if (Sp > c.max_pos && S_in > c.max_pos) return fail(h, MV_ERR_INVALID, "sequence longer than max_pos");
   if (Mpad > h->cap_tokens) return fail(h, MV_ERR_CAPACITY, "B*S exceeds mv_config.max_tokens");
   if (n_layers < 0 || n_layers > c.layers) n_layers = c.layers;
@@ -248,7 +279,7 @@ int encode_dev(mv_handle* h, const int32_t* d_ids, const int32_t* d_lens, int B,
     // K2: QKV projection
     g.A = h->x16; g.W = w.wqkv; g.bias = w.bqkv; g.N = 3 * MV_HIDDEN; g.K = MV_HIDDEN;
     g.q = h->q; g.k = h->k; g.vt = h->vt;
-    if (int rc = launch_gemm128<EPI_QKV, true>(h, KC_GEMM_QKV, g)) return rc;
+    if (int rc = launch_gemm<EPI_QKV>(h, KC_GEMM_QKV, g)) return rc;
     // K3: attention
     {
       AttnArgs a{h->q, h->k, h->vt, d_lens, h->ctx, Sp, B};
@@ -264,7 +295,7 @@ int encode_dev(mv_handle* h, const int32_t* d_ids, const int32_t* d_lens, int B,
     }
     // K4: attention output projection + bias + residual (in place), then LayerNorm
     g.A = h->ctx; g.W = w.wo; g.bias = w.bo; g.N = MV_HIDDEN; g.K = MV_HIDDEN; g.xres = h->xres;
-    if (int rc = launch_gemm128<EPI_RES, true>(h, KC_GEMM_OUT, g)) return rc;
+    if (int rc = launch_gemm<EPI_RES>(h, KC_GEMM_OUT, g)) return rc;
     {
       ProfScope ps(h, KC_LN);
       hipLaunchKernelGGL(ln_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, h->stream, h->xres, h->x16, (int)M, w.ln1g, w.ln1b, c.ln_eps);
@@ -272,10 +303,10 @@ int encode_dev(mv_handle* h, const int32_t* d_ids, const int32_t* d_lens, int B,
     }
     // K5: FFN-1 + exact-erf GELU
     g.A = h->x16; g.W = w.w1; g.bias = w.b1; g.N = MV_INTER; g.K = MV_HIDDEN; g.out16 = h->h16;
-    if (int rc = launch_gemm128<EPI_GELU, true>(h, KC_GEMM_FFN1, g)) return rc;
+    if (int rc = launch_gemm<EPI_GELU>(h, KC_GEMM_FFN1, g)) return rc;
     // K6: FFN-2 + bias + residual, then LayerNorm
     g.A = h->h16; g.W = w.w2; g.bias = w.b2; g.N = MV_HIDDEN; g.K = MV_INTER; g.xres = h->xres;
-    if (int rc = launch_gemm128<EPI_RES, true>(h, KC_GEMM_FFN2, g)) return rc;
+    if (int rc = launch_gemm<EPI_RES>(h, KC_GEMM_FFN2, g)) return rc;
     {
       ProfScope ps(h, KC_LN);
       hipLaunchKernelGGL(ln_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, h->stream, h->xres, h->x16, (int)M, w.ln2g, w.ln2b, c.ln_eps);
@@ -294,7 +325,7 @@ int encode_dev(mv_handle* h, const int32_t* d_ids, const int32_t* d_lens, int B,
 // largest batch one encoder pass can take at padded length Sp
 int max_rows_for(mv_handle* h, int S_in) {
   const int Sp = (int)round_up(S_in, 64);
-  int64_t r = (h->cap_tokens - 128) / Sp;
+  int64_t r = (h->cap_tokens - 256) / Sp;
   if (r > h->cfg.max_batch) r = h->cfg.max_batch;
   return (int)r;
 }
@@ -395,9 +426,14 @@ int mv_create(int device, const mv_config* cfg, mv_handle** out) {
   // dynamic LDS above 64 KiB needs an explicit opt-in
   hipFuncSetAttribute((const void*)attention_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   hipFuncSetAttribute((const void*)attention_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  hipFuncSetAttribute((const void*)gemm256_kernel<EPI_F32>, hipFuncAttributeMaxDynamicSharedMemorySize, G256_LDS_BYTES);
+  hipFuncSetAttribute((const void*)gemm256_kernel<EPI_QKV>, hipFuncAttributeMaxDynamicSharedMemorySize, G256_LDS_BYTES);
+  hipFuncSetAttribute((const void*)gemm256_kernel<EPI_GELU>, hipFuncAttributeMaxDynamicSharedMemorySize, G256_LDS_BYTES);
+  hipFuncSetAttribute((const void*)gemm256_kernel<EPI_RES>, hipFuncAttributeMaxDynamicSharedMemorySize, G256_LDS_BYTES);
   (void)hipGetLastError();
+  if (const char* e = getenv("MEMVUL_GEMM_TILE")) h->gemm_tile = atoi(e);
 
-  h->cap_tokens = round_up(cfg->max_tokens, 128) + 128;
+  h->cap_tokens = round_up(cfg->max_tokens, 256) + 256;
   const int64_t T = h->cap_tokens;
   int rc = MV_OK;
   auto A = [&](int r) { if (rc == MV_OK) rc = r; };
@@ -841,6 +877,7 @@ int mv_test_gemm(mv_handle* h, int variant, int M, int N, int K, const uint16_t*
     switch (variant) {
       case 0: return launch_gemm128<EPI_F32, true>(h, KC_TEST_GEMM, g);
       case 1: return launch_gemm128<EPI_F32, false>(h, KC_TEST_GEMM, g);
+      case 2: return launch_gemm256<EPI_F32>(h, KC_TEST_GEMM, g);
       default: return fail(h, MV_ERR_INVALID, "mv_test_gemm: unknown variant");
     }
   };

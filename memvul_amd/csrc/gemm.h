@@ -2,17 +2,30 @@
 //   C[M,N] = A[M,K] (fp16) x W[N,K]^T (fp16, torch Linear.weight layout) + bias, fp32 accumulate,
 // with the reference's elementwise work fused into the epilogue.
 //
-// v1 structure ("128^2 tile, LDS-DMA, one barrier per K-step", cdna_hip_programming.md §5):
-//   * 256 threads = 4 waves as 2(M) x 2(N); each wave owns a 64x64 sub-tile = 2x2 fragments of
-//     v_mfma_f32_32x32x16_f16 (64 accumulator VGPRs).
-//   * K-step 64: the A and W tiles are both [128 rows][64 halfs] = 128-B rows in LDS, double-buffered
-//     (2 x 32 KB => two workgroups per CU).  They are filled by global_load_lds_dwordx4 (16 B per lane,
-//     1 KiB per wave-instruction, LDS image lane-linear), so the bank-conflict swizzle is applied on the
-//     per-lane SOURCE address and again on the ds_read_b128 (rule 21): 16-B chunk c of row r lives at
-//     chunk slot c ^ ((r >> 1) & 7); with that, the four 16-lane groups of a ds_read_b128 fragment read
-//     (32 rows x one chunk) hit 16 distinct bank slots.
-//   * blockIdx -> tile through xcd_remap(): each XCD sweeps a contiguous run of tiles, N fastest, so the
-//     A row panel and the (small) W matrix stay in that XCD's L2.
+// Common to both tile shapes below (v_mfma_f32_32x32x16_f16, wave64):
+//   * operand tiles are [rows][64 halfs] = 128-B rows in LDS, double-buffered, filled by
+//     global_load_lds_dwordx4 (16 B per lane, 1 KiB per wave-instruction, LDS image lane-linear), so the
+//     bank-conflict swizzle is applied on the per-lane SOURCE address and again on the ds_read_b128
+//     (cdna_hip_programming.md §5.4 rule 21): 16-B chunk c of row r lives at chunk slot c ^ ((r >> 1) & 7);
+//     with that, the four 16-lane groups of a ds_read_b128 fragment read (32 rows x one chunk) hit 16
+//     distinct bank slots.
+//   * blockIdx -> tile through xcd_remap() + a grouped raster: the logical tile sequence is
+//     (column group of GN tiles) > tile_m > tile_n-in-group and each XCD takes one contiguous run of it.
+//     The W panels of a group (GN x rows x K x 2 B, ~1.5 MB) stay in that XCD's 4 MiB L2 while it sweeps the
+//     A row panels; with the plain N-fastest order W (4.7 MB for FFN-1) thrashed the L2 and FETCH_SIZE showed
+//     1.5 GB per FFN-1 launch against 105 MB of operands (profiles/r01_a_pmc_hbm_v1.txt).
+//   * the accumulation order over K is the same in every variant (ascending 16-wide MFMA steps), so the
+//     128^2 and 256^2 kernels produce bit-identical results.
+//
+// gemm128: 256 threads = 4 waves as 2(M) x 2(N), 64x64 per wave, 2 x 32 KB LDS => two workgroups per CU;
+//          one barrier per K-step ("step-3" structure of the guide).  Used for small M.
+// gemm256: 512 threads = 8 waves as 2(M) x 4(N), 128x64 per wave (128 accumulator VGPRs), 2 x 64 KB LDS
+//          => one workgroup per CU; one barrier per K-step, operand fragments register-double-buffered across
+//          the 16-wide sub-steps and across the barrier (the last sub-step's MFMAs run after the barrier and
+//          cover the first fragment reads of the next tile); the LDS-DMA for tile t+2 is issued right after the
+//          barrier that retires tile t, so every load has a full K-step (~2k cycles) in flight and the
+//          `s_waitcnt vmcnt(0)` at the next barrier is not a stall.  Halves both the LDS and the L2 bytes per
+//          FLOP of gemm128.
 #pragma once
 #include "common.h"
 
@@ -25,6 +38,7 @@ struct GemmArgs {
   int M;              // rows to compute (multiple of the M tile)
   int Mreal;          // rows that exist (scatter epilogues skip the rest)
   int N, K;
+  int GN;             // raster group width in tiles (divides N / tile)
   float* outf;        // EPI_F32: [M][N]
   half_t* out16;      // EPI_GELU: [M][N]
   float* xres;        // EPI_RES: [M][N] residual stream, updated in place
@@ -34,11 +48,70 @@ struct GemmArgs {
   int S;              // padded sequence length (multiple of 64)
 };
 
-#define G128_BM 128
-#define G128_BN 128
-#define G128_BK 64
-#define G128_TILE_BYTES (128 * 64 * 2)          // 16 KiB per operand tile
-#define G128_LDS_BYTES (4 * G128_TILE_BYTES)    // 2 buffers x (A + W)
+// logical tile index -> (tile_m, tile_n) under the grouped raster
+__device__ __forceinline__ void raster(int t, int tm_count, int tn_count, int GN, int& tile_m, int& tile_n) {
+  const int per_group = tm_count * GN;
+  const int g = t / per_group;
+  const int r = t - g * per_group;
+  tile_m = r / GN;
+  tile_n = g * GN + (r - tile_m * GN);
+}
+
+// Epilogue of one 32x32 accumulator fragment whose top-left element is (mb, nb): for register r a
+// half-wave covers 32 consecutive columns of one row (col = lane & 31, row = mfma32_row(r, hi)).
+template <int EPI>
+__device__ __forceinline__ void epilogue_frag(const GemmArgs& a, const floatx16& acc, int mb, int nb, int lane) {
+  const int hi = lane >> 5;
+  const int n = nb + (lane & 31);
+  const float bias = a.bias ? a.bias[n] : 0.f;
+  if constexpr (EPI == EPI_F32) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) a.outf[(size_t)(mb + mfma32_row(r, hi)) * a.N + n] = acc[r] + bias;
+  } else if constexpr (EPI == EPI_GELU) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) a.out16[(size_t)(mb + mfma32_row(r, hi)) * a.N + n] = (half_t)gelu_erf(acc[r] + bias);
+  } else if constexpr (EPI == EPI_RES) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      float* p = a.xres + (size_t)(mb + mfma32_row(r, hi)) * a.N + n;
+      *p = acc[r] + bias + *p;
+    }
+  } else {  // EPI_QKV: n in [0, 2304) = which * 768 + head * 64 + d; a fragment never straddles a head half
+    const int which = nb / MV_HIDDEN;
+    const int hn = nb - which * MV_HIDDEN;
+    const int head = hn >> 6;
+    const int d = (hn & 63) + (lane & 31);
+    const int b = mb / a.S;  // S % 64 == 0 and mb % 32 == 0: one batch row per fragment
+    const int s_base = mb - b * a.S;
+    if (which < 2) {
+      half_t* dst = (which == 0 ? a.q : a.k) + ((size_t)(b * MV_HEADS + head) * a.S) * MV_HEAD_DIM + d;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int rr = mfma32_row(r, hi);
+        if (mb + rr < a.Mreal) dst[(size_t)(s_base + rr) * MV_HEAD_DIM] = (half_t)(acc[r] + bias);
+      }
+    } else {
+      half_t* dst = a.vt + ((size_t)(b * MV_HEADS + head) * MV_HEAD_DIM + d) * a.S;
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) {
+        const int rr = 8 * rg + 4 * hi;  // rows rr..rr+3 are registers 4*rg..4*rg+3
+        half4_t v4;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v4[e] = (half_t)(acc[4 * rg + e] + bias);
+        if (mb + rr < a.Mreal) *(half4_t*)(dst + s_base + rr) = v4;
+      }
+    }
+  }
+}
+
+__device__ __forceinline__ void glds16(const half_t* src, char* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+// =================================================================================================
+#define G128_TILE_BYTES (128 * 64 * 2)        // 16 KiB per operand tile
+#define G128_LDS_BYTES (4 * G128_TILE_BYTES)  // 2 buffers x (A + W)
 
 template <int EPI, bool GLDS>
 __global__ __launch_bounds__(256, 2) void gemm128_kernel(GemmArgs a) {
@@ -47,42 +120,34 @@ __global__ __launch_bounds__(256, 2) void gemm128_kernel(GemmArgs a) {
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int hi = lane >> 5;
-  const int tn = a.N >> 7;
-  const int tile = xcd_remap(blockIdx.x, gridDim.x);
-  const int tile_m = tile / tn;
-  const int tile_n = tile - tile_m * tn;
+  int tile_m, tile_n;
+  raster(xcd_remap(blockIdx.x, gridDim.x), a.M >> 7, a.N >> 7, a.GN, tile_m, tile_n);
   const int m0 = tile_m << 7, n0 = tile_n << 7;
   const int wm = wave >> 1, wn = wave & 1;
   const int K = a.K;
 
-  // ---- staging: wave w fills slabs w*4 .. w*4+3 (8 rows x 128 B each) of both operand tiles.
+  // staging: wave w fills slabs w*4 .. w*4+3 (8 rows x 128 B each) of both operand tiles.
   // lane -> (row = slab*8 + lane/8, chunk slot = lane%8); source chunk = slot ^ ((row>>1)&7).
   const half_t* srcA[4];
   const half_t* srcW[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    const int slab = wave * 4 + i;
-    const int row = slab * 8 + (lane >> 3);
+    const int row = (wave * 4 + i) * 8 + (lane >> 3);
     const int sc = (lane & 7) ^ ((row >> 1) & 7);
     srcA[i] = a.A + (size_t)(m0 + row) * K + sc * 8;
     srcW[i] = a.W + (size_t)(n0 + row) * K + sc * 8;
   }
-
   auto stage_glds = [&](int buf, int kt) {
-    char* baseA = smem + buf * (2 * G128_TILE_BYTES);
+    char* baseA = smem + buf * (2 * G128_TILE_BYTES) + wave * 4096;
     char* baseW = baseA + G128_TILE_BYTES;
-    const int koff = kt * G128_BK;
+    const int koff = kt * 64;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const int slab = wave * 4 + i;
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcA[i] + koff),
-                                       (__attribute__((address_space(3))) void*)(baseA + slab * 1024), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcW[i] + koff),
-                                       (__attribute__((address_space(3))) void*)(baseW + slab * 1024), 16, 0, 0);
+      glds16(srcA[i] + koff, baseA + i * 1024);
+      glds16(srcW[i] + koff, baseW + i * 1024);
     }
   };
 
-  // ---- fragment read offsets (bytes inside an operand tile)
   const int swz = (lane >> 1) & 7;  // ((row >> 1) & 7) with row = 32*x + (lane & 31)
   const int arow = (wm * 64 + (lane & 31)) * 128;
   const int brow = (wn * 64 + (lane & 31)) * 128;
@@ -114,7 +179,7 @@ __global__ __launch_bounds__(256, 2) void gemm128_kernel(GemmArgs a) {
     }
   };
 
-  const int nk = K / G128_BK;
+  const int nk = K / 64;
   if constexpr (GLDS) {
     stage_glds(0, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -131,7 +196,7 @@ __global__ __launch_bounds__(256, 2) void gemm128_kernel(GemmArgs a) {
     // register staging: global -> VGPR -> ds_write_b128 (same LDS image as the LDS-DMA path)
     half8_t ra[4], rw[4];
     auto gload = [&](int kt) {
-      const int koff = kt * G128_BK;
+      const int koff = kt * 64;
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         ra[i] = *(const half8_t*)(srcA[i] + koff);
@@ -139,13 +204,12 @@ __global__ __launch_bounds__(256, 2) void gemm128_kernel(GemmArgs a) {
       }
     };
     auto lwrite = [&](int buf) {
-      char* baseA = smem + buf * (2 * G128_TILE_BYTES);
+      char* baseA = smem + buf * (2 * G128_TILE_BYTES) + wave * 4096 + lane * 16;
       char* baseW = baseA + G128_TILE_BYTES;
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        const int slab = wave * 4 + i;
-        *(half8_t*)(baseA + slab * 1024 + lane * 16) = ra[i];
-        *(half8_t*)(baseW + slab * 1024 + lane * 16) = rw[i];
+        *(half8_t*)(baseA + i * 1024) = ra[i];
+        *(half8_t*)(baseW + i * 1024) = rw[i];
       }
     };
     gload(0);
@@ -161,61 +225,107 @@ __global__ __launch_bounds__(256, 2) void gemm128_kernel(GemmArgs a) {
     }
   }
 
-  // ---- epilogue straight from the accumulator layout: for register r a half-wave covers 32
-  // consecutive columns of one row (col = lane & 31, row = mfma32_row(r, hi)).
-  const int col_in = lane & 31;
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int mb = m0 + wm * 64 + i * 32;  // first row of this 32-row fragment
+  for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int n = n0 + wn * 64 + j * 32 + col_in;
-      const float bias = a.bias ? a.bias[n] : 0.f;
-      if constexpr (EPI == EPI_F32) {
+    for (int j = 0; j < 2; ++j)
+      epilogue_frag<EPI>(a, acc[i][j], m0 + wm * 64 + i * 32, n0 + wn * 64 + j * 32, lane);
+}
+
+// =================================================================================================
+#define G256_TILE_BYTES (256 * 64 * 2)        // 32 KiB per operand tile
+#define G256_LDS_BYTES (4 * G256_TILE_BYTES)  // 2 buffers x (A + W) = 128 KiB
+
+template <int EPI>
+__global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int hi = lane >> 5;
+  int tile_m, tile_n;
+  raster(xcd_remap(blockIdx.x, gridDim.x), a.M >> 8, a.N >> 8, a.GN, tile_m, tile_n);
+  const int m0 = tile_m << 8, n0 = tile_n << 8;
+  const int wm = wave >> 2, wn = wave & 3;
+  const int K = a.K;
+
+  // staging: wave w fills slabs w*4 .. w*4+3 (8 rows each) of the 256-row A and W tiles
+  const half_t* srcA[4];
+  const half_t* srcW[4];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int m = mb + mfma32_row(r, hi);
-          a.outf[(size_t)m * a.N + n] = acc[i][j][r] + bias;
-        }
-      } else if constexpr (EPI == EPI_GELU) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int m = mb + mfma32_row(r, hi);
-          a.out16[(size_t)m * a.N + n] = (half_t)gelu_erf(acc[i][j][r] + bias);
-        }
-      } else if constexpr (EPI == EPI_RES) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int m = mb + mfma32_row(r, hi);
-          float* p = a.xres + (size_t)m * a.N + n;
-          *p = acc[i][j][r] + bias + *p;
-        }
-      } else {  // EPI_QKV
-        const int which = n0 / MV_HIDDEN;                          // 0 q, 1 k, 2 v (block-uniform)
-        const int hn0 = n0 - which * MV_HIDDEN + wn * 64;          // first column of this wave inside [0,768)
-        const int head = hn0 >> 6;                                 // wave-uniform
-        const int d = j * 32 + col_in;
-        const int b = mb / a.S;                                    // S % 64 == 0 and mb % 32 == 0: one b per fragment
-        const int s_base = mb - b * a.S;
-        if (which < 2) {
-          half_t* dst = (which == 0 ? a.q : a.k) + ((size_t)(b * MV_HEADS + head) * a.S) * MV_HEAD_DIM + d;
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int rr = mfma32_row(r, hi);
-            if (mb + rr < a.Mreal) dst[(size_t)(s_base + rr) * MV_HEAD_DIM] = (half_t)(acc[i][j][r] + bias);
-          }
-        } else {
-          half_t* dst = a.vt + ((size_t)(b * MV_HEADS + head) * MV_HEAD_DIM + d) * a.S;
-#pragma unroll
-          for (int rg = 0; rg < 4; ++rg) {
-            const int rr = 8 * rg + 4 * hi;  // rows rr..rr+3 are registers 4*rg..4*rg+3
-            half4_t v4;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v4[e] = (half_t)(acc[i][j][4 * rg + e] + bias);
-            if (mb + rr < a.Mreal) *(half4_t*)(dst + s_base + rr) = v4;
-          }
-        }
-      }
-    }
+  for (int i = 0; i < 4; ++i) {
+    const int row = (wave * 4 + i) * 8 + (lane >> 3);
+    const int sc = (lane & 7) ^ ((row >> 1) & 7);
+    srcA[i] = a.A + (size_t)(m0 + row) * K + sc * 8;
+    srcW[i] = a.W + (size_t)(n0 + row) * K + sc * 8;
   }
+  auto stage = [&](int buf, int kt) {
+    char* baseA = smem + buf * (2 * G256_TILE_BYTES) + wave * 4096;
+    char* baseW = baseA + G256_TILE_BYTES;
+    const int koff = kt * 64;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      glds16(srcA[i] + koff, baseA + i * 1024);
+      glds16(srcW[i] + koff, baseW + i * 1024);
+    }
+  };
+
+  const int swz = (lane >> 1) & 7;
+  const int arow = (wm * 128 + (lane & 31)) * 128;
+  const int brow = (wn * 64 + (lane & 31)) * 128;
+
+  floatx16 acc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  auto load_frags = [&](int buf, int kk, half8_t (&fa)[4], half8_t (&fb)[2]) {
+    const char* baseA = smem + buf * (2 * G256_TILE_BYTES);
+    const char* baseW = baseA + G256_TILE_BYTES;
+    const int coff = ((kk * 2 + hi) ^ swz) << 4;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) fb[j] = *(const half8_t*)(baseW + brow + j * 32 * 128 + coff);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) fa[i] = *(const half8_t*)(baseA + arow + i * 32 * 128 + coff);
+  };
+  auto mma = [&](const half8_t (&fa)[4], const half8_t (&fb)[2]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+  };
+
+  const int nk = K / 64;
+  half8_t fa0[4], fb0[2], fa1[4], fb1[2];
+  stage(0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (nk > 1) stage(1, 1);
+  load_frags(0, 0, fa0, fb0);
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+    load_frags(cur, 1, fa1, fb1);
+    mma(fa0, fb0);
+    load_frags(cur, 2, fa0, fb0);
+    mma(fa1, fb1);
+    load_frags(cur, 3, fa1, fb1);
+    mma(fa0, fb0);
+    // tile kt+1 (issued one K-step ago) has landed for this wave; all waves are done READING buffer `cur`
+    // once they pass the barrier (their fragment reads are complete: __syncthreads waits lgkmcnt(0)).
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (kt + 1 < nk) load_frags(cur ^ 1, 0, fa0, fb0);
+    if (kt + 2 < nk) stage(cur, kt + 2);
+    mma(fa1, fb1);
+  }
+
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+      epilogue_frag<EPI>(a, acc[i][j], m0 + wm * 128 + i * 32, n0 + wn * 64 + j * 32, lane);
 }

@@ -18,15 +18,15 @@ w = synth.make_weights(dims)
 eng = Engine(0, vocab_size=dims.vocab_size, layers=dims.layers, max_tokens=65536, max_batch=256, max_anchors=128)
 eng.load_state_dict(w)
 
-variants = [int(v) for v in os.environ.get("PROBE_VARIANTS", "0,1").split(",")]
-M = int(os.environ.get("PROBE_M", 16384))
+variants = [int(v) for v in os.environ.get("PROBE_VARIANTS", "0,2").split(",")]
+M = int(os.environ.get("PROBE_M", 65536))
 rng = np.random.default_rng(0)
 for (N, K) in [(2304, 768), (768, 768), (3072, 768), (768, 3072)]:
     A = rng.standard_normal((M, K)).astype(np.float16)
     W = (rng.standard_normal((N, K)) * 0.05).astype(np.float16)
     for v in variants:
         try:
-            _, ms = eng.test_gemm(A, W, None, variant=v, iters=20)
+            _, ms = eng.test_gemm(A, W, None, variant=v, iters=10)
             tf = 2.0 * M * N * K / (ms * 1e-3) / 1e12
             out["gemm"].append({"variant": v, "M": M, "N": N, "K": K, "ms": ms, "tflops": tf})
             print(f"gemm v{v} M={M} N={N} K={K}: {ms:.4f} ms  {tf:.1f} TFLOP/s", flush=True)

@@ -17,10 +17,15 @@ def gu():
     return gpu_util
 
 
-@pytest.mark.parametrize("variant", [0, 1])
-@pytest.mark.parametrize("shape", [(128, 128, 64), (256, 384, 768), (384, 256, 3072)])
+@pytest.mark.parametrize("variant", [0, 1, 2])
+@pytest.mark.parametrize("shape", [(128, 128, 64), (256, 384, 768), (384, 256, 3072), (512, 768, 128), (1024, 2304, 768)])
 def test_gemm_variants(gu, variant, shape):
+    """0: 128^2 tile LDS-DMA, 1: 128^2 register-staged, 2: 256^2 tile.  All accumulate over K in the same
+    order, so they must agree bit-for-bit with each other (checked against variant 0) and with fp32 numpy to
+    rounding."""
     M, N, K = shape
+    if variant == 2 and (M % 256 or N % 256):
+        pytest.skip("256^2 tile needs M, N % 256 == 0")
     rng = np.random.default_rng(M + N + K)
     A = rng.standard_normal((M, K)).astype(np.float16)
     W = (rng.standard_normal((N, K)) * 0.05).astype(np.float16)
@@ -31,6 +36,9 @@ def test_gemm_variants(gu, variant, shape):
     err = float(np.abs(out - ref).max())
     gu.record("gemm", variant=variant, M=M, N=N, K=K, max_err=err)
     assert err < 2e-4 * np.sqrt(K / 64.0), f"gemm variant {variant} {shape}: max err {err}"
+    if variant != 0:
+        out0, _ = eng.test_gemm(A, W, bias, variant=0, iters=1)
+        assert np.array_equal(out, out0), "tile variants must be bit-identical"
 
 
 def _taps(gu, B, S, ragged):
