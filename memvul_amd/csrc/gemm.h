@@ -63,18 +63,19 @@ template <int EPI>
 __device__ __forceinline__ void epilogue_frag(const GemmArgs& a, const floatx16& acc, int mb, int nb, int lane) {
   const int hi = lane >> 5;
   const int n = nb + (lane & 31);
-  const float bias = a.bias ? a.bias[n] : 0.f;
+  const float bias = (EPI != EPI_RES && a.bias) ? a.bias[n] : 0.f;
   if constexpr (EPI == EPI_F32) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) a.outf[(size_t)(mb + mfma32_row(r, hi)) * a.N + n] = acc[r] + bias;
   } else if constexpr (EPI == EPI_GELU) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) a.out16[(size_t)(mb + mfma32_row(r, hi)) * a.N + n] = (half_t)gelu_erf(acc[r] + bias);
-  } else if constexpr (EPI == EPI_RES) {
+  } else if constexpr (EPI == EPI_RES) {  // N == 768 (the residual stream)
+    const int lane_off = 4 * hi * MV_HIDDEN + (lane & 31);
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      float* p = a.xres + (size_t)(mb + mfma32_row(r, hi)) * a.N + n;
-      *p = acc[r] + bias + *p;
+      float* rowbase = a.xres + (size_t)(mb + (r & 3) + 8 * (r >> 2)) * MV_HIDDEN + nb;
+      rowbase[lane_off] = acc[r];
     }
   } else {  // EPI_QKV: n in [0, 2304) = which * 768 + head * 64 + d; a fragment never straddles a head half
     const int which = nb / MV_HIDDEN;
@@ -101,6 +102,27 @@ __device__ __forceinline__ void epilogue_frag(const GemmArgs& a, const floatx16&
         if (mb + rr < a.Mreal) *(half4_t*)(dst + s_base + rr) = v4;
       }
     }
+  }
+}
+
+// Accumulator init for one fragment.  EPI_RES: start from bias + residual instead of zero — the 16 dword
+// loads per fragment are issued before the main loop (their latency overlaps the first LDS-DMA stage), so the
+// epilogue is store-only; doing the read-modify-write after the loop cost 125-160 us per launch (latency-bound
+// batches of dword loads at one workgroup per CU).  The tile is owned by this workgroup, so in-place is safe.
+template <int EPI>
+__device__ __forceinline__ void init_frag(const GemmArgs& a, floatx16& acc, int mb, int nb, int lane) {
+  if constexpr (EPI == EPI_RES) {
+    // wave-uniform row base (SGPR) + one 32-bit per-lane offset: no per-load 64-bit VGPR address math
+    const int lane_off = 4 * (lane >> 5) * MV_HIDDEN + (lane & 31);
+    const float bias = a.bias[nb + (lane & 31)];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float* rowbase = a.xres + (size_t)(mb + (r & 3) + 8 * (r >> 2)) * MV_HIDDEN + nb;
+      acc[r] = rowbase[lane_off] + bias;
+    }
+  } else {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
   }
 }
 
@@ -156,9 +178,7 @@ __global__ __launch_bounds__(256, 2) void gemm128_kernel(GemmArgs a) {
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    for (int j = 0; j < 2; ++j) init_frag<EPI>(a, acc[i][j], m0 + wm * 64 + i * 32, n0 + wn * 64 + j * 32, lane);
 
   auto compute = [&](int buf) {
     const char* baseA = smem + buf * (2 * G128_TILE_BYTES);
@@ -278,9 +298,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs a) {
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    for (int j = 0; j < 2; ++j) init_frag<EPI>(a, acc[i][j], m0 + wm * 128 + i * 32, n0 + wn * 64 + j * 32, lane);
 
   auto load_frags = [&](int buf, int kk, half8_t (&fa)[4], half8_t (&fb)[2]) {
     const char* baseA = smem + buf * (2 * G256_TILE_BYTES);
