@@ -246,6 +246,26 @@ int launch_gemm256(mv_handle* h, int cls, GemmArgs a) {
   return launch_check(h, "gemm256");
 }
 
+template <int EPI, int FR_M, int FR_N, int WM, int WN, int BK, int ST, int MINW, int ABL = 0>
+int launch_ring(mv_handle* h, int cls, GemmArgs a, int gn_max) {
+  constexpr int BM = WM * FR_M * 32, BN = WN * FR_N * 32;
+  constexpr int LDS = ST * (BM + BN) * BK * 2;
+  static_assert(LDS <= 160 * 1024, "LDS ring exceeds 160 KiB");
+  if (a.M % BM || a.N % BN || a.K % BK) return fail(h, MV_ERR_INVALID, "gemm_ring: shape not a multiple of the tile");
+  auto kern = gemm_ring_kernel<EPI, FR_M, FR_N, WM, WN, BK, ST, MINW, ABL>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    (void)hipGetLastError();
+    attr_set = true;
+  }
+  a.GN = choose_gn(a.N / BN, gn_max);
+  const int grid = (a.M / BM) * (a.N / BN);
+  ProfScope ps(h, cls);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * WM * WN), LDS, h->stream, a);
+  return launch_check(h, "gemm_ring");
+}
+
 // tile choice: the 256^2 kernel needs enough tiles to fill 256 CUs (one workgroup each)
 template <int EPI>
 int launch_gemm(mv_handle* h, int cls, const GemmArgs& a) {
@@ -856,6 +876,7 @@ int mv_test_gemm(mv_handle* h, int variant, int M, int N, int K, const uint16_t*
                  float* C, int iters, float* ms) {
   if (!h || !A || !W || M <= 0 || N <= 0 || K <= 0) return fail(h, MV_ERR_INVALID, "mv_test_gemm: bad argument");
   if (M % 128 || N % 128 || K % 64) return fail(h, MV_ERR_INVALID, "mv_test_gemm: M,N % 128 and K % 64 required");
+  if (variant >= 2 && (M % 256 || N % 256)) return fail(h, MV_ERR_INVALID, "mv_test_gemm: this variant needs M,N % 256");
   HIPCHK(h, hipSetDevice(h->device));
   half_t *dA = nullptr, *dW = nullptr;
   float *dB = nullptr, *dC = nullptr;
@@ -878,6 +899,20 @@ int mv_test_gemm(mv_handle* h, int variant, int M, int N, int K, const uint16_t*
       case 0: return launch_gemm128<EPI_F32, true>(h, KC_TEST_GEMM, g);
       case 1: return launch_gemm128<EPI_F32, false>(h, KC_TEST_GEMM, g);
       case 2: return launch_gemm256<EPI_F32>(h, KC_TEST_GEMM, g);
+      //                       EPI     FR_M FR_N WM WN BK ST minw            raster group
+      case 10: return launch_ring<EPI_F32, 4, 2, 2, 4, 64, 2, 2>(h, KC_TEST_GEMM, g, 4);  // 256x256, 8 waves, 128 KB
+      case 11: return launch_ring<EPI_F32, 4, 2, 2, 4, 32, 4, 2>(h, KC_TEST_GEMM, g, 4);  // 256x256, 8 waves, 128 KB
+      case 12: return launch_ring<EPI_F32, 4, 2, 2, 2, 32, 3, 2>(h, KC_TEST_GEMM, g, 8);  // 256x128, 4 waves, 72 KB (2 WG/CU)
+      case 13: return launch_ring<EPI_F32, 4, 2, 2, 2, 64, 3, 2>(h, KC_TEST_GEMM, g, 8);  // 256x128, 4 waves, 144 KB
+      case 14: return launch_ring<EPI_F32, 2, 2, 2, 2, 32, 4, 2>(h, KC_TEST_GEMM, g, 8);  // 128x128, 4 waves, 64 KB (2 WG/CU)
+      case 15: return launch_ring<EPI_F32, 4, 2, 2, 4, 32, 5, 2>(h, KC_TEST_GEMM, g, 4);  // 256x256, 8 waves, 160 KB
+      case 16: return launch_ring<EPI_F32, 4, 4, 2, 2, 32, 3, 1>(h, KC_TEST_GEMM, g, 4);  // 256x256, 4 waves x 128x128, 96 KB
+      case 17: return launch_ring<EPI_F32, 4, 2, 2, 2, 32, 4, 2>(h, KC_TEST_GEMM, g, 8);  // 256x128, 4 waves, 96 KB
+      case 18: return launch_ring<EPI_F32, 2, 4, 4, 2, 32, 4, 2>(h, KC_TEST_GEMM, g, 4);  // 256x256, 8 waves x 64x128, 128 KB
+      // timing ablations of variant 10 (results are wrong by construction)
+      case 21: return launch_ring<EPI_F32, 4, 2, 2, 4, 64, 2, 2, 1>(h, KC_TEST_GEMM, g, 4);  // no LDS-DMA in the loop
+      case 22: return launch_ring<EPI_F32, 4, 2, 2, 4, 64, 2, 2, 2>(h, KC_TEST_GEMM, g, 4);  // no MFMA
+      case 23: return launch_ring<EPI_F32, 4, 2, 2, 4, 64, 2, 2, 3>(h, KC_TEST_GEMM, g, 4);  // no fragment reads
       default: return fail(h, MV_ERR_INVALID, "mv_test_gemm: unknown variant");
     }
   };

@@ -347,3 +347,142 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs a) {
     for (int j = 0; j < 2; ++j)
       epilogue_frag<EPI>(a, acc[i][j], m0 + wm * 128 + i * 32, n0 + wn * 64 + j * 32, lane);
 }
+
+// =================================================================================================
+// gemm_ring: the same MFMA mainloop over a RING of LDS stages with counted `s_waitcnt vmcnt(N)`, so that
+// STAGES-1 operand stages are in flight across barriers (cdna_hip_programming.md T3/T4).  PMC on gemm256
+// (profiles/r01_c_pmc_*): 0 bank conflicts, LDS 10 % busy, MFMA 28-34 % busy, waves parked ~40 % of the time:
+// with one 64-KB stage in flight per CU the K-loop runs at ~12 B/cycle/CU of operand delivery — latency-bound.
+//   tile  = (WAVES_M * FR_M * 32) x (WAVES_N * FR_N * 32), K-step BK in {32, 64}
+//   stage = [A rows | W rows] x BK halfs, 1-KiB slabs dealt round-robin to the waves
+//   loop  : wait(stage kt landed, newer stages stay in flight) -> barrier -> issue stage kt+STAGES-1 into the
+//           slot of tile kt-1 (every wave finished reading it before the barrier) -> MFMAs on stage kt.
+// The raw s_barrier is fenced with `asm volatile("" ::: "memory")` so no LDS access moves across it.
+template <int BK>
+struct RingGeom {
+  static constexpr int ROW_BYTES = BK * 2;
+  static constexpr int ROWS_PER_SLAB = 1024 / ROW_BYTES;      // 8 (BK=64) or 16 (BK=32)
+  static constexpr int CHUNKS = ROW_BYTES / 16;               // 8 or 4
+  static constexpr int LANES_PER_ROW = CHUNKS;
+  __device__ static __forceinline__ int swz(int row) { return BK == 64 ? ((row >> 1) & 7) : ((row >> 2) & 3); }
+};
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+  static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit field");
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// ABL (timing ablations, wrong results by construction; cdna_hip_programming.md §5.4 rule 8/17):
+//   0 = real kernel, 1 = no LDS-DMA inside the loop, 2 = no MFMA (fragments kept live), 3 = no fragment reads.
+template <int EPI, int FR_M, int FR_N, int WAVES_M, int WAVES_N, int BK, int STAGES, int MIN_WAVES_PER_SIMD, int ABL = 0>
+__global__ __launch_bounds__(64 * WAVES_M * WAVES_N, MIN_WAVES_PER_SIMD) void gemm_ring_kernel(GemmArgs a) {
+  using Gm = RingGeom<BK>;
+  constexpr int NW = WAVES_M * WAVES_N;
+  constexpr int BM = WAVES_M * FR_M * 32, BN = WAVES_N * FR_N * 32;
+  constexpr int STAGE_BYTES = (BM + BN) * Gm::ROW_BYTES;
+  constexpr int SLABS = STAGE_BYTES / 1024;
+  static_assert(SLABS % NW == 0, "slabs must deal evenly to the waves");
+  constexpr int G = SLABS / NW;  // LDS-DMA instructions per wave per stage
+  constexpr int KK = BK / 16;    // MFMA k-substeps per stage
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int hi = lane >> 5;
+  int tile_m, tile_n;
+  raster(xcd_remap(blockIdx.x, gridDim.x), a.M / BM, a.N / BN, a.GN, tile_m, tile_n);
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const int wm = wave / WAVES_N, wn = wave - wm * WAVES_N;
+  const int K = a.K;
+
+  floatx16 acc[FR_M][FR_N];
+#pragma unroll
+  for (int i = 0; i < FR_M; ++i)
+#pragma unroll
+    for (int j = 0; j < FR_N; ++j) init_frag<EPI>(a, acc[i][j], m0 + (wm * FR_M + i) * 32, n0 + (wn * FR_N + j) * 32, lane);
+
+  // slab s = wave + i*NW covers stage rows [s*RPS, (s+1)*RPS): rows < BM belong to A, the rest to W
+  const half_t* src[G];
+#pragma unroll
+  for (int i = 0; i < G; ++i) {
+    const int row = (wave + i * NW) * Gm::ROWS_PER_SLAB + lane / Gm::LANES_PER_ROW;  // row inside the stage image
+    const int sc = (lane % Gm::CHUNKS) ^ Gm::swz(row);  // BM % 32 == 0: the swizzle key is the same in A- and W-local rows
+    src[i] = (row < BM) ? a.A + (size_t)(m0 + row) * K + sc * 8 : a.W + (size_t)(n0 + row - BM) * K + sc * 8;
+  }
+  auto stage = [&](int slot, int kt) {
+    char* base = smem + slot * STAGE_BYTES + wave * 1024;
+    const int koff = kt * BK;
+#pragma unroll
+    for (int i = 0; i < G; ++i) glds16(src[i] + koff, base + i * NW * 1024);
+  };
+
+  const int swzl = Gm::swz(lane & 31);
+  const int arow = ((wm * FR_M) * 32 + (lane & 31)) * Gm::ROW_BYTES;
+  const int brow = (BM + (wn * FR_N) * 32 + (lane & 31)) * Gm::ROW_BYTES;
+  half8_t fa_c[FR_M], fb_c[FR_N];  // ABL 3: constant fragments
+  if constexpr (ABL == 3) {
+#pragma unroll
+    for (int i = 0; i < FR_M; ++i) fa_c[i] = *(const half8_t*)(a.A + (size_t)(m0 + i * 32 + (lane & 31)) * K + hi * 8);
+#pragma unroll
+    for (int j = 0; j < FR_N; ++j) fb_c[j] = *(const half8_t*)(a.W + (size_t)(n0 + j * 32 + (lane & 31)) * K + hi * 8);
+  }
+  auto compute = [&](int slot) {
+    const char* base = smem + slot * STAGE_BYTES;
+#pragma unroll
+    for (int kk = 0; kk < KK; ++kk) {
+      const int coff = ((kk * 2 + hi) ^ swzl) << 4;
+      half8_t fa[FR_M], fb[FR_N];
+      if constexpr (ABL == 3) {
+#pragma unroll
+        for (int j = 0; j < FR_N; ++j) fb[j] = fb_c[j];
+#pragma unroll
+        for (int i = 0; i < FR_M; ++i) fa[i] = fa_c[i];
+      } else {
+#pragma unroll
+        for (int j = 0; j < FR_N; ++j) fb[j] = *(const half8_t*)(base + brow + j * 32 * Gm::ROW_BYTES + coff);
+#pragma unroll
+        for (int i = 0; i < FR_M; ++i) fa[i] = *(const half8_t*)(base + arow + i * 32 * Gm::ROW_BYTES + coff);
+      }
+      if constexpr (ABL == 2) {
+#pragma unroll
+        for (int j = 0; j < FR_N; ++j) asm volatile("" ::"v"(fb[j]));
+#pragma unroll
+        for (int i = 0; i < FR_M; ++i) asm volatile("" ::"v"(fa[i]));
+      } else {
+#pragma unroll
+        for (int i = 0; i < FR_M; ++i)
+#pragma unroll
+          for (int j = 0; j < FR_N; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+      }
+    }
+  };
+
+  const int nk = K / BK;
+#pragma unroll
+  for (int s = 0; s < STAGES - 1; ++s)
+    if (s < nk) stage(s, s);
+  int slot = 0, fill = STAGES - 1;  // slot of tile kt; slot to fill next (= slot of tile kt-1)
+  for (int kt = 0; kt < nk; ++kt) {
+    const int newer = nk - 1 - kt;  // stages issued after tile kt that may stay in flight (at most STAGES-2)
+    if (STAGES >= 5 && newer >= 3) wait_vmcnt<(STAGES >= 5 ? 3 : 0) * G>();
+    else if (STAGES >= 4 && newer >= 2) wait_vmcnt<(STAGES >= 4 ? 2 : 0) * G>();
+    else if (STAGES >= 3 && newer >= 1) wait_vmcnt<(STAGES >= 3 ? 1 : 0) * G>();
+    else wait_vmcnt<0>();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wave's reads of the slot about to be refilled are done
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (ABL != 1 && kt + STAGES - 1 < nk) stage(fill, kt + STAGES - 1);
+    compute(slot);
+    asm volatile("" ::: "memory");
+    slot = (slot + 1 == STAGES) ? 0 : slot + 1;
+    fill = (fill + 1 == STAGES) ? 0 : fill + 1;
+  }
+
+#pragma unroll
+  for (int i = 0; i < FR_M; ++i)
+#pragma unroll
+    for (int j = 0; j < FR_N; ++j)
+      epilogue_frag<EPI>(a, acc[i][j], m0 + (wm * FR_M + i) * 32, n0 + (wn * FR_N + j) * 32, lane);
+}

@@ -18,7 +18,7 @@ w = synth.make_weights(dims)
 eng = Engine(0, vocab_size=dims.vocab_size, layers=dims.layers, max_tokens=65536, max_batch=256, max_anchors=128)
 eng.load_state_dict(w)
 
-variants = [int(v) for v in os.environ.get("PROBE_VARIANTS", "0,2").split(",")]
+variants = [int(v) for v in os.environ.get("PROBE_VARIANTS", "10,21,22,23").split(",")]
 M = int(os.environ.get("PROBE_M", 65536))
 rng = np.random.default_rng(0)
 for (N, K) in [(2304, 768), (768, 768), (3072, 768), (768, 3072)]:
