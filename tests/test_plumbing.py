@@ -1,0 +1,74 @@
+"""predict_memory.py plumbing (BASELINE.json configs[0], scaled down): reader -> model -> metrics -> JSON-lines
+-> cal_metrics.  On CPU the engine is replaced by the oracle-backed stand-in (tests only); on the GPU the real
+HIP engine runs the same files and must agree with the oracle-backed run."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import plumbing_util as pu
+from memvul_amd import model_memory, predict_memory
+from oracle import stats_oracle as so
+
+
+def _run(fx, tag):
+    root, arch, golden, test_path, w, dims = fx
+    out_metric = os.path.join(root, "test_results", f"{tag}_metric.json")
+    out_results = os.path.join(root, "test_results", f"{tag}_result.json")
+    metrics = predict_memory.test_siamese(archive_file=arch, input_file=test_path, input_golden_file=golden, test_config=pu.TEST_CONFIG,
+                                          output_file=out_metric, predictions_output_file=out_results, batch_size=16, cuda_device=0,
+                                          engine_options=dict(max_tokens=16 * 256, max_batch=16, max_anchors=16))
+    records = []
+    for line in open(out_results):
+        records.extend(json.loads(line))
+    return metrics, records, out_results
+
+
+def _check_format_and_metrics(fx, metrics, records, tag):
+    root = fx[0]
+    recs_in = json.load(open(fx[3]))
+    assert len(records) == len(recs_in)
+    # positives first (reversed concatenation), every record has one score per anchor
+    anchors = list(json.load(open(fx[2])).keys())
+    assert [r["label"] != "neg" for r in records][: sum(r["Security_Issue_Full"] == "1" for r in recs_in)] == [True] * sum(r["Security_Issue_Full"] == "1" for r in recs_in)
+    for r in records:
+        assert set(r) == {"Issue_Url", "label", "predict"} and list(r["predict"].keys()) == anchors
+        assert all(0.0 <= v <= 1.0 for v in r["predict"].values())
+    # second pass (cal_metrics) == the scalar oracle on the same records
+    m = predict_memory.cal_metrics(f"{tag}_result", thres=0.5, data_path=root)
+    ref = so.cal_metrics_records(records, thres=0.5)
+    for k in ("TP", "FN", "TN", "FP", "f1", "auc", "ap"):
+        assert m[k] == pytest.approx(ref[k], abs=1e-12), k
+    assert os.path.exists(os.path.join(root, "test_results", f"{tag}_metric_all.json"))
+    # evaluate()'s streaming metrics: siamese stats recomputed from the written records
+    labels = [0 if r["label"] == "neg" else 1 for r in records]
+    scores = [float(np.float32(max(r["predict"].values()))) for r in records]
+    s = so.siamese_get_metric(labels, scores)
+    assert metrics["s_f1-score"] == pytest.approx(s["f1"], abs=1e-9) and metrics["s_auc"] == pytest.approx(s["auc"], abs=1e-9)
+    assert 0.0 <= metrics["accuracy"] <= 1.0 and "same_f1-score" in metrics and "diff_recall" in metrics
+
+
+def test_plumbing_cpu_with_oracle_engine(monkeypatch):
+    fx = pu.make_fixture()
+    monkeypatch.setattr(model_memory, "Engine", pu.OracleEngine)
+    metrics, records, _ = _run(fx, "oracle")
+    _check_format_and_metrics(fx, metrics, records, "oracle")
+
+
+@pytest.mark.gpu
+def test_plumbing_gpu_matches_oracle_run(monkeypatch):
+    fx = pu.make_fixture()
+    metrics, records, _ = _run(fx, "hip")
+    _check_format_and_metrics(fx, metrics, records, "hip")
+    monkeypatch.setattr(model_memory, "Engine", pu.OracleEngine)
+    metrics_o, records_o, _ = _run(fx, "oracle")
+    gpu = np.array([list(r["predict"].values()) for r in records])
+    ref = np.array([list(r["predict"].values()) for r in records_o])
+    assert [r["Issue_Url"] for r in records] == [r["Issue_Url"] for r in records_o]
+    assert np.abs(gpu - ref).max() <= 1e-3
+    # CIR/NCIR decisions at 0.5 agree wherever the oracle score is not within tolerance of the threshold
+    sg, sr = gpu.max(1), ref.max(1)
+    clear = np.abs(sr - 0.5) > 1e-3
+    assert np.array_equal((sg >= 0.5)[clear], (sr >= 0.5)[clear])
+    assert metrics["accuracy"] == pytest.approx(metrics_o["accuracy"], abs=0.1)
