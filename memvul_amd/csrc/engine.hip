@@ -15,6 +15,7 @@
 #include "attention.h"
 #include "common.h"
 #include "gemm.h"
+#include "gemm_pp.h"
 #include "misc_kernels.h"
 
 namespace {
@@ -141,7 +142,10 @@ struct mv_handle {
   std::vector<ProfRec> recs;
   std::vector<hipEvent_t> free_events;
 
-  int gemm_tile = 0;  // 0 auto, 128 or 256 (env MEMVUL_GEMM_TILE; both give bit-identical results)
+  // GEMM path (env MEMVUL_GEMM_TILE): 0 auto (persistent ping-pong kernel when the launch fills the chip, else the
+  // 128^2 tile), 128 / 256 force the one-tile-per-workgroup kernels, 512 forces the ping-pong kernel.
+  int gemm_tile = 0;
+  int num_cu = 256;
 
   // debug
   int dbg_B = 0, dbg_Sp = 0;
@@ -266,13 +270,48 @@ int launch_ring(mv_handle* h, int cls, GemmArgs a, int gn_max) {
   return launch_check(h, "gemm_ring");
 }
 
-// tile choice: the 256^2 kernel needs enough tiles to fill 256 CUs (one workgroup each)
+constexpr int PP_DIST = 6;  // half-tile issue distance of the production ping-pong GEMM (tools/gemm_bench.hip sweeps it)
+
+template <int PPEPI>
+int launch_pp_raw(mv_handle* h, GemmArgs a) {
+  if (a.M % 256 || a.N % 256 || a.K % 128 || a.N > MV_INTER)
+    return fail(h, MV_ERR_INVALID, "gemm_pp: M,N % 256, K % 128, N <= 3072 required");
+  a.GN = choose_gn(a.N / 256, 4);
+  const int tiles = (a.M / 256) * (a.N / 256);
+  const int grid = tiles < h->num_cu ? tiles : h->num_cu;
+  hipLaunchKernelGGL((gemm_pp_kernel<PPEPI, PP_DIST, 0>), dim3(grid), dim3(512), PP_LDS_BYTES, h->stream, a);
+  return launch_check(h, "gemm_pp");
+}
+
+template <int EPI>
+int launch_pp(mv_handle* h, int cls, const GemmArgs& a) {
+  ProfScope ps(h, cls);
+  if constexpr (EPI == EPI_QKV) {  // Q,K columns (row-per-lane stores) and the V^T block (token-contiguous stores)
+    GemmArgs qk = a;
+    qk.N = 2 * MV_HIDDEN;
+    if (int rc = launch_pp_raw<PP_QK>(h, qk)) return rc;
+    GemmArgs v = a;
+    v.W = a.W + (size_t)2 * MV_HIDDEN * a.K;
+    v.bias = a.bias ? a.bias + 2 * MV_HIDDEN : nullptr;
+    v.N = MV_HIDDEN;
+    return launch_pp_raw<PP_VT>(h, v);
+  } else if constexpr (EPI == EPI_GELU) {
+    return launch_pp_raw<PP_GELU>(h, a);
+  } else if constexpr (EPI == EPI_RES) {
+    return launch_pp_raw<PP_RES>(h, a);
+  } else {
+    return launch_pp_raw<PP_F32>(h, a);
+  }
+}
+
+// path choice: the persistent kernels need enough 256^2 tiles to fill the CUs (one workgroup each)
 template <int EPI>
 int launch_gemm(mv_handle* h, int cls, const GemmArgs& a) {
-  const bool big = (a.M % 256 == 0) && (a.N % 256 == 0) && ((int64_t)(a.M / 256) * (a.N / 256) >= 256);
-  if (h->gemm_tile == 256 || (h->gemm_tile == 0 && big)) {
-    if (a.M % 256 == 0 && a.N % 256 == 0) return launch_gemm256<EPI>(h, cls, a);
-  }
+  const bool tile256 = (a.M % 256 == 0) && (a.N % 256 == 0);
+  const bool big = tile256 && ((int64_t)(a.M / 256) * (a.N / 256) >= 256);
+  const bool pp_ok = tile256 && (a.K % 128 == 0) && a.N <= MV_INTER;
+  if (pp_ok && (h->gemm_tile == 512 || (h->gemm_tile == 0 && big))) return launch_pp<EPI>(h, cls, a);
+  if (tile256 && (h->gemm_tile == 256 || (h->gemm_tile == 0 && big))) return launch_gemm256<EPI>(h, cls, a);
   return launch_gemm128<EPI, true>(h, cls, a);
 }
 
@@ -450,8 +489,17 @@ int mv_create(int device, const mv_config* cfg, mv_handle** out) {
   hipFuncSetAttribute((const void*)gemm256_kernel<EPI_QKV>, hipFuncAttributeMaxDynamicSharedMemorySize, G256_LDS_BYTES);
   hipFuncSetAttribute((const void*)gemm256_kernel<EPI_GELU>, hipFuncAttributeMaxDynamicSharedMemorySize, G256_LDS_BYTES);
   hipFuncSetAttribute((const void*)gemm256_kernel<EPI_RES>, hipFuncAttributeMaxDynamicSharedMemorySize, G256_LDS_BYTES);
+  hipFuncSetAttribute((const void*)gemm_pp_kernel<PP_F32, PP_DIST, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS_BYTES);
+  hipFuncSetAttribute((const void*)gemm_pp_kernel<PP_QK, PP_DIST, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS_BYTES);
+  hipFuncSetAttribute((const void*)gemm_pp_kernel<PP_VT, PP_DIST, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS_BYTES);
+  hipFuncSetAttribute((const void*)gemm_pp_kernel<PP_GELU, PP_DIST, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS_BYTES);
+  hipFuncSetAttribute((const void*)gemm_pp_kernel<PP_RES, PP_DIST, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS_BYTES);
   (void)hipGetLastError();
   if (const char* e = getenv("MEMVUL_GEMM_TILE")) h->gemm_tile = atoi(e);
+  {
+    int ncu = 0;
+    if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && ncu > 0) h->num_cu = ncu;
+  }
 
   h->cap_tokens = round_up(cfg->max_tokens, 256) + 256;
   const int64_t T = h->cap_tokens;
@@ -877,6 +925,7 @@ int mv_test_gemm(mv_handle* h, int variant, int M, int N, int K, const uint16_t*
   if (!h || !A || !W || M <= 0 || N <= 0 || K <= 0) return fail(h, MV_ERR_INVALID, "mv_test_gemm: bad argument");
   if (M % 128 || N % 128 || K % 64) return fail(h, MV_ERR_INVALID, "mv_test_gemm: M,N % 128 and K % 64 required");
   if (variant >= 2 && (M % 256 || N % 256)) return fail(h, MV_ERR_INVALID, "mv_test_gemm: this variant needs M,N % 256");
+  if (variant == 30 && K % 128) return fail(h, MV_ERR_INVALID, "mv_test_gemm: variant 30 needs K % 128");
   HIPCHK(h, hipSetDevice(h->device));
   half_t *dA = nullptr, *dW = nullptr;
   float *dB = nullptr, *dC = nullptr;
@@ -899,6 +948,7 @@ int mv_test_gemm(mv_handle* h, int variant, int M, int N, int K, const uint16_t*
       case 0: return launch_gemm128<EPI_F32, true>(h, KC_TEST_GEMM, g);
       case 1: return launch_gemm128<EPI_F32, false>(h, KC_TEST_GEMM, g);
       case 2: return launch_gemm256<EPI_F32>(h, KC_TEST_GEMM, g);
+      case 30: { ProfScope ps(h, KC_TEST_GEMM); return launch_pp_raw<PP_F32>(h, g); }  // persistent ping-pong kernel
       //                       EPI     FR_M FR_N WM WN BK ST minw            raster group
       case 10: return launch_ring<EPI_F32, 4, 2, 2, 4, 64, 2, 2>(h, KC_TEST_GEMM, g, 4);  // 256x256, 8 waves, 128 KB
       case 11: return launch_ring<EPI_F32, 4, 2, 2, 4, 32, 4, 2>(h, KC_TEST_GEMM, g, 4);  // 256x256, 8 waves, 128 KB

@@ -63,13 +63,14 @@ template <int EPI>
 __device__ __forceinline__ void epilogue_frag(const GemmArgs& a, const floatx16& acc, int mb, int nb, int lane) {
   const int hi = lane >> 5;
   const int n = nb + (lane & 31);
-  const float bias = (EPI != EPI_RES && a.bias) ? a.bias[n] : 0.f;
+  // the bias is already in the accumulators (init_frag): every kernel of this library starts the K sum from
+  // the bias, so all tile shapes / orientations produce the same bits for a given output element
   if constexpr (EPI == EPI_F32) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) a.outf[(size_t)(mb + mfma32_row(r, hi)) * a.N + n] = acc[r] + bias;
+    for (int r = 0; r < 16; ++r) a.outf[(size_t)(mb + mfma32_row(r, hi)) * a.N + n] = acc[r];
   } else if constexpr (EPI == EPI_GELU) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) a.out16[(size_t)(mb + mfma32_row(r, hi)) * a.N + n] = (half_t)gelu_erf(acc[r] + bias);
+    for (int r = 0; r < 16; ++r) a.out16[(size_t)(mb + mfma32_row(r, hi)) * a.N + n] = (half_t)gelu_erf(acc[r]);
   } else if constexpr (EPI == EPI_RES) {  // N == 768 (the residual stream)
     const int lane_off = 4 * hi * MV_HIDDEN + (lane & 31);
 #pragma unroll
@@ -89,7 +90,7 @@ __device__ __forceinline__ void epilogue_frag(const GemmArgs& a, const floatx16&
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int rr = mfma32_row(r, hi);
-        if (mb + rr < a.Mreal) dst[(size_t)(s_base + rr) * MV_HEAD_DIM] = (half_t)(acc[r] + bias);
+        if (mb + rr < a.Mreal) dst[(size_t)(s_base + rr) * MV_HEAD_DIM] = (half_t)acc[r];
       }
     } else {
       half_t* dst = a.vt + ((size_t)(b * MV_HEADS + head) * MV_HEAD_DIM + d) * a.S;
@@ -98,7 +99,7 @@ __device__ __forceinline__ void epilogue_frag(const GemmArgs& a, const floatx16&
         const int rr = 8 * rg + 4 * hi;  // rows rr..rr+3 are registers 4*rg..4*rg+3
         half4_t v4;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v4[e] = (half_t)(acc[4 * rg + e] + bias);
+        for (int e = 0; e < 4; ++e) v4[e] = (half_t)acc[4 * rg + e];
         if (mb + rr < a.Mreal) *(half4_t*)(dst + s_base + rr) = v4;
       }
     }
@@ -121,8 +122,9 @@ __device__ __forceinline__ void init_frag(const GemmArgs& a, floatx16& acc, int 
       acc[r] = rowbase[lane_off] + bias;
     }
   } else {
+    const float bias = a.bias ? a.bias[nb + (lane & 31)] : 0.f;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    for (int r = 0; r < 16; ++r) acc[r] = bias;
   }
 }
 

@@ -1,0 +1,397 @@
+// Persistent ping-pong MFMA GEMM for the BERT projections at bench scale:
+//   C[M,N] = A[M,K] (fp16) x W[N,K]^T (fp16, torch Linear.weight layout) + bias, fp32 accumulate,
+// with the reference's elementwise work fused (HF BertSelfAttention / BertSelfOutput / BertIntermediate /
+// BertOutput as invoked from custom_PTM_embedder.py:228).
+//
+// Structure (cdna_hip_programming.md §5 "256^2 8-phase template", T1-T5; MI355X_MICROARCH.md "Two waves per SIMD"):
+//   * 256x256x64 tile, 512 threads = 8 waves as 2(M) x 4(N), 128x64 of C per wave (128 accumulator VGPRs),
+//     v_mfma_f32_32x32x16_f16, ONE workgroup per CU, grid = #CUs, each workgroup walks a strided list of
+//     output tiles (persistent): the K-tile stream never drains between output tiles, so the next tile's
+//     operands are already in flight while the epilogue stores.
+//   * The two M-halves of the workgroup (waves 0-3 / 4-7: one wave of each per SIMD) run the same phase
+//     sequence ONE s_barrier apart: while one wave of a SIMD issues its 8 MFMAs of a phase (256 matrix-pipe
+//     cycles) its partner reads the next fragments from LDS and issues its LDS-DMA, then they swap.  Every
+//     s_barrier is workgroup-wide; a phase is [ds_read + DMA issue] barrier [MFMA] barrier.
+//   * A K-tile is 4 phases = the 4 quadrants (64 x 32) of the wave's C block in the order (a0,b0) (a0,b1)
+//     (a1,b1) (a1,b0'): each phase reads at most ONE operand half-tile (8 or 4 ds_read_b128 per wave), and
+//     the 4th reads b0 of the NEXT K-tile into the register set b1 just vacated (the two W register sets swap
+//     roles every K-tile; the loop is unrolled by two K-tiles so this is static).
+//   * Operand half-tiles (128 rows x 64 halfs = 16 KiB = 2 LDS-DMA instructions per wave) are the unit of
+//     staging: LDS holds two K-tiles x {a0,a1,b0,b1} = 128 KiB, half-tile h(phi) is read in phase phi only and
+//     re-issued for the K-tile two ahead DIST phases before its read (DIST <= 6: a region is rewritten no
+//     sooner than two phases after its last read, which covers the one-barrier skew between the wave halves).
+//     One counted `s_waitcnt vmcnt(2 (DIST-1))` per phase retires exactly the half-tile the NEXT phase reads;
+//     loads stay in flight across barriers (raw s_barrier, never __syncthreads), 2 DIST KiB x 8 per CU.
+//   * LDS image of a half-tile is lane-linear per DMA instruction (1 KiB = 8 rows x 128 B); the bank swizzle
+//     (16-B chunk c of row r at slot c ^ ((r >> 1) & 7)) is applied on the per-lane SOURCE address and on the
+//     ds_read_b128 (rule 21).  The DMA uses the SGPR-base + 32-bit-VGPR-offset form.
+//   * Orientation: SWAP computes C^T fragments (W rows as the MFMA A operand), so a lane holds 4 CONSECUTIVE
+//     output columns of one token row per register group -> 16-byte epilogue stores (fp32 directly, fp16 after
+//     one v_permlane32_swap per dword, T21).  The V^T epilogue uses the other orientation (lane = head dim,
+//     registers = consecutive tokens) for the same reason.
+//   * bias is staged once per workgroup into LDS and the accumulators START from it (and, for the residual
+//     epilogue, from x + bias), so the epilogue has no loads; non-residual kernels have no VGPR-destination
+//     VMEM load anywhere in the persistent loop (hipcc would drain the DMA queue with vmcnt(0) at each one).
+//   * Tile order: logical tile sequence = (column group of GN tiles) > tile_m > tile_n-in-group; per persistent
+//     iteration the 256 concurrent tiles are consecutive in it and each XCD takes a contiguous run of 32 (the
+//     group's W panels stay in that XCD's L2 while it sweeps the A row panels).
+//   * K accumulation order per output element is ascending 16-wide MFMA steps, the same as gemm128/gemm256.
+#pragma once
+#include "common.h"
+#include <type_traits>
+
+#include "gemm.h"
+
+enum { PP_F32 = 0, PP_QK = 1, PP_VT = 2, PP_GELU = 3, PP_RES = 4, PP_F16 = 5 };
+// timing ablations (wrong results by construction; cdna_hip_programming.md §5.4 rules 8/17)
+enum { PP_ABL_NODMA = 1, PP_ABL_NOMFMA = 2, PP_ABL_NOREAD = 4, PP_ABL_NOEPI = 8, PP_ABL_NOPRIO = 16, PP_ABL_NOSTAGGER = 32 };
+
+#define PP_LDS_A 0           // [par][a][wr][64 rows][128 B]
+#define PP_LDS_B 65536       // [par][b][wc][32 rows][128 B]
+#define PP_LDS_BIAS 131072   // [N] fp32 (N <= 3072)
+#define PP_LDS_BYTES (131072 + MV_INTER * 4)
+
+__device__ __forceinline__ uint32_t pack_h2(float a, float b) {
+  half2_t h;
+  h[0] = (half_t)a;
+  h[1] = (half_t)b;
+  return __builtin_bit_cast(uint32_t, h);
+}
+
+// 16 fp32 of one 32x32 fragment in the "4 consecutive elements per register group" orientation ->
+// two 16-byte stores per lane: after the swaps lanes 0-31 hold elements 16p..16p+7 and lanes 32-63 hold
+// 16p+8..16p+15 of the fragment's 32-wide contiguous axis.  `rowptr` = this lane's row start (fp16).
+template <typename T>
+__device__ __forceinline__ void keep_live(const T& v) {
+#if defined(__HIP_DEVICE_COMPILE__)  // the host pass of hipcc parses kernel bodies too and rejects the VGPR constraint
+  asm volatile("" ::"v"(v));
+#endif
+}
+
+template <typename F>
+__device__ __forceinline__ void store_frag_f16(const floatx16& v, half_t* rowptr, int hi, F f) {
+  uint32_t d[4][2];
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    d[g][0] = pack_h2(f(v[4 * g + 0]), f(v[4 * g + 1]));
+    d[g][1] = pack_h2(f(v[4 * g + 2]), f(v[4 * g + 3]));
+  }
+#pragma unroll
+  for (int p = 0; p < 2; ++p) {
+    auto rx = __builtin_amdgcn_permlane32_swap(d[2 * p][0], d[2 * p + 1][0], false, false);
+    auto ry = __builtin_amdgcn_permlane32_swap(d[2 * p][1], d[2 * p + 1][1], false, false);
+    uint4 o;
+    o.x = rx[0]; o.y = ry[0]; o.z = rx[1]; o.w = ry[1];
+    *(uint4*)(rowptr + 16 * p + 8 * hi) = o;
+  }
+}
+
+template <int EPI, int DIST, int ABL>
+__global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmArgs a) {
+  static_assert(DIST >= 2 && DIST <= 6, "half-tile issue distance");
+  constexpr bool SWAP = (EPI != PP_VT);
+  constexpr int WAITN = 2 * (DIST - 1);
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int hi = lane >> 5, l31 = lane & 31;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 2, wc = wave & 3;
+  const int K = a.K, nk = K >> 6;
+  const int tm_count = a.M >> 8, tn_count = a.N >> 8;
+  const int ntiles = tm_count * tn_count;
+  const int G = gridDim.x;
+  const int bslot = xcd_remap(blockIdx.x, G);
+
+  // ---- bias -> LDS (once per workgroup)
+  {
+    float* lb = (float*)(smem + PP_LDS_BIAS);
+    for (int n = tid; n < a.N; n += 512) lb[n] = a.bias ? a.bias[n] : 0.f;
+  }
+
+  // ---- staging geometry: wave w fills slabs 2w, 2w+1 (8 rows x 128 B each) of every half-tile
+  uint32_t offA[2], offB[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int rho = (2 * wave + j) * 8 + (lane >> 3);
+    const int c = (lane & 7) ^ ((rho >> 1) & 7);
+    const int rowA = (rho >> 6) * 128 + (rho & 63);
+    const int rowB = (rho >> 5) * 64 + (rho & 31);
+    offA[j] = (uint32_t)(rowA * K + c * 8) * 2u;
+    offB[j] = (uint32_t)(rowB * K + c * 8) * 2u;
+  }
+  // issue cursor (wave-uniform): output tile being staged, its operand panels and K-tile index
+  int i_it = 0, i_kt = 0;
+  const char* iA = (const char*)a.A;
+  const char* iW = (const char*)a.W;
+  auto set_issue_tile = [&](int it) {
+    const int L = it * G + bslot;
+    if (L < ntiles) {  // past the end: keep staging the last valid tile (never read, keeps the vmcnt ledger exact)
+      int tm, tn;
+      raster(L, tm_count, tn_count, a.GN, tm, tn);
+      iA = (const char*)a.A + (size_t)tm * 256 * K * 2;
+      iW = (const char*)a.W + (size_t)tn * 256 * K * 2;
+    }
+  };
+  set_issue_tile(0);
+  // kind: 0 = a0, 1 = a1, 2 = b0, 3 = b1; issue order per K-tile: b0, a0, b1, a1 (= read order)
+  auto issue = [&](auto kindc, auto parc) {
+    constexpr int kind = decltype(kindc)::value;
+    constexpr int par = decltype(parc)::value;
+    if constexpr (!(ABL & PP_ABL_NODMA)) {
+      const char* src;
+      char* dst;
+      if constexpr (kind < 2) {
+        src = iA + (size_t)(kind * 64) * K * 2 + i_kt * 128;
+        dst = smem + PP_LDS_A + par * 32768 + kind * 16384 + wave * 2048;
+        glds16((const half_t*)(src + offA[0]), dst);
+        glds16((const half_t*)(src + offA[1]), dst + 1024);
+      } else {
+        src = iW + (size_t)((kind - 2) * 32) * K * 2 + i_kt * 128;
+        dst = smem + PP_LDS_B + par * 32768 + (kind - 2) * 16384 + wave * 2048;
+        glds16((const half_t*)(src + offB[0]), dst);
+        glds16((const half_t*)(src + offB[1]), dst + 1024);
+      }
+    }
+    if constexpr (kind == 1) {  // last half-tile of this K-tile: advance the cursor
+      if (++i_kt == nk) {
+        i_kt = 0;
+        set_issue_tile(++i_it);
+      }
+    }
+  };
+  // psi-th half-tile of the stream (psi = phase + 1): psi % 4 -> kind, (psi / 4) & 1 -> LDS parity
+  auto issue_psi = [&](auto psic) {
+    constexpr int psi = decltype(psic)::value;
+    constexpr int q = psi & 3;
+    constexpr int kind = (q == 0) ? 2 : (q == 1) ? 0 : (q == 2) ? 3 : 1;
+    issue(std::integral_constant<int, kind>{}, std::integral_constant<int, (psi >> 2) & 1>{});
+  };
+
+  // ---- fragment read addresses
+  const int swz = (lane >> 1) & 7;
+  int rdA[4], rdB[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) {
+    const int o = l31 * 128 + (((ks * 2 + hi) ^ swz) << 4);
+    rdA[ks] = PP_LDS_A + wr * 8192 + o;
+    rdB[ks] = PP_LDS_B + wc * 4096 + o;
+  }
+  half8_t Xf[2][4], Wx[4], Wy[4];
+  auto read_a = [&](int par, int asub) {
+#pragma unroll
+    for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks)
+        Xf[ii][ks] = *(const half8_t*)(smem + rdA[ks] + par * 32768 + asub * 16384 + ii * 4096);
+  };
+  auto read_b = [&](half8_t (&Wf)[4], int par, int bsub) {
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) Wf[ks] = *(const half8_t*)(smem + rdB[ks] + par * 32768 + bsub * 16384);
+  };
+  if constexpr (ABL & PP_ABL_NOREAD) {
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      Xf[0][ks] = *(const half8_t*)(a.A + (size_t)l31 * K + ks * 16 + hi * 8);
+      Xf[1][ks] = *(const half8_t*)(a.A + (size_t)(32 + l31) * K + ks * 16 + hi * 8);
+      Wx[ks] = *(const half8_t*)(a.W + (size_t)l31 * K + ks * 16 + hi * 8);
+      Wy[ks] = *(const half8_t*)(a.W + (size_t)(32 + l31) * K + ks * 16 + hi * 8);
+    }
+  }
+
+  floatx16 acc[4][2];
+  auto mma_quadrant = [&](auto asubc, auto bc, const half8_t (&Wf)[4]) {
+    constexpr int asub = decltype(asubc)::value;
+    constexpr int b = decltype(bc)::value;
+    if constexpr (ABL & PP_ABL_NOMFMA) {
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        keep_live(Wf[ks]);
+        keep_live(Xf[0][ks]);
+        keep_live(Xf[1][ks]);
+      }
+    } else {
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+        for (int ii = 0; ii < 2; ++ii) {
+          if constexpr (SWAP)
+            acc[asub * 2 + ii][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Wf[ks], Xf[ii][ks], acc[asub * 2 + ii][b], 0, 0, 0);
+          else
+            acc[asub * 2 + ii][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Xf[ii][ks], Wf[ks], acc[asub * 2 + ii][b], 0, 0, 0);
+        }
+    }
+  };
+
+  // One phase.  s = phase index inside the 8-phase (two K-tile) loop body; P = s & 3, par = s >> 2.
+  // Even K-tile: b0 in Wx, b1 -> Wy, next b0 -> Wy.  Odd K-tile: b0 in Wy, b1 -> Wx, next b0 -> Wx.
+  auto phase = [&](auto sc) {
+    constexpr int s = decltype(sc)::value;
+    constexpr int P = s & 3, par = s >> 2;
+    // ---- read section
+    if constexpr (!(ABL & PP_ABL_NOREAD)) {
+      if constexpr (P == 0) read_a(par, 0);
+      if constexpr (P == 1) { if constexpr (par == 0) read_b(Wy, par, 1); else read_b(Wx, par, 1); }
+      if constexpr (P == 2) read_a(par, 1);
+      if constexpr (P == 3) { if constexpr (par == 0) read_b(Wy, par ^ 1, 0); else read_b(Wx, par ^ 1, 0); }
+    }
+    issue_psi(std::integral_constant<int, (s + 1 + DIST) & 7>{});
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WAITN) : "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- matrix section
+    if constexpr (!(ABL & PP_ABL_NOPRIO)) __builtin_amdgcn_s_setprio(1);
+    if constexpr (P == 0) { if constexpr (par == 0) mma_quadrant(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, Wx);
+                            else mma_quadrant(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, Wy); }
+    if constexpr (P == 1) { if constexpr (par == 0) mma_quadrant(std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{}, Wy);
+                            else mma_quadrant(std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{}, Wx); }
+    if constexpr (P == 2) { if constexpr (par == 0) mma_quadrant(std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{}, Wy);
+                            else mma_quadrant(std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{}, Wx); }
+    if constexpr (P == 3) { if constexpr (par == 0) mma_quadrant(std::integral_constant<int, 1>{}, std::integral_constant<int, 0>{}, Wx);
+                            else mma_quadrant(std::integral_constant<int, 1>{}, std::integral_constant<int, 0>{}, Wy); }
+    if constexpr (!(ABL & PP_ABL_NOPRIO)) __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+  };
+
+  // ---- prologue: half-tiles psi = 0 .. DIST in flight, psi = 0 (b0 of K-tile 0) and 1 (a0) landed
+  issue_psi(std::integral_constant<int, 0>{});
+  issue_psi(std::integral_constant<int, 1>{});
+  if constexpr (DIST >= 2) issue_psi(std::integral_constant<int, 2>{});
+  if constexpr (DIST >= 3) issue_psi(std::integral_constant<int, 3>{});
+  if constexpr (DIST >= 4) issue_psi(std::integral_constant<int, 4>{});
+  if constexpr (DIST >= 5) issue_psi(std::integral_constant<int, 5>{});
+  if constexpr (DIST >= 6) issue_psi(std::integral_constant<int, 6>{});
+  asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(WAITN) : "memory");  // lgkmcnt: the bias image writes
+  __builtin_amdgcn_sched_barrier(0);
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_sched_barrier(0);
+  if constexpr (!(ABL & PP_ABL_NOREAD)) read_b(Wx, 0, 0);
+  __builtin_amdgcn_sched_barrier(0);
+  if constexpr (!(ABL & PP_ABL_NOSTAGGER)) {
+    if (wr == 1) __builtin_amdgcn_s_barrier();  // the second M-half runs one barrier behind the first
+  }
+  __builtin_amdgcn_sched_barrier(0);
+
+  for (int it = 0;; ++it) {
+    const int L = it * G + bslot;
+    if (L >= ntiles) break;
+    int tile_m, tile_n;
+    raster(L, tm_count, tn_count, a.GN, tile_m, tile_n);
+    const int mw = (tile_m << 8) + wr * 128;  // first token row of this wave
+    const int nw = (tile_n << 8) + wc * 64;   // first output column of this wave
+
+    // ---- accumulator init: bias (+ residual).  The bias image is read with inline-asm ds_reads: hipcc would
+    // put `s_waitcnt vmcnt(0)` in front of a compiler-visible LDS load here (LDS-DMA in flight) and drain the
+    // operand pipeline once per output tile.  Loads and their lgkmcnt wait are one statement (guide §5.7 form i).
+    if constexpr (SWAP) {
+      float4 bv[2][4];
+      const uint32_t baddr = (uint32_t)(PP_LDS_BIAS + (nw + 4 * hi) * 4);
+      asm volatile(
+          "ds_read_b128 %0, %8\n\tds_read_b128 %1, %8 offset:32\n\tds_read_b128 %2, %8 offset:64\n\t"
+          "ds_read_b128 %3, %8 offset:96\n\tds_read_b128 %4, %8 offset:128\n\tds_read_b128 %5, %8 offset:160\n\t"
+          "ds_read_b128 %6, %8 offset:192\n\tds_read_b128 %7, %8 offset:224\n\ts_waitcnt lgkmcnt(0)"
+          : "=&v"(bv[0][0]), "=&v"(bv[0][1]), "=&v"(bv[0][2]), "=&v"(bv[0][3]), "=&v"(bv[1][0]), "=&v"(bv[1][1]),
+            "=&v"(bv[1][2]), "=&v"(bv[1][3])
+          : "v"(baddr)
+          : "memory");
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            if constexpr (EPI == PP_RES) {
+              const float4 xv = *(const float4*)(a.xres + (size_t)(mw + i * 32 + l31) * MV_HIDDEN + nw + j * 32 + 8 * g + 4 * hi);
+              acc[i][j][4 * g + 0] = xv.x + bv[j][g].x; acc[i][j][4 * g + 1] = xv.y + bv[j][g].y;
+              acc[i][j][4 * g + 2] = xv.z + bv[j][g].z; acc[i][j][4 * g + 3] = xv.w + bv[j][g].w;
+            } else {
+              acc[i][j][4 * g + 0] = bv[j][g].x; acc[i][j][4 * g + 1] = bv[j][g].y;
+              acc[i][j][4 * g + 2] = bv[j][g].z; acc[i][j][4 * g + 3] = bv[j][g].w;
+            }
+          }
+    } else {  // lane = output column
+      float b0, b1;
+      const uint32_t baddr = (uint32_t)(PP_LDS_BIAS + (nw + l31) * 4);
+      asm volatile("ds_read_b32 %0, %2\n\tds_read_b32 %1, %2 offset:128\n\ts_waitcnt lgkmcnt(0)"
+                   : "=&v"(b0), "=&v"(b1)
+                   : "v"(baddr)
+                   : "memory");
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          acc[i][0][r] = b0;
+          acc[i][1][r] = b1;
+        }
+    }
+
+    for (int kt = 0; kt < nk; kt += 2) {
+      phase(std::integral_constant<int, 0>{});
+      phase(std::integral_constant<int, 1>{});
+      phase(std::integral_constant<int, 2>{});
+      phase(std::integral_constant<int, 3>{});
+      phase(std::integral_constant<int, 4>{});
+      phase(std::integral_constant<int, 5>{});
+      phase(std::integral_constant<int, 6>{});
+      phase(std::integral_constant<int, 7>{});
+    }
+
+    // ---- epilogue (store only)
+    if constexpr (ABL & PP_ABL_NOEPI) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) keep_live(acc[i][j]);
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int mb = mw + i * 32;  // 32-row block: wave-uniform
+        if constexpr (EPI == PP_F32 || EPI == PP_RES) {
+          float* base = (EPI == PP_RES ? a.xres : a.outf) + (size_t)(mb + l31) * a.N + nw + 4 * hi;
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+              float4 v;
+              v.x = acc[i][j][4 * g + 0]; v.y = acc[i][j][4 * g + 1]; v.z = acc[i][j][4 * g + 2]; v.w = acc[i][j][4 * g + 3];
+              *(float4*)(base + j * 32 + 8 * g) = v;
+            }
+        } else if constexpr (EPI == PP_F16 || EPI == PP_GELU) {
+          half_t* rowptr = a.out16 + (size_t)(mb + l31) * a.N + nw;
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            if constexpr (EPI == PP_GELU) store_frag_f16(acc[i][j], rowptr + j * 32, hi, [](float x) { return gelu_erf(x); });
+            else store_frag_f16(acc[i][j], rowptr + j * 32, hi, [](float x) { return x; });
+          }
+        } else if constexpr (EPI == PP_QK) {  // N = 1536: columns [0,768) -> Q, [768,1536) -> K; 64 columns of a wave = one head
+          if (mb < a.Mreal) {
+            const int which = nw >= MV_HIDDEN;
+            const int head = (nw - which * MV_HIDDEN) >> 6;
+            const int b = mb / a.S, s0 = mb - b * a.S;
+            half_t* rowptr = (which ? a.k : a.q) + ((size_t)(b * MV_HEADS + head) * a.S + s0 + l31) * MV_HEAD_DIM;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) store_frag_f16(acc[i][j], rowptr + j * 32, hi, [](float x) { return x; });
+          }
+        } else {  // PP_VT: N = 768 (the V block); lane = head dim, registers = consecutive tokens
+          if (mb < a.Mreal) {
+            const int head = nw >> 6;
+            const int b = mb / a.S, s0 = mb - b * a.S;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+              half_t* rowptr = a.vt + ((size_t)(b * MV_HEADS + head) * MV_HEAD_DIM + j * 32 + l31) * a.S + s0;
+              store_frag_f16(acc[i][j], rowptr, hi, [](float x) { return x; });
+            }
+          }
+        }
+      }
+    }
+  }
+
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // no LDS-DMA may outlive the workgroup's LDS allocation
+  if constexpr (!(ABL & PP_ABL_NOSTAGGER)) {
+    if (wr == 0) __builtin_amdgcn_s_barrier();
+  }
+}

@@ -32,8 +32,10 @@ def weights_for(dims_kw: dict, w_kw: dict):
     return _weights[key]
 
 
-def engine_for(dims_kw: dict, w_kw: dict, **eng_kw) -> Engine:
-    key = (tuple(sorted(dims_kw.items())), tuple(sorted(w_kw.items())), tuple(sorted(eng_kw.items())))
+def engine_for(dims_kw: dict, w_kw: dict, gemm_tile: int = 0, **eng_kw) -> Engine:
+    """gemm_tile: 0 = the engine's own choice, 128 / 256 = one-tile-per-workgroup kernels, 512 = persistent
+    ping-pong kernel forced (MEMVUL_GEMM_TILE, read at mv_create)."""
+    key = (tuple(sorted(dims_kw.items())), tuple(sorted(w_kw.items())), tuple(sorted(eng_kw.items())), gemm_tile)
     if key not in _engines:
         if len(_engines) >= 2:  # keep HBM use bounded: drop the oldest engine
             k0 = next(iter(_engines))
@@ -41,7 +43,18 @@ def engine_for(dims_kw: dict, w_kw: dict, **eng_kw) -> Engine:
         dims, w = weights_for(dims_kw, w_kw)
         kw = dict(max_tokens=16384, max_batch=64, max_anchors=64)
         kw.update(eng_kw)
-        e = Engine(0, vocab_size=dims.vocab_size, layers=dims.layers, max_pos=dims.max_pos, **kw)
+        old = os.environ.get("MEMVUL_GEMM_TILE")
+        if gemm_tile:
+            os.environ["MEMVUL_GEMM_TILE"] = str(gemm_tile)
+        else:
+            os.environ.pop("MEMVUL_GEMM_TILE", None)
+        try:
+            e = Engine(0, vocab_size=dims.vocab_size, layers=dims.layers, max_pos=dims.max_pos, **kw)
+        finally:
+            if old is None:
+                os.environ.pop("MEMVUL_GEMM_TILE", None)
+            else:
+                os.environ["MEMVUL_GEMM_TILE"] = old
         e.load_state_dict(w)
         _engines[key] = e
     return _engines[key]

@@ -17,7 +17,7 @@ def gu():
     return gpu_util
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 10, 11, 12, 13, 14, 15, 16, 17, 18])
+@pytest.mark.parametrize("variant", [0, 1, 2, 10, 11, 12, 13, 14, 15, 16, 17, 18, 30])
 @pytest.mark.parametrize("shape", [(128, 128, 64), (256, 384, 768), (384, 256, 3072), (256, 256, 64), (512, 768, 128), (1024, 2304, 768)])
 def test_gemm_variants(gu, variant, shape):
     """0: 128^2 tile LDS-DMA, 1: 128^2 register-staged, 2: 256^2 tile, 10+: LDS-ring variants (tile / BK /
@@ -27,6 +27,8 @@ def test_gemm_variants(gu, variant, shape):
     M, N, K = shape
     if variant >= 2 and (M % 256 or N % 256):
         pytest.skip("256^2 tile needs M, N % 256 == 0")
+    if variant == 30 and K % 128:
+        pytest.skip("the ping-pong kernel walks K two 64-wide tiles at a time")
     rng = np.random.default_rng(M + N + K)
     A = rng.standard_normal((M, K)).astype(np.float16)
     W = (rng.standard_normal((N, K)) * 0.05).astype(np.float16)
@@ -64,12 +66,13 @@ def test_embeddings_layernorm(gu, B, S, ragged):
     assert np.abs(x16 - taps["embed"]).max() < 4e-3
 
 
+@pytest.mark.parametrize("gemm_tile", [0, 512])
 @pytest.mark.parametrize("B,S,ragged", [(2, 64, False), (3, 128, True), (2, 256, True), (1, 320, True), (2, 100, True)])
-def test_layer0_stages(gu, B, S, ragged):
+def test_layer0_stages(gu, B, S, ragged, gemm_tile):
     """QKV projection, attention, FFN and both LayerNorms of encoder layer 0 against the oracle taps.
     Tolerances are fp16-operand level (inputs rounded to fp16, fp32 accumulation)."""
     dims, w, ids, lens, mask, taps, _ = _taps(gu, B, S, ragged)
-    eng = gu.engine_for(L2, WK)
+    eng = gu.engine_for(L2, WK, gemm_tile=gemm_tile)  # 512: every projection through the persistent ping-pong GEMM
     eng.debug_encode(ids, lens, 1)
     q = eng.debug_read(2)[:, :, :S].astype(np.float32) * 8.0  # engine folds 1/sqrt(64) into W_q
     k = eng.debug_read(3)[:, :, :S].astype(np.float32)
@@ -86,7 +89,7 @@ def test_layer0_stages(gu, B, S, ragged):
         gelu=np.abs(h16 - taps["l0_gelu"])[m].max(),
         layer0=np.abs(x - taps["layer0"])[m].max(),
     )
-    gu.record("layer0", B=B, S=S, **{k_: float(v_) for k_, v_ in errs.items()})
+    gu.record("layer0", B=B, S=S, gemm_tile=gemm_tile, **{k_: float(v_) for k_, v_ in errs.items()})
     scale_q = float(np.abs(taps["l0_q"]).max())
     assert errs["q"] < 3e-3 * max(1.0, scale_q), errs
     assert errs["k"] < 3e-3 * max(1.0, float(np.abs(taps["l0_k"]).max())), errs

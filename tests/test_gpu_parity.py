@@ -19,12 +19,13 @@ def gu():
     return gpu_util
 
 
+@pytest.mark.parametrize("gemm_tile", [0, 512])
 @pytest.mark.parametrize("name", ["l2_peaky_full", "l2_ragged", "l12_base_ragged", "l12_base_s256"])
-def test_golden_logits(gu, golden_dir, name):
+def test_golden_logits(gu, golden_dir, name, gemm_tile):
     import make_golden
     g = np.load(os.path.join(golden_dir, f"{name}.npz"))
     dk, wk, B, S, ragged, G, SA = make_golden.CASES[name]
-    eng = gu.engine_for(dk, wk)
+    eng = gu.engine_for(dk, wk, gemm_tile=gemm_tile)  # 512 = the bench-scale GEMM path forced at test sizes
     eng.anchor_reset()
     LA = int(g["anchor_lens"].max())
     eng.anchor_append(g["anchor_ids"][:, :LA], g["anchor_lens"])  # one chunk padded to its longest (predict_memory.py:81)
@@ -35,7 +36,7 @@ def test_golden_logits(gu, golden_dir, name):
         logits=float(np.abs(out["logits"] - g["logits"]).max()), p=float(np.abs(out["probs"] - g["p"]).max()),
         logit_scale=float(np.abs(g["logits"]).max()),
     )
-    gu.record("golden", case=name, **errs)
+    gu.record("golden", case=name, gemm_tile=gemm_tile, **errs)
     assert errs["logits"] <= LOGIT_TOL, errs
     assert errs["p"] <= LOGIT_TOL, errs
     # decisions: best-anchor index agrees wherever the reference's top-2 margin exceeds the tolerance
