@@ -45,18 +45,46 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 // exact-erf GELU (HF "gelu", BertIntermediate): gelu(x) = x Phi(x) = 0.5 x (1 + erf(x / sqrt 2)).
 // erfc(z), z = |x|/sqrt 2 >= 0, by Abramowitz & Stegun 7.1.26 (|abs error| <= 1.5e-7):
 //   erfc(z) = t (a1 + t (a2 + t (a3 + t (a4 + t a5)))) exp(-z^2),  t = 1 / (1 + p z)
-// and gelu(x) = 0.5 x erfc(z) for x < 0, x - 0.5 x erfc(z) for x >= 0: no cancellation, no branches, one
-// v_rcp + one v_exp (ocml erff costs ~45 VALU with two divergent branches per element, which made the FFN-1
-// epilogue as long as its main loop).  The result is stored as fp16 (rel. step 4.9e-4), so 1.5e-7 is noise.
+// and gelu(x) = max(x, 0) - 0.5 |x| erfc(z) (for x >= 0: x - x (1 - Phi); for x < 0: x Phi): no cancellation, no
+// branches or selects, one v_rcp + one v_exp, and every other operation is an fma/mul that hipcc pairs into
+// v_pk_fma_f32 / v_pk_mul_f32 when two values are processed together (gelu_erf2): 9 VALU issues per element
+// instead of ~14 for the select form and ~45 with two divergent branches for ocml erff (the FFN-1 epilogue is
+// VALU-bound: profiles/r01_e_*).  The result is stored as fp16 (rel. step 4.9e-4), so 1.5e-7 is noise.
+// gelu_erf and gelu_erf2 perform the same IEEE operations in the same order -> identical bits.
+typedef float float2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float2_t gelu_erf2(float2_t x) {
+  const float2_t az = __builtin_elementwise_abs(x);
+  const float2_t d = __builtin_elementwise_fma(az, (float2_t)(0.3275911f * 0.70710678118654752440f), (float2_t)(1.0f));
+  float2_t t;
+  t.x = __builtin_amdgcn_rcpf(d.x);
+  t.y = __builtin_amdgcn_rcpf(d.y);
+  float2_t p = __builtin_elementwise_fma(t, (float2_t)(1.061405429f), (float2_t)(-1.453152027f));
+  p = __builtin_elementwise_fma(t, p, (float2_t)(1.421413741f));
+  p = __builtin_elementwise_fma(t, p, (float2_t)(-0.284496736f));
+  p = __builtin_elementwise_fma(t, p, (float2_t)(0.254829592f));
+  p = p * t;
+  float2_t m = az * az;
+  m = m * (float2_t)(-0.5f * 1.44269504088896340736f);  // -z^2 log2(e)
+  float2_t e;
+  e.x = __builtin_amdgcn_exp2f(m.x);
+  e.y = __builtin_amdgcn_exp2f(m.y);
+  const float2_t pe = p * e;                             // erfc(|x| / sqrt 2)
+  const float2_t ha = az * (float2_t)(0.5f);
+  const float2_t s = __builtin_elementwise_fma(x, (float2_t)(0.5f), ha);  // max(x, 0), exactly
+  return __builtin_elementwise_fma(-ha, pe, s);
+}
 __device__ __forceinline__ float gelu_erf(float x) {
-  const float z = fabsf(x) * 0.70710678118654752440f;
-  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
-  float poly = fmaf(t, 1.061405429f, -1.453152027f);
-  poly = fmaf(t, poly, 1.421413741f);
-  poly = fmaf(t, poly, -0.284496736f);
-  poly = fmaf(t, poly, 0.254829592f);
-  poly *= t;
-  const float e = __builtin_amdgcn_exp2f(z * z * -1.44269504088896340736f);
-  const float q = 0.5f * x * poly * e;  // 0.5 x erfc(|x|/sqrt2)
-  return x >= 0.f ? x - q : q;
+  const float az = fabsf(x);
+  const float t = __builtin_amdgcn_rcpf(__builtin_fmaf(az, 0.3275911f * 0.70710678118654752440f, 1.0f));
+  float p = __builtin_fmaf(t, 1.061405429f, -1.453152027f);
+  p = __builtin_fmaf(t, p, 1.421413741f);
+  p = __builtin_fmaf(t, p, -0.284496736f);
+  p = __builtin_fmaf(t, p, 0.254829592f);
+  p = p * t;
+  float m = az * az;
+  m = m * (-0.5f * 1.44269504088896340736f);
+  const float pe = p * __builtin_amdgcn_exp2f(m);
+  const float ha = az * 0.5f;
+  const float s = __builtin_fmaf(x, 0.5f, ha);
+  return __builtin_fmaf(-ha, pe, s);
 }

@@ -270,7 +270,9 @@ int launch_ring(mv_handle* h, int cls, GemmArgs a, int gn_max) {
   return launch_check(h, "gemm_ring");
 }
 
-constexpr int PP_DIST = 6;  // half-tile issue distance of the production ping-pong GEMM (tools/gemm_bench.hip sweeps it)
+// production configuration of the ping-pong GEMM (tools/gemm_bench.hip sweeps the alternatives): one barrier per
+// phase (SCHED 1), 4 half-tiles in flight across each barrier, epilogue / residual I/O through the LDS transposition
+constexpr int PP_DIST = 4, PP_SCHED = 1, PP_COAL = 1;
 
 template <int PPEPI>
 int launch_pp_raw(mv_handle* h, GemmArgs a) {
@@ -279,7 +281,7 @@ int launch_pp_raw(mv_handle* h, GemmArgs a) {
   a.GN = choose_gn(a.N / 256, 4);
   const int tiles = (a.M / 256) * (a.N / 256);
   const int grid = tiles < h->num_cu ? tiles : h->num_cu;
-  hipLaunchKernelGGL((gemm_pp_kernel<PPEPI, PP_DIST, 0>), dim3(grid), dim3(512), PP_LDS_BYTES, h->stream, a);
+  hipLaunchKernelGGL((gemm_pp_kernel<PPEPI, PP_DIST, 0, PP_SCHED, PP_COAL>), dim3(grid), dim3(512), PP_LDS_BYTES, h->stream, a);
   return launch_check(h, "gemm_pp");
 }
 
@@ -489,11 +491,11 @@ int mv_create(int device, const mv_config* cfg, mv_handle** out) {
   hipFuncSetAttribute((const void*)gemm256_kernel<EPI_QKV>, hipFuncAttributeMaxDynamicSharedMemorySize, G256_LDS_BYTES);
   hipFuncSetAttribute((const void*)gemm256_kernel<EPI_GELU>, hipFuncAttributeMaxDynamicSharedMemorySize, G256_LDS_BYTES);
   hipFuncSetAttribute((const void*)gemm256_kernel<EPI_RES>, hipFuncAttributeMaxDynamicSharedMemorySize, G256_LDS_BYTES);
-  hipFuncSetAttribute((const void*)gemm_pp_kernel<PP_F32, PP_DIST, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS_BYTES);
-  hipFuncSetAttribute((const void*)gemm_pp_kernel<PP_QK, PP_DIST, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS_BYTES);
-  hipFuncSetAttribute((const void*)gemm_pp_kernel<PP_VT, PP_DIST, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS_BYTES);
-  hipFuncSetAttribute((const void*)gemm_pp_kernel<PP_GELU, PP_DIST, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS_BYTES);
-  hipFuncSetAttribute((const void*)gemm_pp_kernel<PP_RES, PP_DIST, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS_BYTES);
+  hipFuncSetAttribute((const void*)gemm_pp_kernel<PP_F32, PP_DIST, 0, PP_SCHED, PP_COAL>, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS_BYTES);
+  hipFuncSetAttribute((const void*)gemm_pp_kernel<PP_QK, PP_DIST, 0, PP_SCHED, PP_COAL>, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS_BYTES);
+  hipFuncSetAttribute((const void*)gemm_pp_kernel<PP_VT, PP_DIST, 0, PP_SCHED, PP_COAL>, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS_BYTES);
+  hipFuncSetAttribute((const void*)gemm_pp_kernel<PP_GELU, PP_DIST, 0, PP_SCHED, PP_COAL>, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS_BYTES);
+  hipFuncSetAttribute((const void*)gemm_pp_kernel<PP_RES, PP_DIST, 0, PP_SCHED, PP_COAL>, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS_BYTES);
   (void)hipGetLastError();
   if (const char* e = getenv("MEMVUL_GEMM_TILE")) h->gemm_tile = atoi(e);
   {

@@ -46,6 +46,7 @@ struct GemmArgs {
   half_t* k;          //          [B][12][S][64]
   half_t* vt;         //          [B][12][64][S]
   int S;              // padded sequence length (multiple of 64)
+  unsigned long long* clk;  // optional (development probe): per-workgroup s_memtime span of the persistent kernel
 };
 
 // logical tile index -> (tile_m, tile_n) under the grouped raster

@@ -49,7 +49,8 @@ enum { PP_ABL_NODMA = 1, PP_ABL_NOMFMA = 2, PP_ABL_NOREAD = 4, PP_ABL_NOEPI = 8,
 #define PP_LDS_A 0           // [par][a][wr][64 rows][128 B]
 #define PP_LDS_B 65536       // [par][b][wc][32 rows][128 B]
 #define PP_LDS_BIAS 131072   // [N] fp32 (N <= 3072)
-#define PP_LDS_BYTES (131072 + MV_INTER * 4)
+#define PP_LDS_SCR (PP_LDS_BIAS + MV_INTER * 4)  // 8 waves x 2 KiB: wave-private transposition scratch
+#define PP_LDS_BYTES (PP_LDS_SCR + 8 * 2048)     // 159,744 of 163,840
 
 __device__ __forceinline__ uint32_t pack_h2(float a, float b) {
   half2_t h;
@@ -86,11 +87,66 @@ __device__ __forceinline__ void store_frag_f16(const floatx16& v, half_t* rowptr
   }
 }
 
-template <int EPI, int DIST, int ABL>
+// (hipcc/ROCm 7.2: __builtin_bit_cast applied directly to an ext_vector ELEMENT expression reads element 0 —
+// always go through a scalar copy)
+__device__ __forceinline__ uint32_t f2u(float x) { return __float_as_uint(x); }
+__device__ __forceinline__ float u2f(uint32_t x) { return __uint_as_float(x); }
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+// Wave-private transposition through a [32 rows][64 B] LDS image (16-B chunk c of row r at slot c ^ ((r >> 2) & 3)):
+// the MFMA C/D layout gives a lane 8 or 16 contiguous bytes of ONE row (lane = row), so storing it directly makes
+// every wave-store touch 64 scattered 16-B pieces (measured: ~64 cycles of address processing per instruction,
+// 3.6 us per 256^2 tile).  Through the image each store covers 16 rows x 64 contiguous bytes.  Inline asm keeps
+// these LDS accesses out of hipcc's LDS-DMA alias bookkeeping (it would put `s_waitcnt vmcnt(0)` before them and
+// wait for the epilogue's own stores); LDS executes a wave's instructions in order, so the read-after-write
+// needs no wait, only the read results do (same statement, guide §5.7 form i).
+// Two fp16 fragments (j = 0, 1) per statement: LDS executes a wave's instructions in order, so the second
+// fragment's writes may follow the first one's reads into the same image without a wait in between.
+__device__ __forceinline__ void scr_f16x2(uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3, const u32x2 (&da)[4],
+                                          const u32x2 (&db)[4], uint32_t r, u32x4 (&o)[4]) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm volatile(
+      "ds_write_b64 %4, %8\n\tds_write_b64 %5, %9\n\tds_write_b64 %6, %10\n\tds_write_b64 %7, %11\n\t"
+      "ds_read_b128 %0, %16\n\tds_read_b128 %1, %16 offset:1024\n\t"
+      "ds_write_b64 %4, %12\n\tds_write_b64 %5, %13\n\tds_write_b64 %6, %14\n\tds_write_b64 %7, %15\n\t"
+      "ds_read_b128 %2, %16\n\tds_read_b128 %3, %16 offset:1024\n\ts_waitcnt lgkmcnt(0)"
+      : "=&v"(o[0]), "=&v"(o[1]), "=&v"(o[2]), "=&v"(o[3])
+      : "v"(w0), "v"(w1), "v"(w2), "v"(w3), "v"(da[0]), "v"(da[1]), "v"(da[2]), "v"(da[3]), "v"(db[0]), "v"(db[1]),
+        "v"(db[2]), "v"(db[3]), "v"(r)
+      : "memory");
+#endif
+}
+// Four fp32 rounds (32 rows x 16 columns each) per statement: writes at (wa, wb), reads at (ra, rb).
+__device__ __forceinline__ void scr_f32x4(uint32_t wa, uint32_t wb, const u32x4 (&d)[8], uint32_t ra, uint32_t rb,
+                                          u32x4 (&o)[8]) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm volatile(
+      "ds_write_b128 %8, %10\n\tds_write_b128 %9, %11\n\tds_read_b128 %0, %18\n\tds_read_b128 %1, %19\n\t"
+      "ds_write_b128 %8, %12\n\tds_write_b128 %9, %13\n\tds_read_b128 %2, %18\n\tds_read_b128 %3, %19\n\t"
+      "ds_write_b128 %8, %14\n\tds_write_b128 %9, %15\n\tds_read_b128 %4, %18\n\tds_read_b128 %5, %19\n\t"
+      "ds_write_b128 %8, %16\n\tds_write_b128 %9, %17\n\tds_read_b128 %6, %18\n\tds_read_b128 %7, %19\n\t"
+      "s_waitcnt lgkmcnt(0)"
+      : "=&v"(o[0]), "=&v"(o[1]), "=&v"(o[2]), "=&v"(o[3]), "=&v"(o[4]), "=&v"(o[5]), "=&v"(o[6]), "=&v"(o[7])
+      : "v"(wa), "v"(wb), "v"(d[0]), "v"(d[1]), "v"(d[2]), "v"(d[3]), "v"(d[4]), "v"(d[5]), "v"(d[6]), "v"(d[7]), "v"(ra),
+        "v"(rb)
+      : "memory");
+#endif
+}
+
+// SCHED 0: two barriers per phase, the M-halves one barrier apart (DIST = issue distance in phases, 2..6).
+// SCHED 1: ONE barrier per phase; the first M-half runs [MFMA(j), read fragments(j+1)] and the second
+//          [read fragments(j), MFMA(j)] inside the same barrier interval, so each SIMD's matrix pipe is handed from
+//          one wave to the other in the middle of the interval without a barrier in between (DIST = F, the number
+//          of half-tiles kept in flight across each barrier, 2..4: half-tile H is issued in interval H-3-F, is
+//          landed for every wave at the barrier that ends interval H-3, and its LDS region was last read in
+//          interval H-8 or H-9).
+// COAL 1: epilogue stores (and the residual loads) go through the wave-private LDS transposition above.
+template <int EPI, int DIST, int ABL, int SCHED = 0, int COAL = 0>
 __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmArgs a) {
-  static_assert(DIST >= 2 && DIST <= 6, "half-tile issue distance");
+  static_assert(SCHED == 0 ? (DIST >= 2 && DIST <= 6) : (DIST >= 2 && DIST <= 4), "half-tile issue distance");
   constexpr bool SWAP = (EPI != PP_VT);
-  constexpr int WAITN = 2 * (DIST - 1);
+  constexpr int WAITN = SCHED == 0 ? 2 * (DIST - 1) : 2 * DIST;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -102,6 +158,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmArgs a) {
   const int ntiles = tm_count * tn_count;
   const int G = gridDim.x;
   const int bslot = xcd_remap(blockIdx.x, G);
+  const unsigned long long clk0 = a.clk ? __builtin_amdgcn_s_memtime() : 0ull;
 
   // ---- bias -> LDS (once per workgroup)
   {
@@ -256,25 +313,72 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmArgs a) {
     __builtin_amdgcn_sched_barrier(0);
   };
 
-  // ---- prologue: half-tiles psi = 0 .. DIST in flight, psi = 0 (b0 of K-tile 0) and 1 (a0) landed
+  // ---- SCHED 1 building blocks: fragment set / quadrant of phase s (P = s & 3, LDS parity = s >> 2)
+  auto read_set = [&](auto sc) {
+    constexpr int s = decltype(sc)::value & 7;
+    constexpr int P = s & 3, par = s >> 2;
+    if constexpr (!(ABL & PP_ABL_NOREAD)) {
+      if constexpr (P == 0) { read_a(par, 0); read_b(Wx, par, 0); }
+      if constexpr (P == 1) read_b(Wy, par, 1);
+      if constexpr (P == 2) read_a(par, 1);
+    }
+  };
+  auto mma_set = [&](auto sc) {
+    constexpr int P = decltype(sc)::value & 3;
+    if constexpr (P == 0) mma_quadrant(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, Wx);
+    if constexpr (P == 1) mma_quadrant(std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{}, Wy);
+    if constexpr (P == 2) mma_quadrant(std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{}, Wy);
+    if constexpr (P == 3) mma_quadrant(std::integral_constant<int, 1>{}, std::integral_constant<int, 0>{}, Wx);
+  };
+  auto interval = [&](auto sc, auto grpc, bool last_of_tile = false) {
+    constexpr int s = decltype(sc)::value;
+    constexpr int grp = decltype(grpc)::value;
+    if constexpr (grp == 0) {  // matrix pipe first, then the NEXT phase's fragments
+      if constexpr (!(ABL & PP_ABL_NOPRIO)) __builtin_amdgcn_s_setprio(1);
+      mma_set(sc);
+      if constexpr (!(ABL & PP_ABL_NOPRIO)) __builtin_amdgcn_s_setprio(0);
+      __builtin_amdgcn_sched_barrier(0);
+      // the next OUTPUT tile's first fragments are read after its accumulator init instead (run_tiles): keeping
+      // 48 fragment VGPRs live across the epilogue + init costs more than one exposed LDS read per tile
+      if (!(s == 7 && last_of_tile)) read_set(std::integral_constant<int, (s + 1) & 7>{});
+      issue_psi(std::integral_constant<int, (s + 3 + DIST) & 7>{});
+    } else {  // this phase's fragments first, then the matrix pipe as the other half releases it
+      read_set(sc);
+      issue_psi(std::integral_constant<int, (s + 3 + DIST) & 7>{});
+      __builtin_amdgcn_sched_barrier(0);
+      mma_set(sc);
+    }
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WAITN) : "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+  };
+
+  // ---- prologue.  SCHED 0: half-tiles psi = 0 .. DIST in flight, psi 0 (b0 of K-tile 0) and 1 (a0) landed.
+  //               SCHED 1: psi = 0 .. 2 + F in flight, psi 0 .. 2 landed.
+  constexpr int NPRO = SCHED == 0 ? DIST + 1 : DIST + 3;
   issue_psi(std::integral_constant<int, 0>{});
   issue_psi(std::integral_constant<int, 1>{});
-  if constexpr (DIST >= 2) issue_psi(std::integral_constant<int, 2>{});
-  if constexpr (DIST >= 3) issue_psi(std::integral_constant<int, 3>{});
-  if constexpr (DIST >= 4) issue_psi(std::integral_constant<int, 4>{});
-  if constexpr (DIST >= 5) issue_psi(std::integral_constant<int, 5>{});
-  if constexpr (DIST >= 6) issue_psi(std::integral_constant<int, 6>{});
+  issue_psi(std::integral_constant<int, 2>{});
+  if constexpr (NPRO > 3) issue_psi(std::integral_constant<int, 3>{});
+  if constexpr (NPRO > 4) issue_psi(std::integral_constant<int, 4>{});
+  if constexpr (NPRO > 5) issue_psi(std::integral_constant<int, 5>{});
+  if constexpr (NPRO > 6) issue_psi(std::integral_constant<int, 6>{});
   asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(WAITN) : "memory");  // lgkmcnt: the bias image writes
   __builtin_amdgcn_sched_barrier(0);
   __builtin_amdgcn_s_barrier();
   __builtin_amdgcn_sched_barrier(0);
-  if constexpr (!(ABL & PP_ABL_NOREAD)) read_b(Wx, 0, 0);
-  __builtin_amdgcn_sched_barrier(0);
-  if constexpr (!(ABL & PP_ABL_NOSTAGGER)) {
-    if (wr == 1) __builtin_amdgcn_s_barrier();  // the second M-half runs one barrier behind the first
+  constexpr bool STAGGER = !(ABL & PP_ABL_NOSTAGGER);
+  if constexpr (SCHED == 0) {
+    if constexpr (!(ABL & PP_ABL_NOREAD)) read_b(Wx, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (STAGGER) {
+      if (wr == 1) __builtin_amdgcn_s_barrier();  // the second M-half runs one barrier behind the first
+    }
+    __builtin_amdgcn_sched_barrier(0);
   }
-  __builtin_amdgcn_sched_barrier(0);
 
+  auto run_tiles = [&](auto grpc) {
   for (int it = 0;; ++it) {
     const int L = it * G + bslot;
     if (L >= ntiles) break;
@@ -297,6 +401,40 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmArgs a) {
             "=&v"(bv[1][2]), "=&v"(bv[1][3])
           : "v"(baddr)
           : "memory");
+      // scratch addresses of this lane: MFMA layout (row = lane & 31) and coalesced layout (row = lane >> 2)
+      const uint32_t scr = (uint32_t)(PP_LDS_SCR + wave * 2048);
+      const uint32_t sf = (uint32_t)((l31 >> 2) & 3);
+      const uint32_t scr_m32 = scr + l31 * 64 + (((uint32_t)hi ^ sf) << 4);          // fp32 rounds: chunk 2 gg + hi -> ^ (gg * 32)
+      const uint32_t scr_c = scr + (lane >> 2) * 64 + ((((uint32_t)lane & 3) ^ (((uint32_t)lane >> 4) & 3)) << 4);
+      if constexpr (EPI == PP_RES && COAL) {
+        // residual tile by full-line loads (16 rows x 64 B per instruction), transposed into the C/D layout
+        // (the raw lines are parked in the accumulator registers they will be transposed into)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+              for (int x = 0; x < 2; ++x) {
+                const float4 t = *(const float4*)(a.xres + (size_t)(mw + i * 32 + x * 16 + (lane >> 2)) * MV_HIDDEN + nw + j * 32 + h * 16 + 4 * (lane & 3));
+                acc[i][j][4 * (2 * h + x) + 0] = t.x; acc[i][j][4 * (2 * h + x) + 1] = t.y;
+                acc[i][j][4 * (2 * h + x) + 2] = t.z; acc[i][j][4 * (2 * h + x) + 3] = t.w;
+              }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          u32x4 d[8], o[8];
+#pragma unroll
+          for (int q = 0; q < 8; ++q)  // q = (j, h, x): registers 4 q .. 4 q + 3 of fragment pair i
+#pragma unroll
+            for (int e = 0; e < 4; ++e) d[q][e] = f2u(acc[i][q >> 2][4 * (q & 3) + e]);
+          scr_f32x4(scr_c, scr_c + 1024, d, scr_m32, scr_m32 ^ 32u, o);
+#pragma unroll
+          for (int q = 0; q < 8; ++q)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[i][q >> 2][4 * (q & 3) + e] = u2f(o[q][e]) + ((const float*)&bv[q >> 2][q & 3])[e];
+        }
+      } else {
 #pragma unroll
       for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -312,6 +450,8 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmArgs a) {
               acc[i][j][4 * g + 2] = bv[j][g].z; acc[i][j][4 * g + 3] = bv[j][g].w;
             }
           }
+      }
+      (void)scr_m32; (void)scr_c;
     } else {  // lane = output column
       float b0, b1;
       const uint32_t baddr = (uint32_t)(PP_LDS_BIAS + (nw + l31) * 4);
@@ -328,15 +468,27 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmArgs a) {
         }
     }
 
+    if constexpr (SCHED == 1 && decltype(grpc)::value == 0) read_set(std::integral_constant<int, 0>{});
     for (int kt = 0; kt < nk; kt += 2) {
-      phase(std::integral_constant<int, 0>{});
-      phase(std::integral_constant<int, 1>{});
-      phase(std::integral_constant<int, 2>{});
-      phase(std::integral_constant<int, 3>{});
-      phase(std::integral_constant<int, 4>{});
-      phase(std::integral_constant<int, 5>{});
-      phase(std::integral_constant<int, 6>{});
-      phase(std::integral_constant<int, 7>{});
+      if constexpr (SCHED == 0) {
+        phase(std::integral_constant<int, 0>{});
+        phase(std::integral_constant<int, 1>{});
+        phase(std::integral_constant<int, 2>{});
+        phase(std::integral_constant<int, 3>{});
+        phase(std::integral_constant<int, 4>{});
+        phase(std::integral_constant<int, 5>{});
+        phase(std::integral_constant<int, 6>{});
+        phase(std::integral_constant<int, 7>{});
+      } else {
+        interval(std::integral_constant<int, 0>{}, grpc);
+        interval(std::integral_constant<int, 1>{}, grpc);
+        interval(std::integral_constant<int, 2>{}, grpc);
+        interval(std::integral_constant<int, 3>{}, grpc);
+        interval(std::integral_constant<int, 4>{}, grpc);
+        interval(std::integral_constant<int, 5>{}, grpc);
+        interval(std::integral_constant<int, 6>{}, grpc);
+        interval(std::integral_constant<int, 7>{}, grpc, kt + 2 >= nk);
+      }
     }
 
     // ---- epilogue (store only)
@@ -345,6 +497,88 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmArgs a) {
       for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) keep_live(acc[i][j]);
+    } else if constexpr (COAL) {
+      // ---- coalesced epilogue: every 32x32 fragment goes through the wave's [32][64 B] LDS image
+      const uint32_t scr = (uint32_t)(PP_LDS_SCR + wave * 2048);
+      const uint32_t sf = (uint32_t)((l31 >> 2) & 3);
+      const uint32_t scr_c = scr + (lane >> 2) * 64 + ((((uint32_t)lane & 3) ^ (((uint32_t)lane >> 4) & 3)) << 4);
+      const int crow = lane >> 2, cchunk = lane & 3;  // coalesced layout: row (+16 for the second read), 16-B chunk
+      if constexpr (EPI == PP_F32 || EPI == PP_RES) {
+        const uint32_t scr_m32 = scr + l31 * 64 + (((uint32_t)hi ^ sf) << 4);
+        float* obase = (EPI == PP_RES ? a.xres : a.outf) + (size_t)(mw + crow) * a.N + nw + 4 * cchunk;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          u32x4 d[8], o[8];
+#pragma unroll
+          for (int q = 0; q < 8; ++q)  // q = (j, h, gg): C/D registers 4 q .. 4 q + 3 of fragment pair i
+#pragma unroll
+            for (int e = 0; e < 4; ++e) d[q][e] = f2u(acc[i][q >> 2][4 * (q & 3) + e]);
+          scr_f32x4(scr_m32, scr_m32 ^ 32u, d, scr_c, scr_c + 1024, o);
+#pragma unroll
+          for (int q = 0; q < 8; ++q) {  // q = (j, h, x): rows 16 x + crow, columns 32 j + 16 h + 4 cchunk
+            float* op = obase + (size_t)(i * 32 + (q & 1) * 16) * a.N + (q >> 2) * 32 + ((q >> 1) & 1) * 16;
+            *(u32x4*)op = o[q];
+          }
+        }
+      } else {
+        // fp16 outputs: 8-B units (4 values) of the C/D layout -> chunk g, half hi of the row
+        const uint32_t wbase = scr + l31 * 64 + hi * 8 + (sf << 4);
+        half_t* obase;    // pointer of (row crow, chunk cchunk) of fragment (i = 0, j = 0)
+        size_t rstride;   // elements between image rows in the output
+        size_t istride;   // elements between i blocks (32 C/D rows along the register axis or the lane axis)
+        size_t jstride;   // elements between j blocks
+        bool live = true;
+        if constexpr (EPI == PP_F16 || EPI == PP_GELU) {
+          obase = a.out16 + (size_t)(mw + crow) * a.N + nw + 8 * cchunk;
+          rstride = a.N; istride = (size_t)32 * a.N; jstride = 32;
+        } else if constexpr (EPI == PP_QK) {  // one head per wave; S % 64 == 0 so a 128-row block may span two batch rows
+          const int which = nw >= MV_HIDDEN;
+          const int head = (nw - which * MV_HIDDEN) >> 6;
+          obase = (which ? a.k : a.q) + (size_t)head * a.S * MV_HEAD_DIM + (size_t)crow * MV_HEAD_DIM + 8 * cchunk;
+          rstride = MV_HEAD_DIM; istride = 0; jstride = 32;  // the batch-row part is added per i below
+        } else {  // PP_VT: image rows = head dims, image columns = tokens
+          const int head = nw >> 6;
+          obase = a.vt + ((size_t)head * MV_HEAD_DIM + crow) * a.S + 8 * cchunk;
+          rstride = a.S; istride = 0; jstride = (size_t)32 * a.S;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int mb = mw + i * 32;
+          half_t* ob = obase + i * istride;
+          if constexpr (EPI == PP_QK || EPI == PP_VT) {
+            live = mb < a.Mreal;
+            const int b = mb / a.S, s0 = mb - b * a.S;
+            if constexpr (EPI == PP_QK) ob = obase + ((size_t)b * MV_HEADS * a.S + s0) * MV_HEAD_DIM;
+            else ob = obase + (size_t)b * MV_HEADS * MV_HEAD_DIM * a.S + s0;
+          }
+          u32x2 d[2][4];
+          u32x4 o[4];
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+              float v0 = acc[i][j][4 * g + 0], v1 = acc[i][j][4 * g + 1], v2 = acc[i][j][4 * g + 2], v3 = acc[i][j][4 * g + 3];
+              if constexpr (EPI == PP_GELU) {
+                float2_t a01, a23;
+                a01.x = v0; a01.y = v1; a23.x = v2; a23.y = v3;
+                a01 = gelu_erf2(a01);
+                a23 = gelu_erf2(a23);
+                v0 = a01.x; v1 = a01.y; v2 = a23.x; v3 = a23.y;
+              }
+              d[j][g][0] = pack_h2(v0, v1);
+              d[j][g][1] = pack_h2(v2, v3);
+            }
+          scr_f16x2(wbase, wbase ^ 16u, wbase ^ 32u, wbase ^ 48u, d[0], d[1], scr_c, o);
+          if (live) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+              half_t* op = ob + j * jstride;
+              *(u32x4*)op = o[2 * j];
+              *(u32x4*)(op + 16 * rstride) = o[2 * j + 1];
+            }
+          }
+        }
+      }
     } else {
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
@@ -390,8 +624,17 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmArgs a) {
     }
   }
 
+  };  // run_tiles
+  if constexpr (SCHED == 1 && STAGGER) {
+    if (wr == 0) run_tiles(std::integral_constant<int, 0>{});
+    else run_tiles(std::integral_constant<int, 1>{});
+  } else {
+    run_tiles(std::integral_constant<int, 1>{});
+  }
+
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // no LDS-DMA may outlive the workgroup's LDS allocation
-  if constexpr (!(ABL & PP_ABL_NOSTAGGER)) {
+  if (a.clk && tid == 0) a.clk[blockIdx.x] = __builtin_amdgcn_s_memtime() - clk0;
+  if constexpr (SCHED == 0 && STAGGER) {
     if (wr == 0) __builtin_amdgcn_s_barrier();
   }
 }

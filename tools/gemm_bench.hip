@@ -85,9 +85,10 @@ void run_old(GemmArgs a) {
   a.GN = choose_gn(a.N / 256, 4);
   hipLaunchKernelGGL((gemm256_kernel<EPI>), dim3((a.M / 256) * (a.N / 256)), dim3(512), G256_LDS_BYTES, st, a);
 }
-template <int EPI, int DIST, int ABL>
+static int g_grid_override = 0;
+template <int EPI, int DIST, int ABL, int SCHED = 0, int COAL = 0>
 void run_pp(GemmArgs a) {
-  auto kern = gemm_pp_kernel<EPI, DIST, ABL>;
+  auto kern = gemm_pp_kernel<EPI, DIST, ABL, SCHED, COAL>;
   static bool attr = false;
   if (!attr) {
     CK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS_BYTES));
@@ -95,7 +96,7 @@ void run_pp(GemmArgs a) {
   }
   a.GN = choose_gn(a.N / 256, 4);
   const int tiles = (a.M / 256) * (a.N / 256);
-  hipLaunchKernelGGL(kern, dim3(std::min(tiles, NCU)), dim3(512), PP_LDS_BYTES, st, a);
+  hipLaunchKernelGGL(kern, dim3(g_grid_override ? g_grid_override : std::min(tiles, NCU)), dim3(512), PP_LDS_BYTES, st, a);
 }
 
 struct Variant {
@@ -200,18 +201,34 @@ int main(int argc, char** argv) {
     ok &= compare("f32 N2304 K768 D2", of_ref, of_new, (size_t)M * 2304, 1e-4f);
     CK(hipMemsetAsync(of_new, 0xff, (size_t)M * 2304 * 4, st)); run_pp<PP_F32, 6, PP_ABL_NOSTAGGER>(g);
     ok &= compare("f32 N2304 K768 D6 nostagger", of_ref, of_new, (size_t)M * 2304, 1e-4f);
+    CK(hipMemsetAsync(of_new, 0xff, (size_t)M * 2304 * 4, st)); run_pp<PP_F32, 4, 0, 1>(g);
+    ok &= compare("f32 N2304 K768 S1 F4", of_ref, of_new, (size_t)M * 2304, 1e-4f);
+    CK(hipMemsetAsync(of_new, 0xff, (size_t)M * 2304 * 4, st)); run_pp<PP_F32, 4, 0, 1, 1>(g);
+    ok &= compare("f32 N2304 K768 S1 F4 COAL", of_ref, of_new, (size_t)M * 2304, 1e-4f);
+    CK(hipMemsetAsync(of_new, 0xff, (size_t)M * 2304 * 4, st)); run_pp<PP_F32, 3, 0, 1>(g);
+    ok &= compare("f32 N2304 K768 S1 F3", of_ref, of_new, (size_t)M * 2304, 1e-4f);
+    CK(hipMemsetAsync(of_new, 0xff, (size_t)M * 2304 * 4, st)); run_pp<PP_F32, 2, 0, 1>(g);
+    ok &= compare("f32 N2304 K768 S1 F2", of_ref, of_new, (size_t)M * 2304, 1e-4f);
+    CK(hipMemsetAsync(of_new, 0xff, (size_t)M * 2304 * 4, st)); run_pp<PP_F32, 4, PP_ABL_NOSTAGGER, 1>(g);
+    ok &= compare("f32 N2304 K768 S1 F4 nostagger", of_ref, of_new, (size_t)M * 2304, 1e-4f);
   }
   {  // F32, N=768 K=3072
     GemmArgs g = base(A3072, W2, 768, 3072);
     g.outf = of_ref; run_old<EPI_F32>(g);
     g.outf = of_new; CK(hipMemsetAsync(of_new, 0xff, (size_t)M * 768 * 4, st)); run_pp<PP_F32, 6, 0>(g);
     ok &= compare("f32 N768 K3072 D6", of_ref, of_new, (size_t)M * 768, 1e-4f);
+    CK(hipMemsetAsync(of_new, 0xff, (size_t)M * 768 * 4, st)); run_pp<PP_F32, 4, 0, 1>(g);
+    ok &= compare("f32 N768 K3072 S1 F4", of_ref, of_new, (size_t)M * 768, 1e-4f);
   }
   {  // GELU
     GemmArgs g = base(A768, W1, 3072, 768);
     g.out16 = o16_ref; run_old<EPI_GELU>(g);
     g.out16 = o16_new; CK(hipMemsetAsync(o16_new, 0xff, (size_t)M * 3072 * 2, st)); run_pp<PP_GELU, 6, 0>(g);
     ok &= compare("gelu N3072 K768 D6", o16_ref, o16_new, (size_t)M * 3072, 2e-3f);
+    CK(hipMemsetAsync(o16_new, 0xff, (size_t)M * 3072 * 2, st)); run_pp<PP_GELU, 4, 0, 1>(g);
+    ok &= compare("gelu N3072 K768 S1 F4", o16_ref, o16_new, (size_t)M * 3072, 2e-3f);
+    CK(hipMemsetAsync(o16_new, 0xff, (size_t)M * 3072 * 2, st)); run_pp<PP_GELU, 4, 0, 1, 1>(g);
+    ok &= compare("gelu N3072 K768 S1 F4 COAL", o16_ref, o16_new, (size_t)M * 3072, 2e-3f);
   }
   {  // RES (both K)
     GemmArgs g = base(A768, Wo, 768, 768);
@@ -226,6 +243,12 @@ int main(int argc, char** argv) {
     h.xres = xr_ref; run_old<EPI_RES>(h);
     h.xres = xr_new; run_pp<PP_RES, 6, 0>(h);
     ok &= compare("res N768 K3072 D6", xr_ref, xr_new, (size_t)M * 768, 1e-4f);
+    CK(hipMemcpyAsync(xr_new, xr_src, (size_t)M * 768 * 4, hipMemcpyDeviceToDevice, st));
+    h.xres = xr_new; run_pp<PP_RES, 4, 0, 1>(h);
+    ok &= compare("res N768 K3072 S1 F4", xr_ref, xr_new, (size_t)M * 768, 1e-4f);
+    CK(hipMemcpyAsync(xr_new, xr_src, (size_t)M * 768 * 4, hipMemcpyDeviceToDevice, st));
+    h.xres = xr_new; run_pp<PP_RES, 4, 0, 1, 1>(h);
+    ok &= compare("res N768 K3072 S1 F4 COAL", xr_ref, xr_new, (size_t)M * 768, 1e-4f);
   }
   {  // QKV
     GemmArgs g = base(A768, Wqkv, 2304, 768);
@@ -238,6 +261,11 @@ int main(int argc, char** argv) {
     ok &= compare("qkv q", q_ref, q_new, qn, 2e-3f);
     ok &= compare("qkv k", k_ref, k_new, qn, 2e-3f);
     ok &= compare("qkv vt", vt_ref, vt_new, qn, 2e-3f);
+    CK(hipMemsetAsync(q_new, 0xff, qn * 2, st)); CK(hipMemsetAsync(k_new, 0xff, qn * 2, st)); CK(hipMemsetAsync(vt_new, 0xff, qn * 2, st));
+    run_pp<PP_QK, 4, 0, 1, 1>(a1); run_pp<PP_VT, 4, 0, 1, 1>(a2);
+    ok &= compare("qkv q S1 COAL", q_ref, q_new, qn, 2e-3f);
+    ok &= compare("qkv k S1 COAL", k_ref, k_new, qn, 2e-3f);
+    ok &= compare("qkv vt S1 COAL", vt_ref, vt_new, qn, 2e-3f);
   }
   printf("CORRECTNESS %s\n", ok ? "ALL OK" : "FAILED");
   if (js) fprintf(js, "{\"correct\":%s}\n", ok ? "true" : "false");
@@ -249,19 +277,13 @@ int main(int argc, char** argv) {
     const double fl = 2.0 * M * 3072.0 * 768.0;
     std::vector<Variant> vs;
     vs.push_back({"old256 gelu", fl, [=] { run_old<EPI_GELU>(g); }, {}});
-    vs.push_back({"pp gelu D6", fl, [=] { run_pp<PP_GELU, 6, 0>(g); }, {}});
-    vs.push_back({"pp gelu D4", fl, [=] { run_pp<PP_GELU, 4, 0>(g); }, {}});
-    vs.push_back({"pp gelu D2", fl, [=] { run_pp<PP_GELU, 2, 0>(g); }, {}});
-    vs.push_back({"pp f16 D6 (no gelu)", fl, [=] { run_pp<PP_F16, 6, 0>(g); }, {}});
-    vs.push_back({"pp gelu D6 noprio", fl, [=] { run_pp<PP_GELU, 6, PP_ABL_NOPRIO>(g); }, {}});
-    vs.push_back({"pp gelu D6 nostagger", fl, [=] { run_pp<PP_GELU, 6, PP_ABL_NOSTAGGER>(g); }, {}});
-    vs.push_back({"pp gelu D6 ABL noepi", fl, [=] { run_pp<PP_GELU, 6, PP_ABL_NOEPI>(g); }, {}});
-    vs.push_back({"pp gelu D6 ABL nodma", fl, [=] { run_pp<PP_GELU, 6, PP_ABL_NODMA>(g); }, {}});
-    vs.push_back({"pp gelu D6 ABL nomfma", fl, [=] { run_pp<PP_GELU, 6, PP_ABL_NOMFMA>(g); }, {}});
-    vs.push_back({"pp gelu D6 ABL noread", fl, [=] { run_pp<PP_GELU, 6, PP_ABL_NOREAD>(g); }, {}});
-    vs.push_back({"pp D6 ABL nomfma+noread+noepi", fl, [=] { run_pp<PP_GELU, 6, 14>(g); }, {}});
-    vs.push_back({"pp D6 ABL nodma+noepi", fl, [=] { run_pp<PP_GELU, 6, 9>(g); }, {}});
-    vs.push_back({"pp D6 ABL nodma+noread+noepi", fl, [=] { run_pp<PP_GELU, 6, 13>(g); }, {}});
+    vs.push_back({"pp S0 D6 gelu", fl, [=] { run_pp<PP_GELU, 6, 0>(g); }, {}});
+    vs.push_back({"pp S1 F4 gelu", fl, [=] { run_pp<PP_GELU, 4, 0, 1>(g); }, {}});
+    vs.push_back({"pp S1 F4 gelu COAL", fl, [=] { run_pp<PP_GELU, 4, 0, 1, 1>(g); }, {}});
+    vs.push_back({"pp S0 D6 gelu COAL", fl, [=] { run_pp<PP_GELU, 6, 0, 0, 1>(g); }, {}});
+    vs.push_back({"pp S1 F4 f16 (no gelu)", fl, [=] { run_pp<PP_F16, 4, 0, 1>(g); }, {}});
+    vs.push_back({"pp S1 F4 f16 COAL", fl, [=] { run_pp<PP_F16, 4, 0, 1, 1>(g); }, {}});
+    vs.push_back({"pp S1 F4 ABL noepi", fl, [=] { run_pp<PP_GELU, 4, PP_ABL_NOEPI, 1>(g); }, {}});
     time_group("ffn1 M x3072 x768 (gelu)", vs, rounds, reps, js);
   }
   {
@@ -275,6 +297,8 @@ int main(int argc, char** argv) {
     std::vector<Variant> vs;
     vs.push_back({"old256 qkv", fl, [=] { run_old<EPI_QKV>(g); }, {}});
     vs.push_back({"pp qk+vt D6", fl, [=] { run_pp<PP_QK, 6, 0>(a1); run_pp<PP_VT, 6, 0>(a2); }, {}});
+    vs.push_back({"pp S1 F4 qk+vt", fl, [=] { run_pp<PP_QK, 4, 0, 1>(a1); run_pp<PP_VT, 4, 0, 1>(a2); }, {}});
+    vs.push_back({"pp S1 F4 qk+vt COAL", fl, [=] { run_pp<PP_QK, 4, 0, 1, 1>(a1); run_pp<PP_VT, 4, 0, 1, 1>(a2); }, {}});
     vs.push_back({"pp qk only D6 (2/3 flops)", fl * 2 / 3, [=] { run_pp<PP_QK, 6, 0>(a1); }, {}});
     vs.push_back({"pp vt only D6 (1/3 flops)", fl / 3, [=] { run_pp<PP_VT, 6, 0>(a2); }, {}});
     time_group("qkv M x2304 x768", vs, rounds, reps, js);
@@ -286,7 +310,8 @@ int main(int argc, char** argv) {
     std::vector<Variant> vs;
     vs.push_back({"old256 res", fl, [=] { run_old<EPI_RES>(g); }, {}});
     vs.push_back({"pp res D6", fl, [=] { run_pp<PP_RES, 6, 0>(g); }, {}});
-    vs.push_back({"pp res D4", fl, [=] { run_pp<PP_RES, 4, 0>(g); }, {}});
+    vs.push_back({"pp S1 F4 res", fl, [=] { run_pp<PP_RES, 4, 0, 1>(g); }, {}});
+    vs.push_back({"pp S1 F4 res COAL", fl, [=] { run_pp<PP_RES, 4, 0, 1, 1>(g); }, {}});
     time_group("attn-out M x768 x768 (res)", vs, rounds, reps, js);
   }
   {
@@ -296,8 +321,62 @@ int main(int argc, char** argv) {
     std::vector<Variant> vs;
     vs.push_back({"old256 res", fl, [=] { run_old<EPI_RES>(g); }, {}});
     vs.push_back({"pp res D6", fl, [=] { run_pp<PP_RES, 6, 0>(g); }, {}});
-    vs.push_back({"pp res D4", fl, [=] { run_pp<PP_RES, 4, 0>(g); }, {}});
+    vs.push_back({"pp S1 F4 res", fl, [=] { run_pp<PP_RES, 4, 0, 1>(g); }, {}});
+    vs.push_back({"pp S1 F4 res COAL", fl, [=] { run_pp<PP_RES, 4, 0, 1, 1>(g); }, {}});
     time_group("ffn2 M x768 x3072 (res)", vs, rounds, reps, js);
+  }
+  {  // per-tile time of one workgroup as a function of how many workgroups run (memory-burst contention)
+    GemmArgs g = base(A768, W1, 3072, 768);
+    g.out16 = o16_new;
+    GemmArgs r = base(A768, Wo, 768, 768);
+    r.xres = xr_new;
+    GemmArgs r2 = base(A3072, W2, 768, 3072);
+    r2.xres = xr_new;
+    for (int grid : {256, 64, 8}) {
+      std::vector<Variant> vs;
+      const double fl = 2.0 * M * 3072.0 * 768.0;
+      auto G = [grid](std::function<void()> f) { return [=] { g_grid_override = grid; f(); g_grid_override = 0; }; };
+      vs.push_back({"gelu S1F4 COAL", fl, G([=] { run_pp<PP_GELU, 4, 0, 1, 1>(g); }), {}});
+      vs.push_back({"f16 S1F4 COAL", fl, G([=] { run_pp<PP_F16, 4, 0, 1, 1>(g); }), {}});
+      vs.push_back({"noepi S1F4", fl, G([=] { run_pp<PP_GELU, 4, PP_ABL_NOEPI, 1>(g); }), {}});
+      vs.push_back({"res K768 S1F4 COAL", 2.0 * M * 768.0 * 768.0, G([=] { run_pp<PP_RES, 4, 0, 1, 1>(r); }), {}});
+      vs.push_back({"res K3072 S1F4 COAL", 2.0 * M * 768.0 * 3072.0, G([=] { run_pp<PP_RES, 4, 0, 1, 1>(r2); }), {}});
+      char title[64];
+      snprintf(title, sizeof title, "grid=%d (us x grid/256 = per-256-normalised)", grid);
+      time_group(title, vs, 2, 1, js);
+    }
+  }
+  {  // effective shader clock: s_memtime ticks of each workgroup's whole run / wall time of the launch
+    unsigned long long* dclk;
+    CK(hipMalloc(&dclk, 256 * 8));
+    GemmArgs g = base(A768, W1, 3072, 768);
+    g.out16 = o16_new;
+    g.clk = dclk;
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    for (int grid : {256, 64, 8}) {
+      for (int which = 0; which < 3; ++which) {
+        g_grid_override = grid;
+        CK(hipMemsetAsync(dclk, 0, 256 * 8, st));
+        for (int rep = 0; rep < 3; ++rep) {
+          if (rep == 2) CK(hipEventRecord(e0, st));
+          if (which == 0) run_pp<PP_GELU, 4, PP_ABL_NOEPI, 1>(g);
+          else if (which == 1) run_pp<PP_GELU, 4, 0, 1>(g);
+          else run_pp<PP_GELU, 4, 13, 1>(g);
+          if (rep == 2) CK(hipEventRecord(e1, st));
+        }
+        CK(hipEventSynchronize(e1));
+        g_grid_override = 0;
+        float ms;
+        CK(hipEventElapsedTime(&ms, e0, e1));
+        std::vector<unsigned long long> hc(256);
+        CK(hipMemcpy(hc.data(), dclk, 256 * 8, hipMemcpyDeviceToHost));
+        double sum = 0, mx = 0;
+        for (int i = 0; i < grid; ++i) { sum += (double)hc[i]; mx = std::max(mx, (double)hc[i]); }
+        printf("CLOCK grid=%3d %-22s wall %8.1f us  ticks avg %.0f max %.0f  -> %.3f GHz (max ticks / wall)\n", grid,
+               which == 0 ? "noepi" : which == 1 ? "gelu" : "mfma-only skeleton", ms * 1e3, sum / grid, mx, mx / (ms * 1e-3) / 1e9);
+      }
+    }
   }
   if (js) fclose(js);
   return ok ? 0 : 1;
