@@ -131,8 +131,12 @@ int mv_corpus_results(mv_handle* h, int64_t first, int64_t count, float* best, i
 /* ---- measurement / test hooks ---------------------------------------------------------------- */
 
 /* Per-kernel-class HIP-event timing on the engine's own stream. Classes: see mv_kernel_class_name. */
-#define MV_NUM_KERNEL_CLASSES 12
+#define MV_NUM_KERNEL_CLASSES 14
 int mv_profile_enable(mv_handle* h, int on);
+/* Restrict the events to the classes whose bit is set (default: all).  bench.py times its K steps with events
+ * on the dominant GEMM class only (the `roofline` figure) and takes the full breakdown in a separate pass, so
+ * the timed region carries ~12 event pairs per step instead of ~90. */
+int mv_profile_select(mv_handle* h, uint32_t class_mask);
 /* Synchronises, adds up the recorded launches since the last read: ms[c], launches[c]; then clears. */
 int mv_profile_read(mv_handle* h, double* ms, int64_t* launches, int n);
 const char* mv_kernel_class_name(int cls);

@@ -15,14 +15,14 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libmemvul_hip.so")
 
 MV_F32, MV_F16, MV_BF16, MV_I32, MV_I64 = 0, 1, 2, 3, 4
-NUM_KERNEL_CLASSES = 12
+NUM_KERNEL_CLASSES = 14
 
 # every symbol include/memvul_hip.h declares (tests check the .so exports all of them)
 ABI_SYMBOLS = [
     "mv_create", "mv_destroy", "mv_last_error", "mv_sync", "mv_load_tensor", "mv_finalize_weights",
     "mv_anchor_reset", "mv_anchor_append", "mv_anchor_count", "mv_anchor_get", "mv_anchor_set",
     "mv_forward", "mv_encode", "mv_match", "mv_topk", "mv_corpus_upload", "mv_corpus_run",
-    "mv_corpus_results", "mv_profile_enable", "mv_profile_read", "mv_kernel_class_name",
+    "mv_corpus_results", "mv_profile_enable", "mv_profile_select", "mv_profile_read", "mv_kernel_class_name",
     "mv_debug_encode", "mv_debug_read", "mv_test_gemm",
 ]
 
@@ -77,6 +77,7 @@ def load_library(path: Optional[str] = None):
         "mv_corpus_run": (C.c_int, [vp, C.c_int64, C.c_int64, C.c_int, C.c_int]),
         "mv_corpus_results": (C.c_int, [vp, C.c_int64, C.c_int64, vp, vp, vp]),
         "mv_profile_enable": (C.c_int, [vp, C.c_int]),
+        "mv_profile_select": (C.c_int, [vp, C.c_uint32]),
         "mv_profile_read": (C.c_int, [vp, P(C.c_double), P(C.c_int64), C.c_int]),
         "mv_kernel_class_name": (C.c_char_p, [C.c_int]),
         "mv_debug_encode": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, C.c_int]),
@@ -235,6 +236,17 @@ class Engine:
     # -- measurement / debug
     def profile_enable(self, on: bool = True):
         self._check(self._lib.mv_profile_enable(self._h, int(on)), "mv_profile_enable")
+
+    def profile_select(self, names=None):
+        """Restrict HIP-event recording to the named kernel classes (None = all)."""
+        if names is None:
+            mask = 0xFFFFFFFF
+        else:
+            all_names = [self._lib.mv_kernel_class_name(i).decode() for i in range(NUM_KERNEL_CLASSES)]
+            mask = 0
+            for nm in names:
+                mask |= 1 << all_names.index(nm)
+        self._check(self._lib.mv_profile_select(self._h, mask), "mv_profile_select")
 
     def profile_read(self) -> Dict[str, Tuple[float, int]]:
         ms = (C.c_double * NUM_KERNEL_CLASSES)()

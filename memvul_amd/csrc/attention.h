@@ -166,3 +166,75 @@ __global__ __launch_bounds__(NW * 64, 2) void attention_kernel(AttnArgs a) {
       *(half4_t*)(dst + dt * 32 + 8 * rg + 4 * hi) = v4;
     }
 }
+
+// Last encoder layer: only the [CLS] query (token 0) of each issue report is consumed downstream
+// (BertPooler takes hidden[:, 0], model_memory.py:99), so its attention is one query row per (batch row, head):
+// scores over the S keys, softmax, one V^T-weighted sum.  One wave per (b, h); HBM-bound (reads the layer's K and
+// V^T once: 2 x B x 12 x S x 128 B).  Numerics mirror attention_kernel: fp16 q, k, v and fp16-rounded P, fp32
+// scores / statistics / accumulation, additive -10000 on padded keys.
+// q: [Bpad][768] fp32 (the Q projection of the gathered [CLS] rows, 1/8 already folded into W_q), ctx: [Bpad][768] fp16.
+__global__ __launch_bounds__(256) void attention_cls_kernel(const float* __restrict__ q, const half_t* __restrict__ k,
+                                                            const half_t* __restrict__ vt, const int32_t* __restrict__ lens,
+                                                            half_t* __restrict__ ctx, int S, int nbh) {
+  __shared__ float ps[4][512];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int bh = blockIdx.x * 4 + wave;
+  if (bh >= nbh) return;  // no workgroup barrier below: waves are independent
+  const int b = bh / MV_HEADS, h = bh - b * MV_HEADS;
+  const int len = lens[b];
+  // every lane holds the whole fp16-rounded query (64 values, broadcast loads)
+  float qv[64];
+  {
+    const float4* qp = (const float4*)(q + (size_t)b * MV_HIDDEN + h * MV_HEAD_DIM);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const float4 t = qp[i];
+      qv[4 * i + 0] = (float)(half_t)t.x; qv[4 * i + 1] = (float)(half_t)t.y;
+      qv[4 * i + 2] = (float)(half_t)t.z; qv[4 * i + 3] = (float)(half_t)t.w;
+    }
+  }
+  const half_t* kb = k + (size_t)bh * S * MV_HEAD_DIM;
+  float sc[8];
+  float mx = -3.0e38f;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int key = lane + 64 * j;
+    sc[j] = -3.0e38f;
+    if (key < S) {
+      const half8_t* kr = (const half8_t*)(kb + (size_t)key * MV_HEAD_DIM);
+      float s = 0.f;
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        const half8_t kk = kr[c];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s = __builtin_fmaf(qv[8 * c + e], (float)kk[e], s);
+      }
+      if (key >= len) s += -10000.0f;
+      sc[j] = s;
+      mx = fmaxf(mx, s);
+    }
+  }
+  mx = wave_max(mx);
+  float psum = 0.f;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int key = lane + 64 * j;
+    if (key < S) {
+      const float p = __expf(sc[j] - mx);
+      psum += p;
+      ps[wave][key] = (float)(half_t)p;
+    }
+  }
+  const float inv = 1.0f / wave_sum(psum);
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  // lane = head dim d: o[d] = sum_key P[key] V^T[d][key]
+  const half_t* vr = vt + ((size_t)bh * MV_HEAD_DIM + lane) * S;
+  float o = 0.f;
+  for (int kc = 0; kc < S; kc += 8) {
+    const half8_t vv = *(const half8_t*)(vr + kc);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o = __builtin_fmaf(ps[wave][kc + e], (float)vv[e], o);
+  }
+  ctx[(size_t)b * MV_HIDDEN + h * MV_HEAD_DIM + lane] = (half_t)(o * inv);
+}

@@ -22,11 +22,11 @@ namespace {
 
 enum KernelClass {
   KC_EMBED_LN = 0, KC_GEMM_QKV, KC_ATTENTION, KC_GEMM_OUT, KC_LN, KC_GEMM_FFN1, KC_GEMM_FFN2,
-  KC_POOL_HEAD, KC_MATCH, KC_TOPK, KC_TEST_GEMM, KC_OTHER
+  KC_POOL_HEAD, KC_MATCH, KC_TOPK, KC_TEST_GEMM, KC_OTHER, KC_GEMM_KV_LAST, KC_CLS_TAIL
 };
 const char* kKernelClassNames[MV_NUM_KERNEL_CLASSES] = {
     "embed_ln", "gemm_qkv", "attention", "gemm_attn_out", "layernorm", "gemm_ffn1_gelu", "gemm_ffn2",
-    "pool_head", "match", "topk", "test_gemm", "other"};
+    "pool_head", "match", "topk", "test_gemm", "other", "gemm_kv_last", "cls_tail"};
 
 thread_local std::string g_create_error;
 
@@ -137,7 +137,16 @@ struct mv_handle {
   int64_t c_psame_rows = 0;
   int c_G = 0;
 
+  // last-layer pruning ([CLS] rows only after the last layer's K / V projection) and its compact buffers
+  bool cls_prune = true;   // env MEMVUL_CLS_PRUNE=0 disables
+  float *c32 = nullptr, *cq = nullptr;
+  half_t *c16 = nullptr, *cctx = nullptr, *ch16 = nullptr;
+  // LayerNorm folded into the consumer's residual read (gemm_pp PP_RESLN); env MEMVUL_LN_FUSE=0 disables
+  bool ln_fuse = true;
+  float *lnstats = nullptr, *ones = nullptr, *zeros = nullptr;
+
   // profiling
+  uint32_t prof_mask = 0xffffffffu;  // kernel classes that get HIP events while profiling is on
   bool prof = false;
   std::vector<ProfRec> recs;
   std::vector<hipEvent_t> free_events;
@@ -201,7 +210,7 @@ struct ProfScope {
   mv_handle* h;
   ProfRec rec;
   bool on;
-  ProfScope(mv_handle* h_, int cls) : h(h_), on(h_->prof) {
+  ProfScope(mv_handle* h_, int cls) : h(h_), on(h_->prof && ((h_->prof_mask >> cls) & 1u)) {
     if (on) {
       rec.cls = cls;
       rec.e0 = get_event(h);
@@ -289,17 +298,20 @@ template <int EPI>
 int launch_pp(mv_handle* h, int cls, const GemmArgs& a) {
   ProfScope ps(h, cls);
   if constexpr (EPI == EPI_QKV) {  // Q,K columns (row-per-lane stores) and the V^T block (token-contiguous stores)
+    // a.col0 = 768: a.W / a.bias already point at the K block and the launch covers K, V only (last-layer pruning)
+    const int qk_cols = (a.col0 ? 1 : 2) * MV_HIDDEN;
     GemmArgs qk = a;
-    qk.N = 2 * MV_HIDDEN;
+    qk.N = qk_cols;
     if (int rc = launch_pp_raw<PP_QK>(h, qk)) return rc;
     GemmArgs v = a;
-    v.W = a.W + (size_t)2 * MV_HIDDEN * a.K;
-    v.bias = a.bias ? a.bias + 2 * MV_HIDDEN : nullptr;
+    v.W = a.W + (size_t)qk_cols * a.K;
+    v.bias = a.bias ? a.bias + qk_cols : nullptr;
     v.N = MV_HIDDEN;
     return launch_pp_raw<PP_VT>(h, v);
   } else if constexpr (EPI == EPI_GELU) {
     return launch_pp_raw<PP_GELU>(h, a);
   } else if constexpr (EPI == EPI_RES) {
+    if (a.lnstats) return launch_pp_raw<PP_RESLN>(h, a);
     return launch_pp_raw<PP_RES>(h, a);
   } else {
     return launch_pp_raw<PP_F32>(h, a);
@@ -307,18 +319,29 @@ int launch_pp(mv_handle* h, int cls, const GemmArgs& a) {
 }
 
 // path choice: the persistent kernels need enough 256^2 tiles to fill the CUs (one workgroup each)
+bool pp_selected(const mv_handle* h, int64_t M, int N, int K) {
+  const bool tile256 = (M % 256 == 0) && (N % 256 == 0);
+  const bool big = tile256 && ((M / 256) * (N / 256) >= 256);
+  const bool pp_ok = tile256 && (K % 128 == 0) && N <= MV_INTER;
+  return pp_ok && (h->gemm_tile == 512 || (h->gemm_tile == 0 && big));
+}
+
 template <int EPI>
 int launch_gemm(mv_handle* h, int cls, const GemmArgs& a) {
   const bool tile256 = (a.M % 256 == 0) && (a.N % 256 == 0);
   const bool big = tile256 && ((int64_t)(a.M / 256) * (a.N / 256) >= 256);
-  const bool pp_ok = tile256 && (a.K % 128 == 0) && a.N <= MV_INTER;
-  if (pp_ok && (h->gemm_tile == 512 || (h->gemm_tile == 0 && big))) return launch_pp<EPI>(h, cls, a);
+  if (pp_selected(h, a.M, a.N, a.K)) return launch_pp<EPI>(h, cls, a);
+  if (a.lnstats) return fail(h, MV_ERR_STATE, "internal: LayerNorm-fused residual requested on a non-persistent GEMM path");
   if (tile256 && (h->gemm_tile == 256 || (h->gemm_tile == 0 && big))) return launch_gemm256<EPI>(h, cls, a);
   return launch_gemm128<EPI, true>(h, cls, a);
 }
 
 // ---- encoder: ids (device) -> u (device, [B][512]); stops after n_layers (<0: all) ------------
-int encode_dev(mv_handle* h, const int32_t* d_ids, const int32_t* d_lens, int B, int S_in, int n_layers, float* u_out) {
+// `full`: every layer over every token and the normalised fp32 stream left in xres (debug taps); otherwise the
+// last layer is pruned to the [CLS] rows when the pooler follows (cls_prune), and on the persistent-GEMM path the
+// LayerNorm kernels write only the fp16 operand + row statistics, the residual consumers normalise (ln_fuse).
+int encode_dev(mv_handle* h, const int32_t* d_ids, const int32_t* d_lens, int B, int S_in, int n_layers, float* u_out,
+               bool full = false) {
   const mv_config& c = h->cfg;
   const int Sp = (int)round_up(S_in, 64);
   const int64_t M = (int64_t)B * Sp, Mpad = round_up(M, 256);
@@ -327,19 +350,71 @@ int encode_dev(mv_handle* h, const int32_t* d_ids, const int32_t* d_lens, int B,
   if (n_layers < 0 || n_layers > c.layers) n_layers = c.layers;
   h->dbg_B = B;
   h->dbg_Sp = Sp;
+  const bool prune = !full && h->cls_prune && u_out && n_layers == c.layers && n_layers > 0;
+  // both residual GEMMs have N = 768 and K % 128 == 0: one predicate decides the path of every RES launch of this pass
+  const bool fuse = !full && h->ln_fuse && pp_selected(h, Mpad, MV_HIDDEN, MV_HIDDEN);
+  const unsigned ln_grid = (unsigned)((M + 3) / 4);
   {
     ProfScope ps(h, KC_EMBED_LN);
-    hipLaunchKernelGGL(embed_ln_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, h->stream, d_ids, S_in, Sp, (int)M,
-                       c.vocab_size, h->wemb, h->pemb, h->temb, h->embg, h->embb, c.ln_eps, h->xres, h->x16);
+    hipLaunchKernelGGL(embed_ln_kernel, dim3(ln_grid), dim3(256), 0, h->stream, d_ids, S_in, Sp, (int)M,
+                       c.vocab_size, h->wemb, h->pemb, h->temb, h->embg, h->embb, c.ln_eps, h->xres, h->x16,
+                       fuse ? h->lnstats : (float*)nullptr);
     if (int rc = launch_check(h, "embed_ln")) return rc;
   }
+  // LayerNorm whose statistics are pending in lnstats (fuse only): gamma / beta the next residual consumer applies
+  const float *pend_g = h->ones, *pend_b = h->zeros;
+  auto run_ln = [&](float* x32, half_t* x16, int rows, const float* g, const float* b, bool stats_only) -> int {
+    ProfScope ps(h, KC_LN);
+    const unsigned grid = (unsigned)((rows + 3) / 4);
+    if (stats_only)
+      hipLaunchKernelGGL(ln_kernel<false>, dim3(grid), dim3(256), 0, h->stream, x32, x16, rows, g, b, c.ln_eps, h->lnstats);
+    else
+      hipLaunchKernelGGL(ln_kernel<true>, dim3(grid), dim3(256), 0, h->stream, x32, x16, rows, g, b, c.ln_eps, (float*)nullptr);
+    return launch_check(h, "layernorm");
+  };
   for (int l = 0; l < n_layers; ++l) {
     const LayerW& w = h->L[l];
+    const bool last = (l == n_layers - 1);
     GemmArgs g{};
     g.M = (int)Mpad; g.Mreal = (int)M; g.S = Sp;
+    g.q = h->q; g.k = h->k; g.vt = h->vt;
+    if (last && prune) {
+      // ---- last layer, [CLS] rows only: K and V of every token, everything else on B rows
+      const int Bp = (int)round_up(B, 128);
+      g.A = h->x16; g.W = w.wqkv + (size_t)MV_HIDDEN * MV_HIDDEN; g.bias = w.bqkv + MV_HIDDEN; g.N = 2 * MV_HIDDEN; g.K = MV_HIDDEN;
+      g.col0 = MV_HIDDEN;
+      if (int rc = launch_gemm<EPI_QKV>(h, KC_GEMM_KV_LAST, g)) return rc;
+      ProfScope tail(h, KC_CLS_TAIL);
+      const uint32_t keep_mask = h->prof_mask;
+      h->prof_mask = 0;  // the tail is one profiled span; its inner launches carry no events of their own
+      auto tail_rc = [&]() -> int {
+        hipLaunchKernelGGL(cls_gather_kernel, dim3((B + 3) / 4), dim3(256), 0, h->stream, h->xres, h->x16, Sp, B,
+                           fuse ? h->lnstats : (const float*)nullptr, pend_g, pend_b, h->c32, h->c16);
+        if (int rc = launch_check(h, "cls_gather")) return rc;
+        GemmArgs t{};
+        t.M = Bp; t.Mreal = B; t.S = 64;
+        t.A = h->c16; t.W = w.wqkv; t.bias = w.bqkv; t.N = MV_HIDDEN; t.K = MV_HIDDEN; t.outf = h->cq;
+        if (int rc = launch_gemm<EPI_F32>(h, KC_CLS_TAIL, t)) return rc;
+        hipLaunchKernelGGL(attention_cls_kernel, dim3((B * MV_HEADS + 3) / 4), dim3(256), 0, h->stream, h->cq, h->k, h->vt,
+                           d_lens, h->cctx, Sp, B * MV_HEADS);
+        if (int rc = launch_check(h, "attention_cls")) return rc;
+        t.A = h->cctx; t.W = w.wo; t.bias = w.bo; t.N = MV_HIDDEN; t.K = MV_HIDDEN; t.xres = h->c32; t.outf = nullptr;
+        if (int rc = launch_gemm<EPI_RES>(h, KC_CLS_TAIL, t)) return rc;
+        if (int rc = run_ln(h->c32, h->c16, B, w.ln1g, w.ln1b, false)) return rc;
+        t.A = h->c16; t.W = w.w1; t.bias = w.b1; t.N = MV_INTER; t.K = MV_HIDDEN; t.out16 = h->ch16;
+        if (int rc = launch_gemm<EPI_GELU>(h, KC_CLS_TAIL, t)) return rc;
+        t.A = h->ch16; t.W = w.w2; t.bias = w.b2; t.N = MV_HIDDEN; t.K = MV_INTER; t.xres = h->c32;
+        if (int rc = launch_gemm<EPI_RES>(h, KC_CLS_TAIL, t)) return rc;
+        if (int rc = run_ln(h->c32, h->c16, B, w.ln2g, w.ln2b, false)) return rc;
+        hipLaunchKernelGGL(pool_head_kernel, dim3((B + POOL_RB - 1) / POOL_RB), dim3(256), 0, h->stream, h->c32, 1, B, h->WpT,
+                           h->bp, h->WhT, h->bh, u_out);
+        return launch_check(h, "pool_head");
+      }();
+      h->prof_mask = keep_mask;
+      return tail_rc;
+    }
     // K2: QKV projection
     g.A = h->x16; g.W = w.wqkv; g.bias = w.bqkv; g.N = 3 * MV_HIDDEN; g.K = MV_HIDDEN;
-    g.q = h->q; g.k = h->k; g.vt = h->vt;
     if (int rc = launch_gemm<EPI_QKV>(h, KC_GEMM_QKV, g)) return rc;
     // K3: attention
     {
@@ -356,23 +431,20 @@ int encode_dev(mv_handle* h, const int32_t* d_ids, const int32_t* d_lens, int B,
     }
     // K4: attention output projection + bias + residual (in place), then LayerNorm
     g.A = h->ctx; g.W = w.wo; g.bias = w.bo; g.N = MV_HIDDEN; g.K = MV_HIDDEN; g.xres = h->xres;
+    if (fuse) { g.lnstats = h->lnstats; g.lng = pend_g; g.lnb = pend_b; }
     if (int rc = launch_gemm<EPI_RES>(h, KC_GEMM_OUT, g)) return rc;
-    {
-      ProfScope ps(h, KC_LN);
-      hipLaunchKernelGGL(ln_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, h->stream, h->xres, h->x16, (int)M, w.ln1g, w.ln1b, c.ln_eps);
-      if (int rc = launch_check(h, "ln1")) return rc;
-    }
+    if (int rc = run_ln(h->xres, h->x16, (int)M, w.ln1g, w.ln1b, fuse)) return rc;
+    pend_g = w.ln1g; pend_b = w.ln1b;
     // K5: FFN-1 + exact-erf GELU
+    g.lnstats = nullptr;
     g.A = h->x16; g.W = w.w1; g.bias = w.b1; g.N = MV_INTER; g.K = MV_HIDDEN; g.out16 = h->h16;
     if (int rc = launch_gemm<EPI_GELU>(h, KC_GEMM_FFN1, g)) return rc;
     // K6: FFN-2 + bias + residual, then LayerNorm
     g.A = h->h16; g.W = w.w2; g.bias = w.b2; g.N = MV_HIDDEN; g.K = MV_INTER; g.xres = h->xres;
+    if (fuse) { g.lnstats = h->lnstats; g.lng = pend_g; g.lnb = pend_b; }
     if (int rc = launch_gemm<EPI_RES>(h, KC_GEMM_FFN2, g)) return rc;
-    {
-      ProfScope ps(h, KC_LN);
-      hipLaunchKernelGGL(ln_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, h->stream, h->xres, h->x16, (int)M, w.ln2g, w.ln2b, c.ln_eps);
-      if (int rc = launch_check(h, "ln2")) return rc;
-    }
+    if (int rc = run_ln(h->xres, h->x16, (int)M, w.ln2g, w.ln2b, fuse && !last)) return rc;  // the pooler reads a normalised stream
+    pend_g = w.ln2g; pend_b = w.ln2b;
   }
   if (u_out) {
     ProfScope ps(h, KC_POOL_HEAD);
@@ -496,8 +568,11 @@ int mv_create(int device, const mv_config* cfg, mv_handle** out) {
   hipFuncSetAttribute((const void*)gemm_pp_kernel<PP_VT, PP_DIST, 0, PP_SCHED, PP_COAL>, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS_BYTES);
   hipFuncSetAttribute((const void*)gemm_pp_kernel<PP_GELU, PP_DIST, 0, PP_SCHED, PP_COAL>, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS_BYTES);
   hipFuncSetAttribute((const void*)gemm_pp_kernel<PP_RES, PP_DIST, 0, PP_SCHED, PP_COAL>, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS_BYTES);
+  hipFuncSetAttribute((const void*)gemm_pp_kernel<PP_RESLN, PP_DIST, 0, PP_SCHED, PP_COAL>, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS_BYTES);
   (void)hipGetLastError();
   if (const char* e = getenv("MEMVUL_GEMM_TILE")) h->gemm_tile = atoi(e);
+  if (const char* e = getenv("MEMVUL_CLS_PRUNE")) h->cls_prune = atoi(e) != 0;
+  if (const char* e = getenv("MEMVUL_LN_FUSE")) h->ln_fuse = atoi(e) != 0;
   {
     int ncu = 0;
     if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && ncu > 0) h->num_cu = ncu;
@@ -516,6 +591,23 @@ int mv_create(int device, const mv_config* cfg, mv_handle** out) {
   A(dev_alloc(h, &h->vt, T * MV_HIDDEN));
   A(dev_alloc(h, &h->ctx, T * MV_HIDDEN));
   A(dev_alloc(h, &h->h16, T * MV_INTER));
+  A(dev_alloc(h, &h->lnstats, T * 2));
+  A(dev_alloc(h, &h->zeros, MV_HIDDEN));
+  A(dev_alloc(h, &h->ones, MV_HIDDEN, false));
+  if (rc == MV_OK) {
+    const std::vector<float> one(MV_HIDDEN, 1.0f);
+    if (hipMemcpyAsync(h->ones, one.data(), MV_HIDDEN * 4, hipMemcpyHostToDevice, h->stream) != hipSuccess ||
+        hipStreamSynchronize(h->stream) != hipSuccess)
+      rc = MV_ERR_HIP;
+  }
+  {
+    const int64_t Bp = round_up(cfg->max_batch, 256);  // [CLS]-row buffers of the pruned last layer
+    A(dev_alloc(h, &h->c32, Bp * MV_HIDDEN));
+    A(dev_alloc(h, &h->cq, Bp * MV_HIDDEN));
+    A(dev_alloc(h, &h->c16, Bp * MV_HIDDEN));
+    A(dev_alloc(h, &h->cctx, Bp * MV_HIDDEN));
+    A(dev_alloc(h, &h->ch16, Bp * MV_INTER));
+  }
   A(dev_alloc(h, &h->u, (int64_t)cfg->max_batch * MV_PROJ));
   A(dev_alloc(h, &h->u_in, (int64_t)cfg->max_batch * MV_PROJ));
   A(dev_alloc(h, &h->anchors, (int64_t)cfg->max_anchors * MV_PROJ));
@@ -874,6 +966,12 @@ int mv_profile_enable(mv_handle* h, int on) {
   return MV_OK;
 }
 
+int mv_profile_select(mv_handle* h, uint32_t class_mask) {
+  if (!h) return MV_ERR_INVALID;
+  h->prof_mask = class_mask;
+  return MV_OK;
+}
+
 int mv_profile_read(mv_handle* h, double* ms, int64_t* launches, int n) {
   if (!h || !ms || !launches || n < MV_NUM_KERNEL_CLASSES) return fail(h, MV_ERR_INVALID, "mv_profile_read: bad argument");
   HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -895,7 +993,7 @@ int mv_debug_encode(mv_handle* h, const int32_t* ids, const int32_t* lens, int B
   HIPCHK(h, hipSetDevice(h->device));
   HIPCHK(h, hipMemcpyAsync(h->d_ids, ids, (size_t)B * S * 4, hipMemcpyHostToDevice, h->stream));
   HIPCHK(h, hipMemcpyAsync(h->d_lens, lens, (size_t)B * 4, hipMemcpyHostToDevice, h->stream));
-  if (int rc = encode_dev(h, h->d_ids, h->d_lens, B, S, n_layers < 0 ? h->cfg.layers : n_layers, h->u)) return rc;
+  if (int rc = encode_dev(h, h->d_ids, h->d_lens, B, S, n_layers < 0 ? h->cfg.layers : n_layers, h->u, /*full=*/true)) return rc;
   HIPCHK(h, hipStreamSynchronize(h->stream));
   return MV_OK;
 }

@@ -46,6 +46,10 @@ struct GemmArgs {
   half_t* k;          //          [B][12][S][64]
   half_t* vt;         //          [B][12][64][S]
   int S;              // padded sequence length (multiple of 64)
+  int col0;           // EPI_QKV / PP_QK: packed-QKV column of this launch's first output column (0, or 768 = K,V only)
+  const float* lnstats;  // PP_RESLN: [M][2] (mean, rstd) of the residual rows; lng / lnb: that LayerNorm's gamma, beta [768]
+  const float* lng;
+  const float* lnb;
   unsigned long long* clk;  // optional (development probe): per-workgroup s_memtime span of the persistent kernel
 };
 
@@ -80,8 +84,8 @@ __device__ __forceinline__ void epilogue_frag(const GemmArgs& a, const floatx16&
       rowbase[lane_off] = acc[r];
     }
   } else {  // EPI_QKV: n in [0, 2304) = which * 768 + head * 64 + d; a fragment never straddles a head half
-    const int which = nb / MV_HIDDEN;
-    const int hn = nb - which * MV_HIDDEN;
+    const int which = (nb + a.col0) / MV_HIDDEN;
+    const int hn = nb + a.col0 - which * MV_HIDDEN;
     const int head = hn >> 6;
     const int d = (hn & 63) + (lane & 31);
     const int b = mb / a.S;  // S % 64 == 0 and mb % 32 == 0: one batch row per fragment

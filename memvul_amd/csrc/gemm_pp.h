@@ -42,7 +42,11 @@
 
 #include "gemm.h"
 
-enum { PP_F32 = 0, PP_QK = 1, PP_VT = 2, PP_GELU = 3, PP_RES = 4, PP_F16 = 5 };
+enum { PP_F32 = 0, PP_QK = 1, PP_VT = 2, PP_GELU = 3, PP_RES = 4, PP_F16 = 5, PP_RESLN = 6 };
+// PP_RESLN: PP_RES whose residual tile is the PRE-LayerNorm stream: the accumulators start from
+//   LN(x) + bias = fma((x - mean) * rstd, gamma, beta) + bias   (row statistics from ln_kernel<stats>),
+// the same IEEE operations ln_row_store performs, so the result equals PP_RES on a normalised stream bit for bit
+// while the LayerNorm kernel no longer writes the fp32 stream back (201 MB per LayerNorm at the bench shape).
 // timing ablations (wrong results by construction; cdna_hip_programming.md §5.4 rules 8/17)
 enum { PP_ABL_NODMA = 1, PP_ABL_NOMFMA = 2, PP_ABL_NOREAD = 4, PP_ABL_NOEPI = 8, PP_ABL_NOPRIO = 16, PP_ABL_NOSTAGGER = 32 };
 
@@ -134,6 +138,24 @@ __device__ __forceinline__ void scr_f32x4(uint32_t wa, uint32_t wb, const u32x4 
 #endif
 }
 
+// PP_RESLN accumulator init: the 4 float4 (columns 8 g + 4 hi .. + 3, g = 0..3, of one 32-column block) of the
+// bias, gamma and beta images (gamma at +3072 B, beta at +6144 B of the bias image) in one statement.
+__device__ __forceinline__ void lds_read_bgb(uint32_t addr, float4 (&bi)[4], float4 (&ga)[4], float4 (&be)[4]) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm volatile(
+      "ds_read_b128 %0, %12\n\tds_read_b128 %1, %12 offset:32\n\tds_read_b128 %2, %12 offset:64\n\t"
+      "ds_read_b128 %3, %12 offset:96\n\tds_read_b128 %4, %12 offset:3072\n\tds_read_b128 %5, %12 offset:3104\n\t"
+      "ds_read_b128 %6, %12 offset:3136\n\tds_read_b128 %7, %12 offset:3168\n\tds_read_b128 %8, %12 offset:6144\n\t"
+      "ds_read_b128 %9, %12 offset:6176\n\tds_read_b128 %10, %12 offset:6208\n\tds_read_b128 %11, %12 offset:6240\n\t"
+      "s_waitcnt lgkmcnt(0)"
+      : "=&v"(bi[0]), "=&v"(bi[1]), "=&v"(bi[2]), "=&v"(bi[3]), "=&v"(ga[0]), "=&v"(ga[1]), "=&v"(ga[2]), "=&v"(ga[3]),
+        "=&v"(be[0]), "=&v"(be[1]), "=&v"(be[2]), "=&v"(be[3])
+      : "v"(addr)
+      : "memory");
+  __builtin_amdgcn_sched_barrier(0);
+#endif
+}
+
 // SCHED 0: two barriers per phase, the M-halves one barrier apart (DIST = issue distance in phases, 2..6).
 // SCHED 1: ONE barrier per phase; the first M-half runs [MFMA(j), read fragments(j+1)] and the second
 //          [read fragments(j), MFMA(j)] inside the same barrier interval, so each SIMD's matrix pipe is handed from
@@ -146,6 +168,8 @@ template <int EPI, int DIST, int ABL, int SCHED = 0, int COAL = 0>
 __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmArgs a) {
   static_assert(SCHED == 0 ? (DIST >= 2 && DIST <= 6) : (DIST >= 2 && DIST <= 4), "half-tile issue distance");
   constexpr bool SWAP = (EPI != PP_VT);
+  constexpr bool IS_RES = (EPI == PP_RES || EPI == PP_RESLN);
+  static_assert(EPI != PP_RESLN || COAL == 1, "the LayerNorm-fused residual init is written for the transposed (COAL) path");
   constexpr int WAITN = SCHED == 0 ? 2 * (DIST - 1) : 2 * DIST;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
@@ -164,6 +188,12 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmArgs a) {
   {
     float* lb = (float*)(smem + PP_LDS_BIAS);
     for (int n = tid; n < a.N; n += 512) lb[n] = a.bias ? a.bias[n] : 0.f;
+    if constexpr (EPI == PP_RESLN) {  // N == 768: gamma at [768, 1536), beta at [1536, 2304) of the same image
+      for (int n = tid; n < MV_HIDDEN; n += 512) {
+        lb[MV_HIDDEN + n] = a.lng[n];
+        lb[2 * MV_HIDDEN + n] = a.lnb[n];
+      }
+    }
   }
 
   // ---- staging geometry: wave w fills slabs 2w, 2w+1 (8 rows x 128 B each) of every half-tile
@@ -406,9 +436,14 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmArgs a) {
       const uint32_t sf = (uint32_t)((l31 >> 2) & 3);
       const uint32_t scr_m32 = scr + l31 * 64 + (((uint32_t)hi ^ sf) << 4);          // fp32 rounds: chunk 2 gg + hi -> ^ (gg * 32)
       const uint32_t scr_c = scr + (lane >> 2) * 64 + ((((uint32_t)lane & 3) ^ (((uint32_t)lane >> 4) & 3)) << 4);
-      if constexpr (EPI == PP_RES && COAL) {
+      if constexpr (IS_RES && COAL) {
         // residual tile by full-line loads (16 rows x 64 B per instruction), transposed into the C/D layout
         // (the raw lines are parked in the accumulator registers they will be transposed into)
+        float2 lnst[4];  // PP_RESLN: (mean, rstd) of this lane's four token rows
+        if constexpr (EPI == PP_RESLN) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) lnst[i] = *(const float2*)(a.lnstats + 2 * (size_t)(mw + i * 32 + l31));
+        }
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -429,10 +464,26 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmArgs a) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) d[q][e] = f2u(acc[i][q >> 2][4 * (q & 3) + e]);
           scr_f32x4(scr_c, scr_c + 1024, d, scr_m32, scr_m32 ^ 32u, o);
+          if constexpr (EPI == PP_RESLN) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+              float4 bi[4], ga[4], be[4];
+              lds_read_bgb(baddr + j * 128, bi, ga, be);
+#pragma unroll
+              for (int g = 0; g < 4; ++g)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                  const float t = (u2f(o[4 * j + g][e]) - lnst[i].x) * lnst[i].y;
+                  acc[i][j][4 * g + e] =
+                      __builtin_fmaf(t, ((const float*)&ga[g])[e], ((const float*)&be[g])[e]) + ((const float*)&bi[g])[e];
+                }
+            }
+          } else {
 #pragma unroll
           for (int q = 0; q < 8; ++q)
 #pragma unroll
             for (int e = 0; e < 4; ++e) acc[i][q >> 2][4 * (q & 3) + e] = u2f(o[q][e]) + ((const float*)&bv[q >> 2][q & 3])[e];
+          }
         }
       } else {
 #pragma unroll
@@ -441,7 +492,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmArgs a) {
         for (int g = 0; g < 4; ++g)
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
-            if constexpr (EPI == PP_RES) {
+            if constexpr (IS_RES) {
               const float4 xv = *(const float4*)(a.xres + (size_t)(mw + i * 32 + l31) * MV_HIDDEN + nw + j * 32 + 8 * g + 4 * hi);
               acc[i][j][4 * g + 0] = xv.x + bv[j][g].x; acc[i][j][4 * g + 1] = xv.y + bv[j][g].y;
               acc[i][j][4 * g + 2] = xv.z + bv[j][g].z; acc[i][j][4 * g + 3] = xv.w + bv[j][g].w;
@@ -503,9 +554,9 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmArgs a) {
       const uint32_t sf = (uint32_t)((l31 >> 2) & 3);
       const uint32_t scr_c = scr + (lane >> 2) * 64 + ((((uint32_t)lane & 3) ^ (((uint32_t)lane >> 4) & 3)) << 4);
       const int crow = lane >> 2, cchunk = lane & 3;  // coalesced layout: row (+16 for the second read), 16-B chunk
-      if constexpr (EPI == PP_F32 || EPI == PP_RES) {
+      if constexpr (EPI == PP_F32 || IS_RES) {
         const uint32_t scr_m32 = scr + l31 * 64 + (((uint32_t)hi ^ sf) << 4);
-        float* obase = (EPI == PP_RES ? a.xres : a.outf) + (size_t)(mw + crow) * a.N + nw + 4 * cchunk;
+        float* obase = (IS_RES ? a.xres : a.outf) + (size_t)(mw + crow) * a.N + nw + 4 * cchunk;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           u32x4 d[8], o[8];
@@ -532,8 +583,8 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmArgs a) {
           obase = a.out16 + (size_t)(mw + crow) * a.N + nw + 8 * cchunk;
           rstride = a.N; istride = (size_t)32 * a.N; jstride = 32;
         } else if constexpr (EPI == PP_QK) {  // one head per wave; S % 64 == 0 so a 128-row block may span two batch rows
-          const int which = nw >= MV_HIDDEN;
-          const int head = (nw - which * MV_HIDDEN) >> 6;
+          const int which = (nw + a.col0) >= MV_HIDDEN;  // col0 = 768: the launch covers the K block only
+          const int head = (nw + a.col0 - which * MV_HIDDEN) >> 6;
           obase = (which ? a.k : a.q) + (size_t)head * a.S * MV_HEAD_DIM + (size_t)crow * MV_HEAD_DIM + 8 * cchunk;
           rstride = MV_HEAD_DIM; istride = 0; jstride = 32;  // the batch-row part is added per i below
         } else {  // PP_VT: image rows = head dims, image columns = tokens
@@ -583,8 +634,8 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmArgs a) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int mb = mw + i * 32;  // 32-row block: wave-uniform
-        if constexpr (EPI == PP_F32 || EPI == PP_RES) {
-          float* base = (EPI == PP_RES ? a.xres : a.outf) + (size_t)(mb + l31) * a.N + nw + 4 * hi;
+        if constexpr (EPI == PP_F32 || IS_RES) {
+          float* base = (IS_RES ? a.xres : a.outf) + (size_t)(mb + l31) * a.N + nw + 4 * hi;
 #pragma unroll
           for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -602,8 +653,8 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmArgs a) {
           }
         } else if constexpr (EPI == PP_QK) {  // N = 1536: columns [0,768) -> Q, [768,1536) -> K; 64 columns of a wave = one head
           if (mb < a.Mreal) {
-            const int which = nw >= MV_HIDDEN;
-            const int head = (nw - which * MV_HIDDEN) >> 6;
+            const int which = (nw + a.col0) >= MV_HIDDEN;
+            const int head = (nw + a.col0 - which * MV_HIDDEN) >> 6;
             const int b = mb / a.S, s0 = mb - b * a.S;
             half_t* rowptr = (which ? a.k : a.q) + ((size_t)(b * MV_HEADS + head) * a.S + s0 + l31) * MV_HEAD_DIM;
 #pragma unroll

@@ -8,9 +8,14 @@
 // One wave per token row of 768 fp32: lane owns elements 4*lane + 256*i .. +3, i = 0..2
 // (three coalesced 1-KiB float4 sweeps per row).
 // ---------------------------------------------------------------------------------------------
+// W32: write the normalised fp32 row; otherwise only the fp16 copy (the GEMM operand) and, when `stats` is given,
+// (mean, rstd) of the row: the consumer of the fp32 stream (gemm_pp PP_RESLN) then normalises the raw row itself
+// with exactly the operations below — (x - mean) * rstd, one fma with gamma / beta — so both routes give the same bits.
+template <bool W32>
 __device__ __forceinline__ void ln_row_store(const float4 (&x)[3], const float* __restrict__ gamma,
                                              const float* __restrict__ beta, float eps, int lane,
-                                             float* __restrict__ out32, half_t* __restrict__ out16) {
+                                             float* __restrict__ out32, half_t* __restrict__ out16,
+                                             float* __restrict__ stats) {
   float s = 0.f;
 #pragma unroll
   for (int i = 0; i < 3; ++i) s += x[i].x + x[i].y + x[i].z + x[i].w;
@@ -22,17 +27,22 @@ __device__ __forceinline__ void ln_row_store(const float4 (&x)[3], const float* 
     v += a * a + b * b + c * c + d * d;
   }
   const float rstd = 1.0f / sqrtf(wave_sum(v) * (1.0f / MV_HIDDEN) + eps);
+  if (stats && lane == 0) {
+    float2 st;
+    st.x = mean; st.y = rstd;
+    *(float2*)stats = st;
+  }
 #pragma unroll
   for (int i = 0; i < 3; ++i) {
     const int c = 4 * lane + 256 * i;
     const float4 g = *(const float4*)(gamma + c);
     const float4 bb = *(const float4*)(beta + c);
     float4 y;
-    y.x = (x[i].x - mean) * rstd * g.x + bb.x;
-    y.y = (x[i].y - mean) * rstd * g.y + bb.y;
-    y.z = (x[i].z - mean) * rstd * g.z + bb.z;
-    y.w = (x[i].w - mean) * rstd * g.w + bb.w;
-    *(float4*)(out32 + c) = y;
+    y.x = __builtin_fmaf((x[i].x - mean) * rstd, g.x, bb.x);
+    y.y = __builtin_fmaf((x[i].y - mean) * rstd, g.y, bb.y);
+    y.z = __builtin_fmaf((x[i].z - mean) * rstd, g.z, bb.z);
+    y.w = __builtin_fmaf((x[i].w - mean) * rstd, g.w, bb.w);
+    if constexpr (W32) *(float4*)(out32 + c) = y;
     half4_t h;
     h[0] = (half_t)y.x; h[1] = (half_t)y.y; h[2] = (half_t)y.z; h[3] = (half_t)y.w;
     *(half4_t*)(out16 + c) = h;
@@ -45,7 +55,8 @@ __global__ __launch_bounds__(256) void embed_ln_kernel(const int32_t* __restrict
                                                        int vocab, const float* __restrict__ wemb,
                                                        const float* __restrict__ pemb, const float* __restrict__ temb,
                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                       float eps, float* __restrict__ x32, half_t* __restrict__ x16) {
+                                                       float eps, float* __restrict__ x32, half_t* __restrict__ x16,
+                                                       float* __restrict__ stats) {
   const int lane = threadIdx.x & 63;
   const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (t >= n_tok) return;
@@ -61,13 +72,22 @@ __global__ __launch_bounds__(256) void embed_ln_kernel(const int32_t* __restrict
     const float4 a = *(const float4*)(w + c), q = *(const float4*)(p + c), r = *(const float4*)(temb + c);
     x[i].x = a.x + q.x + r.x; x[i].y = a.y + q.y + r.y; x[i].z = a.z + q.z + r.z; x[i].w = a.w + q.w + r.w;
   }
-  ln_row_store(x, gamma, beta, eps, lane, x32 + (size_t)t * MV_HIDDEN, x16 + (size_t)t * MV_HIDDEN);
+  ln_row_store<true>(x, gamma, beta, eps, lane, x32 + (size_t)t * MV_HIDDEN, x16 + (size_t)t * MV_HIDDEN, nullptr);
+  // the embedding output IS the normalised stream: identity statistics for a PP_RESLN consumer (with gamma = 1, beta = 0)
+  if (stats && lane == 0) {
+    float2 st;
+    st.x = 0.f; st.y = 1.f;
+    *(float2*)(stats + 2 * (size_t)t) = st;
+  }
 }
 
-// LayerNorm of the residual stream in place (the GEMM epilogue already added bias + residual):
-// x32 <- LN(x32), x16 <- fp16(x32).
+// LayerNorm of the residual stream (the GEMM epilogue already added bias + residual).
+// W32 = true : x32 <- LN(x32) in place, x16 <- fp16(LN(x32)).
+// W32 = false: x32 is left as the raw (pre-LN) stream; x16 <- fp16(LN(x32)), stats[t] <- (mean, rstd).
+template <bool W32>
 __global__ __launch_bounds__(256) void ln_kernel(float* __restrict__ x32, half_t* __restrict__ x16, int n_tok,
-                                                 const float* __restrict__ gamma, const float* __restrict__ beta, float eps) {
+                                                 const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+                                                 float* __restrict__ stats) {
   const int lane = threadIdx.x & 63;
   const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (t >= n_tok) return;
@@ -75,7 +95,37 @@ __global__ __launch_bounds__(256) void ln_kernel(float* __restrict__ x32, half_t
   float4 x[3];
 #pragma unroll
   for (int i = 0; i < 3; ++i) x[i] = *(const float4*)(row + 4 * lane + 256 * i);
-  ln_row_store(x, gamma, beta, eps, lane, row, x16 + (size_t)t * MV_HIDDEN);
+  ln_row_store<W32>(x, gamma, beta, eps, lane, row, x16 + (size_t)t * MV_HIDDEN, W32 ? nullptr : stats + 2 * (size_t)t);
+}
+
+// Last-layer pruning (only token 0 of each issue report reaches the pooler, model_memory.py:99): gather the
+// [CLS] rows of the fp32 stream and of the fp16 GEMM operand into compact [B][768] buffers.  With `stats` the
+// stream holds raw (pre-LN) rows and is normalised here (same operations as ln_row_store).
+__global__ __launch_bounds__(256) void cls_gather_kernel(const float* __restrict__ x32, const half_t* __restrict__ x16, int Sp,
+                                                         int B, const float* __restrict__ stats,
+                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                         float* __restrict__ c32, half_t* __restrict__ c16) {
+  const int lane = threadIdx.x & 63;
+  const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (b >= B) return;
+  const size_t t = (size_t)b * Sp;
+  float mean = 0.f, rstd = 1.f;
+  if (stats) { mean = stats[2 * t]; rstd = stats[2 * t + 1]; }
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const int c = 4 * lane + 256 * i;
+    float4 y = *(const float4*)(x32 + t * MV_HIDDEN + c);
+    if (stats) {
+      const float4 g = *(const float4*)(gamma + c);
+      const float4 bb = *(const float4*)(beta + c);
+      y.x = __builtin_fmaf((y.x - mean) * rstd, g.x, bb.x);
+      y.y = __builtin_fmaf((y.y - mean) * rstd, g.y, bb.y);
+      y.z = __builtin_fmaf((y.z - mean) * rstd, g.z, bb.z);
+      y.w = __builtin_fmaf((y.w - mean) * rstd, g.w, bb.w);
+    }
+    *(float4*)(c32 + (size_t)b * MV_HIDDEN + c) = y;
+    *(half4_t*)(c16 + (size_t)b * MV_HIDDEN + c) = *(const half4_t*)(x16 + t * MV_HIDDEN + c);
+  }
 }
 
 // K7+K8 (model_memory.py:99-102): u = relu(W_h tanh(W_p h[:,0] + b_p) + b_h), all fp32.

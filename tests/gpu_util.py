@@ -32,10 +32,14 @@ def weights_for(dims_kw: dict, w_kw: dict):
     return _weights[key]
 
 
-def engine_for(dims_kw: dict, w_kw: dict, gemm_tile: int = 0, **eng_kw) -> Engine:
+def engine_for(dims_kw: dict, w_kw: dict, gemm_tile: int = 0, env: dict = None, **eng_kw) -> Engine:
     """gemm_tile: 0 = the engine's own choice, 128 / 256 = one-tile-per-workgroup kernels, 512 = persistent
-    ping-pong kernel forced (MEMVUL_GEMM_TILE, read at mv_create)."""
-    key = (tuple(sorted(dims_kw.items())), tuple(sorted(w_kw.items())), tuple(sorted(eng_kw.items())), gemm_tile)
+    ping-pong kernel forced (MEMVUL_GEMM_TILE, read at mv_create).  env: further MEMVUL_* switches read at
+    mv_create (MEMVUL_CLS_PRUNE, MEMVUL_LN_FUSE, MEMVUL_ATTN), e.g. {"MEMVUL_CLS_PRUNE": "0"}."""
+    env = dict(env or {})
+    if gemm_tile:
+        env["MEMVUL_GEMM_TILE"] = str(gemm_tile)
+    key = (tuple(sorted(dims_kw.items())), tuple(sorted(w_kw.items())), tuple(sorted(eng_kw.items())), tuple(sorted(env.items())))
     if key not in _engines:
         if len(_engines) >= 2:  # keep HBM use bounded: drop the oldest engine
             k0 = next(iter(_engines))
@@ -43,18 +47,19 @@ def engine_for(dims_kw: dict, w_kw: dict, gemm_tile: int = 0, **eng_kw) -> Engin
         dims, w = weights_for(dims_kw, w_kw)
         kw = dict(max_tokens=16384, max_batch=64, max_anchors=64)
         kw.update(eng_kw)
-        old = os.environ.get("MEMVUL_GEMM_TILE")
-        if gemm_tile:
-            os.environ["MEMVUL_GEMM_TILE"] = str(gemm_tile)
-        else:
-            os.environ.pop("MEMVUL_GEMM_TILE", None)
+        switches = ("MEMVUL_GEMM_TILE", "MEMVUL_CLS_PRUNE", "MEMVUL_LN_FUSE", "MEMVUL_ATTN")
+        old = {k: os.environ.get(k) for k in switches}
+        for k in switches:
+            os.environ.pop(k, None)
+        os.environ.update(env)
         try:
             e = Engine(0, vocab_size=dims.vocab_size, layers=dims.layers, max_pos=dims.max_pos, **kw)
         finally:
-            if old is None:
-                os.environ.pop("MEMVUL_GEMM_TILE", None)
-            else:
-                os.environ["MEMVUL_GEMM_TILE"] = old
+            for k, v in old.items():
+                if v is None:
+                    os.environ.pop(k, None)
+                else:
+                    os.environ[k] = v
         e.load_state_dict(w)
         _engines[key] = e
     return _engines[key]

@@ -147,3 +147,35 @@ def test_engine_coexists_with_torch_hip_runtime():
         assert r.returncode == 0 and "OK" in r.stdout, f"{name}: {r.stderr[-1500:]}"
         outs.append([ln for ln in r.stdout.splitlines() if ln.startswith("OK")][-1])
     assert outs[0] == outs[1] == outs[2]  # same numbers whichever HIP runtime copy serves the engine
+
+
+@pytest.mark.parametrize("gemm_tile", [0, 512])
+@pytest.mark.parametrize("B,S,ragged", [(5, 64, False), (3, 200, True), (2, 320, True)])
+def test_last_layer_pruning_matches_full_forward(gu, B, S, ragged, gemm_tile):
+    """MEMVUL_CLS_PRUNE: after the last layer's K / V projection only the [CLS] rows are processed (the pooler
+    reads hidden[:, 0], model_memory.py:99).  Same embedding as the all-token forward up to the different
+    summation order of the single-query attention (fp32 rounding), and the same oracle parity."""
+    dk, wk = dict(layers=2, vocab_size=2048), dict(qk_scale=3.0)
+    dims, w = gu.weights_for(dk, wk)
+    ids, lens = synth.make_ids(B, S, dims.vocab_size, ragged=ragged, min_len=7)
+    u_full = gu.engine_for(dk, wk, gemm_tile=gemm_tile, env={"MEMVUL_CLS_PRUNE": "0"}).encode(ids, lens)
+    u_cls = gu.engine_for(dk, wk, gemm_tile=gemm_tile).encode(ids, lens)
+    u_ref = orc.instance_forward(w, ids.astype(np.int64), synth.mask_from_lens(lens, S))
+    d = float(np.abs(u_full - u_cls).max())
+    gu.record("cls_prune", B=B, S=S, gemm_tile=gemm_tile, full_vs_pruned=d, pruned_vs_oracle=float(np.abs(u_cls - u_ref).max()),
+              full_vs_oracle=float(np.abs(u_full - u_ref).max()))
+    assert d < 2e-5
+    assert np.abs(u_cls - u_ref).max() < 2e-3
+
+
+@pytest.mark.parametrize("prune", ["0", "1"])
+def test_layernorm_folded_into_residual_read_is_bit_identical(gu, prune):
+    """MEMVUL_LN_FUSE (persistent-GEMM path): the LayerNorm kernels write fp16 operand + row statistics only and the
+    next residual GEMM normalises the raw stream while initialising its accumulators, with the same IEEE
+    operations -> the embeddings must not change by a single bit."""
+    dk, wk = dict(layers=3, vocab_size=2048), dict(qk_scale=2.0)
+    dims, w = gu.weights_for(dk, wk)
+    ids, lens = synth.make_ids(6, 128, dims.vocab_size, ragged=True, min_len=9)
+    u_f = gu.engine_for(dk, wk, gemm_tile=512, env={"MEMVUL_CLS_PRUNE": prune}).encode(ids, lens)
+    u_n = gu.engine_for(dk, wk, gemm_tile=512, env={"MEMVUL_CLS_PRUNE": prune, "MEMVUL_LN_FUSE": "0"}).encode(ids, lens)
+    assert np.array_equal(u_f, u_n)
