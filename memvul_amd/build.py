@@ -12,7 +12,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIB_DIR = os.path.join(HERE, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libmemvul_hip.so")
 SOURCES = ["engine.hip"]
-HEADERS = ["common.h", "gemm.h", "gemm_pp.h", "attention.h", "misc_kernels.h", os.path.join(ROOT, "include", "memvul_hip.h")]
+HEADERS = ["common.h", "gemm.h", "gemm_pp.h", "attention.h", "attention_v2.h", "misc_kernels.h", os.path.join(ROOT, "include", "memvul_hip.h")]
 ARCH = "gfx950"
 
 

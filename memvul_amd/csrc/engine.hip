@@ -16,6 +16,7 @@
 #include "common.h"
 #include "gemm.h"
 #include "gemm_pp.h"
+#include "attention_v2.h"
 #include "misc_kernels.h"
 
 namespace {
@@ -143,6 +144,8 @@ struct mv_handle {
   half_t *c16 = nullptr, *cctx = nullptr, *ch16 = nullptr;
   // LayerNorm folded into the consumer's residual read (gemm_pp PP_RESLN); env MEMVUL_LN_FUSE=0 disables
   bool ln_fuse = true;
+  // persistent LDS-DMA attention kernel for padded lengths <= 256 (attention_v2.h); env MEMVUL_ATTN=0 selects attention.h
+  bool attn_v2 = true;
   float *lnstats = nullptr, *ones = nullptr, *zeros = nullptr;
 
   // profiling
@@ -420,7 +423,17 @@ int encode_dev(mv_handle* h, const int32_t* d_ids, const int32_t* d_lens, int B,
     {
       AttnArgs a{h->q, h->k, h->vt, d_lens, h->ctx, Sp, B};
       ProfScope ps(h, KC_ATTENTION);
-      if (Sp <= 256) {
+      if (h->attn_v2 && Sp <= 256) {
+        const int nkb = Sp / 64, items = B * MV_HEADS;
+        const int slots = h->num_cu * (nkb == 1 ? 4 : nkb == 2 ? 2 : 1);  // resident workgroups: 8 waves and <= 128 KiB LDS per CU
+        const int grid = items < slots ? items : slots;
+        switch (nkb) {
+          case 1: hipLaunchKernelGGL((attention_v2_kernel<1>), dim3(grid), dim3(128), ATT2_LDS_BYTES(1), h->stream, a, items); break;
+          case 2: hipLaunchKernelGGL((attention_v2_kernel<2>), dim3(grid), dim3(256), ATT2_LDS_BYTES(2), h->stream, a, items); break;
+          case 3: hipLaunchKernelGGL((attention_v2_kernel<3>), dim3(grid), dim3(384), ATT2_LDS_BYTES(3), h->stream, a, items); break;
+          default: hipLaunchKernelGGL((attention_v2_kernel<4>), dim3(grid), dim3(512), ATT2_LDS_BYTES(4), h->stream, a, items); break;
+        }
+      } else if (Sp <= 256) {
         const int qblocks = (Sp + 127) / 128;
         hipLaunchKernelGGL((attention_kernel<4>), dim3(B * MV_HEADS * qblocks), dim3(256), ATT_LDS_BYTES(Sp), h->stream, a);
       } else {
@@ -573,6 +586,12 @@ int mv_create(int device, const mv_config* cfg, mv_handle** out) {
   if (const char* e = getenv("MEMVUL_GEMM_TILE")) h->gemm_tile = atoi(e);
   if (const char* e = getenv("MEMVUL_CLS_PRUNE")) h->cls_prune = atoi(e) != 0;
   if (const char* e = getenv("MEMVUL_LN_FUSE")) h->ln_fuse = atoi(e) != 0;
+  if (const char* e = getenv("MEMVUL_ATTN")) h->attn_v2 = atoi(e) != 0;
+  hipFuncSetAttribute((const void*)attention_v2_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT2_LDS_BYTES(1));
+  hipFuncSetAttribute((const void*)attention_v2_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT2_LDS_BYTES(2));
+  hipFuncSetAttribute((const void*)attention_v2_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT2_LDS_BYTES(3));
+  hipFuncSetAttribute((const void*)attention_v2_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT2_LDS_BYTES(4));
+  (void)hipGetLastError();
   {
     int ncu = 0;
     if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && ncu > 0) h->num_cu = ncu;

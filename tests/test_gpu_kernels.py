@@ -66,13 +66,15 @@ def test_embeddings_layernorm(gu, B, S, ragged):
     assert np.abs(x16 - taps["embed"]).max() < 4e-3
 
 
+@pytest.mark.parametrize("attn", ["1", "0"])
 @pytest.mark.parametrize("gemm_tile", [0, 512])
-@pytest.mark.parametrize("B,S,ragged", [(2, 64, False), (3, 128, True), (2, 256, True), (1, 320, True), (2, 100, True)])
-def test_layer0_stages(gu, B, S, ragged, gemm_tile):
+@pytest.mark.parametrize("B,S,ragged", [(2, 64, False), (3, 128, True), (2, 192, True), (2, 256, True), (1, 320, True), (2, 100, True)])
+def test_layer0_stages(gu, B, S, ragged, gemm_tile, attn):
     """QKV projection, attention, FFN and both LayerNorms of encoder layer 0 against the oracle taps.
     Tolerances are fp16-operand level (inputs rounded to fp16, fp32 accumulation)."""
     dims, w, ids, lens, mask, taps, _ = _taps(gu, B, S, ragged)
-    eng = gu.engine_for(L2, WK, gemm_tile=gemm_tile)  # 512: every projection through the persistent ping-pong GEMM
+    # 512: every projection through the persistent ping-pong GEMM; attn 1: attention_v2.h for Sp <= 256, 0: attention.h
+    eng = gu.engine_for(L2, WK, gemm_tile=gemm_tile, env={"MEMVUL_ATTN": attn})
     eng.debug_encode(ids, lens, 1)
     q = eng.debug_read(2)[:, :, :S].astype(np.float32) * 8.0  # engine folds 1/sqrt(64) into W_q
     k = eng.debug_read(3)[:, :, :S].astype(np.float32)
@@ -89,7 +91,7 @@ def test_layer0_stages(gu, B, S, ragged, gemm_tile):
         gelu=np.abs(h16 - taps["l0_gelu"])[m].max(),
         layer0=np.abs(x - taps["layer0"])[m].max(),
     )
-    gu.record("layer0", B=B, S=S, gemm_tile=gemm_tile, **{k_: float(v_) for k_, v_ in errs.items()})
+    gu.record("layer0", B=B, S=S, gemm_tile=gemm_tile, attn=attn, **{k_: float(v_) for k_, v_ in errs.items()})
     scale_q = float(np.abs(taps["l0_q"]).max())
     assert errs["q"] < 3e-3 * max(1.0, scale_q), errs
     assert errs["k"] < 3e-3 * max(1.0, float(np.abs(taps["l0_k"]).max())), errs
@@ -97,6 +99,19 @@ def test_layer0_stages(gu, B, S, ragged, gemm_tile):
     assert errs["ctx"] < 8e-3, errs  # peaked attention (qk_scale=4): fp16 rounding of P and V
     assert errs["gelu"] < 4e-3, errs
     assert errs["layer0"] < 1e-2, errs
+
+
+@pytest.mark.parametrize("B,S", [(48, 256), (70, 128), (40, 192)])
+def test_attention_persistent_item_loop(gu, B, S):
+    """attention_v2 walks (batch row, head) items with a 2-deep LDS ring: more items than resident workgroups, uneven
+    tails (B * 12 not a multiple of the grid) and ragged lengths; checked against the oracle's layer-0 context."""
+    dims, w, ids, lens, mask, taps, _ = _taps(gu, B, S, True)
+    eng = gu.engine_for(L2, WK, max_tokens=B * S, max_batch=B)
+    eng.debug_encode(ids, lens, 1)
+    ctx = eng.debug_read(5)[:, :S].astype(np.float32)
+    err = float(np.abs(ctx - taps["l0_ctx"])[mask].max())
+    gu.record("attention_items", B=B, S=S, max_err=err)
+    assert err < 8e-3
 
 
 def test_match_and_topk_vs_oracle(gu):
