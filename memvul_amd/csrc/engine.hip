@@ -120,7 +120,7 @@ struct mv_handle {
   int32_t *d_ids = nullptr, *d_lens = nullptr;
   float* xres = nullptr;
   half_t *x16 = nullptr, *q = nullptr, *k = nullptr, *vt = nullptr, *ctx = nullptr, *h16 = nullptr;
-  float *u = nullptr, *anchors = nullptr;
+  float *u = nullptr, *anchors = nullptr, *pooled = nullptr;
   int n_anchors = 0;
   float *logits = nullptr, *probs = nullptr, *psame = nullptr, *best = nullptr;
   int32_t* best_idx = nullptr;
@@ -339,6 +339,17 @@ int launch_gemm(mv_handle* h, int cls, const GemmArgs& a) {
   return launch_gemm128<EPI, true>(h, cls, a);
 }
 
+// K7 + K8: pooler on the [CLS] rows (row_stride floats apart), then the header
+int pool_head(mv_handle* h, const float* x, size_t row_stride, int B, float* u_out) {
+  const unsigned gx = (unsigned)((B + POOL_RB - 1) / POOL_RB);
+  hipLaunchKernelGGL(dense768_kernel<0>, dim3(gx, MV_HIDDEN / 256), dim3(256), 0, h->stream, x, row_stride, B, h->WpT, h->bp,
+                     MV_HIDDEN, h->pooled);
+  if (int rc = launch_check(h, "pooler")) return rc;
+  hipLaunchKernelGGL(dense768_kernel<1>, dim3(gx, MV_PROJ / 256), dim3(256), 0, h->stream, h->pooled, (size_t)MV_HIDDEN, B, h->WhT,
+                     h->bh, MV_PROJ, u_out);
+  return launch_check(h, "header");
+}
+
 // ---- encoder: ids (device) -> u (device, [B][512]); stops after n_layers (<0: all) ------------
 // `full`: every layer over every token and the normalised fp32 stream left in xres (debug taps); otherwise the
 // last layer is pruned to the [CLS] rows when the pooler follows (cls_prune), and on the persistent-GEMM path the
@@ -409,9 +420,7 @@ int encode_dev(mv_handle* h, const int32_t* d_ids, const int32_t* d_lens, int B,
         t.A = h->ch16; t.W = w.w2; t.bias = w.b2; t.N = MV_HIDDEN; t.K = MV_INTER; t.xres = h->c32;
         if (int rc = launch_gemm<EPI_RES>(h, KC_CLS_TAIL, t)) return rc;
         if (int rc = run_ln(h->c32, h->c16, B, w.ln2g, w.ln2b, false)) return rc;
-        hipLaunchKernelGGL(pool_head_kernel, dim3((B + POOL_RB - 1) / POOL_RB), dim3(256), 0, h->stream, h->c32, 1, B, h->WpT,
-                           h->bp, h->WhT, h->bh, u_out);
-        return launch_check(h, "pool_head");
+        return pool_head(h, h->c32, MV_HIDDEN, B, u_out);
       }();
       h->prof_mask = keep_mask;
       return tail_rc;
@@ -461,9 +470,7 @@ int encode_dev(mv_handle* h, const int32_t* d_ids, const int32_t* d_lens, int B,
   }
   if (u_out) {
     ProfScope ps(h, KC_POOL_HEAD);
-    hipLaunchKernelGGL(pool_head_kernel, dim3((B + POOL_RB - 1) / POOL_RB), dim3(256), 0, h->stream, h->xres, Sp, B, h->WpT,
-                       h->bp, h->WhT, h->bh, u_out);
-    if (int rc = launch_check(h, "pool_head")) return rc;
+    if (int rc = pool_head(h, h->xres, (size_t)Sp * MV_HIDDEN, B, u_out)) return rc;
   }
   return MV_OK;
 }
@@ -476,15 +483,25 @@ int max_rows_for(mv_handle* h, int S_in) {
   return (int)r;
 }
 
+// K9: 16 issue reports per workgroup when that fills the chip, otherwise 4 (same bits either way)
+int launch_match(mv_handle* h, const float* u_dev, int B, float* logits, float* probs, float* psame) {
+  const int G = h->n_anchors, gx = (G + MT_G - 1) / MT_G;
+  if ((int64_t)gx * ((B + 15) / 16) >= h->num_cu)
+    hipLaunchKernelGGL(match_kernel<4>, dim3(gx, (B + 15) / 16), dim3(256), 0, h->stream, u_dev, h->anchors, h->Wm, B, G,
+                       h->cfg.same_idx, logits, probs, psame);
+  else
+    hipLaunchKernelGGL(match_kernel<1>, dim3(gx, (B + 3) / 4), dim3(256), 0, h->stream, u_dev, h->anchors, h->Wm, B, G,
+                       h->cfg.same_idx, logits, probs, psame);
+  return launch_check(h, "match");
+}
+
 // ---- matcher on device embeddings ------------------------------------------------------------
 int match_dev(mv_handle* h, const float* u_dev, int B, float* psame_out, int k, float* best_out, int32_t* idx_out) {
   const int G = h->n_anchors;
   if (G <= 0) return fail(h, MV_ERR_STATE, "anchor bank is empty (call mv_anchor_append / mv_anchor_set first)");
   {
     ProfScope ps(h, KC_MATCH);
-    hipLaunchKernelGGL(match_kernel, dim3((G + MT_G - 1) / MT_G, (B + MT_B - 1) / MT_B), dim3(256), 0, h->stream, u_dev,
-                       h->anchors, h->Wm, B, G, h->cfg.same_idx, h->logits, h->probs, psame_out);
-    if (int rc = launch_check(h, "match")) return rc;
+    if (int rc = launch_match(h, u_dev, B, h->logits, h->probs, psame_out)) return rc;
   }
   {
     ProfScope ps(h, KC_TOPK);
@@ -628,6 +645,7 @@ int mv_create(int device, const mv_config* cfg, mv_handle** out) {
     A(dev_alloc(h, &h->ch16, Bp * MV_INTER));
   }
   A(dev_alloc(h, &h->u, (int64_t)cfg->max_batch * MV_PROJ));
+  A(dev_alloc(h, &h->pooled, (int64_t)cfg->max_batch * MV_HIDDEN));
   A(dev_alloc(h, &h->u_in, (int64_t)cfg->max_batch * MV_PROJ));
   A(dev_alloc(h, &h->anchors, (int64_t)cfg->max_anchors * MV_PROJ));
   const int64_t BG = (int64_t)cfg->max_batch * cfg->max_anchors;
@@ -901,9 +919,7 @@ int mv_topk(mv_handle* h, const float* u, int B, int k, float* topk_p, int32_t* 
     const int G = h->n_anchors;
     {
       ProfScope ps(h, KC_MATCH);
-      hipLaunchKernelGGL(match_kernel, dim3((G + MT_G - 1) / MT_G, (B + MT_B - 1) / MT_B), dim3(256), 0, h->stream, h->u_in,
-                         h->anchors, h->Wm, B, G, h->cfg.same_idx, (float*)nullptr, (float*)nullptr, h->psame);
-      if (int rc = launch_check(h, "match")) return rc;
+      if (int rc = launch_match(h, h->u_in, B, nullptr, nullptr, h->psame)) return rc;
     }
     {
       ProfScope ps(h, KC_TOPK);

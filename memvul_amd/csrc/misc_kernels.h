@@ -128,92 +128,63 @@ __global__ __launch_bounds__(256) void cls_gather_kernel(const float* __restrict
   }
 }
 
-// K7+K8 (model_memory.py:99-102): u = relu(W_h tanh(W_p h[:,0] + b_p) + b_h), all fp32.
-// One workgroup handles POOL_RB issue reports; thread n owns output column n; the weights are stored
-// transposed ([k][n]) so a wave reads 256 contiguous bytes per k.
+// K7, K8 (model_memory.py:99-102): u = relu(W_h tanh(W_p h[:,0] + b_p) + b_h), all fp32, as two launches of one
+// dense kernel: out[b][n] = act(sum_k x[b][k] W^T[k][n] + bias[n]), K = 768.  A workgroup handles POOL_RB rows x 256
+// output columns (grid = rows / POOL_RB x N / 256: 192 + 128 workgroups at B = 256 instead of the 64 a fused
+// pooler+header kernel gets); thread n owns one column; the weights are stored transposed ([k][n]) so a wave reads
+// 256 contiguous bytes per k; every output is one ascending-k fma chain (tile shape never changes the bits).
 #define POOL_RB 4
-__global__ __launch_bounds__(256) void pool_head_kernel(const float* __restrict__ x32, int Sp, int B,
-                                                        const float* __restrict__ WpT, const float* __restrict__ bp,
-                                                        const float* __restrict__ WhT, const float* __restrict__ bh,
-                                                        float* __restrict__ u) {
-  __shared__ float cls[POOL_RB][MV_HIDDEN];
-  __shared__ float pooled[POOL_RB][MV_HIDDEN];
+template <int ACT>  // 0: tanh (BertPooler), 1: ReLU (header FeedForward)
+__global__ __launch_bounds__(256) void dense768_kernel(const float* __restrict__ x, size_t row_stride, int B,
+                                                       const float* __restrict__ WT, const float* __restrict__ bias, int N,
+                                                       float* __restrict__ out) {
+  __shared__ float xs[POOL_RB][MV_HIDDEN];
   const int b0 = blockIdx.x * POOL_RB;
-  const int tid = threadIdx.x;
+  const int tid = threadIdx.x, n = blockIdx.y * 256 + tid;
   for (int e = tid; e < POOL_RB * MV_HIDDEN; e += 256) {
     const int r = e / MV_HIDDEN, c = e - r * MV_HIDDEN;
-    cls[r][c] = (b0 + r < B) ? x32[(size_t)(b0 + r) * Sp * MV_HIDDEN + c] : 0.f;
+    xs[r][c] = (b0 + r < B) ? x[(size_t)(b0 + r) * row_stride + c] : 0.f;
   }
   __syncthreads();
-  {
-    float acc[3][POOL_RB];
+  float acc[POOL_RB];
 #pragma unroll
-    for (int j = 0; j < 3; ++j)
+  for (int r = 0; r < POOL_RB; ++r) acc[r] = 0.f;
+#pragma unroll 4
+  for (int k = 0; k < MV_HIDDEN; ++k) {
+    const float w = WT[(size_t)k * N + n];
 #pragma unroll
-      for (int r = 0; r < POOL_RB; ++r) acc[j][r] = 0.f;
-    for (int k = 0; k < MV_HIDDEN; ++k) {
-      float w[3];
-#pragma unroll
-      for (int j = 0; j < 3; ++j) w[j] = WpT[(size_t)k * MV_HIDDEN + tid + 256 * j];
-#pragma unroll
-      for (int r = 0; r < POOL_RB; ++r) {
-        const float c = cls[r][k];
-#pragma unroll
-        for (int j = 0; j < 3; ++j) acc[j][r] = fmaf(w[j], c, acc[j][r]);
-      }
-    }
-#pragma unroll
-    for (int j = 0; j < 3; ++j)
-#pragma unroll
-      for (int r = 0; r < POOL_RB; ++r) pooled[r][tid + 256 * j] = tanhf(acc[j][r] + bp[tid + 256 * j]);
+    for (int r = 0; r < POOL_RB; ++r) acc[r] = fmaf(w, xs[r][k], acc[r]);
   }
-  __syncthreads();
-  {
-    float acc[2][POOL_RB];
+  const float bn = bias[n];
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int r = 0; r < POOL_RB; ++r) acc[j][r] = 0.f;
-    for (int k = 0; k < MV_HIDDEN; ++k) {
-      float w[2];
-#pragma unroll
-      for (int j = 0; j < 2; ++j) w[j] = WhT[(size_t)k * MV_PROJ + tid + 256 * j];
-#pragma unroll
-      for (int r = 0; r < POOL_RB; ++r) {
-        const float c = pooled[r][k];
-#pragma unroll
-        for (int j = 0; j < 2; ++j) acc[j][r] = fmaf(w[j], c, acc[j][r]);
-      }
-    }
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int r = 0; r < POOL_RB; ++r)
-        if (b0 + r < B) u[(size_t)(b0 + r) * MV_PROJ + tid + 256 * j] = fmaxf(acc[j][r] + bh[tid + 256 * j], 0.f);
-  }
+  for (int r = 0; r < POOL_RB; ++r)
+    if (b0 + r < B) out[(size_t)(b0 + r) * N + n] = ACT == 0 ? tanhf(acc[r] + bn) : fmaxf(acc[r] + bn, 0.f);
 }
 
 // K9 (model_memory.py:135-142): logits[b,g,:] = W_m [u_b ; v_g ; |u_b - v_g|], p = softmax_2.
 // W_m is [2][1536] row-major: columns 0..511 multiply u, 512..1023 v, 1024..1535 |u-v|.
 // A workgroup covers MT_B issue reports x MT_G anchors; the 512-long feature axis is walked in chunks
 // of MT_I staged through LDS (u tile, anchor tile with a +1 pad => conflict-free column reads, and the
-// two |u-v| weight rows).  Thread (wave w, lane l) owns anchor l and issue reports 4w..4w+3.
-#define MT_B 16
+// two |u-v| weight rows).  Thread (wave w, lane l) owns anchor l and issue reports RB w .. RB w + RB - 1; RB = 4
+// (16 issue reports per workgroup) when that already fills the chip, else RB = 1 (4 per workgroup, 4x the workgroups).
+// Every logit is three ascending-i fma chains whatever RB is.
 #define MT_G 64
 #define MT_I 128
+template <int RB>
 __global__ __launch_bounds__(256) void match_kernel(const float* __restrict__ u, const float* __restrict__ v,
                                                     const float* __restrict__ Wm, int B, int G, int same_idx,
                                                     float* __restrict__ logits, float* __restrict__ probs,
                                                     float* __restrict__ psame) {
+  constexpr int MT_B = 4 * RB;
   __shared__ float su[MT_B][MT_I];
   __shared__ float sv[MT_G][MT_I + 1];
   __shared__ float sw[4][MT_I];  // Wa0, Wa1 (u part) are folded below; rows: Wb0, Wb1, Wc0, Wc1
   __shared__ float swa[2][MT_I];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int b0 = blockIdx.y * MT_B, g0 = blockIdx.x * MT_G;
-  float accc[4][2], accu[4][2], accv[2];
+  float accc[RB][2], accu[RB][2], accv[2];
 #pragma unroll
-  for (int r = 0; r < 4; ++r) { accc[r][0] = accc[r][1] = 0.f; accu[r][0] = accu[r][1] = 0.f; }
+  for (int r = 0; r < RB; ++r) { accc[r][0] = accc[r][1] = 0.f; accu[r][0] = accu[r][1] = 0.f; }
   accv[0] = accv[1] = 0.f;
   for (int i0 = 0; i0 < MV_PROJ; i0 += MT_I) {
     __syncthreads();
@@ -239,8 +210,8 @@ __global__ __launch_bounds__(256) void match_kernel(const float* __restrict__ u,
       accv[0] = fmaf(sw[0][i], vv, accv[0]);
       accv[1] = fmaf(sw[1][i], vv, accv[1]);
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float uu = su[4 * w + r][i];
+      for (int r = 0; r < RB; ++r) {
+        const float uu = su[RB * w + r][i];
         const float dd = fabsf(uu - vv);
         accu[r][0] = fmaf(wa0, uu, accu[r][0]);
         accu[r][1] = fmaf(wa1, uu, accu[r][1]);
@@ -252,8 +223,8 @@ __global__ __launch_bounds__(256) void match_kernel(const float* __restrict__ u,
   const int g = g0 + lane;
   if (g >= G) return;
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const int b = b0 + 4 * w + r;
+  for (int r = 0; r < RB; ++r) {
+    const int b = b0 + RB * w + r;
     if (b >= B) continue;
     const float l0 = accu[r][0] + accv[0] + accc[r][0];
     const float l1 = accu[r][1] + accv[1] + accc[r][1];
