@@ -37,6 +37,8 @@ def engine_for(dims_kw: dict, w_kw: dict, gemm_tile: int = 0, env: dict = None, 
     ping-pong kernel forced (MEMVUL_GEMM_TILE, read at mv_create).  env: further MEMVUL_* switches read at
     mv_create (MEMVUL_CLS_PRUNE, MEMVUL_LN_FUSE, MEMVUL_ATTN), e.g. {"MEMVUL_CLS_PRUNE": "0"}."""
     env = dict(env or {})
+    if os.environ.get("MEMVUL_FORCE_ATTN"):  # GPU-visit hang guard (scripts/gpu_round2.sh)
+        env["MEMVUL_ATTN"] = os.environ["MEMVUL_FORCE_ATTN"]
     if gemm_tile:
         env["MEMVUL_GEMM_TILE"] = str(gemm_tile)
     key = (tuple(sorted(dims_kw.items())), tuple(sorted(w_kw.items())), tuple(sorted(eng_kw.items())), tuple(sorted(env.items())))
