@@ -170,8 +170,11 @@ __global__ __launch_bounds__(NW * 64, 2) void attention_kernel(AttnArgs a) {
 // Last encoder layer: only the [CLS] query (token 0) of each issue report is consumed downstream
 // (BertPooler takes hidden[:, 0], model_memory.py:99), so its attention is one query row per (batch row, head):
 // scores over the S keys, softmax, one V^T-weighted sum.  One wave per (b, h); HBM-bound (reads the layer's K and
-// V^T once: 2 x B x 12 x S x 128 B).  Numerics mirror attention_kernel: fp16 q, k, v and fp16-rounded P, fp32
-// scores / statistics / accumulation, additive -10000 on padded keys.
+// V^T once: 2 x B x 12 x S x 128 B), so every load instruction covers eight whole 128-B lines: lane = (row
+// lane >> 3, 16-B chunk lane & 7) for the K rows (8 keys per instruction) and for the V^T rows (8 head dims x 64
+// keys per instruction); the 8 lanes of a row combine their partial sums with three xor-shuffles.
+// Numerics mirror attention_kernel: fp16 q, k, v and fp16-rounded P, fp32 scores / statistics / accumulation,
+// additive -10000 on padded keys.
 // q: [Bpad][768] fp32 (the Q projection of the gathered [CLS] rows, 1/8 already folded into W_q), ctx: [Bpad][768] fp16.
 __global__ __launch_bounds__(256) void attention_cls_kernel(const float* __restrict__ q, const half_t* __restrict__ k,
                                                             const half_t* __restrict__ vt, const int32_t* __restrict__ lens,
@@ -182,59 +185,64 @@ __global__ __launch_bounds__(256) void attention_cls_kernel(const float* __restr
   if (bh >= nbh) return;  // no workgroup barrier below: waves are independent
   const int b = bh / MV_HEADS, h = bh - b * MV_HEADS;
   const int len = lens[b];
-  // every lane holds the whole fp16-rounded query (64 values, broadcast loads)
-  float qv[64];
+  const int c = lane & 7, sub = lane >> 3;
+  float* pw = ps[wave];
+  float qv[8];  // this lane's 8 dims of the fp16-rounded query
   {
-    const float4* qp = (const float4*)(q + (size_t)b * MV_HIDDEN + h * MV_HEAD_DIM);
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      const float4 t = qp[i];
-      qv[4 * i + 0] = (float)(half_t)t.x; qv[4 * i + 1] = (float)(half_t)t.y;
-      qv[4 * i + 2] = (float)(half_t)t.z; qv[4 * i + 3] = (float)(half_t)t.w;
-    }
+    const float4* qp = (const float4*)(q + (size_t)b * MV_HIDDEN + h * MV_HEAD_DIM + 8 * c);
+    const float4 t0 = qp[0], t1 = qp[1];
+    qv[0] = (float)(half_t)t0.x; qv[1] = (float)(half_t)t0.y; qv[2] = (float)(half_t)t0.z; qv[3] = (float)(half_t)t0.w;
+    qv[4] = (float)(half_t)t1.x; qv[5] = (float)(half_t)t1.y; qv[6] = (float)(half_t)t1.z; qv[7] = (float)(half_t)t1.w;
   }
-  const half_t* kb = k + (size_t)bh * S * MV_HEAD_DIM;
-  float sc[8];
+  // ---- scores -> LDS (key = key0 + sub)
+  const half_t* kb = k + (size_t)bh * S * MV_HEAD_DIM + (size_t)sub * MV_HEAD_DIM + 8 * c;
+#pragma unroll 8
+  for (int key0 = 0; key0 < S; key0 += 8) {
+    const half8_t kk = *(const half8_t*)(kb + (size_t)key0 * MV_HEAD_DIM);
+    float s = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s = __builtin_fmaf(qv[e], (float)kk[e], s);
+    s += __shfl_xor(s, 1, 64);
+    s += __shfl_xor(s, 2, 64);
+    s += __shfl_xor(s, 4, 64);
+    if (c == 0) pw[key0 + sub] = s + ((key0 + sub >= len) ? -10000.0f : 0.0f);
+  }
+  __builtin_amdgcn_wave_barrier();
+  // ---- softmax statistics; P (fp16-rounded) back to LDS
   float mx = -3.0e38f;
-#pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    const int key = lane + 64 * j;
-    sc[j] = -3.0e38f;
-    if (key < S) {
-      const half8_t* kr = (const half8_t*)(kb + (size_t)key * MV_HEAD_DIM);
-      float s = 0.f;
-#pragma unroll
-      for (int c = 0; c < 8; ++c) {
-        const half8_t kk = kr[c];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) s = __builtin_fmaf(qv[8 * c + e], (float)kk[e], s);
-      }
-      if (key >= len) s += -10000.0f;
-      sc[j] = s;
-      mx = fmaxf(mx, s);
-    }
-  }
+  for (int key = lane; key < S; key += 64) mx = fmaxf(mx, pw[key]);
   mx = wave_max(mx);
   float psum = 0.f;
-#pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    const int key = lane + 64 * j;
-    if (key < S) {
-      const float p = __expf(sc[j] - mx);
-      psum += p;
-      ps[wave][key] = (float)(half_t)p;
-    }
+  for (int key = lane; key < S; key += 64) {
+    const float p = __expf(pw[key] - mx);
+    psum += p;
+    pw[key] = (float)(half_t)p;
   }
   const float inv = 1.0f / wave_sum(psum);
   __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  // lane = head dim d: o[d] = sum_key P[key] V^T[d][key]
-  const half_t* vr = vt + ((size_t)bh * MV_HEAD_DIM + lane) * S;
-  float o = 0.f;
-  for (int kc = 0; kc < S; kc += 8) {
-    const half8_t vv = *(const half8_t*)(vr + kc);
+  // ---- o[d] = sum_key P[key] V^T[d][key]: lane = (dim 8 db + sub, keys kb0 + 8 c .. + 7)
+  float acc[8];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) o = __builtin_fmaf(ps[wave][kc + e], (float)vv[e], o);
+  for (int db = 0; db < 8; ++db) acc[db] = 0.f;
+  const half_t* vb = vt + ((size_t)bh * MV_HEAD_DIM + sub) * S + 8 * c;
+  for (int kb0 = 0; kb0 < S; kb0 += 64) {
+    const float4 p0 = *(const float4*)(pw + kb0 + 8 * c), p1 = *(const float4*)(pw + kb0 + 8 * c + 4);
+    const float pr[8] = {p0.x, p0.y, p0.z, p0.w, p1.x, p1.y, p1.z, p1.w};
+#pragma unroll
+    for (int db = 0; db < 8; ++db) {
+      const half8_t vv = *(const half8_t*)(vb + (size_t)(8 * db) * S + kb0);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc[db] = __builtin_fmaf(pr[e], (float)vv[e], acc[db]);
+    }
   }
-  ctx[(size_t)b * MV_HIDDEN + h * MV_HEAD_DIM + lane] = (half_t)(o * inv);
+  float out = 0.f;
+#pragma unroll
+  for (int db = 0; db < 8; ++db) {
+    float t = acc[db];
+    t += __shfl_xor(t, 1, 64);
+    t += __shfl_xor(t, 2, 64);
+    t += __shfl_xor(t, 4, 64);
+    out = (c == db) ? t : out;  // lane (sub, c) keeps dim 8 c + sub
+  }
+  ctx[(size_t)b * MV_HIDDEN + h * MV_HEAD_DIM + 8 * c + sub] = (half_t)(out * inv);
 }

@@ -465,6 +465,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmArgs a) {
             for (int e = 0; e < 4; ++e) d[q][e] = f2u(acc[i][q >> 2][4 * (q & 3) + e]);
           scr_f32x4(scr_c, scr_c + 1024, d, scr_m32, scr_m32 ^ 32u, o);
           if constexpr (EPI == PP_RESLN) {
+#pragma clang fp contract(off)
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
               float4 bi[4], ga[4], be[4];

@@ -16,15 +16,22 @@ __device__ __forceinline__ void ln_row_store(const float4 (&x)[3], const float* 
                                              const float* __restrict__ beta, float eps, int lane,
                                              float* __restrict__ out32, half_t* __restrict__ out16,
                                              float* __restrict__ stats) {
+  // every operation below is spelled out (explicit fma, contraction off): hipcc otherwise contracts the variance
+  // sum differently in different instantiations of this template, and the two routes of the residual stream
+  // (normalised here, or by the PP_RESLN consumer from the statistics) would differ in the last bit of rstd
+#pragma clang fp contract(off)
   float s = 0.f;
 #pragma unroll
-  for (int i = 0; i < 3; ++i) s += x[i].x + x[i].y + x[i].z + x[i].w;
+  for (int i = 0; i < 3; ++i) s += (x[i].x + x[i].y) + (x[i].z + x[i].w);
   const float mean = wave_sum(s) * (1.0f / MV_HIDDEN);
   float v = 0.f;
 #pragma unroll
   for (int i = 0; i < 3; ++i) {
     const float a = x[i].x - mean, b = x[i].y - mean, c = x[i].z - mean, d = x[i].w - mean;
-    v += a * a + b * b + c * c + d * d;
+    v = __builtin_fmaf(a, a, v);
+    v = __builtin_fmaf(b, b, v);
+    v = __builtin_fmaf(c, c, v);
+    v = __builtin_fmaf(d, d, v);
   }
   const float rstd = 1.0f / sqrtf(wave_sum(v) * (1.0f / MV_HIDDEN) + eps);
   if (stats && lane == 0) {
@@ -105,6 +112,7 @@ __global__ __launch_bounds__(256) void cls_gather_kernel(const float* __restrict
                                                          int B, const float* __restrict__ stats,
                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
                                                          float* __restrict__ c32, half_t* __restrict__ c16) {
+#pragma clang fp contract(off)
   const int lane = threadIdx.x & 63;
   const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (b >= B) return;
@@ -149,11 +157,15 @@ __global__ __launch_bounds__(256) void dense768_kernel(const float* __restrict__
   float acc[POOL_RB];
 #pragma unroll
   for (int r = 0; r < POOL_RB; ++r) acc[r] = 0.f;
-#pragma unroll 4
-  for (int k = 0; k < MV_HIDDEN; ++k) {
-    const float w = WT[(size_t)k * N + n];
+  // 16 weight loads in flight per thread: at one workgroup per CU the loop is L2-latency-bound otherwise
+  for (int k0 = 0; k0 < MV_HIDDEN; k0 += 16) {
+    float w[16];
 #pragma unroll
-    for (int r = 0; r < POOL_RB; ++r) acc[r] = fmaf(w, xs[r][k], acc[r]);
+    for (int j = 0; j < 16; ++j) w[j] = WT[(size_t)(k0 + j) * N + n];
+#pragma unroll
+    for (int j = 0; j < 16; ++j)
+#pragma unroll
+      for (int r = 0; r < POOL_RB; ++r) acc[r] = fmaf(w[j], xs[r][k0 + j], acc[r]);
   }
   const float bn = bias[n];
 #pragma unroll
@@ -163,11 +175,12 @@ __global__ __launch_bounds__(256) void dense768_kernel(const float* __restrict__
 
 // K9 (model_memory.py:135-142): logits[b,g,:] = W_m [u_b ; v_g ; |u_b - v_g|], p = softmax_2.
 // W_m is [2][1536] row-major: columns 0..511 multiply u, 512..1023 v, 1024..1535 |u-v|.
-// A workgroup covers MT_B issue reports x MT_G anchors; the 512-long feature axis is walked in chunks
-// of MT_I staged through LDS (u tile, anchor tile with a +1 pad => conflict-free column reads, and the
-// two |u-v| weight rows).  Thread (wave w, lane l) owns anchor l and issue reports RB w .. RB w + RB - 1; RB = 4
-// (16 issue reports per workgroup) when that already fills the chip, else RB = 1 (4 per workgroup, 4x the workgroups).
-// Every logit is three ascending-i fma chains whatever RB is.
+// A workgroup covers 4 RB issue reports x MT_G anchors; the 512-long feature axis is walked in chunks of MT_I with
+// the anchor tile staged through LDS (+1 pad => conflict-free column reads).  Thread (wave w, lane l) owns anchor l
+// and issue reports RB w .. RB w + RB - 1.  The six weight values and the issue-report features of a step are
+// wave-uniform: they are read with scalar loads (SGPR operands of the fmas), so a step is one LDS read + 2 + 5 RB
+// VALU operations.  RB = 4 (16 issue reports per workgroup) when that already fills the chip, else RB = 1 (4x the
+// workgroups).  Every logit is three ascending-i fma chains whatever RB is.
 #define MT_G 64
 #define MT_I 128
 template <int RB>
@@ -176,42 +189,38 @@ __global__ __launch_bounds__(256) void match_kernel(const float* __restrict__ u,
                                                     float* __restrict__ logits, float* __restrict__ probs,
                                                     float* __restrict__ psame) {
   constexpr int MT_B = 4 * RB;
-  __shared__ float su[MT_B][MT_I];
   __shared__ float sv[MT_G][MT_I + 1];
-  __shared__ float sw[4][MT_I];  // Wa0, Wa1 (u part) are folded below; rows: Wb0, Wb1, Wc0, Wc1
-  __shared__ float swa[2][MT_I];
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int b0 = blockIdx.y * MT_B, g0 = blockIdx.x * MT_G;
   float accc[RB][2], accu[RB][2], accv[2];
 #pragma unroll
   for (int r = 0; r < RB; ++r) { accc[r][0] = accc[r][1] = 0.f; accu[r][0] = accu[r][1] = 0.f; }
   accv[0] = accv[1] = 0.f;
+  const float* urow[RB];
+#pragma unroll
+  for (int r = 0; r < RB; ++r) {
+    const int b = b0 + RB * w + r;
+    urow[r] = u + (size_t)(b < B ? b : B - 1) * MV_PROJ;  // rows past B: computed on a valid row, never stored
+  }
   for (int i0 = 0; i0 < MV_PROJ; i0 += MT_I) {
     __syncthreads();
-    for (int e = tid; e < MT_B * MT_I; e += 256) {
-      const int r = e / MT_I, c = e - r * MT_I;
-      su[r][c] = (b0 + r < B) ? u[(size_t)(b0 + r) * MV_PROJ + i0 + c] : 0.f;
-    }
     for (int e = tid; e < MT_G * MT_I; e += 256) {
       const int r = e / MT_I, c = e - r * MT_I;
       sv[r][c] = (g0 + r < G) ? v[(size_t)(g0 + r) * MV_PROJ + i0 + c] : 0.f;
     }
-    for (int e = tid; e < 2 * MT_I; e += 256) {
-      const int r = e / MT_I, c = e - r * MT_I;
-      swa[r][c] = Wm[(size_t)r * 3 * MV_PROJ + i0 + c];
-      sw[r][c] = Wm[(size_t)r * 3 * MV_PROJ + MV_PROJ + i0 + c];
-      sw[2 + r][c] = Wm[(size_t)r * 3 * MV_PROJ + 2 * MV_PROJ + i0 + c];
-    }
     __syncthreads();
+#pragma unroll 8
     for (int i = 0; i < MT_I; ++i) {
       const float vv = sv[lane][i];
-      const float wa0 = swa[0][i], wa1 = swa[1][i];
-      const float wc0 = sw[2][i], wc1 = sw[3][i];
-      accv[0] = fmaf(sw[0][i], vv, accv[0]);
-      accv[1] = fmaf(sw[1][i], vv, accv[1]);
+      const float wa0 = Wm[i0 + i], wa1 = Wm[3 * MV_PROJ + i0 + i];
+      const float wb0 = Wm[MV_PROJ + i0 + i], wb1 = Wm[4 * MV_PROJ + i0 + i];
+      const float wc0 = Wm[2 * MV_PROJ + i0 + i], wc1 = Wm[5 * MV_PROJ + i0 + i];
+      accv[0] = fmaf(wb0, vv, accv[0]);
+      accv[1] = fmaf(wb1, vv, accv[1]);
 #pragma unroll
       for (int r = 0; r < RB; ++r) {
-        const float uu = su[RB * w + r][i];
+        const float uu = urow[r][i0 + i];
         const float dd = fabsf(uu - vv);
         accu[r][0] = fmaf(wa0, uu, accu[r][0]);
         accu[r][1] = fmaf(wa1, uu, accu[r][1]);

@@ -154,7 +154,8 @@ def test_engine_coexists_with_torch_hip_runtime():
 def test_last_layer_pruning_matches_full_forward(gu, B, S, ragged, gemm_tile):
     """MEMVUL_CLS_PRUNE: after the last layer's K / V projection only the [CLS] rows are processed (the pooler
     reads hidden[:, 0], model_memory.py:99).  Same embedding as the all-token forward up to the different
-    summation order of the single-query attention (fp32 rounding), and the same oracle parity."""
+    summation order of the single-query attention (fp32 rounding, then fp16 rounding of the context), and the same
+    oracle parity."""
     dk, wk = dict(layers=2, vocab_size=2048), dict(qk_scale=3.0)
     dims, w = gu.weights_for(dk, wk)
     ids, lens = synth.make_ids(B, S, dims.vocab_size, ragged=ragged, min_len=7)
@@ -164,7 +165,7 @@ def test_last_layer_pruning_matches_full_forward(gu, B, S, ragged, gemm_tile):
     d = float(np.abs(u_full - u_cls).max())
     gu.record("cls_prune", B=B, S=S, gemm_tile=gemm_tile, full_vs_pruned=d, pruned_vs_oracle=float(np.abs(u_cls - u_ref).max()),
               full_vs_oracle=float(np.abs(u_full - u_ref).max()))
-    assert d < 2e-5
+    assert d < 2e-4  # one fp16 ulp of a context value (different summation order) reaches u at the 5e-5 level
     assert np.abs(u_cls - u_ref).max() < 2e-3
 
 
