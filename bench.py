@@ -37,7 +37,11 @@ H, I, P = 768, 3072, 512
 GEMM_CLASSES = ("gemm_qkv", "gemm_attn_out", "gemm_ffn1_gelu", "gemm_ffn2")
 # HBM bytes per launch of each GEMM class at the default workload from the separate rocprofv3 --pmc passes kept
 # under profiles/ (FETCH_SIZE x 2 per the gfx950 correction + WRITE_SIZE); None where no pass has been taken
-PMC_TRAFFIC_BYTES = {}
+PMC_TRAFFIC_BYTES = {
+    # profiles/r01_f_pmc_hbm.txt: gemm_pp_kernel<PP_GELU> FETCH_SIZE 2.222e5 KiB (x2) + WRITE_SIZE 3.901e5 KiB
+    "gemm_ffn1_gelu": int((2 * 2.222e5 + 3.901e5) * 1024),
+    "gemm_ffn2": None, "gemm_qkv": None, "gemm_attn_out": None,
+}
 
 
 def flops_per_ir(S: int, G: int, layers: int = 12) -> float:

@@ -205,9 +205,19 @@ __global__ __launch_bounds__(256) void match_kernel(const float* __restrict__ u,
   }
   for (int i0 = 0; i0 < MV_PROJ; i0 += MT_I) {
     __syncthreads();
-    for (int e = tid; e < MT_G * MT_I; e += 256) {
-      const int r = e / MT_I, c = e - r * MT_I;
-      sv[r][c] = (g0 + r < G) ? v[(size_t)(g0 + r) * MV_PROJ + i0 + c] : 0.f;
+    {  // anchor tile -> LDS: 8 x 16-byte loads per thread, all in flight before the first LDS write (one by one they
+       // cost a DRAM/L2 round trip each: 32 dependent trips per chunk made this kernel latency-bound)
+      float4 t[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int e = tid + 256 * j, r = e >> 5, c4 = e & 31;  // 32 float4 per 128-feature row
+        t[j] = (g0 + r < G) ? *(const float4*)(v + (size_t)(g0 + r) * MV_PROJ + i0 + 4 * c4) : float4{0.f, 0.f, 0.f, 0.f};
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int e = tid + 256 * j, r = e >> 5, c4 = e & 31;
+        sv[r][4 * c4 + 0] = t[j].x; sv[r][4 * c4 + 1] = t[j].y; sv[r][4 * c4 + 2] = t[j].z; sv[r][4 * c4 + 3] = t[j].w;
+      }
     }
     __syncthreads();
 #pragma unroll 8
