@@ -80,6 +80,8 @@ def main():
     ap.add_argument("--no-profile", action="store_true", help="do not record per-kernel HIP events in the timed region")
     args = ap.parse_args()
 
+    if args.cpu_sample > 0 or int(os.environ.get("WORLD_SIZE", "1")) > 1:
+        import torch  # noqa: F401  (torch, when used at all, is loaded BEFORE the engine: see tests/test_gpu_parity.py)
     rank, local_rank, world = mvdist.env_world()
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")

@@ -63,7 +63,6 @@ def load_archive(archive_file: str, weights_file: Optional[str] = None, cuda_dev
         mcfg = dict(config["model"])
         if not str(mcfg.get("device", "cpu")).startswith("cuda") and cuda_device is not None and cuda_device >= 0:
             mcfg["device"] = f"cuda:{cuda_device}"  # AllenNLP moves the model to cuda_device (predict_memory.py:65)
-        model = Model.from_params(mcfg, vocab=vocab, engine_options=engine_options)
         wpath = weights_file
         if wpath is None:
             for cand in ("weights.th", "weights.safetensors", "weights.npz"):
@@ -72,7 +71,11 @@ def load_archive(archive_file: str, weights_file: Optional[str] = None, cuda_dev
                     break
         if wpath is None:
             raise FileNotFoundError(f"no weights.th in {archive_file}")
-        model.load_state_dict(read_state_dict(wpath))
+        # the state dict is read (torch imported, CPU only) BEFORE the model creates its engine: torch, when it is
+        # used at all, is always loaded ahead of libmemvul_hip.so (tests/test_gpu_parity.py: supported load order)
+        state = read_state_dict(wpath)
+        model = Model.from_params(mcfg, vocab=vocab, engine_options=engine_options)
+        model.load_state_dict(state)
         reader = _build_reader(config.get("dataset_reader"))
         vreader = _build_reader(config.get("validation_dataset_reader")) or reader
         return Archive(model=model, config=config, dataset_reader=reader, validation_dataset_reader=vreader)
