@@ -39,6 +39,9 @@ struct HostTensor {
 struct LayerW {
   half_t *wqkv = nullptr, *wo = nullptr, *w1 = nullptr, *w2 = nullptr;
   float *bqkv = nullptr, *bo = nullptr, *b1 = nullptr, *b2 = nullptr;
+  // virtual LayerNorm (gemm_pp.h): the preceding LayerNorm folded in: W'' = rowcentre(W gamma), b' = b + W beta
+  half_t *wqkv_f = nullptr, *w1_f = nullptr;
+  float *bqkv_f = nullptr, *b1_f = nullptr;
   float *ln1g = nullptr, *ln1b = nullptr, *ln2g = nullptr, *ln2b = nullptr;
 };
 
@@ -147,6 +150,9 @@ struct mv_handle {
   // persistent LDS-DMA attention kernel for padded lengths <= 256 (attention_v2.h); env MEMVUL_ATTN=0 selects attention.h
   bool attn_v2 = true;
   float *lnstats = nullptr, *ones = nullptr, *zeros = nullptr;
+  // ... and no LayerNorm kernel at all between the GEMMs (RAW consumers + PP_RESLN2 producers); env MEMVUL_LN_VIRTUAL=0 disables
+  bool ln_virtual = true;
+  float* lnpart = nullptr;  // [T][12][2] partial row sums of the residual GEMMs
 
   // profiling
   uint32_t prof_mask = 0xffffffffu;  // kernel classes that get HIP events while profiling is on
@@ -286,14 +292,15 @@ int launch_ring(mv_handle* h, int cls, GemmArgs a, int gn_max) {
 // phase (SCHED 1), 4 half-tiles in flight across each barrier, epilogue / residual I/O through the LDS transposition
 constexpr int PP_DIST = 4, PP_SCHED = 1, PP_COAL = 1;
 
-template <int PPEPI>
+template <int PPEPI, int RAW = 0>
 int launch_pp_raw(mv_handle* h, GemmArgs a) {
   if (a.M % 256 || a.N % 256 || a.K % 128 || a.N > MV_INTER)
     return fail(h, MV_ERR_INVALID, "gemm_pp: M,N % 256, K % 128, N <= 3072 required");
   a.GN = choose_gn(a.N / 256, 4);
   const int tiles = (a.M / 256) * (a.N / 256);
   const int grid = tiles < h->num_cu ? tiles : h->num_cu;
-  hipLaunchKernelGGL((gemm_pp_kernel<PPEPI, PP_DIST, 0, PP_SCHED, PP_COAL>), dim3(grid), dim3(512), PP_LDS_BYTES, h->stream, a);
+  hipLaunchKernelGGL((gemm_pp_kernel<PPEPI, PP_DIST, 0, PP_SCHED, PP_COAL, RAW>), dim3(grid), dim3(512),
+                     RAW ? PP_LDS_BYTES_RAW : PP_LDS_BYTES, h->stream, a);
   return launch_check(h, "gemm_pp");
 }
 
@@ -305,15 +312,16 @@ int launch_pp(mv_handle* h, int cls, const GemmArgs& a) {
     const int qk_cols = (a.col0 ? 1 : 2) * MV_HIDDEN;
     GemmArgs qk = a;
     qk.N = qk_cols;
-    if (int rc = launch_pp_raw<PP_QK>(h, qk)) return rc;
+    if (int rc = a.raw ? launch_pp_raw<PP_QK, 1>(h, qk) : launch_pp_raw<PP_QK>(h, qk)) return rc;
     GemmArgs v = a;
     v.W = a.W + (size_t)qk_cols * a.K;
     v.bias = a.bias ? a.bias + qk_cols : nullptr;
     v.N = MV_HIDDEN;
-    return launch_pp_raw<PP_VT>(h, v);
+    return a.raw ? launch_pp_raw<PP_VT, 1>(h, v) : launch_pp_raw<PP_VT>(h, v);
   } else if constexpr (EPI == EPI_GELU) {
-    return launch_pp_raw<PP_GELU>(h, a);
+    return a.raw ? launch_pp_raw<PP_GELU, 1>(h, a) : launch_pp_raw<PP_GELU>(h, a);
   } else if constexpr (EPI == EPI_RES) {
+    if (a.lnstats && a.lnpart) return launch_pp_raw<PP_RESLN2>(h, a);
     if (a.lnstats) return launch_pp_raw<PP_RESLN>(h, a);
     return launch_pp_raw<PP_RES>(h, a);
   } else {
@@ -334,7 +342,7 @@ int launch_gemm(mv_handle* h, int cls, const GemmArgs& a) {
   const bool tile256 = (a.M % 256 == 0) && (a.N % 256 == 0);
   const bool big = tile256 && ((int64_t)(a.M / 256) * (a.N / 256) >= 256);
   if (pp_selected(h, a.M, a.N, a.K)) return launch_pp<EPI>(h, cls, a);
-  if (a.lnstats) return fail(h, MV_ERR_STATE, "internal: LayerNorm-fused residual requested on a non-persistent GEMM path");
+  if (a.lnstats || a.raw) return fail(h, MV_ERR_STATE, "internal: LayerNorm-fused GEMM requested on a non-persistent GEMM path");
   if (tile256 && (h->gemm_tile == 256 || (h->gemm_tile == 0 && big))) return launch_gemm256<EPI>(h, cls, a);
   return launch_gemm128<EPI, true>(h, cls, a);
 }
@@ -367,16 +375,23 @@ int encode_dev(mv_handle* h, const int32_t* d_ids, const int32_t* d_lens, int B,
   const bool prune = !full && h->cls_prune && u_out && n_layers == c.layers && n_layers > 0;
   // both residual GEMMs have N = 768 and K % 128 == 0: one predicate decides the path of every RES launch of this pass
   const bool fuse = !full && h->ln_fuse && pp_selected(h, Mpad, MV_HIDDEN, MV_HIDDEN);
+  // virtual LayerNorm (gemm_pp.h): no LayerNorm kernel between the GEMMs; x16 then holds the RAW stream in fp16
+  const bool virt = fuse && h->ln_virtual;
   const unsigned ln_grid = (unsigned)((M + 3) / 4);
   {
     ProfScope ps(h, KC_EMBED_LN);
-    hipLaunchKernelGGL(embed_ln_kernel, dim3(ln_grid), dim3(256), 0, h->stream, d_ids, S_in, Sp, (int)M,
-                       c.vocab_size, h->wemb, h->pemb, h->temb, h->embg, h->embb, c.ln_eps, h->xres, h->x16,
-                       fuse ? h->lnstats : (float*)nullptr);
+    if (virt)
+      hipLaunchKernelGGL(embed_ln_kernel<true>, dim3(ln_grid), dim3(256), 0, h->stream, d_ids, S_in, Sp, (int)M, c.vocab_size,
+                         h->wemb, h->pemb, h->temb, h->embg, h->embb, c.ln_eps, h->xres, h->x16, h->lnstats);
+    else
+      hipLaunchKernelGGL(embed_ln_kernel<false>, dim3(ln_grid), dim3(256), 0, h->stream, d_ids, S_in, Sp, (int)M, c.vocab_size,
+                         h->wemb, h->pemb, h->temb, h->embg, h->embb, c.ln_eps, h->xres, h->x16,
+                         fuse ? h->lnstats : (float*)nullptr);
     if (int rc = launch_check(h, "embed_ln")) return rc;
   }
   // LayerNorm whose statistics are pending in lnstats (fuse only): gamma / beta the next residual consumer applies
-  const float *pend_g = h->ones, *pend_b = h->zeros;
+  // (virt: the embedding LayerNorm itself is pending; otherwise the embedding kernel already applied it)
+  const float *pend_g = virt ? h->embg : h->ones, *pend_b = virt ? h->embb : h->zeros;
   auto run_ln = [&](float* x32, half_t* x16, int rows, const float* g, const float* b, bool stats_only) -> int {
     ProfScope ps(h, KC_LN);
     const unsigned grid = (unsigned)((rows + 3) / 4);
@@ -386,16 +401,25 @@ int encode_dev(mv_handle* h, const int32_t* d_ids, const int32_t* d_lens, int B,
       hipLaunchKernelGGL(ln_kernel<true>, dim3(grid), dim3(256), 0, h->stream, x32, x16, rows, g, b, c.ln_eps, (float*)nullptr);
     return launch_check(h, "layernorm");
   };
+  auto run_finalize = [&]() -> int {  // virt: partial row sums of the residual GEMM -> (mean, rstd)
+    ProfScope ps(h, KC_LN);
+    hipLaunchKernelGGL(ln_finalize_kernel, dim3((unsigned)((Mpad + 255) / 256)), dim3(256), 0, h->stream, h->lnpart, MV_HIDDEN / 64,
+                       (int)Mpad, c.ln_eps, h->lnstats);
+    return launch_check(h, "ln_finalize");
+  };
   for (int l = 0; l < n_layers; ++l) {
     const LayerW& w = h->L[l];
     const bool last = (l == n_layers - 1);
     GemmArgs g{};
     g.M = (int)Mpad; g.Mreal = (int)M; g.S = Sp;
     g.q = h->q; g.k = h->k; g.vt = h->vt;
+    if (virt) { g.raw = 1; g.lnstats = h->lnstats; }
+    const half_t* wqkv = virt ? w.wqkv_f : w.wqkv;
+    const float* bqkv = virt ? w.bqkv_f : w.bqkv;
     if (last && prune) {
       // ---- last layer, [CLS] rows only: K and V of every token, everything else on B rows
       const int Bp = (int)round_up(B, 128);
-      g.A = h->x16; g.W = w.wqkv + (size_t)MV_HIDDEN * MV_HIDDEN; g.bias = w.bqkv + MV_HIDDEN; g.N = 2 * MV_HIDDEN; g.K = MV_HIDDEN;
+      g.A = h->x16; g.W = wqkv + (size_t)MV_HIDDEN * MV_HIDDEN; g.bias = bqkv + MV_HIDDEN; g.N = 2 * MV_HIDDEN; g.K = MV_HIDDEN;
       g.col0 = MV_HIDDEN;
       if (int rc = launch_gemm<EPI_QKV>(h, KC_GEMM_KV_LAST, g)) return rc;
       ProfScope tail(h, KC_CLS_TAIL);
@@ -403,7 +427,7 @@ int encode_dev(mv_handle* h, const int32_t* d_ids, const int32_t* d_lens, int B,
       h->prof_mask = 0;  // the tail is one profiled span; its inner launches carry no events of their own
       auto tail_rc = [&]() -> int {
         hipLaunchKernelGGL(cls_gather_kernel, dim3((B + 3) / 4), dim3(256), 0, h->stream, h->xres, h->x16, Sp, B,
-                           fuse ? h->lnstats : (const float*)nullptr, pend_g, pend_b, h->c32, h->c16);
+                           fuse ? h->lnstats : (const float*)nullptr, pend_g, pend_b, h->c32, h->c16, virt ? 1 : 0);
         if (int rc = launch_check(h, "cls_gather")) return rc;
         GemmArgs t{};
         t.M = Bp; t.Mreal = B; t.S = 64;
@@ -426,7 +450,7 @@ int encode_dev(mv_handle* h, const int32_t* d_ids, const int32_t* d_lens, int B,
       return tail_rc;
     }
     // K2: QKV projection
-    g.A = h->x16; g.W = w.wqkv; g.bias = w.bqkv; g.N = 3 * MV_HIDDEN; g.K = MV_HIDDEN;
+    g.A = h->x16; g.W = wqkv; g.bias = bqkv; g.N = 3 * MV_HIDDEN; g.K = MV_HIDDEN;
     if (int rc = launch_gemm<EPI_QKV>(h, KC_GEMM_QKV, g)) return rc;
     // K3: attention
     {
@@ -452,20 +476,27 @@ int encode_dev(mv_handle* h, const int32_t* d_ids, const int32_t* d_lens, int B,
       if (int rc = launch_check(h, "attention")) return rc;
     }
     // K4: attention output projection + bias + residual (in place), then LayerNorm
+    g.raw = 0; g.lnstats = nullptr; g.lnpart = nullptr;
     g.A = h->ctx; g.W = w.wo; g.bias = w.bo; g.N = MV_HIDDEN; g.K = MV_HIDDEN; g.xres = h->xres;
     if (fuse) { g.lnstats = h->lnstats; g.lng = pend_g; g.lnb = pend_b; }
+    if (virt) { g.lnpart = h->lnpart; g.out16 = h->x16; }  // + the fp16 copy of the new raw stream and its partial row sums
     if (int rc = launch_gemm<EPI_RES>(h, KC_GEMM_OUT, g)) return rc;
-    if (int rc = run_ln(h->xres, h->x16, (int)M, w.ln1g, w.ln1b, fuse)) return rc;
+    if (virt) { if (int rc = run_finalize()) return rc; }
+    else if (int rc = run_ln(h->xres, h->x16, (int)M, w.ln1g, w.ln1b, fuse)) return rc;
     pend_g = w.ln1g; pend_b = w.ln1b;
     // K5: FFN-1 + exact-erf GELU
-    g.lnstats = nullptr;
-    g.A = h->x16; g.W = w.w1; g.bias = w.b1; g.N = MV_INTER; g.K = MV_HIDDEN; g.out16 = h->h16;
+    g.lnstats = nullptr; g.lnpart = nullptr; g.raw = 0;
+    if (virt) { g.raw = 1; g.lnstats = h->lnstats; }
+    g.A = h->x16; g.W = virt ? w.w1_f : w.w1; g.bias = virt ? w.b1_f : w.b1; g.N = MV_INTER; g.K = MV_HIDDEN; g.out16 = h->h16;
     if (int rc = launch_gemm<EPI_GELU>(h, KC_GEMM_FFN1, g)) return rc;
     // K6: FFN-2 + bias + residual, then LayerNorm
+    g.raw = 0; g.lnstats = nullptr;
     g.A = h->h16; g.W = w.w2; g.bias = w.b2; g.N = MV_HIDDEN; g.K = MV_INTER; g.xres = h->xres;
     if (fuse) { g.lnstats = h->lnstats; g.lng = pend_g; g.lnb = pend_b; }
+    if (virt) { g.lnpart = h->lnpart; g.out16 = h->x16; }
     if (int rc = launch_gemm<EPI_RES>(h, KC_GEMM_FFN2, g)) return rc;
-    if (int rc = run_ln(h->xres, h->x16, (int)M, w.ln2g, w.ln2b, fuse && !last)) return rc;  // the pooler reads a normalised stream
+    if (virt && !last) { if (int rc = run_finalize()) return rc; }
+    else if (int rc = run_ln(h->xres, h->x16, (int)M, w.ln2g, w.ln2b, fuse && !last)) return rc;  // the pooler reads a normalised stream
     pend_g = w.ln2g; pend_b = w.ln2b;
   }
   if (u_out) {
@@ -542,6 +573,24 @@ int upload_f32(mv_handle* h, float** dst, const float* src, int64_t n) {
   HIPCHK(h, hipStreamSynchronize(h->stream));
   return MV_OK;
 }
+// Virtual LayerNorm weights (gemm_pp.h): W''[n][k] = W[n][k] gamma[k] - mean_k(W[n][.] gamma[.]),  b'[n] = b[n] + sum_k W[n][k] beta[k]
+void fold_layernorm(const float* W, const float* b, const float* gamma, const float* beta, int64_t N, int64_t K,
+                    std::vector<float>& Wf, std::vector<float>& bf) {
+  Wf.resize((size_t)(N * K));
+  bf.resize((size_t)N);
+  for (int64_t n = 0; n < N; ++n) {
+    double sum = 0.0, wb = 0.0;
+    for (int64_t k = 0; k < K; ++k) {
+      const double v = (double)W[n * K + k] * (double)gamma[k];
+      sum += v;
+      wb += (double)W[n * K + k] * (double)beta[k];
+    }
+    const double mean = sum / (double)K;
+    for (int64_t k = 0; k < K; ++k) Wf[(size_t)(n * K + k)] = (float)((double)W[n * K + k] * (double)gamma[k] - mean);
+    bf[(size_t)n] = (float)((double)b[n] + wb);
+  }
+}
+
 int upload_f16(mv_handle* h, half_t** dst, const float* src, int64_t n, float scale = 1.0f) {
   std::vector<uint16_t> tmp((size_t)n);
   for (int64_t i = 0; i < n; ++i) tmp[(size_t)i] = f32_to_f16_bits(src[i] * scale);
@@ -599,10 +648,15 @@ int mv_create(int device, const mv_config* cfg, mv_handle** out) {
   hipFuncSetAttribute((const void*)gemm_pp_kernel<PP_GELU, PP_DIST, 0, PP_SCHED, PP_COAL>, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS_BYTES);
   hipFuncSetAttribute((const void*)gemm_pp_kernel<PP_RES, PP_DIST, 0, PP_SCHED, PP_COAL>, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS_BYTES);
   hipFuncSetAttribute((const void*)gemm_pp_kernel<PP_RESLN, PP_DIST, 0, PP_SCHED, PP_COAL>, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS_BYTES);
+  hipFuncSetAttribute((const void*)gemm_pp_kernel<PP_RESLN2, PP_DIST, 0, PP_SCHED, PP_COAL>, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS_BYTES);
+  hipFuncSetAttribute((const void*)gemm_pp_kernel<PP_QK, PP_DIST, 0, PP_SCHED, PP_COAL, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS_BYTES_RAW);
+  hipFuncSetAttribute((const void*)gemm_pp_kernel<PP_VT, PP_DIST, 0, PP_SCHED, PP_COAL, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS_BYTES_RAW);
+  hipFuncSetAttribute((const void*)gemm_pp_kernel<PP_GELU, PP_DIST, 0, PP_SCHED, PP_COAL, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS_BYTES_RAW);
   (void)hipGetLastError();
   if (const char* e = getenv("MEMVUL_GEMM_TILE")) h->gemm_tile = atoi(e);
   if (const char* e = getenv("MEMVUL_CLS_PRUNE")) h->cls_prune = atoi(e) != 0;
   if (const char* e = getenv("MEMVUL_LN_FUSE")) h->ln_fuse = atoi(e) != 0;
+  if (const char* e = getenv("MEMVUL_LN_VIRTUAL")) h->ln_virtual = atoi(e) != 0;
   if (const char* e = getenv("MEMVUL_ATTN")) h->attn_v2 = atoi(e) != 0;
   hipFuncSetAttribute((const void*)attention_v2_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT2_LDS_BYTES(1));
   hipFuncSetAttribute((const void*)attention_v2_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT2_LDS_BYTES(2));
@@ -628,6 +682,7 @@ int mv_create(int device, const mv_config* cfg, mv_handle** out) {
   A(dev_alloc(h, &h->ctx, T * MV_HIDDEN));
   A(dev_alloc(h, &h->h16, T * MV_INTER));
   A(dev_alloc(h, &h->lnstats, T * 2));
+  A(dev_alloc(h, &h->lnpart, T * (MV_HIDDEN / 64) * 2));
   A(dev_alloc(h, &h->zeros, MV_HIDDEN));
   A(dev_alloc(h, &h->ones, MV_HIDDEN, false));
   if (rc == MV_OK) {
@@ -734,6 +789,7 @@ int mv_finalize_weights(mv_handle* h, int compute_dtype) {
   for (int l = 0; l < c.layers; ++l) {
     const std::string q = P + "encoder.layer." + std::to_string(l) + ".";
     LayerW& w = h->L[l];
+    std::vector<float> wqkv_host, bqkv_host;
     // packed QKV [2304][768]; 1/sqrt(64) folded into W_q, b_q (exact: power of two)
     if ((rc = need(h, q + "attention.self.query.weight", {H, H}, &t))) return rc;
     if ((rc = need(h, q + "attention.self.key.weight", {H, H}, &t2))) return rc;
@@ -746,6 +802,7 @@ int mv_finalize_weights(mv_handle* h, int compute_dtype) {
         pack[(size_t)(2 * H * H + i)] = t3->data[(size_t)i];
       }
       if ((rc = upload_f16(h, &w.wqkv, pack.data(), 3 * H * H))) return rc;
+      wqkv_host = pack;
     }
     if ((rc = need(h, q + "attention.self.query.bias", {H}, &t))) return rc;
     if ((rc = need(h, q + "attention.self.key.bias", {H}, &t2))) return rc;
@@ -758,6 +815,17 @@ int mv_finalize_weights(mv_handle* h, int compute_dtype) {
         pack[(size_t)(2 * H + i)] = t3->data[(size_t)i];
       }
       if ((rc = upload_f32(h, &w.bqkv, pack.data(), 3 * H))) return rc;
+      bqkv_host = pack;
+    }
+    {  // the LayerNorm in front of this layer's QKV projection: the embedding LayerNorm or the previous layer's output LayerNorm
+      const std::string lnk = l == 0 ? P + "embeddings.LayerNorm." : P + "encoder.layer." + std::to_string(l - 1) + ".output.LayerNorm.";
+      const HostTensor *tg = nullptr, *tb = nullptr;
+      if ((rc = need(h, lnk + "weight", {H}, &tg))) return rc;
+      if ((rc = need(h, lnk + "bias", {H}, &tb))) return rc;
+      std::vector<float> Wf, bf;
+      fold_layernorm(wqkv_host.data(), bqkv_host.data(), tg->data.data(), tb->data.data(), 3 * H, H, Wf, bf);
+      if ((rc = upload_f16(h, &w.wqkv_f, Wf.data(), 3 * H * H))) return rc;
+      if ((rc = upload_f32(h, &w.bqkv_f, bf.data(), 3 * H))) return rc;
     }
     NEED(q + "attention.output.dense.weight", H, H);
     if ((rc = upload_f16(h, &w.wo, t->data.data(), H * H))) return rc;
@@ -771,6 +839,16 @@ int mv_finalize_weights(mv_handle* h, int compute_dtype) {
     if ((rc = upload_f16(h, &w.w1, t->data.data(), I * H))) return rc;
     NEED(q + "intermediate.dense.bias", I);
     if ((rc = upload_f32(h, &w.b1, t->data.data(), I))) return rc;
+    {  // FFN-1 with the attention-output LayerNorm folded in
+      const HostTensor *tw = nullptr, *tg = nullptr, *tb = nullptr;
+      if ((rc = need(h, q + "intermediate.dense.weight", {I, H}, &tw))) return rc;
+      if ((rc = need(h, q + "attention.output.LayerNorm.weight", {H}, &tg))) return rc;
+      if ((rc = need(h, q + "attention.output.LayerNorm.bias", {H}, &tb))) return rc;
+      std::vector<float> Wf, bf;
+      fold_layernorm(tw->data.data(), t->data.data(), tg->data.data(), tb->data.data(), I, H, Wf, bf);
+      if ((rc = upload_f16(h, &w.w1_f, Wf.data(), I * H))) return rc;
+      if ((rc = upload_f32(h, &w.b1_f, bf.data(), I))) return rc;
+    }
     NEED(q + "output.dense.weight", H, I);
     if ((rc = upload_f16(h, &w.w2, t->data.data(), H * I))) return rc;
     NEED(q + "output.dense.bias", H);

@@ -42,11 +42,20 @@
 
 #include "gemm.h"
 
-enum { PP_F32 = 0, PP_QK = 1, PP_VT = 2, PP_GELU = 3, PP_RES = 4, PP_F16 = 5, PP_RESLN = 6 };
+enum { PP_F32 = 0, PP_QK = 1, PP_VT = 2, PP_GELU = 3, PP_RES = 4, PP_F16 = 5, PP_RESLN = 6, PP_RESLN2 = 7 };
 // PP_RESLN: PP_RES whose residual tile is the PRE-LayerNorm stream: the accumulators start from
 //   LN(x) + bias = fma((x - mean) * rstd, gamma, beta) + bias   (row statistics from ln_kernel<stats>),
 // the same IEEE operations ln_row_store performs, so the result equals PP_RES on a normalised stream bit for bit
 // while the LayerNorm kernel no longer writes the fp32 stream back (201 MB per LayerNorm at the bench shape).
+// PP_RESLN2 + RAW consumers ("virtual LayerNorm": no LayerNorm kernel at all).  By linearity
+//   W LN(r) + b = rstd * (W'' r) + b',  W''[n][k] = W[n][k] gamma[k] - mean_k(W[n][.] gamma[.]),  b' = b + W beta
+// (the row mean of r drops out against the row-centred weights), so a consumer GEMM (RAW = 1: PP_QK / PP_VT /
+// PP_GELU) takes the RAW stream rounded to fp16 as its A operand, the folded weights W'' (prepared once on the
+// host), starts its accumulators from zero and applies  fma(rstd_row, acc, b'_col)  in the epilogue; the 256 rows'
+// (mean, rstd) of the workgroup's next tile arrive by two LDS-DMA pieces into a 2 x 2 KiB image.  The producer
+// (PP_RESLN2 = PP_RESLN that ALSO writes the fp16 copy of the raw stream and, per row and 64-column wave slice, the
+// partial (sum, sum of squares)) replaces the LayerNorm kernel's second pass over the stream; ln_finalize_kernel
+// turns the N / 64 partials of a row into (mean, rstd) in a fixed order (deterministic).
 // timing ablations (wrong results by construction; cdna_hip_programming.md §5.4 rules 8/17)
 enum { PP_ABL_NODMA = 1, PP_ABL_NOMFMA = 2, PP_ABL_NOREAD = 4, PP_ABL_NOEPI = 8, PP_ABL_NOPRIO = 16, PP_ABL_NOSTAGGER = 32 };
 
@@ -55,6 +64,8 @@ enum { PP_ABL_NODMA = 1, PP_ABL_NOMFMA = 2, PP_ABL_NOREAD = 4, PP_ABL_NOEPI = 8,
 #define PP_LDS_BIAS 131072   // [N] fp32 (N <= 3072)
 #define PP_LDS_SCR (PP_LDS_BIAS + MV_INTER * 4)  // 8 waves x 2 KiB: wave-private transposition scratch
 #define PP_LDS_BYTES (PP_LDS_SCR + 8 * 2048)     // 159,744 of 163,840
+#define PP_LDS_STATS PP_LDS_BYTES                 // RAW kernels: [2][256 rows][mean, rstd] fp32
+#define PP_LDS_BYTES_RAW (PP_LDS_STATS + 2 * 2048)  // 163,840 = all of the CU's LDS
 
 __device__ __forceinline__ uint32_t pack_h2(float a, float b) {
   half2_t h;
@@ -164,12 +175,14 @@ __device__ __forceinline__ void lds_read_bgb(uint32_t addr, float4 (&bi)[4], flo
 //          landed for every wave at the barrier that ends interval H-3, and its LDS region was last read in
 //          interval H-8 or H-9).
 // COAL 1: epilogue stores (and the residual loads) go through the wave-private LDS transposition above.
-template <int EPI, int DIST, int ABL, int SCHED = 0, int COAL = 0>
+template <int EPI, int DIST, int ABL, int SCHED = 0, int COAL = 0, int RAW = 0>
 __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmArgs a) {
+  static_assert(!RAW || (COAL == 1 && (EPI == PP_QK || EPI == PP_VT || EPI == PP_GELU)), "RAW: the fp16-output kernels of the transposed path");
   static_assert(SCHED == 0 ? (DIST >= 2 && DIST <= 6) : (DIST >= 2 && DIST <= 4), "half-tile issue distance");
   constexpr bool SWAP = (EPI != PP_VT);
-  constexpr bool IS_RES = (EPI == PP_RES || EPI == PP_RESLN);
-  static_assert(EPI != PP_RESLN || COAL == 1, "the LayerNorm-fused residual init is written for the transposed (COAL) path");
+  constexpr bool IS_RESLN = (EPI == PP_RESLN || EPI == PP_RESLN2);
+  constexpr bool IS_RES = (EPI == PP_RES || IS_RESLN);
+  static_assert(!IS_RESLN || COAL == 1, "the LayerNorm-fused residual init is written for the transposed (COAL) path");
   constexpr int WAITN = SCHED == 0 ? 2 * (DIST - 1) : 2 * DIST;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
@@ -188,7 +201,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmArgs a) {
   {
     float* lb = (float*)(smem + PP_LDS_BIAS);
     for (int n = tid; n < a.N; n += 512) lb[n] = a.bias ? a.bias[n] : 0.f;
-    if constexpr (EPI == PP_RESLN) {  // N == 768: gamma at [768, 1536), beta at [1536, 2304) of the same image
+    if constexpr (IS_RESLN) {  // N == 768: gamma at [768, 1536), beta at [1536, 2304) of the same image
       for (int n = tid; n < MV_HIDDEN; n += 512) {
         lb[MV_HIDDEN + n] = a.lng[n];
         lb[2 * MV_HIDDEN + n] = a.lnb[n];
@@ -384,6 +397,24 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmArgs a) {
     __builtin_amdgcn_sched_barrier(0);
   };
 
+  // ---- RAW: (mean, rstd) of the 256 token rows of persistent iteration `itn` -> LDS image itn & 1 (wave 0 only; two
+  // 1-KiB LDS-DMA pieces that ride in the same vmcnt ledger: they are older than anything a later counted wait must
+  // retire, so every wait stays conservative)
+  auto issue_stats = [&](int itn) {
+    const int L = itn * G + bslot;
+    if (L < ntiles) {
+      int tm, tn;
+      raster(L, tm_count, tn_count, a.GN, tm, tn);
+      const char* src = (const char*)a.lnstats + (size_t)tm * 2048 + lane * 16;
+      char* dst = smem + PP_LDS_STATS + (itn & 1) * 2048;
+      glds16((const half_t*)src, dst);
+      glds16((const half_t*)(src + 1024), dst + 1024);
+    }
+  };
+  if constexpr (RAW) {
+    if (wave == 0) issue_stats(0);
+  }
+
   // ---- prologue.  SCHED 0: half-tiles psi = 0 .. DIST in flight, psi 0 (b0 of K-tile 0) and 1 (a0) landed.
   //               SCHED 1: psi = 0 .. 2 + F in flight, psi 0 .. 2 landed.
   constexpr int NPRO = SCHED == 0 ? DIST + 1 : DIST + 3;
@@ -440,7 +471,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmArgs a) {
         // residual tile by full-line loads (16 rows x 64 B per instruction), transposed into the C/D layout
         // (the raw lines are parked in the accumulator registers they will be transposed into)
         float2 lnst[4];  // PP_RESLN: (mean, rstd) of this lane's four token rows
-        if constexpr (EPI == PP_RESLN) {
+        if constexpr (IS_RESLN) {
 #pragma unroll
           for (int i = 0; i < 4; ++i) lnst[i] = *(const float2*)(a.lnstats + 2 * (size_t)(mw + i * 32 + l31));
         }
@@ -464,7 +495,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmArgs a) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) d[q][e] = f2u(acc[i][q >> 2][4 * (q & 3) + e]);
           scr_f32x4(scr_c, scr_c + 1024, d, scr_m32, scr_m32 ^ 32u, o);
-          if constexpr (EPI == PP_RESLN) {
+          if constexpr (IS_RESLN) {
 #pragma clang fp contract(off)
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
@@ -493,7 +524,9 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmArgs a) {
         for (int g = 0; g < 4; ++g)
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
-            if constexpr (IS_RES) {
+            if constexpr (RAW) {
+              acc[i][j][4 * g + 0] = 0.f; acc[i][j][4 * g + 1] = 0.f; acc[i][j][4 * g + 2] = 0.f; acc[i][j][4 * g + 3] = 0.f;
+            } else if constexpr (IS_RES) {
               const float4 xv = *(const float4*)(a.xres + (size_t)(mw + i * 32 + l31) * MV_HIDDEN + nw + j * 32 + 8 * g + 4 * hi);
               acc[i][j][4 * g + 0] = xv.x + bv[j][g].x; acc[i][j][4 * g + 1] = xv.y + bv[j][g].y;
               acc[i][j][4 * g + 2] = xv.z + bv[j][g].z; acc[i][j][4 * g + 3] = xv.w + bv[j][g].w;
@@ -515,13 +548,16 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmArgs a) {
       for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          acc[i][0][r] = b0;
-          acc[i][1][r] = b1;
+          acc[i][0][r] = RAW ? 0.f : b0;
+          acc[i][1][r] = RAW ? 0.f : b1;
         }
     }
 
     if constexpr (SCHED == 1 && decltype(grpc)::value == 0) read_set(std::integral_constant<int, 0>{});
     for (int kt = 0; kt < nk; kt += 2) {
+      if constexpr (RAW) {  // every wave has left the previous tile's epilogue (>= 8 barriers ago): its stats image is free
+        if (kt == 2 && wave == 0) issue_stats(it + 1);
+      }
       if constexpr (SCHED == 0) {
         phase(std::integral_constant<int, 0>{});
         phase(std::integral_constant<int, 1>{});
@@ -555,6 +591,29 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmArgs a) {
       const uint32_t sf = (uint32_t)((l31 >> 2) & 3);
       const uint32_t scr_c = scr + (lane >> 2) * 64 + ((((uint32_t)lane & 3) ^ (((uint32_t)lane >> 4) & 3)) << 4);
       const int crow = lane >> 2, cchunk = lane & 3;  // coalesced layout: row (+16 for the second read), 16-B chunk
+      if constexpr (EPI == PP_RESLN2) {
+        // per-row partial LayerNorm statistics of this wave's 64 columns: lane = token row, the two half-waves hold
+        // disjoint column sets; slot nw / 64 of the row's N / 64 partials (ln_finalize_kernel adds them in order)
+        const int np = a.N >> 6;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const float v = acc[i][j][r];
+              s1 += v;
+              s2 = __builtin_fmaf(v, v, s2);
+            }
+          const auto t1 = __builtin_amdgcn_permlane32_swap(f2u(s1), f2u(s1), false, false);
+          const auto t2 = __builtin_amdgcn_permlane32_swap(f2u(s2), f2u(s2), false, false);
+          float2 st;
+          st.x = u2f(t1[0]) + u2f(t1[1]);
+          st.y = u2f(t2[0]) + u2f(t2[1]);
+          if (hi == 0) *(float2*)(a.lnpart + ((size_t)(mw + i * 32 + l31) * np + (nw >> 6)) * 2) = st;
+        }
+      }
       if constexpr (EPI == PP_F32 || IS_RES) {
         const uint32_t scr_m32 = scr + l31 * 64 + (((uint32_t)hi ^ sf) << 4);
         float* obase = (IS_RES ? a.xres : a.outf) + (size_t)(mw + crow) * a.N + nw + 4 * cchunk;
@@ -572,15 +631,17 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmArgs a) {
             *(u32x4*)op = o[q];
           }
         }
-      } else {
+      }
+      if constexpr (!(EPI == PP_F32 || IS_RES) || EPI == PP_RESLN2) {
         // fp16 outputs: 8-B units (4 values) of the C/D layout -> chunk g, half hi of the row
+        // (PP_RESLN2: the fp16 copy of the raw stream, the A operand of the next RAW consumer)
         const uint32_t wbase = scr + l31 * 64 + hi * 8 + (sf << 4);
         half_t* obase;    // pointer of (row crow, chunk cchunk) of fragment (i = 0, j = 0)
         size_t rstride;   // elements between image rows in the output
         size_t istride;   // elements between i blocks (32 C/D rows along the register axis or the lane axis)
         size_t jstride;   // elements between j blocks
         bool live = true;
-        if constexpr (EPI == PP_F16 || EPI == PP_GELU) {
+        if constexpr (EPI == PP_F16 || EPI == PP_GELU || EPI == PP_RESLN2) {
           obase = a.out16 + (size_t)(mw + crow) * a.N + nw + 8 * cchunk;
           rstride = a.N; istride = (size_t)32 * a.N; jstride = 32;
         } else if constexpr (EPI == PP_QK) {  // one head per wave; S % 64 == 0 so a 128-row block may span two batch rows
@@ -593,10 +654,52 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmArgs a) {
           obase = a.vt + ((size_t)head * MV_HEAD_DIM + crow) * a.S + 8 * cchunk;
           rstride = a.S; istride = 0; jstride = (size_t)32 * a.S;
         }
+        // RAW: bias' of this wave's columns and rstd of its token rows (LDS images), applied as fma(rstd, acc, bias')
+        float4 rbv[2][4];
+        float rrs[4], rb0 = 0.f, rb1 = 0.f;
+        const uint32_t stats_img = (uint32_t)(PP_LDS_STATS + (it & 1) * 2048 + wr * 1024);  // this wave's 128 rows
+        if constexpr (RAW && SWAP) {
+          const uint32_t baddr = (uint32_t)(PP_LDS_BIAS + (nw + 4 * hi) * 4);
+          const uint32_t saddr = stats_img + l31 * 8 + 4;
+          asm volatile(
+              "ds_read_b128 %0, %12\n\tds_read_b128 %1, %12 offset:32\n\tds_read_b128 %2, %12 offset:64\n\t"
+              "ds_read_b128 %3, %12 offset:96\n\tds_read_b128 %4, %12 offset:128\n\tds_read_b128 %5, %12 offset:160\n\t"
+              "ds_read_b128 %6, %12 offset:192\n\tds_read_b128 %7, %12 offset:224\n\t"
+              "ds_read_b32 %8, %13\n\tds_read_b32 %9, %13 offset:256\n\tds_read_b32 %10, %13 offset:512\n\t"
+              "ds_read_b32 %11, %13 offset:768\n\ts_waitcnt lgkmcnt(0)"
+              : "=&v"(rbv[0][0]), "=&v"(rbv[0][1]), "=&v"(rbv[0][2]), "=&v"(rbv[0][3]), "=&v"(rbv[1][0]), "=&v"(rbv[1][1]),
+                "=&v"(rbv[1][2]), "=&v"(rbv[1][3]), "=&v"(rrs[0]), "=&v"(rrs[1]), "=&v"(rrs[2]), "=&v"(rrs[3])
+              : "v"(baddr), "v"(saddr)
+              : "memory");
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        if constexpr (RAW && !SWAP) {
+          const uint32_t baddr = (uint32_t)(PP_LDS_BIAS + (nw + l31) * 4);
+          asm volatile("ds_read_b32 %0, %2\n\tds_read_b32 %1, %2 offset:128\n\ts_waitcnt lgkmcnt(0)"
+                       : "=&v"(rb0), "=&v"(rb1)
+                       : "v"(baddr)
+                       : "memory");
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        (void)rbv; (void)rrs; (void)rb0; (void)rb1; (void)stats_img;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           const int mb = mw + i * 32;
           half_t* ob = obase + i * istride;
+          float4 rst[4][2];  // RAW, lane = column: (mean, rstd) pairs of tokens 32 i + 8 g + 4 hi + 0..3
+          if constexpr (RAW && !SWAP) {
+            const uint32_t saddr = stats_img + (uint32_t)(i * 32 + 4 * hi) * 8;
+            asm volatile(
+                "ds_read_b128 %0, %8\n\tds_read_b128 %1, %8 offset:16\n\tds_read_b128 %2, %8 offset:64\n\t"
+                "ds_read_b128 %3, %8 offset:80\n\tds_read_b128 %4, %8 offset:128\n\tds_read_b128 %5, %8 offset:144\n\t"
+                "ds_read_b128 %6, %8 offset:192\n\tds_read_b128 %7, %8 offset:208\n\ts_waitcnt lgkmcnt(0)"
+                : "=&v"(rst[0][0]), "=&v"(rst[0][1]), "=&v"(rst[1][0]), "=&v"(rst[1][1]), "=&v"(rst[2][0]), "=&v"(rst[2][1]),
+                  "=&v"(rst[3][0]), "=&v"(rst[3][1])
+                : "v"(saddr)
+                : "memory");
+            __builtin_amdgcn_sched_barrier(0);
+          }
+          (void)rst;
           if constexpr (EPI == PP_QK || EPI == PP_VT) {
             live = mb < a.Mreal;
             const int b = mb / a.S, s0 = mb - b * a.S;
@@ -610,6 +713,15 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmArgs a) {
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
               float v0 = acc[i][j][4 * g + 0], v1 = acc[i][j][4 * g + 1], v2 = acc[i][j][4 * g + 2], v3 = acc[i][j][4 * g + 3];
+              if constexpr (RAW && SWAP) {  // lane = token row 32 i + l31, registers = 4 consecutive columns
+                v0 = __builtin_fmaf(rrs[i], v0, rbv[j][g].x); v1 = __builtin_fmaf(rrs[i], v1, rbv[j][g].y);
+                v2 = __builtin_fmaf(rrs[i], v2, rbv[j][g].z); v3 = __builtin_fmaf(rrs[i], v3, rbv[j][g].w);
+              }
+              if constexpr (RAW && !SWAP) {  // lane = column 32 j + l31, registers = tokens 32 i + 8 g + 4 hi + 0..3
+                const float bj = j ? rb1 : rb0;
+                v0 = __builtin_fmaf(rst[g][0].y, v0, bj); v1 = __builtin_fmaf(rst[g][0].w, v1, bj);
+                v2 = __builtin_fmaf(rst[g][1].y, v2, bj); v3 = __builtin_fmaf(rst[g][1].w, v3, bj);
+              }
               if constexpr (EPI == PP_GELU) {
                 float2_t a01, a23;
                 a01.x = v0; a01.y = v1; a23.x = v2; a23.y = v3;

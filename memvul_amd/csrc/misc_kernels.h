@@ -58,6 +58,8 @@ __device__ __forceinline__ void ln_row_store(const float4 (&x)[3], const float* 
 
 // K1: x = LN(word[id] + pos[s] + type[0])   (HF BertEmbeddings; token-type ids are all zero in this
 // path, custom_PTM_embedder.py:199-202).  ids are [B][S_in] (0-padded), the engine row pitch is Sp.
+// RAWOUT (virtual LayerNorm, gemm_pp.h): x32 <- the un-normalised sum, x16 <- its fp16 copy, stats <- (mean, rstd).
+template <bool RAWOUT>
 __global__ __launch_bounds__(256) void embed_ln_kernel(const int32_t* __restrict__ ids, int S_in, int Sp, int n_tok,
                                                        int vocab, const float* __restrict__ wemb,
                                                        const float* __restrict__ pemb, const float* __restrict__ temb,
@@ -79,13 +81,64 @@ __global__ __launch_bounds__(256) void embed_ln_kernel(const int32_t* __restrict
     const float4 a = *(const float4*)(w + c), q = *(const float4*)(p + c), r = *(const float4*)(temb + c);
     x[i].x = a.x + q.x + r.x; x[i].y = a.y + q.y + r.y; x[i].z = a.z + q.z + r.z; x[i].w = a.w + q.w + r.w;
   }
-  ln_row_store<true>(x, gamma, beta, eps, lane, x32 + (size_t)t * MV_HIDDEN, x16 + (size_t)t * MV_HIDDEN, nullptr);
-  // the embedding output IS the normalised stream: identity statistics for a PP_RESLN consumer (with gamma = 1, beta = 0)
-  if (stats && lane == 0) {
-    float2 st;
-    st.x = 0.f; st.y = 1.f;
-    *(float2*)(stats + 2 * (size_t)t) = st;
+  if constexpr (RAWOUT) {
+#pragma clang fp contract(off)
+    float sm = 0.f;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) sm += (x[i].x + x[i].y) + (x[i].z + x[i].w);
+    const float mean = wave_sum(sm) * (1.0f / MV_HIDDEN);
+    float v = 0.f;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const float a = x[i].x - mean, bb = x[i].y - mean, c = x[i].z - mean, d = x[i].w - mean;
+      v = __builtin_fmaf(a, a, v); v = __builtin_fmaf(bb, bb, v); v = __builtin_fmaf(c, c, v); v = __builtin_fmaf(d, d, v);
+    }
+    const float rstd = 1.0f / sqrtf(wave_sum(v) * (1.0f / MV_HIDDEN) + eps);
+    if (lane == 0) {
+      float2 st;
+      st.x = mean; st.y = rstd;
+      *(float2*)(stats + 2 * (size_t)t) = st;
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const int c = 4 * lane + 256 * i;
+      *(float4*)(x32 + (size_t)t * MV_HIDDEN + c) = x[i];
+      half4_t h;
+      h[0] = (half_t)x[i].x; h[1] = (half_t)x[i].y; h[2] = (half_t)x[i].z; h[3] = (half_t)x[i].w;
+      *(half4_t*)(x16 + (size_t)t * MV_HIDDEN + c) = h;
+    }
+  } else {
+    ln_row_store<true>(x, gamma, beta, eps, lane, x32 + (size_t)t * MV_HIDDEN, x16 + (size_t)t * MV_HIDDEN, nullptr);
+    // the embedding output IS the normalised stream: identity statistics for a PP_RESLN consumer (with gamma = 1, beta = 0)
+    if (stats && lane == 0) {
+      float2 st;
+      st.x = 0.f; st.y = 1.f;
+      *(float2*)(stats + 2 * (size_t)t) = st;
+    }
   }
+}
+
+// Virtual LayerNorm: (mean, rstd) of each row from the N / 64 partial (sum, sum of squares) pairs the PP_RESLN2
+// epilogue wrote, added in slot order (deterministic); var = E[x^2] - mean^2 in fp32 (rows are O(1): no cancellation
+// to speak of; clamped at 0).
+__global__ __launch_bounds__(256) void ln_finalize_kernel(const float* __restrict__ part, int np, int n_tok, float eps,
+                                                          float* __restrict__ stats) {
+#pragma clang fp contract(off)
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= n_tok) return;
+  const float2* p = (const float2*)(part + (size_t)t * np * 2);
+  float s1 = 0.f, s2 = 0.f;
+  for (int i = 0; i < np; ++i) {
+    const float2 v = p[i];
+    s1 += v.x;
+    s2 += v.y;
+  }
+  const float mean = s1 * (1.0f / MV_HIDDEN);
+  const float var = fmaxf(s2 * (1.0f / MV_HIDDEN) - mean * mean, 0.f);
+  float2 st;
+  st.x = mean;
+  st.y = 1.0f / sqrtf(var + eps);
+  *(float2*)(stats + 2 * (size_t)t) = st;
 }
 
 // LayerNorm of the residual stream (the GEMM epilogue already added bias + residual).
@@ -111,7 +164,7 @@ __global__ __launch_bounds__(256) void ln_kernel(float* __restrict__ x32, half_t
 __global__ __launch_bounds__(256) void cls_gather_kernel(const float* __restrict__ x32, const half_t* __restrict__ x16, int Sp,
                                                          int B, const float* __restrict__ stats,
                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                         float* __restrict__ c32, half_t* __restrict__ c16) {
+                                                         float* __restrict__ c32, half_t* __restrict__ c16, int raw16) {
 #pragma clang fp contract(off)
   const int lane = threadIdx.x & 63;
   const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -132,7 +185,13 @@ __global__ __launch_bounds__(256) void cls_gather_kernel(const float* __restrict
       y.w = __builtin_fmaf((y.w - mean) * rstd, g.w, bb.w);
     }
     *(float4*)(c32 + (size_t)b * MV_HIDDEN + c) = y;
-    *(half4_t*)(c16 + (size_t)b * MV_HIDDEN + c) = *(const half4_t*)(x16 + t * MV_HIDDEN + c);
+    if (raw16) {  // x16 holds the raw stream (virtual LayerNorm): the fp16 operand is rounded from the normalised row
+      half4_t h;
+      h[0] = (half_t)y.x; h[1] = (half_t)y.y; h[2] = (half_t)y.z; h[3] = (half_t)y.w;
+      *(half4_t*)(c16 + (size_t)b * MV_HIDDEN + c) = h;
+    } else {
+      *(half4_t*)(c16 + (size_t)b * MV_HIDDEN + c) = *(const half4_t*)(x16 + t * MV_HIDDEN + c);
+    }
   }
 }
 

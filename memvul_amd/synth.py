@@ -56,6 +56,7 @@ def make_weights(
     qk_scale: float = 1.0,
     match_scale: float = 1.0,
     plain_init: bool = False,
+    ln_outliers: bool = False,
 ) -> Dict[str, np.ndarray]:
     """Random-init weights of the reference architecture, fp32.
 
@@ -63,7 +64,10 @@ def make_weights(
     unit gammas would hide bias/affine bugs in a kernel, so unless ``plain_init`` the biases,
     gammas and betas are perturbed too.  ``qk_scale`` multiplies the query/key projections so
     attention is peaked rather than uniform (exercises the softmax); ``match_scale`` scales the
-    matcher to produce "trained-like" |logit| ~ 3.
+    matcher to produce "trained-like" |logit| ~ 3.  ``ln_outliers`` gives every
+    LayerNorm two large-offset / large-gain dimensions, as trained BERT checkpoints have (a few hidden
+    dims with |value| ~ 5-10 in every token): rows then have a visibly non-zero mean and a variance dominated by
+    two dims, which is what the engine's folded-LayerNorm arithmetic has to survive.
     """
     rng = np.random.Generator(np.random.PCG64(seed))
     H, I, P = dims.hidden, dims.intermediate, dims.proj_dim
@@ -114,6 +118,14 @@ def make_weights(
     w[KEY_HEAD_W] = uniform_linear(P, H)
     w[KEY_HEAD_B] = rng.uniform(-1 / np.sqrt(H), 1 / np.sqrt(H), size=(P,)).astype(np.float32)
     w[KEY_MATCH_W] = uniform_linear(2, 3 * P) * np.float32(match_scale)
+    if ln_outliers:  # applied after generation: the random stream (and every golden vector) is unchanged without it
+        for k in w:
+            if k.endswith("LayerNorm.bias"):
+                w[k] = w[k].copy()
+                w[k][[H // 3 + 52, H // 2 - 3]] = [-6.0, 4.0]
+            if k.endswith("LayerNorm.weight"):
+                w[k] = w[k].copy()
+                w[k][H // 3 + 52] = 2.5
     return w
 
 

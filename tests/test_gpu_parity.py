@@ -173,12 +173,33 @@ def test_last_layer_pruning_matches_full_forward(gu, B, S, ragged, gemm_tile):
 
 @pytest.mark.parametrize("prune", ["0", "1"])
 def test_layernorm_folded_into_residual_read_is_bit_identical(gu, prune):
-    """MEMVUL_LN_FUSE (persistent-GEMM path): the LayerNorm kernels write fp16 operand + row statistics only and the
-    next residual GEMM normalises the raw stream while initialising its accumulators, with the same IEEE
-    operations -> the embeddings must not change by a single bit."""
+    """MEMVUL_LN_FUSE without the virtual LayerNorm (persistent-GEMM path): the LayerNorm kernels write fp16 operand +
+    row statistics only and the next residual GEMM normalises the raw stream while initialising its accumulators,
+    with the same IEEE operations -> the embeddings must not change by a single bit."""
     dk, wk = dict(layers=3, vocab_size=2048), dict(qk_scale=2.0)
     dims, w = gu.weights_for(dk, wk)
     ids, lens = synth.make_ids(6, 128, dims.vocab_size, ragged=True, min_len=9)
-    u_f = gu.engine_for(dk, wk, gemm_tile=512, env={"MEMVUL_CLS_PRUNE": prune}).encode(ids, lens)
+    u_f = gu.engine_for(dk, wk, gemm_tile=512, env={"MEMVUL_CLS_PRUNE": prune, "MEMVUL_LN_VIRTUAL": "0"}).encode(ids, lens)
     u_n = gu.engine_for(dk, wk, gemm_tile=512, env={"MEMVUL_CLS_PRUNE": prune, "MEMVUL_LN_FUSE": "0"}).encode(ids, lens)
     assert np.array_equal(u_f, u_n)
+
+
+@pytest.mark.parametrize("outliers", [False, True])
+@pytest.mark.parametrize("prune", ["0", "1"])
+@pytest.mark.parametrize("B,S", [(6, 128), (3, 256), (5, 200)])
+def test_virtual_layernorm_matches_explicit_layernorm(gu, B, S, prune, outliers):
+    """MEMVUL_LN_VIRTUAL (default on the persistent-GEMM path): no LayerNorm kernel between the GEMMs — the consumer
+    GEMMs read the raw stream in fp16 with gamma / beta / the row mean folded into their weights and scale rows by
+    rstd in the epilogue (W LN(r) + b = rstd (W'' r) + b'), the residual GEMMs emit the fp16 copy and the partial row
+    sums.  Same mathematics, different roundings: agreement with the explicit-LayerNorm engine and with the oracle at
+    the fp16-operand level, also with trained-checkpoint-like outlier dimensions in every LayerNorm."""
+    dk, wk = dict(layers=4, vocab_size=2048), dict(qk_scale=2.0, ln_outliers=outliers)
+    dims, w = gu.weights_for(dk, wk)
+    ids, lens = synth.make_ids(B, S, dims.vocab_size, ragged=True, min_len=9)
+    u_v = gu.engine_for(dk, wk, gemm_tile=512, env={"MEMVUL_CLS_PRUNE": prune}).encode(ids, lens)
+    u_e = gu.engine_for(dk, wk, gemm_tile=512, env={"MEMVUL_CLS_PRUNE": prune, "MEMVUL_LN_VIRTUAL": "0"}).encode(ids, lens)
+    u_ref = orc.instance_forward(w, ids.astype(np.int64), synth.mask_from_lens(lens, S))
+    ev, ee = float(np.abs(u_v - u_ref).max()), float(np.abs(u_e - u_ref).max())
+    gu.record("virtual_ln", B=B, S=S, prune=prune, outliers=outliers, virtual_vs_oracle=ev, explicit_vs_oracle=ee,
+              virtual_vs_explicit=float(np.abs(u_v - u_e).max()), u_scale=float(np.abs(u_ref).max()))
+    assert ev < 2e-3 and ev < 3 * ee + 2e-4
