@@ -152,6 +152,7 @@ struct mv_handle {
   float *lnstats = nullptr, *ones = nullptr, *zeros = nullptr;
   // ... and no LayerNorm kernel at all between the GEMMs (RAW consumers + PP_RESLN2 producers); env MEMVUL_LN_VIRTUAL=0 disables
   bool ln_virtual = true;
+  int r16_direct = 1;  // PP_RESLN2: fp16 copy from the transposed fp32 image (1) or through its own LDS transposition (0); env MEMVUL_R16_DIRECT
   float* lnpart = nullptr;  // [T][12][2] partial row sums of the residual GEMMs
 
   // profiling
@@ -479,7 +480,7 @@ int encode_dev(mv_handle* h, const int32_t* d_ids, const int32_t* d_lens, int B,
     g.raw = 0; g.lnstats = nullptr; g.lnpart = nullptr;
     g.A = h->ctx; g.W = w.wo; g.bias = w.bo; g.N = MV_HIDDEN; g.K = MV_HIDDEN; g.xres = h->xres;
     if (fuse) { g.lnstats = h->lnstats; g.lng = pend_g; g.lnb = pend_b; }
-    if (virt) { g.lnpart = h->lnpart; g.out16 = h->x16; }  // + the fp16 copy of the new raw stream and its partial row sums
+    if (virt) { g.lnpart = h->lnpart; g.out16 = h->x16; g.raw = h->r16_direct; }  // + the fp16 copy of the new raw stream and its partial row sums
     if (int rc = launch_gemm<EPI_RES>(h, KC_GEMM_OUT, g)) return rc;
     if (virt) { if (int rc = run_finalize()) return rc; }
     else if (int rc = run_ln(h->xres, h->x16, (int)M, w.ln1g, w.ln1b, fuse)) return rc;
@@ -493,7 +494,7 @@ int encode_dev(mv_handle* h, const int32_t* d_ids, const int32_t* d_lens, int B,
     g.raw = 0; g.lnstats = nullptr;
     g.A = h->h16; g.W = w.w2; g.bias = w.b2; g.N = MV_HIDDEN; g.K = MV_INTER; g.xres = h->xres;
     if (fuse) { g.lnstats = h->lnstats; g.lng = pend_g; g.lnb = pend_b; }
-    if (virt) { g.lnpart = h->lnpart; g.out16 = h->x16; }
+    if (virt) { g.lnpart = h->lnpart; g.out16 = h->x16; g.raw = h->r16_direct; }
     if (int rc = launch_gemm<EPI_RES>(h, KC_GEMM_FFN2, g)) return rc;
     if (virt && !last) { if (int rc = run_finalize()) return rc; }
     else if (int rc = run_ln(h->xres, h->x16, (int)M, w.ln2g, w.ln2b, fuse && !last)) return rc;  // the pooler reads a normalised stream
@@ -657,6 +658,7 @@ int mv_create(int device, const mv_config* cfg, mv_handle** out) {
   if (const char* e = getenv("MEMVUL_CLS_PRUNE")) h->cls_prune = atoi(e) != 0;
   if (const char* e = getenv("MEMVUL_LN_FUSE")) h->ln_fuse = atoi(e) != 0;
   if (const char* e = getenv("MEMVUL_LN_VIRTUAL")) h->ln_virtual = atoi(e) != 0;
+  if (const char* e = getenv("MEMVUL_R16_DIRECT")) h->r16_direct = atoi(e) != 0;
   if (const char* e = getenv("MEMVUL_ATTN")) h->attn_v2 = atoi(e) != 0;
   hipFuncSetAttribute((const void*)attention_v2_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT2_LDS_BYTES(1));
   hipFuncSetAttribute((const void*)attention_v2_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT2_LDS_BYTES(2));

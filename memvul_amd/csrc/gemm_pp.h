@@ -629,10 +629,20 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmArgs a) {
           for (int q = 0; q < 8; ++q) {  // q = (j, h, x): rows 16 x + crow, columns 32 j + 16 h + 4 cchunk
             float* op = obase + (size_t)(i * 32 + (q & 1) * 16) * a.N + (q >> 2) * 32 + ((q >> 1) & 1) * 16;
             *(u32x4*)op = o[q];
+            if constexpr (EPI == PP_RESLN2) {
+              if (a.raw) {  // fp16 copy straight from the transposed fp32 image: 8 bytes per lane, 32-byte row pieces
+                half_t* hp = a.out16 + (size_t)(mw + crow + i * 32 + (q & 1) * 16) * a.N + nw + 4 * cchunk + (q >> 2) * 32 + ((q >> 1) & 1) * 16;
+                u32x2 hv;
+                hv[0] = pack_h2(u2f(o[q][0]), u2f(o[q][1]));
+                hv[1] = pack_h2(u2f(o[q][2]), u2f(o[q][3]));
+                *(u32x2*)hp = hv;
+              }
+            }
           }
         }
       }
-      if constexpr (!(EPI == PP_F32 || IS_RES) || EPI == PP_RESLN2) {
+      if constexpr (!(EPI == PP_F32 || IS_RES) || EPI == PP_RESLN2)
+      if (EPI != PP_RESLN2 || !a.raw) {
         // fp16 outputs: 8-B units (4 values) of the C/D layout -> chunk g, half hi of the row
         // (PP_RESLN2: the fp16 copy of the raw stream, the A operand of the next RAW consumer)
         const uint32_t wbase = scr + l31 * 64 + hi * 8 + (sf << 4);
