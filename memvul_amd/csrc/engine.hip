@@ -152,7 +152,8 @@ struct mv_handle {
   float *lnstats = nullptr, *ones = nullptr, *zeros = nullptr;
   // ... and no LayerNorm kernel at all between the GEMMs (RAW consumers + PP_RESLN2 producers); env MEMVUL_LN_VIRTUAL=0 disables
   bool ln_virtual = true;
-  int r16_direct = 1;  // PP_RESLN2: fp16 copy from the transposed fp32 image (1) or through its own LDS transposition (0); env MEMVUL_R16_DIRECT
+  int pp_stagger = 0;  // env MEMVUL_STAGGER: see GemmArgs::stagger
+  int r16_direct = 0;  // PP_RESLN2: fp16 copy from the transposed fp32 image (1) or through its own LDS transposition (0); env MEMVUL_R16_DIRECT
   float* lnpart = nullptr;  // [T][12][2] partial row sums of the residual GEMMs
 
   // profiling
@@ -300,6 +301,7 @@ int launch_pp_raw(mv_handle* h, GemmArgs a) {
   a.GN = choose_gn(a.N / 256, 4);
   const int tiles = (a.M / 256) * (a.N / 256);
   const int grid = tiles < h->num_cu ? tiles : h->num_cu;
+  a.stagger = tiles >= 2 * h->num_cu ? h->pp_stagger : 0;
   hipLaunchKernelGGL((gemm_pp_kernel<PPEPI, PP_DIST, 0, PP_SCHED, PP_COAL, RAW>), dim3(grid), dim3(512),
                      RAW ? PP_LDS_BYTES_RAW : PP_LDS_BYTES, h->stream, a);
   return launch_check(h, "gemm_pp");
@@ -659,6 +661,7 @@ int mv_create(int device, const mv_config* cfg, mv_handle** out) {
   if (const char* e = getenv("MEMVUL_LN_FUSE")) h->ln_fuse = atoi(e) != 0;
   if (const char* e = getenv("MEMVUL_LN_VIRTUAL")) h->ln_virtual = atoi(e) != 0;
   if (const char* e = getenv("MEMVUL_R16_DIRECT")) h->r16_direct = atoi(e) != 0;
+  if (const char* e = getenv("MEMVUL_STAGGER")) h->pp_stagger = atoi(e);
   if (const char* e = getenv("MEMVUL_ATTN")) h->attn_v2 = atoi(e) != 0;
   hipFuncSetAttribute((const void*)attention_v2_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT2_LDS_BYTES(1));
   hipFuncSetAttribute((const void*)attention_v2_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT2_LDS_BYTES(2));

@@ -50,6 +50,7 @@ struct GemmArgs {
   const float* lnstats;  // PP_RESLN: [M][2] (mean, rstd) of the residual rows; lng / lnb: that LayerNorm's gamma, beta [768]
   const float* lng;
   const float* lnb;
+  int stagger;           // gemm_pp: workgroup w starts (hash(w) % (stagger + 1)) x ~8k cycles late (breaks the lockstep of the memory bursts)
   int raw;               // RAW consumer (gemm_pp.h): A is the raw fp16 stream, W / bias are the folded ones, lnstats = row statistics
   float* lnpart;         // PP_RESLN2: [M][N / 64][2] partial (sum, sum of squares) per row and 64-column slice
   unsigned long long* clk;  // optional (development probe): per-workgroup s_memtime span of the persistent kernel

@@ -197,6 +197,14 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmArgs a) {
   const int bslot = xcd_remap(blockIdx.x, G);
   const unsigned long long clk0 = a.clk ? __builtin_amdgcn_s_memtime() : 0ull;
 
+  // ---- optional start-up stagger: all workgroups of a launch otherwise run their tiles in lockstep, so their
+  // accumulator-init loads and epilogue stores hit HBM in bursts (every CU at once) with the matrix pipes idle, and
+  // HBM idles during the main loops.  (Waves 1..7 wait for wave 0 at the prologue barrier.)
+  if (a.stagger > 0 && wave == 0) {
+    const int n = (int)((uint32_t)(bslot * 2654435761u) >> 16) % (a.stagger + 1);
+    for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(127);
+  }
+
   // ---- bias -> LDS (once per workgroup)
   {
     float* lb = (float*)(smem + PP_LDS_BIAS);

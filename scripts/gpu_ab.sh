@@ -9,9 +9,8 @@ ROUNDS=${ROUNDS:-2}
 BENCH_ARGS=${BENCH_ARGS:---steps 30 --warmup 5}
 for r in $(seq 1 $ROUNDS); do
   for spec in "$@"; do
-    set -- $spec
-    name=$1; shift
-    env "$@" timeout 300 python bench.py --cpu-sample 0 $BENCH_ARGS 2> $O/ab_$name.err | tail -1 > $O/ab_$name.json
+    read -r name envs <<< "$spec"
+    env $envs timeout 300 python bench.py --cpu-sample 0 $BENCH_ARGS 2> $O/ab_$name.err | tail -1 > $O/ab_$name.json
     python - "$O/ab_$name.json" "$name" "$r" <<'PY'
 import json, sys
 try:
