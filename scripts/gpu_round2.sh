@@ -9,7 +9,7 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 note() { echo "== $* ($(date +%H:%M:%S))"; }
 
 note "hang guard: one tiny attention_v2 case under a short timeout"
-timeout 240 python -m pytest tests/test_gpu_kernels.py -m gpu -x -q -k "layer0_stages and 64-False" > $O/t_guard.log 2>&1
+timeout 240 python -m pytest tests/test_gpu_kernels.py -m gpu -x -q -k "layer0_stages and 2-64-False" > $O/t_guard.log 2>&1
 GRC=$?
 echo "guard rc=$GRC" >> $O/t_guard.log; tail -3 $O/t_guard.log
 if [ $GRC -eq 124 ]; then
@@ -39,8 +39,10 @@ PY
 note "A/B benches"
 bench default MEMVUL_X=1
 bench attn_v1 MEMVUL_ATTN=0
+bench ln_explicit MEMVUL_LN_VIRTUAL=0
 bench no_lnfuse MEMVUL_LN_FUSE=0
 bench no_prune MEMVUL_CLS_PRUNE=0
+bench all_off MEMVUL_ATTN=0 MEMVUL_LN_FUSE=0 MEMVUL_CLS_PRUNE=0
 bench noprof MEMVUL_X=1 -- --no-profile
 
 note "rocprofv3 kernel trace of the bench command"

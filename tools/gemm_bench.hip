@@ -325,6 +325,22 @@ int main(int argc, char** argv) {
     vs.push_back({"pp S1 F4 res COAL", fl, [=] { run_pp<PP_RES, 4, 0, 1, 1>(g); }, {}});
     time_group("ffn2 M x768 x3072 (res)", vs, rounds, reps, js);
   }
+  {  // residual GEMMs: what the accumulator-init loads and the epilogue stores cost (lockstep bursts)
+    for (int K : {768, 3072}) {
+      GemmArgs g = base(K == 768 ? A768 : A3072, K == 768 ? Wo : W2, 768, K);
+      g.xres = xr_new;
+      g.outf = of_new;
+      const double fl = 2.0 * M * 768.0 * K;
+      std::vector<Variant> vs;
+      vs.push_back({"res  (loads + stores)", fl, [=] { run_pp<PP_RES, 4, 0, 1, 1>(g); }, {}});
+      vs.push_back({"res noepi (loads only)", fl, [=] { run_pp<PP_RES, 4, PP_ABL_NOEPI, 1, 1>(g); }, {}});
+      vs.push_back({"f32  (stores only)", fl, [=] { run_pp<PP_F32, 4, 0, 1, 1>(g); }, {}});
+      vs.push_back({"f32 noepi (neither)", fl, [=] { run_pp<PP_F32, 4, PP_ABL_NOEPI, 1, 1>(g); }, {}});
+      char title[64];
+      snprintf(title, sizeof title, "residual GEMM M x768 x%d: memory phases", K);
+      time_group(title, vs, rounds, reps, js);
+    }
+  }
   {  // per-tile time of one workgroup as a function of how many workgroups run (memory-burst contention)
     GemmArgs g = base(A768, W1, 3072, 768);
     g.out16 = o16_new;
