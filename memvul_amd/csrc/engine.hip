@@ -347,16 +347,20 @@ int launch_gemm(mv_handle* h, int cls, const GemmArgs& a) {
   if (pp_selected(h, a.M, a.N, a.K)) return launch_pp<EPI>(h, cls, a);
   if (a.lnstats || a.raw) return fail(h, MV_ERR_STATE, "internal: LayerNorm-fused GEMM requested on a non-persistent GEMM path");
   if (tile256 && (h->gemm_tile == 256 || (h->gemm_tile == 0 && big))) return launch_gemm256<EPI>(h, cls, a);
+  // skinny problems (the [CLS] tail of the pruned last layer: M = batch rows): 64 x 64 tiles on a 4-stage LDS ring,
+  // 4x the workgroups of the 128^2 kernel and a K loop that is DMA-latency-bound per step rather than per tile
+  if (h->gemm_tile == 0 && a.M <= 512 && a.M % 64 == 0 && a.N % 64 == 0)
+    return launch_ring<EPI, 1, 1, 2, 2, 64, 4, 2>(h, cls, a, 8);
   return launch_gemm128<EPI, true>(h, cls, a);
 }
 
 // K7 + K8: pooler on the [CLS] rows (row_stride floats apart), then the header
 int pool_head(mv_handle* h, const float* x, size_t row_stride, int B, float* u_out) {
-  const unsigned gx = (unsigned)((B + POOL_RB - 1) / POOL_RB);
-  hipLaunchKernelGGL(dense768_kernel<0>, dim3(gx, MV_HIDDEN / 256), dim3(256), 0, h->stream, x, row_stride, B, h->WpT, h->bp,
+  const unsigned gx = (unsigned)((B + 31) / 32);
+  hipLaunchKernelGGL(dense768_kernel<0>, dim3(gx, MV_HIDDEN / 32), dim3(256), 0, h->stream, x, row_stride, B, h->WpT, h->bp,
                      MV_HIDDEN, h->pooled);
   if (int rc = launch_check(h, "pooler")) return rc;
-  hipLaunchKernelGGL(dense768_kernel<1>, dim3(gx, MV_PROJ / 256), dim3(256), 0, h->stream, h->pooled, (size_t)MV_HIDDEN, B, h->WhT,
+  hipLaunchKernelGGL(dense768_kernel<1>, dim3(gx, MV_PROJ / 32), dim3(256), 0, h->stream, h->pooled, (size_t)MV_HIDDEN, B, h->WhT,
                      h->bh, MV_PROJ, u_out);
   return launch_check(h, "header");
 }
@@ -1142,7 +1146,7 @@ int mv_test_gemm(mv_handle* h, int variant, int M, int N, int K, const uint16_t*
                  float* C, int iters, float* ms) {
   if (!h || !A || !W || M <= 0 || N <= 0 || K <= 0) return fail(h, MV_ERR_INVALID, "mv_test_gemm: bad argument");
   if (M % 128 || N % 128 || K % 64) return fail(h, MV_ERR_INVALID, "mv_test_gemm: M,N % 128 and K % 64 required");
-  if (variant >= 2 && (M % 256 || N % 256)) return fail(h, MV_ERR_INVALID, "mv_test_gemm: this variant needs M,N % 256");
+  if (variant >= 2 && variant != 19 && (M % 256 || N % 256)) return fail(h, MV_ERR_INVALID, "mv_test_gemm: this variant needs M,N % 256");
   if (variant == 30 && K % 128) return fail(h, MV_ERR_INVALID, "mv_test_gemm: variant 30 needs K % 128");
   HIPCHK(h, hipSetDevice(h->device));
   half_t *dA = nullptr, *dW = nullptr;
@@ -1177,6 +1181,7 @@ int mv_test_gemm(mv_handle* h, int variant, int M, int N, int K, const uint16_t*
       case 16: return launch_ring<EPI_F32, 4, 4, 2, 2, 32, 3, 1>(h, KC_TEST_GEMM, g, 4);  // 256x256, 4 waves x 128x128, 96 KB
       case 17: return launch_ring<EPI_F32, 4, 2, 2, 2, 32, 4, 2>(h, KC_TEST_GEMM, g, 8);  // 256x128, 4 waves, 96 KB
       case 18: return launch_ring<EPI_F32, 2, 4, 4, 2, 32, 4, 2>(h, KC_TEST_GEMM, g, 4);  // 256x256, 8 waves x 64x128, 128 KB
+      case 19: return launch_ring<EPI_F32, 1, 1, 2, 2, 64, 4, 2>(h, KC_TEST_GEMM, g, 8);  // 64x64, 4 waves, 64 KB: the skinny-M path
       // timing ablations of variant 10 (results are wrong by construction)
       case 21: return launch_ring<EPI_F32, 4, 2, 2, 4, 64, 2, 2, 1>(h, KC_TEST_GEMM, g, 4);  // no LDS-DMA in the loop
       case 22: return launch_ring<EPI_F32, 4, 2, 2, 4, 64, 2, 2, 2>(h, KC_TEST_GEMM, g, 4);  // no MFMA

@@ -196,40 +196,48 @@ __global__ __launch_bounds__(256) void cls_gather_kernel(const float* __restrict
 }
 
 // K7, K8 (model_memory.py:99-102): u = relu(W_h tanh(W_p h[:,0] + b_p) + b_h), all fp32, as two launches of one
-// dense kernel: out[b][n] = act(sum_k x[b][k] W^T[k][n] + bias[n]), K = 768.  A workgroup handles POOL_RB rows x 256
-// output columns (grid = rows / POOL_RB x N / 256: 192 + 128 workgroups at B = 256 instead of the 64 a fused
-// pooler+header kernel gets); thread n owns one column; the weights are stored transposed ([k][n]) so a wave reads
-// 256 contiguous bytes per k; every output is one ascending-k fma chain (tile shape never changes the bits).
-#define POOL_RB 4
+// dense kernel: out[b][n] = act(sum_k x[b][k] W^T[k][n] + bias[n]), K = 768, on the fp32-input matrix cores
+// (v_mfma_f32_32x32x2_f32: exact fp32 products and sums, MI355X_MICROARCH.md "f32-input MFMA").  A workgroup owns
+// one 32 x 32 output tile; its 4 waves split K (192 each, ascending k inside a wave) and the four partial tiles are
+// added in wave order through LDS, so the result is deterministic.  The weights are stored transposed ([k][n]): a
+// B-operand load is two 128-byte row pieces; grid = B / 32 x N / 32 (192 + 128 workgroups at B = 256).
+typedef float floatx16_t __attribute__((ext_vector_type(16)));
 template <int ACT>  // 0: tanh (BertPooler), 1: ReLU (header FeedForward)
 __global__ __launch_bounds__(256) void dense768_kernel(const float* __restrict__ x, size_t row_stride, int B,
                                                        const float* __restrict__ WT, const float* __restrict__ bias, int N,
                                                        float* __restrict__ out) {
-  __shared__ float xs[POOL_RB][MV_HIDDEN];
-  const int b0 = blockIdx.x * POOL_RB;
-  const int tid = threadIdx.x, n = blockIdx.y * 256 + tid;
-  for (int e = tid; e < POOL_RB * MV_HIDDEN; e += 256) {
-    const int r = e / MV_HIDDEN, c = e - r * MV_HIDDEN;
-    xs[r][c] = (b0 + r < B) ? x[(size_t)(b0 + r) * row_stride + c] : 0.f;
+  __shared__ float part[4][16][64];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int b0 = blockIdx.x * 32, n0 = blockIdx.y * 32;
+  const int h = lane >> 5, l31 = lane & 31;
+  const int row = (b0 + l31 < B) ? b0 + l31 : B - 1;  // rows past B: computed on a valid row, never stored
+  const float* xr = x + (size_t)row * row_stride + wave * 192;
+  const float* wc = WT + (size_t)(wave * 192 + h) * N + n0 + l31;
+  floatx16_t acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll 4
+  for (int k0 = 0; k0 < 192; k0 += 8) {
+    const float4 a0 = *(const float4*)(xr + k0), a1 = *(const float4*)(xr + k0 + 4);
+    // lanes 0-31 carry k0 + 2 j, lanes 32-63 k0 + 2 j + 1
+    const float s0 = h ? a0.y : a0.x, s1 = h ? a0.w : a0.z, s2 = h ? a1.y : a1.x, s3 = h ? a1.w : a1.z;
+    const float w0 = wc[(size_t)(k0 + 0) * N], w1 = wc[(size_t)(k0 + 2) * N], w2 = wc[(size_t)(k0 + 4) * N], w3 = wc[(size_t)(k0 + 6) * N];
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(s0, w0, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(s1, w1, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(s2, w2, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(s3, w3, acc, 0, 0, 0);
   }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) part[wave][r][lane] = acc[r];
   __syncthreads();
-  float acc[POOL_RB];
 #pragma unroll
-  for (int r = 0; r < POOL_RB; ++r) acc[r] = 0.f;
-  // 16 weight loads in flight per thread: at one workgroup per CU the loop is L2-latency-bound otherwise
-  for (int k0 = 0; k0 < MV_HIDDEN; k0 += 16) {
-    float w[16];
-#pragma unroll
-    for (int j = 0; j < 16; ++j) w[j] = WT[(size_t)(k0 + j) * N + n];
-#pragma unroll
-    for (int j = 0; j < 16; ++j)
-#pragma unroll
-      for (int r = 0; r < POOL_RB; ++r) acc[r] = fmaf(w[j], xs[r][k0 + j], acc[r]);
+  for (int j = 0; j < 4; ++j) {
+    const int idx = tid + 256 * j, r = idx >> 6, ln = idx & 63;
+    const float v = ((part[0][r][ln] + part[1][r][ln]) + part[2][r][ln]) + part[3][r][ln];
+    const int orow = b0 + (r & 3) + 8 * (r >> 2) + 4 * (ln >> 5), ocol = n0 + (ln & 31);
+    if (orow < B) out[(size_t)orow * N + ocol] = ACT == 0 ? tanhf(v + bias[ocol]) : fmaxf(v + bias[ocol], 0.f);
   }
-  const float bn = bias[n];
-#pragma unroll
-  for (int r = 0; r < POOL_RB; ++r)
-    if (b0 + r < B) out[(size_t)(b0 + r) * N + n] = ACT == 0 ? tanhf(acc[r] + bn) : fmaxf(acc[r] + bn, 0.f);
 }
 
 // K9 (model_memory.py:135-142): logits[b,g,:] = W_m [u_b ; v_g ; |u_b - v_g|], p = softmax_2.
