@@ -167,7 +167,10 @@ def test_last_layer_pruning_matches_full_forward(gu, B, S, ragged, gemm_tile):
     d = float(np.abs(u_full - u_cls).max())
     gu.record("cls_prune", B=B, S=S, gemm_tile=gemm_tile, full_vs_pruned=d, pruned_vs_oracle=float(np.abs(u_cls - u_ref).max()),
               full_vs_oracle=float(np.abs(u_full - u_ref).max()))
-    assert d < 2e-4  # one fp16 ulp of a context value (different summation order) reaches u at the 5e-5 level
+    # one fp16 ulp of a context value (different summation order) reaches u at the 5e-5 level; on the persistent-GEMM
+    # path the full forward's last layer also runs with the virtual LayerNorm while the [CLS] tail uses the explicit one
+    # (different fp16 roundings of the same mathematics: the 2e-4 level, like either of them against the oracle)
+    assert d < 6e-4
     assert np.abs(u_cls - u_ref).max() < 2e-3
 
 
