@@ -675,6 +675,8 @@ int mv_create(int device, const mv_config* cfg, mv_handle** out) {
   {
     int ncu = 0;
     if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && ncu > 0) h->num_cu = ncu;
+    // MEMVUL_NUM_CU: size the persistent grids for a share of the chip (two engines on two streams, scripts/dual_stream_probe.py)
+    if (const char* e = getenv("MEMVUL_NUM_CU")) { const int v = atoi(e); if (v > 0 && v <= h->num_cu) h->num_cu = v; }
   }
 
   h->cap_tokens = round_up(cfg->max_tokens, 256) + 256;
