@@ -77,7 +77,8 @@ def main():
     ap.add_argument("--anchor-len", type=int, default=512)
     ap.add_argument("--layers", type=int, default=12)
     ap.add_argument("--cpu-sample", type=int, default=96, help="IRs timed on the CPU baseline (0 disables)")
-    ap.add_argument("--no-profile", action="store_true", help="do not record per-kernel HIP events in the timed region")
+    ap.add_argument("--no-profile", action="store_true", help="skip the per-kernel HIP-event passes (no `roofline` / `kernels`)")
+    ap.add_argument("--streams", type=int, default=2, choices=(1, 2), help="batches of the resident sweep in flight at once")
     args = ap.parse_args()
 
     if args.cpu_sample > 0 or int(os.environ.get("WORLD_SIZE", "1")) > 1:
@@ -117,11 +118,12 @@ def main():
     if multi:
         mvdist.all_gather_stats(np.zeros(4, np.float32), np.zeros(4, np.uint8))  # RCCL communicator warm-up
         mvdist.barrier()
-    # per-kernel breakdown: a separate, untimed pass with HIP events around every launch; the timed region below
-    # carries events on the dominant GEMM class only (that IS the `roofline` measurement), so `value` is not
-    # slowed by ~90 event pairs per step
+    # per-kernel breakdown: a separate, untimed pass with ONE batch in flight and HIP events around every launch
+    # (with two batches in flight a launch's event span includes the time it shares the chip with the other batch's
+    # kernels, so it says nothing about the kernel)
     breakdown, dom = {}, None
     if not args.no_profile:
+        eng.set_streams(1)
         eng.profile_enable(True)
         eng.profile_select(None)
         eng.profile_read()
@@ -130,7 +132,8 @@ def main():
         breakdown = eng.profile_read()
         gem = {k: v for k, v in breakdown.items() if k.startswith("gemm_") and k in GEMM_CLASSES and v[1]}
         dom = max(gem, key=lambda k: gem[k][0])
-        eng.profile_select([dom])
+        eng.profile_enable(False)
+    eng.set_streams(args.streams)
     lab = synth.make_labels(n_batches * B, seed=synth.SEED + rank)
     if multi:
         mvdist.barrier()
@@ -147,9 +150,24 @@ def main():
         mvdist.barrier()
     t1 = time.perf_counter()
     elapsed = mvdist.all_reduce_max(t1 - t0) if multi else (t1 - t0)
-    prof = {} if args.no_profile else eng.profile_read()
-    eng.profile_enable(False)
-    eng.profile_select(None)
+    # roofline pass: the same K steps once more with one batch in flight and HIP events (engine stream) around the
+    # dominant GEMM class only -> per-launch duration of that kernel alone, and the one-batch-in-flight rate
+    prof, single_rate = {}, None
+    if not args.no_profile:
+        eng.set_streams(1)
+        eng.profile_enable(True)
+        eng.profile_select([dom])
+        eng.profile_read()
+        eng.sync()
+        ts0 = time.perf_counter()
+        for i in range(K):
+            step(W + i)
+        eng.sync()
+        single_rate = K * B / (time.perf_counter() - ts0)
+        prof = eng.profile_read()
+        eng.profile_enable(False)
+        eng.profile_select(None)
+        eng.set_streams(2 if args.streams == 2 else 1)
 
     if rank != 0:
         return
@@ -176,6 +194,7 @@ def main():
         "e2e_tflops_per_gpu": round(value / world * fpi_exec / 1e12, 2),
         "e2e_mfma_frac": round(value / world * fpi_exec / 1e12 / MFMA_PEAK_TFLOPS, 4),
         "gflop_per_ir": {"algorithmic": round(fpi / 1e9, 3), "executed": round(fpi_exec / 1e9, 3), "last_layer_cls_pruning": pruned},
+        "batches_in_flight": args.streams,
         "stats_allgather_ms": round(gather_ms, 3),
         "stats_table_sum": int(table.sum()),
     }
@@ -191,9 +210,12 @@ def main():
         achieved = gemm_flops(dom, M) / (avg_us * 1e-6) / 1e12
         out["roofline"] = {"kernel": dom, "bound": "mfma", "achieved": round(achieved, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                            "frac": round(achieved / MFMA_PEAK_TFLOPS, 4), "traffic": PMC_TRAFFIC_BYTES.get(dom),
-                           "flops_per_launch": gemm_flops(dom, M), "avg_launch_us": round(avg_us, 2), "launches_timed": n}
+                           "flops_per_launch": gemm_flops(dom, M), "avg_launch_us": round(avg_us, 2), "launches_timed": n,
+                           "note": "HIP events around this kernel class over a pass of the same K steps with ONE batch in flight "
+                                   "(`value` runs two: a launch's span then includes time shared with the other batch's kernels)"}
+        out["value_one_batch_in_flight"] = round(world * single_rate, 2)
         out["kernels"] = kernels
-        out["kernels_note"] = "per-class HIP-event breakdown from a separate untimed pass of %d steps" % min(K, 4)
+        out["kernels_note"] = "per-class HIP-event breakdown from a separate untimed pass of %d steps, one batch in flight" % min(K, 4)
     if args.cpu_sample > 0 and world == 1:
         out["cpu_baseline"], out["logit_max_abs_err_vs_cpu"] = cpu_baseline(weights, dims, eng, ids, lens, S, args.cpu_sample)
     print(json.dumps(out), flush=True)

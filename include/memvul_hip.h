@@ -125,6 +125,9 @@ int mv_corpus_upload(mv_handle* h, const int32_t* ids, const int32_t* lens, int6
 /* Runs IRs [first, first+count) in batches of `batch`; asynchronous. keep_probs != 0 also keeps
  * P(same) for every (IR, anchor) pair (what make_output_human_readable serialises, l.169-191). */
 int mv_corpus_run(mv_handle* h, int64_t first, int64_t count, int batch, int keep_probs);
+/* Batches of the resident sweep in flight at once: 2 (default; consecutive batches alternate between two workspace
+ * sets on two HIP streams and overlap on the GPU) or 1.  Results are identical either way. */
+int mv_set_streams(mv_handle* h, int n);
 /* best fp32 [count,2], best_idx int32 [count], p_same fp32 [count,G] (NULL unless kept). Synchronises. */
 int mv_corpus_results(mv_handle* h, int64_t first, int64_t count, float* best, int32_t* best_idx, float* p_same);
 

@@ -22,7 +22,7 @@ ABI_SYMBOLS = [
     "mv_create", "mv_destroy", "mv_last_error", "mv_sync", "mv_load_tensor", "mv_finalize_weights",
     "mv_anchor_reset", "mv_anchor_append", "mv_anchor_count", "mv_anchor_get", "mv_anchor_set",
     "mv_forward", "mv_encode", "mv_match", "mv_topk", "mv_corpus_upload", "mv_corpus_run",
-    "mv_corpus_results", "mv_profile_enable", "mv_profile_select", "mv_profile_read", "mv_kernel_class_name",
+    "mv_corpus_results", "mv_set_streams", "mv_profile_enable", "mv_profile_select", "mv_profile_read", "mv_kernel_class_name",
     "mv_debug_encode", "mv_debug_read", "mv_test_gemm",
 ]
 
@@ -76,6 +76,7 @@ def load_library(path: Optional[str] = None):
         "mv_corpus_upload": (C.c_int, [vp, vp, vp, C.c_int64, C.c_int]),
         "mv_corpus_run": (C.c_int, [vp, C.c_int64, C.c_int64, C.c_int, C.c_int]),
         "mv_corpus_results": (C.c_int, [vp, C.c_int64, C.c_int64, vp, vp, vp]),
+        "mv_set_streams": (C.c_int, [vp, C.c_int]),
         "mv_profile_enable": (C.c_int, [vp, C.c_int]),
         "mv_profile_select": (C.c_int, [vp, C.c_uint32]),
         "mv_profile_read": (C.c_int, [vp, P(C.c_double), P(C.c_int64), C.c_int]),
@@ -234,6 +235,10 @@ class Engine:
         return best, idx, ps
 
     # -- measurement / debug
+    def set_streams(self, n: int):
+        """Batches of the resident sweep in flight at once (1 or 2)."""
+        self._check(self._lib.mv_set_streams(self._h, int(n)), "mv_set_streams")
+
     def profile_enable(self, on: bool = True):
         self._check(self._lib.mv_profile_enable(self._h, int(on)), "mv_profile_enable")
 

@@ -103,9 +103,25 @@ struct ProfRec {
 
 }  // namespace
 
+// Activation buffers of ONE in-flight batch and the stream its kernels run on
+struct Work {
+  hipStream_t stream = nullptr;
+  int32_t *d_ids = nullptr, *d_lens = nullptr;  // host-path inputs
+  float* xres = nullptr;                        // residual stream fp32 [T][768]
+  half_t *x16 = nullptr, *q = nullptr, *k = nullptr, *vt = nullptr, *ctx = nullptr, *h16 = nullptr;
+  float *u = nullptr, *pooled = nullptr;
+  float *logits = nullptr, *probs = nullptr, *psame = nullptr, *best = nullptr;
+  int32_t* best_idx = nullptr;
+  float* topk_p = nullptr;
+  int32_t* topk_idx = nullptr;
+  float* u_in = nullptr;                        // host-provided embeddings for mv_match / mv_topk
+  float *c32 = nullptr, *cq = nullptr;          // [CLS]-row buffers of the pruned last layer
+  half_t *c16 = nullptr, *cctx = nullptr, *ch16 = nullptr;
+  float *lnstats = nullptr, *lnpart = nullptr;  // LayerNorm row statistics / partial row sums
+};
+
 struct mv_handle {
   int device = 0;
-  hipStream_t stream = nullptr;
   mv_config cfg{};
   std::string err;
   bool finalized = false;
@@ -118,18 +134,19 @@ struct mv_handle {
   std::vector<LayerW> L;
   float *WpT = nullptr, *bp = nullptr, *WhT = nullptr, *bh = nullptr, *Wm = nullptr;
 
-  // workspaces
+  // workspaces: two sets, each with its own stream.  mv_corpus_run alternates the batches of a sweep between them,
+  // so two batches are in flight on the GPU at once: the persistent kernels of one batch fill the CUs the other
+  // batch's kernel tails, small kernels and memory phases leave idle (+5 % issue reports/s, scripts/dual_stream_probe.py).
+  // Every other entry point works on set 0 (`w` points at the set in use).
   int64_t cap_tokens = 0;  // rows every activation buffer holds (multiple of 128, + slack)
-  int32_t *d_ids = nullptr, *d_lens = nullptr;
-  float* xres = nullptr;
-  half_t *x16 = nullptr, *q = nullptr, *k = nullptr, *vt = nullptr, *ctx = nullptr, *h16 = nullptr;
-  float *u = nullptr, *anchors = nullptr, *pooled = nullptr;
+  Work work[2];
+  Work* w = &work[0];
+  int n_streams = 2;       // sets in use by the resident sweep (mv_set_streams); env MEMVUL_STREAMS=1: only one is created
+  int n_alloc = 2;         // sets created
+  bool dual_pending = false;  // work[1] may still be running a batch
+  int rr = 0;                 // workspace set of the next resident-sweep batch
+  float* anchors = nullptr;
   int n_anchors = 0;
-  float *logits = nullptr, *probs = nullptr, *psame = nullptr, *best = nullptr;
-  int32_t* best_idx = nullptr;
-  float* topk_p = nullptr;
-  int32_t* topk_idx = nullptr;
-  float* u_in = nullptr;  // host-provided embeddings for mv_match / mv_topk
 
   // resident corpus
   int32_t *c_ids = nullptr, *c_lens = nullptr;
@@ -143,18 +160,15 @@ struct mv_handle {
 
   // last-layer pruning ([CLS] rows only after the last layer's K / V projection) and its compact buffers
   bool cls_prune = true;   // env MEMVUL_CLS_PRUNE=0 disables
-  float *c32 = nullptr, *cq = nullptr;
-  half_t *c16 = nullptr, *cctx = nullptr, *ch16 = nullptr;
   // LayerNorm folded into the consumer's residual read (gemm_pp PP_RESLN); env MEMVUL_LN_FUSE=0 disables
   bool ln_fuse = true;
   // persistent LDS-DMA attention kernel for padded lengths <= 256 (attention_v2.h); env MEMVUL_ATTN=0 selects attention.h
   bool attn_v2 = true;
-  float *lnstats = nullptr, *ones = nullptr, *zeros = nullptr;
+  float *ones = nullptr, *zeros = nullptr;
   // ... and no LayerNorm kernel at all between the GEMMs (RAW consumers + PP_RESLN2 producers); env MEMVUL_LN_VIRTUAL=0 disables
   bool ln_virtual = true;
   int pp_stagger = 0;  // env MEMVUL_STAGGER: see GemmArgs::stagger
   int r16_direct = 0;  // PP_RESLN2: fp16 copy from the transposed fp32 image (1) or through its own LDS transposition (0); env MEMVUL_R16_DIRECT
-  float* lnpart = nullptr;  // [T][12][2] partial row sums of the residual GEMMs
 
   // profiling
   uint32_t prof_mask = 0xffffffffu;  // kernel classes that get HIP events while profiling is on
@@ -192,7 +206,7 @@ int dev_alloc(mv_handle* h, T** p, int64_t count, bool zero = true) {
   hipError_t e = hipMalloc(&d, bytes ? bytes : 16);
   if (e != hipSuccess) return fail(h, MV_ERR_NOMEM, std::string("hipMalloc failed: ") + hipGetErrorString(e));
   if (zero) {
-    e = hipMemsetAsync(d, 0, bytes ? bytes : 16, h->stream);
+    e = hipMemsetAsync(d, 0, bytes ? bytes : 16, h->w->stream);
     if (e != hipSuccess) return fail(h, MV_ERR_HIP, std::string("hipMemset failed: ") + hipGetErrorString(e));
   }
   h->allocs.push_back(d);
@@ -226,12 +240,12 @@ struct ProfScope {
       rec.cls = cls;
       rec.e0 = get_event(h);
       rec.e1 = get_event(h);
-      hipEventRecord(rec.e0, h->stream);
+      hipEventRecord(rec.e0, h->w->stream);
     }
   }
   ~ProfScope() {
     if (on) {
-      hipEventRecord(rec.e1, h->stream);
+      hipEventRecord(rec.e1, h->w->stream);
       h->recs.push_back(rec);
     }
   }
@@ -256,7 +270,7 @@ int launch_gemm128(mv_handle* h, int cls, GemmArgs a) {
   a.GN = choose_gn(a.N / 128, 8);
   const int grid = (a.M / 128) * (a.N / 128);
   ProfScope ps(h, cls);
-  hipLaunchKernelGGL((gemm128_kernel<EPI, GLDS>), dim3(grid), dim3(256), G128_LDS_BYTES, h->stream, a);
+  hipLaunchKernelGGL((gemm128_kernel<EPI, GLDS>), dim3(grid), dim3(256), G128_LDS_BYTES, h->w->stream, a);
   return launch_check(h, "gemm128");
 }
 
@@ -266,7 +280,7 @@ int launch_gemm256(mv_handle* h, int cls, GemmArgs a) {
   a.GN = choose_gn(a.N / 256, 4);
   const int grid = (a.M / 256) * (a.N / 256);
   ProfScope ps(h, cls);
-  hipLaunchKernelGGL((gemm256_kernel<EPI>), dim3(grid), dim3(512), G256_LDS_BYTES, h->stream, a);
+  hipLaunchKernelGGL((gemm256_kernel<EPI>), dim3(grid), dim3(512), G256_LDS_BYTES, h->w->stream, a);
   return launch_check(h, "gemm256");
 }
 
@@ -286,7 +300,7 @@ int launch_ring(mv_handle* h, int cls, GemmArgs a, int gn_max) {
   a.GN = choose_gn(a.N / BN, gn_max);
   const int grid = (a.M / BM) * (a.N / BN);
   ProfScope ps(h, cls);
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * WM * WN), LDS, h->stream, a);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * WM * WN), LDS, h->w->stream, a);
   return launch_check(h, "gemm_ring");
 }
 
@@ -303,7 +317,7 @@ int launch_pp_raw(mv_handle* h, GemmArgs a) {
   const int grid = tiles < h->num_cu ? tiles : h->num_cu;
   a.stagger = tiles >= 2 * h->num_cu ? h->pp_stagger : 0;
   hipLaunchKernelGGL((gemm_pp_kernel<PPEPI, PP_DIST, 0, PP_SCHED, PP_COAL, RAW>), dim3(grid), dim3(512),
-                     RAW ? PP_LDS_BYTES_RAW : PP_LDS_BYTES, h->stream, a);
+                     RAW ? PP_LDS_BYTES_RAW : PP_LDS_BYTES, h->w->stream, a);
   return launch_check(h, "gemm_pp");
 }
 
@@ -357,10 +371,10 @@ int launch_gemm(mv_handle* h, int cls, const GemmArgs& a) {
 // K7 + K8: pooler on the [CLS] rows (row_stride floats apart), then the header
 int pool_head(mv_handle* h, const float* x, size_t row_stride, int B, float* u_out) {
   const unsigned gx = (unsigned)((B + 31) / 32);
-  hipLaunchKernelGGL(dense768_kernel<0>, dim3(gx, MV_HIDDEN / 32), dim3(256), 0, h->stream, x, row_stride, B, h->WpT, h->bp,
-                     MV_HIDDEN, h->pooled);
+  hipLaunchKernelGGL(dense768_kernel<0>, dim3(gx, MV_HIDDEN / 32), dim3(256), 0, h->w->stream, x, row_stride, B, h->WpT, h->bp,
+                     MV_HIDDEN, h->w->pooled);
   if (int rc = launch_check(h, "pooler")) return rc;
-  hipLaunchKernelGGL(dense768_kernel<1>, dim3(gx, MV_PROJ / 32), dim3(256), 0, h->stream, h->pooled, (size_t)MV_HIDDEN, B, h->WhT,
+  hipLaunchKernelGGL(dense768_kernel<1>, dim3(gx, MV_PROJ / 32), dim3(256), 0, h->w->stream, h->w->pooled, (size_t)MV_HIDDEN, B, h->WhT,
                      h->bh, MV_PROJ, u_out);
   return launch_check(h, "header");
 }
@@ -388,12 +402,12 @@ int encode_dev(mv_handle* h, const int32_t* d_ids, const int32_t* d_lens, int B,
   {
     ProfScope ps(h, KC_EMBED_LN);
     if (virt)
-      hipLaunchKernelGGL(embed_ln_kernel<true>, dim3(ln_grid), dim3(256), 0, h->stream, d_ids, S_in, Sp, (int)M, c.vocab_size,
-                         h->wemb, h->pemb, h->temb, h->embg, h->embb, c.ln_eps, h->xres, h->x16, h->lnstats);
+      hipLaunchKernelGGL(embed_ln_kernel<true>, dim3(ln_grid), dim3(256), 0, h->w->stream, d_ids, S_in, Sp, (int)M, c.vocab_size,
+                         h->wemb, h->pemb, h->temb, h->embg, h->embb, c.ln_eps, h->w->xres, h->w->x16, h->w->lnstats);
     else
-      hipLaunchKernelGGL(embed_ln_kernel<false>, dim3(ln_grid), dim3(256), 0, h->stream, d_ids, S_in, Sp, (int)M, c.vocab_size,
-                         h->wemb, h->pemb, h->temb, h->embg, h->embb, c.ln_eps, h->xres, h->x16,
-                         fuse ? h->lnstats : (float*)nullptr);
+      hipLaunchKernelGGL(embed_ln_kernel<false>, dim3(ln_grid), dim3(256), 0, h->w->stream, d_ids, S_in, Sp, (int)M, c.vocab_size,
+                         h->wemb, h->pemb, h->temb, h->embg, h->embb, c.ln_eps, h->w->xres, h->w->x16,
+                         fuse ? h->w->lnstats : (float*)nullptr);
     if (int rc = launch_check(h, "embed_ln")) return rc;
   }
   // LayerNorm whose statistics are pending in lnstats (fuse only): gamma / beta the next residual consumer applies
@@ -403,15 +417,15 @@ int encode_dev(mv_handle* h, const int32_t* d_ids, const int32_t* d_lens, int B,
     ProfScope ps(h, KC_LN);
     const unsigned grid = (unsigned)((rows + 3) / 4);
     if (stats_only)
-      hipLaunchKernelGGL(ln_kernel<false>, dim3(grid), dim3(256), 0, h->stream, x32, x16, rows, g, b, c.ln_eps, h->lnstats);
+      hipLaunchKernelGGL(ln_kernel<false>, dim3(grid), dim3(256), 0, h->w->stream, x32, x16, rows, g, b, c.ln_eps, h->w->lnstats);
     else
-      hipLaunchKernelGGL(ln_kernel<true>, dim3(grid), dim3(256), 0, h->stream, x32, x16, rows, g, b, c.ln_eps, (float*)nullptr);
+      hipLaunchKernelGGL(ln_kernel<true>, dim3(grid), dim3(256), 0, h->w->stream, x32, x16, rows, g, b, c.ln_eps, (float*)nullptr);
     return launch_check(h, "layernorm");
   };
   auto run_finalize = [&]() -> int {  // virt: partial row sums of the residual GEMM -> (mean, rstd)
     ProfScope ps(h, KC_LN);
-    hipLaunchKernelGGL(ln_finalize_kernel, dim3((unsigned)((Mpad + 255) / 256)), dim3(256), 0, h->stream, h->lnpart, MV_HIDDEN / 64,
-                       (int)Mpad, c.ln_eps, h->lnstats);
+    hipLaunchKernelGGL(ln_finalize_kernel, dim3((unsigned)((Mpad + 255) / 256)), dim3(256), 0, h->w->stream, h->w->lnpart, MV_HIDDEN / 64,
+                       (int)Mpad, c.ln_eps, h->w->lnstats);
     return launch_check(h, "ln_finalize");
   };
   for (int l = 0; l < n_layers; ++l) {
@@ -419,96 +433,96 @@ int encode_dev(mv_handle* h, const int32_t* d_ids, const int32_t* d_lens, int B,
     const bool last = (l == n_layers - 1);
     GemmArgs g{};
     g.M = (int)Mpad; g.Mreal = (int)M; g.S = Sp;
-    g.q = h->q; g.k = h->k; g.vt = h->vt;
-    if (virt) { g.raw = 1; g.lnstats = h->lnstats; }
+    g.q = h->w->q; g.k = h->w->k; g.vt = h->w->vt;
+    if (virt) { g.raw = 1; g.lnstats = h->w->lnstats; }
     const half_t* wqkv = virt ? w.wqkv_f : w.wqkv;
     const float* bqkv = virt ? w.bqkv_f : w.bqkv;
     if (last && prune) {
       // ---- last layer, [CLS] rows only: K and V of every token, everything else on B rows
       const int Bp = (int)round_up(B, 128);
-      g.A = h->x16; g.W = wqkv + (size_t)MV_HIDDEN * MV_HIDDEN; g.bias = bqkv + MV_HIDDEN; g.N = 2 * MV_HIDDEN; g.K = MV_HIDDEN;
+      g.A = h->w->x16; g.W = wqkv + (size_t)MV_HIDDEN * MV_HIDDEN; g.bias = bqkv + MV_HIDDEN; g.N = 2 * MV_HIDDEN; g.K = MV_HIDDEN;
       g.col0 = MV_HIDDEN;
       if (int rc = launch_gemm<EPI_QKV>(h, KC_GEMM_KV_LAST, g)) return rc;
       ProfScope tail(h, KC_CLS_TAIL);
       const uint32_t keep_mask = h->prof_mask;
       h->prof_mask = 0;  // the tail is one profiled span; its inner launches carry no events of their own
       auto tail_rc = [&]() -> int {
-        hipLaunchKernelGGL(cls_gather_kernel, dim3((B + 3) / 4), dim3(256), 0, h->stream, h->xres, h->x16, Sp, B,
-                           fuse ? h->lnstats : (const float*)nullptr, pend_g, pend_b, h->c32, h->c16, virt ? 1 : 0);
+        hipLaunchKernelGGL(cls_gather_kernel, dim3((B + 3) / 4), dim3(256), 0, h->w->stream, h->w->xres, h->w->x16, Sp, B,
+                           fuse ? h->w->lnstats : (const float*)nullptr, pend_g, pend_b, h->w->c32, h->w->c16, virt ? 1 : 0);
         if (int rc = launch_check(h, "cls_gather")) return rc;
         GemmArgs t{};
         t.M = Bp; t.Mreal = B; t.S = 64;
-        t.A = h->c16; t.W = w.wqkv; t.bias = w.bqkv; t.N = MV_HIDDEN; t.K = MV_HIDDEN; t.outf = h->cq;
+        t.A = h->w->c16; t.W = w.wqkv; t.bias = w.bqkv; t.N = MV_HIDDEN; t.K = MV_HIDDEN; t.outf = h->w->cq;
         if (int rc = launch_gemm<EPI_F32>(h, KC_CLS_TAIL, t)) return rc;
-        hipLaunchKernelGGL(attention_cls_kernel, dim3((B * MV_HEADS + 3) / 4), dim3(256), 0, h->stream, h->cq, h->k, h->vt,
-                           d_lens, h->cctx, Sp, B * MV_HEADS);
+        hipLaunchKernelGGL(attention_cls_kernel, dim3((B * MV_HEADS + 3) / 4), dim3(256), 0, h->w->stream, h->w->cq, h->w->k, h->w->vt,
+                           d_lens, h->w->cctx, Sp, B * MV_HEADS);
         if (int rc = launch_check(h, "attention_cls")) return rc;
-        t.A = h->cctx; t.W = w.wo; t.bias = w.bo; t.N = MV_HIDDEN; t.K = MV_HIDDEN; t.xres = h->c32; t.outf = nullptr;
+        t.A = h->w->cctx; t.W = w.wo; t.bias = w.bo; t.N = MV_HIDDEN; t.K = MV_HIDDEN; t.xres = h->w->c32; t.outf = nullptr;
         if (int rc = launch_gemm<EPI_RES>(h, KC_CLS_TAIL, t)) return rc;
-        if (int rc = run_ln(h->c32, h->c16, B, w.ln1g, w.ln1b, false)) return rc;
-        t.A = h->c16; t.W = w.w1; t.bias = w.b1; t.N = MV_INTER; t.K = MV_HIDDEN; t.out16 = h->ch16;
+        if (int rc = run_ln(h->w->c32, h->w->c16, B, w.ln1g, w.ln1b, false)) return rc;
+        t.A = h->w->c16; t.W = w.w1; t.bias = w.b1; t.N = MV_INTER; t.K = MV_HIDDEN; t.out16 = h->w->ch16;
         if (int rc = launch_gemm<EPI_GELU>(h, KC_CLS_TAIL, t)) return rc;
-        t.A = h->ch16; t.W = w.w2; t.bias = w.b2; t.N = MV_HIDDEN; t.K = MV_INTER; t.xres = h->c32;
+        t.A = h->w->ch16; t.W = w.w2; t.bias = w.b2; t.N = MV_HIDDEN; t.K = MV_INTER; t.xres = h->w->c32;
         if (int rc = launch_gemm<EPI_RES>(h, KC_CLS_TAIL, t)) return rc;
-        if (int rc = run_ln(h->c32, h->c16, B, w.ln2g, w.ln2b, false)) return rc;
-        return pool_head(h, h->c32, MV_HIDDEN, B, u_out);
+        if (int rc = run_ln(h->w->c32, h->w->c16, B, w.ln2g, w.ln2b, false)) return rc;
+        return pool_head(h, h->w->c32, MV_HIDDEN, B, u_out);
       }();
       h->prof_mask = keep_mask;
       return tail_rc;
     }
     // K2: QKV projection
-    g.A = h->x16; g.W = wqkv; g.bias = bqkv; g.N = 3 * MV_HIDDEN; g.K = MV_HIDDEN;
+    g.A = h->w->x16; g.W = wqkv; g.bias = bqkv; g.N = 3 * MV_HIDDEN; g.K = MV_HIDDEN;
     if (int rc = launch_gemm<EPI_QKV>(h, KC_GEMM_QKV, g)) return rc;
     // K3: attention
     {
-      AttnArgs a{h->q, h->k, h->vt, d_lens, h->ctx, Sp, B};
+      AttnArgs a{h->w->q, h->w->k, h->w->vt, d_lens, h->w->ctx, Sp, B};
       ProfScope ps(h, KC_ATTENTION);
       if (h->attn_v2 && Sp <= 256) {
         const int nkb = Sp / 64, items = B * MV_HEADS;
         const int slots = h->num_cu * (nkb == 1 ? 4 : nkb == 2 ? 2 : 1);  // resident workgroups: 8 waves and <= 128 KiB LDS per CU
         const int grid = items < slots ? items : slots;
         switch (nkb) {
-          case 1: hipLaunchKernelGGL((attention_v2_kernel<1>), dim3(grid), dim3(128), ATT2_LDS_BYTES(1), h->stream, a, items); break;
-          case 2: hipLaunchKernelGGL((attention_v2_kernel<2>), dim3(grid), dim3(256), ATT2_LDS_BYTES(2), h->stream, a, items); break;
-          case 3: hipLaunchKernelGGL((attention_v2_kernel<3>), dim3(grid), dim3(384), ATT2_LDS_BYTES(3), h->stream, a, items); break;
-          default: hipLaunchKernelGGL((attention_v2_kernel<4>), dim3(grid), dim3(512), ATT2_LDS_BYTES(4), h->stream, a, items); break;
+          case 1: hipLaunchKernelGGL((attention_v2_kernel<1>), dim3(grid), dim3(128), ATT2_LDS_BYTES(1), h->w->stream, a, items); break;
+          case 2: hipLaunchKernelGGL((attention_v2_kernel<2>), dim3(grid), dim3(256), ATT2_LDS_BYTES(2), h->w->stream, a, items); break;
+          case 3: hipLaunchKernelGGL((attention_v2_kernel<3>), dim3(grid), dim3(384), ATT2_LDS_BYTES(3), h->w->stream, a, items); break;
+          default: hipLaunchKernelGGL((attention_v2_kernel<4>), dim3(grid), dim3(512), ATT2_LDS_BYTES(4), h->w->stream, a, items); break;
         }
       } else if (Sp <= 256) {
         const int qblocks = (Sp + 127) / 128;
-        hipLaunchKernelGGL((attention_kernel<4>), dim3(B * MV_HEADS * qblocks), dim3(256), ATT_LDS_BYTES(Sp), h->stream, a);
+        hipLaunchKernelGGL((attention_kernel<4>), dim3(B * MV_HEADS * qblocks), dim3(256), ATT_LDS_BYTES(Sp), h->w->stream, a);
       } else {
         const int qblocks = (Sp + 255) / 256;
-        hipLaunchKernelGGL((attention_kernel<8>), dim3(B * MV_HEADS * qblocks), dim3(512), ATT_LDS_BYTES(Sp), h->stream, a);
+        hipLaunchKernelGGL((attention_kernel<8>), dim3(B * MV_HEADS * qblocks), dim3(512), ATT_LDS_BYTES(Sp), h->w->stream, a);
       }
       if (int rc = launch_check(h, "attention")) return rc;
     }
     // K4: attention output projection + bias + residual (in place), then LayerNorm
     g.raw = 0; g.lnstats = nullptr; g.lnpart = nullptr;
-    g.A = h->ctx; g.W = w.wo; g.bias = w.bo; g.N = MV_HIDDEN; g.K = MV_HIDDEN; g.xres = h->xres;
-    if (fuse) { g.lnstats = h->lnstats; g.lng = pend_g; g.lnb = pend_b; }
-    if (virt) { g.lnpart = h->lnpart; g.out16 = h->x16; g.raw = h->r16_direct; }  // + the fp16 copy of the new raw stream and its partial row sums
+    g.A = h->w->ctx; g.W = w.wo; g.bias = w.bo; g.N = MV_HIDDEN; g.K = MV_HIDDEN; g.xres = h->w->xres;
+    if (fuse) { g.lnstats = h->w->lnstats; g.lng = pend_g; g.lnb = pend_b; }
+    if (virt) { g.lnpart = h->w->lnpart; g.out16 = h->w->x16; g.raw = h->r16_direct; }  // + the fp16 copy of the new raw stream and its partial row sums
     if (int rc = launch_gemm<EPI_RES>(h, KC_GEMM_OUT, g)) return rc;
     if (virt) { if (int rc = run_finalize()) return rc; }
-    else if (int rc = run_ln(h->xres, h->x16, (int)M, w.ln1g, w.ln1b, fuse)) return rc;
+    else if (int rc = run_ln(h->w->xres, h->w->x16, (int)M, w.ln1g, w.ln1b, fuse)) return rc;
     pend_g = w.ln1g; pend_b = w.ln1b;
     // K5: FFN-1 + exact-erf GELU
     g.lnstats = nullptr; g.lnpart = nullptr; g.raw = 0;
-    if (virt) { g.raw = 1; g.lnstats = h->lnstats; }
-    g.A = h->x16; g.W = virt ? w.w1_f : w.w1; g.bias = virt ? w.b1_f : w.b1; g.N = MV_INTER; g.K = MV_HIDDEN; g.out16 = h->h16;
+    if (virt) { g.raw = 1; g.lnstats = h->w->lnstats; }
+    g.A = h->w->x16; g.W = virt ? w.w1_f : w.w1; g.bias = virt ? w.b1_f : w.b1; g.N = MV_INTER; g.K = MV_HIDDEN; g.out16 = h->w->h16;
     if (int rc = launch_gemm<EPI_GELU>(h, KC_GEMM_FFN1, g)) return rc;
     // K6: FFN-2 + bias + residual, then LayerNorm
     g.raw = 0; g.lnstats = nullptr;
-    g.A = h->h16; g.W = w.w2; g.bias = w.b2; g.N = MV_HIDDEN; g.K = MV_INTER; g.xres = h->xres;
-    if (fuse) { g.lnstats = h->lnstats; g.lng = pend_g; g.lnb = pend_b; }
-    if (virt) { g.lnpart = h->lnpart; g.out16 = h->x16; g.raw = h->r16_direct; }
+    g.A = h->w->h16; g.W = w.w2; g.bias = w.b2; g.N = MV_HIDDEN; g.K = MV_INTER; g.xres = h->w->xres;
+    if (fuse) { g.lnstats = h->w->lnstats; g.lng = pend_g; g.lnb = pend_b; }
+    if (virt) { g.lnpart = h->w->lnpart; g.out16 = h->w->x16; g.raw = h->r16_direct; }
     if (int rc = launch_gemm<EPI_RES>(h, KC_GEMM_FFN2, g)) return rc;
     if (virt && !last) { if (int rc = run_finalize()) return rc; }
-    else if (int rc = run_ln(h->xres, h->x16, (int)M, w.ln2g, w.ln2b, fuse && !last)) return rc;  // the pooler reads a normalised stream
+    else if (int rc = run_ln(h->w->xres, h->w->x16, (int)M, w.ln2g, w.ln2b, fuse && !last)) return rc;  // the pooler reads a normalised stream
     pend_g = w.ln2g; pend_b = w.ln2b;
   }
   if (u_out) {
     ProfScope ps(h, KC_POOL_HEAD);
-    if (int rc = pool_head(h, h->xres, (size_t)Sp * MV_HIDDEN, B, u_out)) return rc;
+    if (int rc = pool_head(h, h->w->xres, (size_t)Sp * MV_HIDDEN, B, u_out)) return rc;
   }
   return MV_OK;
 }
@@ -525,10 +539,10 @@ int max_rows_for(mv_handle* h, int S_in) {
 int launch_match(mv_handle* h, const float* u_dev, int B, float* logits, float* probs, float* psame) {
   const int G = h->n_anchors, gx = (G + MT_G - 1) / MT_G;
   if ((int64_t)gx * ((B + 15) / 16) >= h->num_cu)
-    hipLaunchKernelGGL(match_kernel<4>, dim3(gx, (B + 15) / 16), dim3(256), 0, h->stream, u_dev, h->anchors, h->Wm, B, G,
+    hipLaunchKernelGGL(match_kernel<4>, dim3(gx, (B + 15) / 16), dim3(256), 0, h->w->stream, u_dev, h->anchors, h->Wm, B, G,
                        h->cfg.same_idx, logits, probs, psame);
   else
-    hipLaunchKernelGGL(match_kernel<1>, dim3(gx, (B + 3) / 4), dim3(256), 0, h->stream, u_dev, h->anchors, h->Wm, B, G,
+    hipLaunchKernelGGL(match_kernel<1>, dim3(gx, (B + 3) / 4), dim3(256), 0, h->w->stream, u_dev, h->anchors, h->Wm, B, G,
                        h->cfg.same_idx, logits, probs, psame);
   return launch_check(h, "match");
 }
@@ -539,20 +553,33 @@ int match_dev(mv_handle* h, const float* u_dev, int B, float* psame_out, int k, 
   if (G <= 0) return fail(h, MV_ERR_STATE, "anchor bank is empty (call mv_anchor_append / mv_anchor_set first)");
   {
     ProfScope ps(h, KC_MATCH);
-    if (int rc = launch_match(h, u_dev, B, h->logits, h->probs, psame_out)) return rc;
+    if (int rc = launch_match(h, u_dev, B, h->w->logits, h->w->probs, psame_out)) return rc;
   }
   {
     ProfScope ps(h, KC_TOPK);
-    hipLaunchKernelGGL(topk_kernel, dim3((B + 3) / 4), dim3(256), 0, h->stream, psame_out, h->probs, B, G, k, best_out,
-                       idx_out, k > 1 ? h->topk_p : nullptr, k > 1 ? h->topk_idx : nullptr);
+    hipLaunchKernelGGL(topk_kernel, dim3((B + 3) / 4), dim3(256), 0, h->w->stream, psame_out, h->w->probs, B, G, k, best_out,
+                       idx_out, k > 1 ? h->w->topk_p : nullptr, k > 1 ? h->w->topk_idx : nullptr);
     if (int rc = launch_check(h, "topk")) return rc;
   }
   return MV_OK;
 }
 
+int sync_all(mv_handle* h) {
+  for (int wi = 0; wi < h->n_alloc; ++wi) HIPCHK(h, hipStreamSynchronize(h->work[wi].stream));
+  h->dual_pending = false;
+  return MV_OK;
+}
+
+// Every entry point but the resident sweep works on set 0; a sweep may have left set 1 busy (it reads the anchor
+// bank and the resident corpus): wait for it first.
 int check_ready(mv_handle* h) {
   if (!h) return MV_ERR_INVALID;
   if (!h->finalized) return fail(h, MV_ERR_STATE, "weights not finalized (mv_finalize_weights)");
+  if (h->dual_pending) {
+    HIPCHK(h, hipStreamSynchronize(h->work[1].stream));
+    h->dual_pending = false;
+  }
+  h->w = &h->work[0];
   return MV_OK;
 }
 
@@ -576,8 +603,8 @@ int need(mv_handle* h, const std::string& k, std::initializer_list<int64_t> shap
 
 int upload_f32(mv_handle* h, float** dst, const float* src, int64_t n) {
   if (int rc = dev_alloc(h, dst, n, false)) return rc;
-  HIPCHK(h, hipMemcpyAsync(*dst, src, (size_t)n * 4, hipMemcpyHostToDevice, h->stream));
-  HIPCHK(h, hipStreamSynchronize(h->stream));
+  HIPCHK(h, hipMemcpyAsync(*dst, src, (size_t)n * 4, hipMemcpyHostToDevice, h->w->stream));
+  HIPCHK(h, hipStreamSynchronize(h->w->stream));
   return MV_OK;
 }
 // Virtual LayerNorm weights (gemm_pp.h): W''[n][k] = W[n][k] gamma[k] - mean_k(W[n][.] gamma[.]),  b'[n] = b[n] + sum_k W[n][k] beta[k]
@@ -602,8 +629,8 @@ int upload_f16(mv_handle* h, half_t** dst, const float* src, int64_t n, float sc
   std::vector<uint16_t> tmp((size_t)n);
   for (int64_t i = 0; i < n; ++i) tmp[(size_t)i] = f32_to_f16_bits(src[i] * scale);
   if (int rc = dev_alloc(h, dst, n, false)) return rc;
-  HIPCHK(h, hipMemcpyAsync(*dst, tmp.data(), (size_t)n * 2, hipMemcpyHostToDevice, h->stream));
-  HIPCHK(h, hipStreamSynchronize(h->stream));
+  HIPCHK(h, hipMemcpyAsync(*dst, tmp.data(), (size_t)n * 2, hipMemcpyHostToDevice, h->w->stream));
+  HIPCHK(h, hipStreamSynchronize(h->w->stream));
   return MV_OK;
 }
 
@@ -636,11 +663,14 @@ int mv_create(int device, const mv_config* cfg, mv_handle** out) {
   if (!h) return fail(nullptr, MV_ERR_NOMEM, "out of host memory");
   h->device = device;
   h->cfg = *cfg;
-  e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
-  if (e != hipSuccess) {
-    g_create_error = std::string("hipStreamCreate: ") + hipGetErrorString(e);
-    delete h;
-    return MV_ERR_HIP;
+  if (const char* ev = getenv("MEMVUL_STREAMS")) h->n_streams = h->n_alloc = (atoi(ev) == 1 ? 1 : 2);
+  for (int wi = 0; wi < h->n_alloc; ++wi) {
+    e = hipStreamCreateWithFlags(&h->work[wi].stream, hipStreamNonBlocking);
+    if (e != hipSuccess) {
+      g_create_error = std::string("hipStreamCreate: ") + hipGetErrorString(e);
+      mv_destroy(h);
+      return MV_ERR_HIP;
+    }
   }
   // dynamic LDS above 64 KiB needs an explicit opt-in
   hipFuncSetAttribute((const void*)attention_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -683,46 +713,49 @@ int mv_create(int device, const mv_config* cfg, mv_handle** out) {
   const int64_t T = h->cap_tokens;
   int rc = MV_OK;
   auto A = [&](int r) { if (rc == MV_OK) rc = r; };
-  A(dev_alloc(h, &h->d_ids, T));
-  A(dev_alloc(h, &h->d_lens, (int64_t)cfg->max_batch + 16));
-  A(dev_alloc(h, &h->xres, T * MV_HIDDEN));
-  A(dev_alloc(h, &h->x16, T * MV_HIDDEN));
-  A(dev_alloc(h, &h->q, T * MV_HIDDEN));
-  A(dev_alloc(h, &h->k, T * MV_HIDDEN));
-  A(dev_alloc(h, &h->vt, T * MV_HIDDEN));
-  A(dev_alloc(h, &h->ctx, T * MV_HIDDEN));
-  A(dev_alloc(h, &h->h16, T * MV_INTER));
-  A(dev_alloc(h, &h->lnstats, T * 2));
-  A(dev_alloc(h, &h->lnpart, T * (MV_HIDDEN / 64) * 2));
+  const int64_t BG = (int64_t)cfg->max_batch * cfg->max_anchors;
+  const int64_t Bp = round_up(cfg->max_batch, 256);  // [CLS]-row buffers of the pruned last layer
+  for (int wi = 0; wi < h->n_alloc; ++wi) {
+    h->w = &h->work[wi];
+    A(dev_alloc(h, &h->w->d_ids, T));
+    A(dev_alloc(h, &h->w->d_lens, (int64_t)cfg->max_batch + 16));
+    A(dev_alloc(h, &h->w->xres, T * MV_HIDDEN));
+    A(dev_alloc(h, &h->w->x16, T * MV_HIDDEN));
+    A(dev_alloc(h, &h->w->q, T * MV_HIDDEN));
+    A(dev_alloc(h, &h->w->k, T * MV_HIDDEN));
+    A(dev_alloc(h, &h->w->vt, T * MV_HIDDEN));
+    A(dev_alloc(h, &h->w->ctx, T * MV_HIDDEN));
+    A(dev_alloc(h, &h->w->h16, T * MV_INTER));
+    A(dev_alloc(h, &h->w->lnstats, T * 2));
+    A(dev_alloc(h, &h->w->lnpart, T * (MV_HIDDEN / 64) * 2));
+    A(dev_alloc(h, &h->w->c32, Bp * MV_HIDDEN));
+    A(dev_alloc(h, &h->w->cq, Bp * MV_HIDDEN));
+    A(dev_alloc(h, &h->w->c16, Bp * MV_HIDDEN));
+    A(dev_alloc(h, &h->w->cctx, Bp * MV_HIDDEN));
+    A(dev_alloc(h, &h->w->ch16, Bp * MV_INTER));
+    A(dev_alloc(h, &h->w->u, (int64_t)cfg->max_batch * MV_PROJ));
+    A(dev_alloc(h, &h->w->pooled, (int64_t)cfg->max_batch * MV_HIDDEN));
+    A(dev_alloc(h, &h->w->u_in, (int64_t)cfg->max_batch * MV_PROJ));
+    A(dev_alloc(h, &h->w->logits, BG * 2));
+    A(dev_alloc(h, &h->w->probs, BG * 2));
+    A(dev_alloc(h, &h->w->psame, BG));
+    A(dev_alloc(h, &h->w->best, (int64_t)cfg->max_batch * 2));
+    A(dev_alloc(h, &h->w->best_idx, cfg->max_batch));
+    A(dev_alloc(h, &h->w->topk_p, (int64_t)cfg->max_batch * 64));
+    A(dev_alloc(h, &h->w->topk_idx, (int64_t)cfg->max_batch * 64));
+    if (rc == MV_OK && hipStreamSynchronize(h->w->stream) != hipSuccess) rc = MV_ERR_HIP;
+  }
+  h->w = &h->work[0];
+  A(dev_alloc(h, &h->anchors, (int64_t)cfg->max_anchors * MV_PROJ));
   A(dev_alloc(h, &h->zeros, MV_HIDDEN));
   A(dev_alloc(h, &h->ones, MV_HIDDEN, false));
   if (rc == MV_OK) {
     const std::vector<float> one(MV_HIDDEN, 1.0f);
-    if (hipMemcpyAsync(h->ones, one.data(), MV_HIDDEN * 4, hipMemcpyHostToDevice, h->stream) != hipSuccess ||
-        hipStreamSynchronize(h->stream) != hipSuccess)
+    if (hipMemcpyAsync(h->ones, one.data(), MV_HIDDEN * 4, hipMemcpyHostToDevice, h->w->stream) != hipSuccess ||
+        hipStreamSynchronize(h->w->stream) != hipSuccess)
       rc = MV_ERR_HIP;
   }
-  {
-    const int64_t Bp = round_up(cfg->max_batch, 256);  // [CLS]-row buffers of the pruned last layer
-    A(dev_alloc(h, &h->c32, Bp * MV_HIDDEN));
-    A(dev_alloc(h, &h->cq, Bp * MV_HIDDEN));
-    A(dev_alloc(h, &h->c16, Bp * MV_HIDDEN));
-    A(dev_alloc(h, &h->cctx, Bp * MV_HIDDEN));
-    A(dev_alloc(h, &h->ch16, Bp * MV_INTER));
-  }
-  A(dev_alloc(h, &h->u, (int64_t)cfg->max_batch * MV_PROJ));
-  A(dev_alloc(h, &h->pooled, (int64_t)cfg->max_batch * MV_HIDDEN));
-  A(dev_alloc(h, &h->u_in, (int64_t)cfg->max_batch * MV_PROJ));
-  A(dev_alloc(h, &h->anchors, (int64_t)cfg->max_anchors * MV_PROJ));
-  const int64_t BG = (int64_t)cfg->max_batch * cfg->max_anchors;
-  A(dev_alloc(h, &h->logits, BG * 2));
-  A(dev_alloc(h, &h->probs, BG * 2));
-  A(dev_alloc(h, &h->psame, BG));
-  A(dev_alloc(h, &h->best, (int64_t)cfg->max_batch * 2));
-  A(dev_alloc(h, &h->best_idx, cfg->max_batch));
-  A(dev_alloc(h, &h->topk_p, (int64_t)cfg->max_batch * 64));
-  A(dev_alloc(h, &h->topk_idx, (int64_t)cfg->max_batch * 64));
-  if (rc == MV_OK && hipStreamSynchronize(h->stream) != hipSuccess) rc = MV_ERR_HIP;
+  if (rc == MV_OK && hipStreamSynchronize(h->w->stream) != hipSuccess) rc = MV_ERR_HIP;
   if (rc != MV_OK) {
     g_create_error = h->err.empty() ? "workspace allocation failed" : h->err;
     mv_destroy(h);
@@ -735,18 +768,19 @@ int mv_create(int device, const mv_config* cfg, mv_handle** out) {
 void mv_destroy(mv_handle* h) {
   if (!h) return;
   hipSetDevice(h->device);
-  if (h->stream) hipStreamSynchronize(h->stream);
+  for (auto& wk : h->work)
+    if (wk.stream) hipStreamSynchronize(wk.stream);
   for (auto& r : h->recs) { hipEventDestroy(r.e0); hipEventDestroy(r.e1); }
   for (auto e : h->free_events) hipEventDestroy(e);
   for (void* p : h->allocs) hipFree(p);
-  if (h->stream) hipStreamDestroy(h->stream);
+  for (auto& wk : h->work)
+    if (wk.stream) hipStreamDestroy(wk.stream);
   delete h;
 }
 
 int mv_sync(mv_handle* h) {
   if (!h) return MV_ERR_INVALID;
-  HIPCHK(h, hipStreamSynchronize(h->stream));
-  return MV_OK;
+  return sync_all(h);
 }
 
 int mv_load_tensor(mv_handle* h, const char* name, const void* host_ptr, int dtype, const int64_t* shape, int ndim) {
@@ -911,10 +945,10 @@ int mv_anchor_append(mv_handle* h, const int32_t* ids, const int32_t* lens, int 
   if (rows <= 0) return fail(h, MV_ERR_CAPACITY, "mv_config.max_tokens too small for one anchor of this length");
   for (int off = 0; off < n; off += rows) {
     const int nb = (n - off < rows) ? (n - off) : rows;
-    HIPCHK(h, hipMemcpyAsync(h->d_ids, ids + (size_t)off * S, (size_t)nb * S * 4, hipMemcpyHostToDevice, h->stream));
-    HIPCHK(h, hipMemcpyAsync(h->d_lens, lens + off, (size_t)nb * 4, hipMemcpyHostToDevice, h->stream));
-    if (int rc = encode_dev(h, h->d_ids, h->d_lens, nb, S, -1, h->anchors + (size_t)(h->n_anchors + off) * MV_PROJ)) return rc;
-    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->w->d_ids, ids + (size_t)off * S, (size_t)nb * S * 4, hipMemcpyHostToDevice, h->w->stream));
+    HIPCHK(h, hipMemcpyAsync(h->w->d_lens, lens + off, (size_t)nb * 4, hipMemcpyHostToDevice, h->w->stream));
+    if (int rc = encode_dev(h, h->w->d_ids, h->w->d_lens, nb, S, -1, h->anchors + (size_t)(h->n_anchors + off) * MV_PROJ)) return rc;
+    HIPCHK(h, hipStreamSynchronize(h->w->stream));
   }
   h->n_anchors += n;
   return MV_OK;
@@ -922,16 +956,16 @@ int mv_anchor_append(mv_handle* h, const int32_t* ids, const int32_t* lens, int 
 
 int mv_anchor_get(mv_handle* h, float* out) {
   if (!h || !out) return MV_ERR_INVALID;
-  HIPCHK(h, hipMemcpyAsync(out, h->anchors, (size_t)h->n_anchors * MV_PROJ * 4, hipMemcpyDeviceToHost, h->stream));
-  HIPCHK(h, hipStreamSynchronize(h->stream));
+  HIPCHK(h, hipMemcpyAsync(out, h->anchors, (size_t)h->n_anchors * MV_PROJ * 4, hipMemcpyDeviceToHost, h->w->stream));
+  HIPCHK(h, hipStreamSynchronize(h->w->stream));
   return MV_OK;
 }
 
 int mv_anchor_set(mv_handle* h, const float* v, int G) {
   if (!h || !v || G <= 0) return fail(h, MV_ERR_INVALID, "mv_anchor_set: bad argument");
   if (G > h->cfg.max_anchors) return fail(h, MV_ERR_CAPACITY, "anchor bank capacity (mv_config.max_anchors) exceeded");
-  HIPCHK(h, hipMemcpyAsync(h->anchors, v, (size_t)G * MV_PROJ * 4, hipMemcpyHostToDevice, h->stream));
-  HIPCHK(h, hipStreamSynchronize(h->stream));
+  HIPCHK(h, hipMemcpyAsync(h->anchors, v, (size_t)G * MV_PROJ * 4, hipMemcpyHostToDevice, h->w->stream));
+  HIPCHK(h, hipStreamSynchronize(h->w->stream));
   h->n_anchors = G;
   return MV_OK;
 }
@@ -944,11 +978,11 @@ int mv_encode(mv_handle* h, const int32_t* ids, const int32_t* lens, int B, int 
   if (rows <= 0) return fail(h, MV_ERR_CAPACITY, "mv_config.max_tokens too small for this sequence length");
   for (int off = 0; off < B; off += rows) {
     const int nb = (B - off < rows) ? (B - off) : rows;
-    HIPCHK(h, hipMemcpyAsync(h->d_ids, ids + (size_t)off * S, (size_t)nb * S * 4, hipMemcpyHostToDevice, h->stream));
-    HIPCHK(h, hipMemcpyAsync(h->d_lens, lens + off, (size_t)nb * 4, hipMemcpyHostToDevice, h->stream));
-    if (int rc = encode_dev(h, h->d_ids, h->d_lens, nb, S, -1, h->u)) return rc;
-    if (embed) HIPCHK(h, hipMemcpyAsync(embed + (size_t)off * MV_PROJ, h->u, (size_t)nb * MV_PROJ * 4, hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->w->d_ids, ids + (size_t)off * S, (size_t)nb * S * 4, hipMemcpyHostToDevice, h->w->stream));
+    HIPCHK(h, hipMemcpyAsync(h->w->d_lens, lens + off, (size_t)nb * 4, hipMemcpyHostToDevice, h->w->stream));
+    if (int rc = encode_dev(h, h->w->d_ids, h->w->d_lens, nb, S, -1, h->w->u)) return rc;
+    if (embed) HIPCHK(h, hipMemcpyAsync(embed + (size_t)off * MV_PROJ, h->w->u, (size_t)nb * MV_PROJ * 4, hipMemcpyDeviceToHost, h->w->stream));
+    HIPCHK(h, hipStreamSynchronize(h->w->stream));
   }
   return MV_OK;
 }
@@ -964,17 +998,17 @@ int mv_forward(mv_handle* h, const int32_t* ids, const int32_t* lens, int B, int
   const int G = h->n_anchors;
   for (int off = 0; off < B; off += rows) {
     const int nb = (B - off < rows) ? (B - off) : rows;
-    HIPCHK(h, hipMemcpyAsync(h->d_ids, ids + (size_t)off * S, (size_t)nb * S * 4, hipMemcpyHostToDevice, h->stream));
-    HIPCHK(h, hipMemcpyAsync(h->d_lens, lens + off, (size_t)nb * 4, hipMemcpyHostToDevice, h->stream));
-    if (int rc = encode_dev(h, h->d_ids, h->d_lens, nb, S, -1, h->u)) return rc;
-    if (int rc = match_dev(h, h->u, nb, h->psame, 1, h->best, h->best_idx)) return rc;
+    HIPCHK(h, hipMemcpyAsync(h->w->d_ids, ids + (size_t)off * S, (size_t)nb * S * 4, hipMemcpyHostToDevice, h->w->stream));
+    HIPCHK(h, hipMemcpyAsync(h->w->d_lens, lens + off, (size_t)nb * 4, hipMemcpyHostToDevice, h->w->stream));
+    if (int rc = encode_dev(h, h->w->d_ids, h->w->d_lens, nb, S, -1, h->w->u)) return rc;
+    if (int rc = match_dev(h, h->w->u, nb, h->w->psame, 1, h->w->best, h->w->best_idx)) return rc;
     const size_t bg = (size_t)nb * G;
-    if (logits) HIPCHK(h, hipMemcpyAsync(logits + (size_t)off * G * 2, h->logits, bg * 8, hipMemcpyDeviceToHost, h->stream));
-    if (probs) HIPCHK(h, hipMemcpyAsync(probs + (size_t)off * G * 2, h->probs, bg * 8, hipMemcpyDeviceToHost, h->stream));
-    if (best) HIPCHK(h, hipMemcpyAsync(best + (size_t)off * 2, h->best, (size_t)nb * 8, hipMemcpyDeviceToHost, h->stream));
-    if (best_idx) HIPCHK(h, hipMemcpyAsync(best_idx + off, h->best_idx, (size_t)nb * 4, hipMemcpyDeviceToHost, h->stream));
-    if (embed) HIPCHK(h, hipMemcpyAsync(embed + (size_t)off * MV_PROJ, h->u, (size_t)nb * MV_PROJ * 4, hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (logits) HIPCHK(h, hipMemcpyAsync(logits + (size_t)off * G * 2, h->w->logits, bg * 8, hipMemcpyDeviceToHost, h->w->stream));
+    if (probs) HIPCHK(h, hipMemcpyAsync(probs + (size_t)off * G * 2, h->w->probs, bg * 8, hipMemcpyDeviceToHost, h->w->stream));
+    if (best) HIPCHK(h, hipMemcpyAsync(best + (size_t)off * 2, h->w->best, (size_t)nb * 8, hipMemcpyDeviceToHost, h->w->stream));
+    if (best_idx) HIPCHK(h, hipMemcpyAsync(best_idx + off, h->w->best_idx, (size_t)nb * 4, hipMemcpyDeviceToHost, h->w->stream));
+    if (embed) HIPCHK(h, hipMemcpyAsync(embed + (size_t)off * MV_PROJ, h->w->u, (size_t)nb * MV_PROJ * 4, hipMemcpyDeviceToHost, h->w->stream));
+    HIPCHK(h, hipStreamSynchronize(h->w->stream));
   }
   return MV_OK;
 }
@@ -985,14 +1019,14 @@ int mv_match(mv_handle* h, const float* u, int B, float* logits, float* probs, f
   if (B > h->cfg.max_batch) return fail(h, MV_ERR_CAPACITY, "B exceeds mv_config.max_batch");
   HIPCHK(h, hipSetDevice(h->device));
   const int G = h->n_anchors;
-  HIPCHK(h, hipMemcpyAsync(h->u_in, u, (size_t)B * MV_PROJ * 4, hipMemcpyHostToDevice, h->stream));
-  if (int rc = match_dev(h, h->u_in, B, h->psame, 1, h->best, h->best_idx)) return rc;
+  HIPCHK(h, hipMemcpyAsync(h->w->u_in, u, (size_t)B * MV_PROJ * 4, hipMemcpyHostToDevice, h->w->stream));
+  if (int rc = match_dev(h, h->w->u_in, B, h->w->psame, 1, h->w->best, h->w->best_idx)) return rc;
   const size_t bg = (size_t)B * G;
-  if (logits) HIPCHK(h, hipMemcpyAsync(logits, h->logits, bg * 8, hipMemcpyDeviceToHost, h->stream));
-  if (probs) HIPCHK(h, hipMemcpyAsync(probs, h->probs, bg * 8, hipMemcpyDeviceToHost, h->stream));
-  if (best) HIPCHK(h, hipMemcpyAsync(best, h->best, (size_t)B * 8, hipMemcpyDeviceToHost, h->stream));
-  if (best_idx) HIPCHK(h, hipMemcpyAsync(best_idx, h->best_idx, (size_t)B * 4, hipMemcpyDeviceToHost, h->stream));
-  HIPCHK(h, hipStreamSynchronize(h->stream));
+  if (logits) HIPCHK(h, hipMemcpyAsync(logits, h->w->logits, bg * 8, hipMemcpyDeviceToHost, h->w->stream));
+  if (probs) HIPCHK(h, hipMemcpyAsync(probs, h->w->probs, bg * 8, hipMemcpyDeviceToHost, h->w->stream));
+  if (best) HIPCHK(h, hipMemcpyAsync(best, h->w->best, (size_t)B * 8, hipMemcpyDeviceToHost, h->w->stream));
+  if (best_idx) HIPCHK(h, hipMemcpyAsync(best_idx, h->w->best_idx, (size_t)B * 4, hipMemcpyDeviceToHost, h->w->stream));
+  HIPCHK(h, hipStreamSynchronize(h->w->stream));
   return MV_OK;
 }
 
@@ -1002,24 +1036,24 @@ int mv_topk(mv_handle* h, const float* u, int B, int k, float* topk_p, int32_t* 
   if (B > h->cfg.max_batch) return fail(h, MV_ERR_CAPACITY, "B exceeds mv_config.max_batch");
   if (k > h->n_anchors) return fail(h, MV_ERR_INVALID, "k exceeds the number of anchors");
   HIPCHK(h, hipSetDevice(h->device));
-  HIPCHK(h, hipMemcpyAsync(h->u_in, u, (size_t)B * MV_PROJ * 4, hipMemcpyHostToDevice, h->stream));
+  HIPCHK(h, hipMemcpyAsync(h->w->u_in, u, (size_t)B * MV_PROJ * 4, hipMemcpyHostToDevice, h->w->stream));
   // k == 1 goes through the same kernel; force the top-k outputs on
   {
     const int G = h->n_anchors;
     {
       ProfScope ps(h, KC_MATCH);
-      if (int rc = launch_match(h, h->u_in, B, nullptr, nullptr, h->psame)) return rc;
+      if (int rc = launch_match(h, h->w->u_in, B, nullptr, nullptr, h->w->psame)) return rc;
     }
     {
       ProfScope ps(h, KC_TOPK);
-      hipLaunchKernelGGL(topk_kernel, dim3((B + 3) / 4), dim3(256), 0, h->stream, h->psame, (const float*)nullptr, B, G, k,
-                         (float*)nullptr, (int32_t*)nullptr, h->topk_p, h->topk_idx);
+      hipLaunchKernelGGL(topk_kernel, dim3((B + 3) / 4), dim3(256), 0, h->w->stream, h->w->psame, (const float*)nullptr, B, G, k,
+                         (float*)nullptr, (int32_t*)nullptr, h->w->topk_p, h->w->topk_idx);
       if (int rc = launch_check(h, "topk")) return rc;
     }
   }
-  HIPCHK(h, hipMemcpyAsync(topk_p, h->topk_p, (size_t)B * k * 4, hipMemcpyDeviceToHost, h->stream));
-  HIPCHK(h, hipMemcpyAsync(topk_idx, h->topk_idx, (size_t)B * k * 4, hipMemcpyDeviceToHost, h->stream));
-  HIPCHK(h, hipStreamSynchronize(h->stream));
+  HIPCHK(h, hipMemcpyAsync(topk_p, h->w->topk_p, (size_t)B * k * 4, hipMemcpyDeviceToHost, h->w->stream));
+  HIPCHK(h, hipMemcpyAsync(topk_idx, h->w->topk_idx, (size_t)B * k * 4, hipMemcpyDeviceToHost, h->w->stream));
+  HIPCHK(h, hipStreamSynchronize(h->w->stream));
   return MV_OK;
 }
 
@@ -1028,7 +1062,7 @@ int mv_corpus_upload(mv_handle* h, const int32_t* ids, const int32_t* lens, int6
   if (int rc = check_ready(h)) return rc;
   if (!ids || !lens || n <= 0 || S <= 0 || S > h->cfg.max_pos) return fail(h, MV_ERR_INVALID, "mv_corpus_upload: bad argument");
   HIPCHK(h, hipSetDevice(h->device));
-  HIPCHK(h, hipStreamSynchronize(h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->w->stream));
   dev_free(h, h->c_ids); dev_free(h, h->c_lens); dev_free(h, h->c_best); dev_free(h, h->c_idx); dev_free(h, h->c_psame);
   h->c_ids = nullptr; h->c_lens = nullptr; h->c_best = nullptr; h->c_idx = nullptr; h->c_psame = nullptr;
   h->c_psame_rows = 0;
@@ -1036,50 +1070,65 @@ int mv_corpus_upload(mv_handle* h, const int32_t* ids, const int32_t* lens, int6
   if (int rc = dev_alloc(h, &h->c_lens, n, false)) return rc;
   if (int rc = dev_alloc(h, &h->c_best, n * 2)) return rc;
   if (int rc = dev_alloc(h, &h->c_idx, n)) return rc;
-  HIPCHK(h, hipMemcpyAsync(h->c_ids, ids, (size_t)n * S * 4, hipMemcpyHostToDevice, h->stream));
-  HIPCHK(h, hipMemcpyAsync(h->c_lens, lens, (size_t)n * 4, hipMemcpyHostToDevice, h->stream));
-  HIPCHK(h, hipStreamSynchronize(h->stream));
+  HIPCHK(h, hipMemcpyAsync(h->c_ids, ids, (size_t)n * S * 4, hipMemcpyHostToDevice, h->w->stream));
+  HIPCHK(h, hipMemcpyAsync(h->c_lens, lens, (size_t)n * 4, hipMemcpyHostToDevice, h->w->stream));
+  HIPCHK(h, hipStreamSynchronize(h->w->stream));
   h->c_n = n;
   h->c_S = S;
   return MV_OK;
 }
 
 int mv_corpus_run(mv_handle* h, int64_t first, int64_t count, int batch, int keep_probs) {
-  if (int rc = check_ready(h)) return rc;
+  if (!h) return MV_ERR_INVALID;
+  if (!h->finalized) return fail(h, MV_ERR_STATE, "weights not finalized (mv_finalize_weights)");
   if (!h->c_ids) return fail(h, MV_ERR_STATE, "no resident corpus (mv_corpus_upload)");
   if (first < 0 || count <= 0 || first + count > h->c_n || batch <= 0) return fail(h, MV_ERR_INVALID, "mv_corpus_run: bad range");
   if (h->n_anchors <= 0) return fail(h, MV_ERR_STATE, "anchor bank is empty");
   HIPCHK(h, hipSetDevice(h->device));
+  h->w = &h->work[0];
   const int rows = max_rows_for(h, h->c_S);
   if (batch > rows) return fail(h, MV_ERR_CAPACITY, "batch exceeds mv_config.max_batch / max_tokens");
   const int G = h->n_anchors;
   if (keep_probs && (h->c_psame_rows != h->c_n || h->c_G != G)) {
+    if (int rc = sync_all(h)) return rc;
     dev_free(h, h->c_psame);
     h->c_psame = nullptr;
     if (int rc = dev_alloc(h, &h->c_psame, h->c_n * G)) return rc;
     h->c_psame_rows = h->c_n;
     h->c_G = G;
   }
-  for (int64_t off = first; off < first + count; off += batch) {
+  // consecutive batches (also across calls) alternate between the two workspace sets / streams: two batches are in
+  // flight at once; their results go to disjoint slices of the resident arrays
+  int rc = MV_OK;
+  for (int64_t off = first; off < first + count && rc == MV_OK; off += batch) {
     const int nb = (int)((first + count - off < batch) ? (first + count - off) : batch);
-    if (int rc = encode_dev(h, h->c_ids + (size_t)off * h->c_S, h->c_lens + off, nb, h->c_S, -1, h->u)) return rc;
-    float* ps = keep_probs ? h->c_psame + (size_t)off * G : h->psame;
-    if (int rc = match_dev(h, h->u, nb, ps, 1, h->c_best + (size_t)off * 2, h->c_idx + off)) return rc;
+    h->w = &h->work[h->rr];
+    if (h->n_streams == 2) {
+      if (h->rr == 1) h->dual_pending = true;
+      h->rr ^= 1;
+    }
+    rc = encode_dev(h, h->c_ids + (size_t)off * h->c_S, h->c_lens + off, nb, h->c_S, -1, h->w->u);
+    if (rc != MV_OK) break;
+    float* ps = keep_probs ? h->c_psame + (size_t)off * G : h->w->psame;
+    rc = match_dev(h, h->w->u, nb, ps, 1, h->c_best + (size_t)off * 2, h->c_idx + off);
   }
-  return MV_OK;
+  h->w = &h->work[0];
+  return rc;
 }
 
 int mv_corpus_results(mv_handle* h, int64_t first, int64_t count, float* best, int32_t* best_idx, float* p_same) {
   if (!h) return MV_ERR_INVALID;
   if (!h->c_ids) return fail(h, MV_ERR_STATE, "no resident corpus (mv_corpus_upload)");
   if (first < 0 || count <= 0 || first + count > h->c_n) return fail(h, MV_ERR_INVALID, "mv_corpus_results: bad range");
-  if (best) HIPCHK(h, hipMemcpyAsync(best, h->c_best + (size_t)first * 2, (size_t)count * 8, hipMemcpyDeviceToHost, h->stream));
-  if (best_idx) HIPCHK(h, hipMemcpyAsync(best_idx, h->c_idx + first, (size_t)count * 4, hipMemcpyDeviceToHost, h->stream));
+  h->w = &h->work[0];
+  if (int rc = sync_all(h)) return rc;
+  if (best) HIPCHK(h, hipMemcpyAsync(best, h->c_best + (size_t)first * 2, (size_t)count * 8, hipMemcpyDeviceToHost, h->w->stream));
+  if (best_idx) HIPCHK(h, hipMemcpyAsync(best_idx, h->c_idx + first, (size_t)count * 4, hipMemcpyDeviceToHost, h->w->stream));
   if (p_same) {
     if (!h->c_psame) return fail(h, MV_ERR_STATE, "P(same) was not kept (mv_corpus_run keep_probs=0)");
-    HIPCHK(h, hipMemcpyAsync(p_same, h->c_psame + (size_t)first * h->c_G, (size_t)count * h->c_G * 4, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipMemcpyAsync(p_same, h->c_psame + (size_t)first * h->c_G, (size_t)count * h->c_G * 4, hipMemcpyDeviceToHost, h->w->stream));
   }
-  HIPCHK(h, hipStreamSynchronize(h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->w->stream));
   return MV_OK;
 }
 
@@ -1087,6 +1136,15 @@ int mv_corpus_results(mv_handle* h, int64_t first, int64_t count, float* best, i
 int mv_profile_enable(mv_handle* h, int on) {
   if (!h) return MV_ERR_INVALID;
   h->prof = on != 0;
+  return MV_OK;
+}
+
+int mv_set_streams(mv_handle* h, int n) {
+  if (!h || (n != 1 && n != 2)) return fail(h, MV_ERR_INVALID, "mv_set_streams: 1 or 2");
+  if (n == 2 && !h->work[1].stream) return fail(h, MV_ERR_STATE, "mv_set_streams: the second workspace set was not created (MEMVUL_STREAMS=1)");
+  if (int rc = sync_all(h)) return rc;
+  h->n_streams = n;
+  h->rr = 0;
   return MV_OK;
 }
 
@@ -1098,7 +1156,7 @@ int mv_profile_select(mv_handle* h, uint32_t class_mask) {
 
 int mv_profile_read(mv_handle* h, double* ms, int64_t* launches, int n) {
   if (!h || !ms || !launches || n < MV_NUM_KERNEL_CLASSES) return fail(h, MV_ERR_INVALID, "mv_profile_read: bad argument");
-  HIPCHK(h, hipStreamSynchronize(h->stream));
+  if (int rc = sync_all(h)) return rc;
   for (int i = 0; i < n; ++i) { ms[i] = 0; launches[i] = 0; }
   for (auto& r : h->recs) {
     float t = 0.f;
@@ -1115,10 +1173,10 @@ int mv_debug_encode(mv_handle* h, const int32_t* ids, const int32_t* lens, int B
   if (!ids || !lens || B <= 0 || S <= 0 || S > h->cfg.max_pos) return fail(h, MV_ERR_INVALID, "mv_debug_encode: bad argument");
   if (B > max_rows_for(h, S)) return fail(h, MV_ERR_CAPACITY, "mv_debug_encode: batch too large for one pass");
   HIPCHK(h, hipSetDevice(h->device));
-  HIPCHK(h, hipMemcpyAsync(h->d_ids, ids, (size_t)B * S * 4, hipMemcpyHostToDevice, h->stream));
-  HIPCHK(h, hipMemcpyAsync(h->d_lens, lens, (size_t)B * 4, hipMemcpyHostToDevice, h->stream));
-  if (int rc = encode_dev(h, h->d_ids, h->d_lens, B, S, n_layers < 0 ? h->cfg.layers : n_layers, h->u, /*full=*/true)) return rc;
-  HIPCHK(h, hipStreamSynchronize(h->stream));
+  HIPCHK(h, hipMemcpyAsync(h->w->d_ids, ids, (size_t)B * S * 4, hipMemcpyHostToDevice, h->w->stream));
+  HIPCHK(h, hipMemcpyAsync(h->w->d_lens, lens, (size_t)B * 4, hipMemcpyHostToDevice, h->w->stream));
+  if (int rc = encode_dev(h, h->w->d_ids, h->w->d_lens, B, S, n_layers < 0 ? h->cfg.layers : n_layers, h->w->u, /*full=*/true)) return rc;
+  HIPCHK(h, hipStreamSynchronize(h->w->stream));
   return MV_OK;
 }
 
@@ -1128,19 +1186,19 @@ int mv_debug_read(mv_handle* h, int buffer, void* dst, int64_t bytes) {
   const void* src = nullptr;
   int64_t avail = 0;
   switch (buffer) {
-    case 0: src = h->xres; avail = T * MV_HIDDEN * 4; break;
-    case 1: src = h->x16; avail = T * MV_HIDDEN * 2; break;
-    case 2: src = h->q; avail = T * MV_HIDDEN * 2; break;
-    case 3: src = h->k; avail = T * MV_HIDDEN * 2; break;
-    case 4: src = h->vt; avail = T * MV_HIDDEN * 2; break;
-    case 5: src = h->ctx; avail = T * MV_HIDDEN * 2; break;
-    case 6: src = h->h16; avail = T * MV_INTER * 2; break;
-    case 7: src = h->u; avail = (int64_t)h->dbg_B * MV_PROJ * 4; break;
+    case 0: src = h->w->xres; avail = T * MV_HIDDEN * 4; break;
+    case 1: src = h->w->x16; avail = T * MV_HIDDEN * 2; break;
+    case 2: src = h->w->q; avail = T * MV_HIDDEN * 2; break;
+    case 3: src = h->w->k; avail = T * MV_HIDDEN * 2; break;
+    case 4: src = h->w->vt; avail = T * MV_HIDDEN * 2; break;
+    case 5: src = h->w->ctx; avail = T * MV_HIDDEN * 2; break;
+    case 6: src = h->w->h16; avail = T * MV_INTER * 2; break;
+    case 7: src = h->w->u; avail = (int64_t)h->dbg_B * MV_PROJ * 4; break;
     default: return fail(h, MV_ERR_INVALID, "mv_debug_read: unknown buffer");
   }
   if (bytes > avail) return fail(h, MV_ERR_INVALID, "mv_debug_read: more bytes requested than the buffer holds");
-  HIPCHK(h, hipMemcpyAsync(dst, src, (size_t)bytes, hipMemcpyDeviceToHost, h->stream));
-  HIPCHK(h, hipStreamSynchronize(h->stream));
+  HIPCHK(h, hipMemcpyAsync(dst, src, (size_t)bytes, hipMemcpyDeviceToHost, h->w->stream));
+  HIPCHK(h, hipStreamSynchronize(h->w->stream));
   return MV_OK;
 }
 
@@ -1158,9 +1216,9 @@ int mv_test_gemm(mv_handle* h, int variant, int M, int N, int K, const uint16_t*
   if ((rc = dev_alloc(h, &dW, (int64_t)N * K, false))) return rc;
   if ((rc = dev_alloc(h, &dB, N))) return rc;
   if ((rc = dev_alloc(h, &dC, (int64_t)M * N))) return rc;
-  HIPCHK(h, hipMemcpyAsync(dA, A, (size_t)M * K * 2, hipMemcpyHostToDevice, h->stream));
-  HIPCHK(h, hipMemcpyAsync(dW, W, (size_t)N * K * 2, hipMemcpyHostToDevice, h->stream));
-  if (bias) HIPCHK(h, hipMemcpyAsync(dB, bias, (size_t)N * 4, hipMemcpyHostToDevice, h->stream));
+  HIPCHK(h, hipMemcpyAsync(dA, A, (size_t)M * K * 2, hipMemcpyHostToDevice, h->w->stream));
+  HIPCHK(h, hipMemcpyAsync(dW, W, (size_t)N * K * 2, hipMemcpyHostToDevice, h->w->stream));
+  if (bias) HIPCHK(h, hipMemcpyAsync(dB, bias, (size_t)N * 4, hipMemcpyHostToDevice, h->w->stream));
   GemmArgs g{};
   g.A = dA; g.W = dW; g.bias = dB; g.M = M; g.Mreal = M; g.N = N; g.K = K; g.outf = dC; g.S = 64;
   if (iters < 1) iters = 1;
@@ -1193,11 +1251,11 @@ int mv_test_gemm(mv_handle* h, int variant, int M, int N, int K, const uint16_t*
   };
   rc = run();  // warm-up / correctness launch
   if (rc == MV_OK) {
-    hipEventRecord(e0, h->stream);
+    hipEventRecord(e0, h->w->stream);
     for (int i = 0; i < iters && rc == MV_OK; ++i) rc = run();
-    hipEventRecord(e1, h->stream);
+    hipEventRecord(e1, h->w->stream);
   }
-  hipError_t se = hipStreamSynchronize(h->stream);
+  hipError_t se = hipStreamSynchronize(h->w->stream);
   float t = 0.f;
   hipEventElapsedTime(&t, e0, e1);
   hipEventDestroy(e0);
