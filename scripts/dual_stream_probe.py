@@ -48,11 +48,16 @@ def run(engs, batch):
     return STEPS * len(engs) * batch / dt
 
 
+os.environ["MEMVUL_STREAMS"] = "1"  # each engine runs one batch at a time; the engines supply the concurrency
 one = make(0)
 print("one engine, 256 CUs, B=256:", round(run([one], 256), 1), "IR/s", flush=True)
 one.close()
-for ncu in (128, 160, 256):
+for n in (2, 3, 4):
+    engs = [make(0) for _ in range(n)]
+    print(f"{n} engines, full-size grids, B=256 each:", round(run(engs, 256), 1), "IR/s", flush=True)
+    for e in engs:
+        e.close()
+for ncu in (128,):
     a, b = make(ncu), make(ncu)
     print(f"two engines, {ncu} CUs each, B=256 each:", round(run([a, b], 256), 1), "IR/s", flush=True)
-    print(f"two engines, {ncu} CUs each, B=128 each:", round(run([a, b], 128), 1), "IR/s", flush=True)
     a.close(); b.close()

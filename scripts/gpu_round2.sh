@@ -42,18 +42,19 @@ bench attn_v1 MEMVUL_ATTN=0
 bench ln_explicit MEMVUL_LN_VIRTUAL=0
 bench no_lnfuse MEMVUL_LN_FUSE=0
 bench no_prune MEMVUL_CLS_PRUNE=0
-bench all_off MEMVUL_ATTN=0 MEMVUL_LN_FUSE=0 MEMVUL_CLS_PRUNE=0
+bench all_off MEMVUL_ATTN=0 MEMVUL_LN_FUSE=0 MEMVUL_CLS_PRUNE=0 -- --streams 1
+bench one_stream MEMVUL_X=1 -- --streams 1
 bench noprof MEMVUL_X=1 -- --no-profile
 
 note "rocprofv3 kernel trace of the bench command"
 rm -rf $O/prof_stats $O/prof_fetch $O/prof_write
-( cd /tmp && timeout 420 rocprofv3 --kernel-trace --stats -d $R/$O/prof_stats -o ks -- python $R/bench.py --steps 10 --warmup 3 --cpu-sample 0 > $R/$O/prof_stats.log 2>&1 )
+( cd /tmp && timeout 420 rocprofv3 --kernel-trace --stats -d $R/$O/prof_stats -o ks -- python $R/bench.py --steps 10 --warmup 3 --cpu-sample 0 --streams 1 > $R/$O/prof_stats.log 2>&1 )
 DB=$(find $O/prof_stats -name "*.db" | head -1)
-[ -n "$DB" ] && python scripts/rocpd_summary.py stats $DB > $O/kernel_stats.txt 2>&1 && head -30 $O/kernel_stats.txt
+[ -n "$DB" ] && python scripts/rocpd_summary.py stats $DB > $O/kernel_stats.txt 2>&1 && head -34 $O/kernel_stats.txt
 
 note "PMC passes (HBM traffic), one counter group per run"
-( cd /tmp && timeout 420 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $R/$O/prof_fetch -o pf -- python $R/bench.py --steps 2 --warmup 1 --cpu-sample 0 --no-profile > $R/$O/prof_fetch.log 2>&1 )
-( cd /tmp && timeout 420 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $R/$O/prof_write -o pw -- python $R/bench.py --steps 2 --warmup 1 --cpu-sample 0 --no-profile > $R/$O/prof_write.log 2>&1 )
+( cd /tmp && timeout 420 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $R/$O/prof_fetch -o pf -- python $R/bench.py --steps 2 --warmup 1 --cpu-sample 0 --no-profile --streams 1 > $R/$O/prof_fetch.log 2>&1 )
+( cd /tmp && timeout 420 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $R/$O/prof_write -o pw -- python $R/bench.py --steps 2 --warmup 1 --cpu-sample 0 --no-profile --streams 1 > $R/$O/prof_write.log 2>&1 )
 DBS=$(find $O/prof_fetch $O/prof_write -name "*.db" | tr '\n' ' ')
 [ -n "$DBS" ] && python scripts/rocpd_summary.py pmc $DBS > $O/pmc_hbm.txt 2>&1 && head -30 $O/pmc_hbm.txt
 
