@@ -78,6 +78,8 @@ def main():
     ap.add_argument("--layers", type=int, default=12)
     ap.add_argument("--cpu-sample", type=int, default=96, help="IRs timed on the CPU baseline (0 disables)")
     ap.add_argument("--no-profile", action="store_true", help="skip the per-kernel HIP-event passes (no `roofline` / `kernels`)")
+    ap.add_argument("--ragged", action="store_true", help="also time a ragged corpus (lengths uniform in [16, seq_len]) swept "
+                    "padded to seq_len and length-bucketed (each batch at its longest member); adds a `ragged` object")
     ap.add_argument("--streams", type=int, default=2, choices=(1, 2), help="batches of the resident sweep in flight at once")
     args = ap.parse_args()
 
@@ -216,9 +218,43 @@ def main():
         out["value_one_batch_in_flight"] = round(world * single_rate, 2)
         out["kernels"] = kernels
         out["kernels_note"] = "per-class HIP-event breakdown from a separate untimed pass of %d steps, one batch in flight" % min(K, 4)
+    if args.ragged:
+        out["ragged"] = ragged_leg(eng, dims, B, S, rank)
     if args.cpu_sample > 0 and world == 1:
         out["cpu_baseline"], out["logit_max_abs_err_vs_cpu"] = cpu_baseline(weights, dims, eng, ids, lens, S, args.cpu_sample)
     print(json.dumps(out), flush=True)
+
+
+def ragged_leg(eng, dims, B, S, rank, n_batches=16):
+    """Real issue reports are not all seq_len tokens long.  The reference pads every batch to its longest member
+    (predict_memory.py:97-101); the engine form is a corpus uploaded sorted by length and swept with mv_corpus_run_len.
+    Times the same ragged synthetic corpus (lengths uniform in [16, S]) both ways, inputs resident before the clock starts."""
+    n = n_batches * B
+    ids, lens = synth.make_ids(n, S, dims.vocab_size, seed=synth.SEED + 77 + rank, ragged=True, min_len=16)
+    res = {}
+    eng.corpus_upload(ids, lens)
+    for rep in range(2):  # first pass = warm-up
+        eng.sync()
+        t0 = time.perf_counter()
+        eng.corpus_run(0, n, B)
+        best_p, idx_p, _ = eng.corpus_results(0, n)
+        res["padded_to_seq_len_irs"] = round(n / (time.perf_counter() - t0), 1)
+    order = np.argsort(lens, kind="stable")
+    sl = lens[order]
+    eng.corpus_upload(ids[order], sl)
+    for rep in range(2):
+        eng.sync()
+        t0 = time.perf_counter()
+        for s0 in range(0, n, B):
+            eng.corpus_run(s0, B, B, s_eff=int(sl[s0 + B - 1]))
+        best_b, idx_b, _ = eng.corpus_results(0, n)
+        res["length_bucketed_irs"] = round(n / (time.perf_counter() - t0), 1)
+    inv = np.empty(n, np.int64)
+    inv[order] = np.arange(n)
+    res["max_abs_diff_best_prob"] = float(np.abs(best_b[inv] - best_p).max())
+    res["mean_len"] = float(lens.mean())
+    res["note"] = "same %d synthetic IRs, lengths uniform in [16, %d]; bucketed = sorted by length, each batch of %d run at its longest member's length rounded up to 64" % (n, S, B)
+    return res
 
 
 def cpu_baseline(weights, dims, eng, ids, lens, S, n):

@@ -125,6 +125,11 @@ int mv_corpus_upload(mv_handle* h, const int32_t* ids, const int32_t* lens, int6
 /* Runs IRs [first, first+count) in batches of `batch`; asynchronous. keep_probs != 0 also keeps
  * P(same) for every (IR, anchor) pair (what make_output_human_readable serialises, l.169-191). */
 int mv_corpus_run(mv_handle* h, int64_t first, int64_t count, int batch, int keep_probs);
+/* Same, processing only the first s_eff tokens of every row in the range (0 = all S): for a corpus uploaded sorted by
+ * length, a batch runs at its own longest member's length (padded to 64) instead of the corpus-wide S — the engine
+ * form of padding each batch to its longest instance (predict_memory.py:97-101). Rows longer than s_eff must not be
+ * in the range (their tail would be cut). */
+int mv_corpus_run_len(mv_handle* h, int64_t first, int64_t count, int batch, int keep_probs, int s_eff);
 /* Batches of the resident sweep in flight at once: 2 (default; consecutive batches alternate between two workspace
  * sets on two HIP streams and overlap on the GPU) or 1.  Results are identical either way. */
 int mv_set_streams(mv_handle* h, int n);

@@ -21,7 +21,7 @@ NUM_KERNEL_CLASSES = 14
 ABI_SYMBOLS = [
     "mv_create", "mv_destroy", "mv_last_error", "mv_sync", "mv_load_tensor", "mv_finalize_weights",
     "mv_anchor_reset", "mv_anchor_append", "mv_anchor_count", "mv_anchor_get", "mv_anchor_set",
-    "mv_forward", "mv_encode", "mv_match", "mv_topk", "mv_corpus_upload", "mv_corpus_run",
+    "mv_forward", "mv_encode", "mv_match", "mv_topk", "mv_corpus_upload", "mv_corpus_run", "mv_corpus_run_len",
     "mv_corpus_results", "mv_set_streams", "mv_profile_enable", "mv_profile_select", "mv_profile_read", "mv_kernel_class_name",
     "mv_debug_encode", "mv_debug_read", "mv_test_gemm",
 ]
@@ -75,6 +75,7 @@ def load_library(path: Optional[str] = None):
         "mv_topk": (C.c_int, [vp, vp, C.c_int, C.c_int, vp, vp]),
         "mv_corpus_upload": (C.c_int, [vp, vp, vp, C.c_int64, C.c_int]),
         "mv_corpus_run": (C.c_int, [vp, C.c_int64, C.c_int64, C.c_int, C.c_int]),
+        "mv_corpus_run_len": (C.c_int, [vp, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_int]),
         "mv_corpus_results": (C.c_int, [vp, C.c_int64, C.c_int64, vp, vp, vp]),
         "mv_set_streams": (C.c_int, [vp, C.c_int]),
         "mv_profile_enable": (C.c_int, [vp, C.c_int]),
@@ -224,8 +225,28 @@ class Engine:
         self._check(self._lib.mv_corpus_upload(self._h, _ptr(ids), _ptr(lens), ids.shape[0], ids.shape[1]), "mv_corpus_upload")
         self._corpus_n = ids.shape[0]
 
-    def corpus_run(self, first: int, count: int, batch: int, keep_probs: bool = False):
-        self._check(self._lib.mv_corpus_run(self._h, first, count, batch, int(keep_probs)), "mv_corpus_run")
+    def corpus_run(self, first: int, count: int, batch: int, keep_probs: bool = False, s_eff: int = 0):
+        """Enqueue IRs [first, first+count) of the resident corpus in batches of `batch` (asynchronous).  s_eff > 0:
+        process only the first s_eff tokens of each row (length-bucketed sweeps, see bucketed_sweep)."""
+        self._check(self._lib.mv_corpus_run_len(self._h, first, count, batch, int(keep_probs), int(s_eff)), "mv_corpus_run_len")
+
+    def bucketed_sweep(self, ids: np.ndarray, lens: np.ndarray, batch: int, with_probs: bool = False):
+        """Score a ragged corpus with each batch padded to ITS longest member (the reference's pad-to-longest collation,
+        predict_memory.py:97-101) instead of the corpus-wide S: rows are sorted by length, uploaded once, swept batch by
+        batch at that batch's length (rounded up to 64 tokens), and the results are returned in the ORIGINAL order."""
+        ids = np.ascontiguousarray(ids, np.int32)
+        lens = np.ascontiguousarray(lens, np.int32)
+        n = ids.shape[0]
+        order = np.argsort(lens, kind="stable")
+        self.corpus_upload(ids[order], lens[order])
+        sl = lens[order]
+        for s0 in range(0, n, batch):
+            nb = min(batch, n - s0)
+            self.corpus_run(s0, nb, nb, keep_probs=with_probs, s_eff=int(sl[s0 + nb - 1]))
+        best, idx, ps = self.corpus_results(0, n, with_probs=with_probs)
+        inv = np.empty(n, np.int64)
+        inv[order] = np.arange(n)
+        return best[inv], idx[inv], (ps[inv] if ps is not None else None)
 
     def corpus_results(self, first: int, count: int, with_probs: bool = False):
         best = np.empty((count, 2), np.float32)

@@ -384,7 +384,8 @@ int pool_head(mv_handle* h, const float* x, size_t row_stride, int B, float* u_o
 // last layer is pruned to the [CLS] rows when the pooler follows (cls_prune), and on the persistent-GEMM path the
 // LayerNorm kernels write only the fp16 operand + row statistics, the residual consumers normalise (ln_fuse).
 int encode_dev(mv_handle* h, const int32_t* d_ids, const int32_t* d_lens, int B, int S_in, int n_layers, float* u_out,
-               bool full = false) {
+               bool full = false, int pitch = 0) {
+  if (pitch <= 0) pitch = S_in;  // ints between the rows of d_ids
   const mv_config& c = h->cfg;
   const int Sp = (int)round_up(S_in, 64);
   const int64_t M = (int64_t)B * Sp, Mpad = round_up(M, 256);
@@ -402,10 +403,10 @@ int encode_dev(mv_handle* h, const int32_t* d_ids, const int32_t* d_lens, int B,
   {
     ProfScope ps(h, KC_EMBED_LN);
     if (virt)
-      hipLaunchKernelGGL(embed_ln_kernel<true>, dim3(ln_grid), dim3(256), 0, h->w->stream, d_ids, S_in, Sp, (int)M, c.vocab_size,
+      hipLaunchKernelGGL(embed_ln_kernel<true>, dim3(ln_grid), dim3(256), 0, h->w->stream, d_ids, pitch, S_in, Sp, (int)M, c.vocab_size,
                          h->wemb, h->pemb, h->temb, h->embg, h->embb, c.ln_eps, h->w->xres, h->w->x16, h->w->lnstats);
     else
-      hipLaunchKernelGGL(embed_ln_kernel<false>, dim3(ln_grid), dim3(256), 0, h->w->stream, d_ids, S_in, Sp, (int)M, c.vocab_size,
+      hipLaunchKernelGGL(embed_ln_kernel<false>, dim3(ln_grid), dim3(256), 0, h->w->stream, d_ids, pitch, S_in, Sp, (int)M, c.vocab_size,
                          h->wemb, h->pemb, h->temb, h->embg, h->embb, c.ln_eps, h->w->xres, h->w->x16,
                          fuse ? h->w->lnstats : (float*)nullptr);
     if (int rc = launch_check(h, "embed_ln")) return rc;
@@ -1079,6 +1080,10 @@ int mv_corpus_upload(mv_handle* h, const int32_t* ids, const int32_t* lens, int6
 }
 
 int mv_corpus_run(mv_handle* h, int64_t first, int64_t count, int batch, int keep_probs) {
+  return mv_corpus_run_len(h, first, count, batch, keep_probs, 0);
+}
+
+int mv_corpus_run_len(mv_handle* h, int64_t first, int64_t count, int batch, int keep_probs, int s_eff) {
   if (!h) return MV_ERR_INVALID;
   if (!h->finalized) return fail(h, MV_ERR_STATE, "weights not finalized (mv_finalize_weights)");
   if (!h->c_ids) return fail(h, MV_ERR_STATE, "no resident corpus (mv_corpus_upload)");
@@ -1086,7 +1091,9 @@ int mv_corpus_run(mv_handle* h, int64_t first, int64_t count, int batch, int kee
   if (h->n_anchors <= 0) return fail(h, MV_ERR_STATE, "anchor bank is empty");
   HIPCHK(h, hipSetDevice(h->device));
   h->w = &h->work[0];
-  const int rows = max_rows_for(h, h->c_S);
+  if (s_eff < 0 || s_eff > h->c_S) return fail(h, MV_ERR_INVALID, "mv_corpus_run_len: s_eff must be in [0, S of the resident corpus]");
+  const int S_use = s_eff > 0 ? s_eff : h->c_S;  // tokens per row actually processed (rows longer than this must not be in the range)
+  const int rows = max_rows_for(h, S_use);
   if (batch > rows) return fail(h, MV_ERR_CAPACITY, "batch exceeds mv_config.max_batch / max_tokens");
   const int G = h->n_anchors;
   if (keep_probs && (h->c_psame_rows != h->c_n || h->c_G != G)) {
@@ -1107,7 +1114,7 @@ int mv_corpus_run(mv_handle* h, int64_t first, int64_t count, int batch, int kee
       if (h->rr == 1) h->dual_pending = true;
       h->rr ^= 1;
     }
-    rc = encode_dev(h, h->c_ids + (size_t)off * h->c_S, h->c_lens + off, nb, h->c_S, -1, h->w->u);
+    rc = encode_dev(h, h->c_ids + (size_t)off * h->c_S, h->c_lens + off, nb, S_use, -1, h->w->u, false, h->c_S);
     if (rc != MV_OK) break;
     float* ps = keep_probs ? h->c_psame + (size_t)off * G : h->w->psame;
     rc = match_dev(h, h->w->u, nb, ps, 1, h->c_best + (size_t)off * 2, h->c_idx + off);

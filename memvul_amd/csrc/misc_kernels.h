@@ -59,8 +59,9 @@ __device__ __forceinline__ void ln_row_store(const float4 (&x)[3], const float* 
 // K1: x = LN(word[id] + pos[s] + type[0])   (HF BertEmbeddings; token-type ids are all zero in this
 // path, custom_PTM_embedder.py:199-202).  ids are [B][S_in] (0-padded), the engine row pitch is Sp.
 // RAWOUT (virtual LayerNorm, gemm_pp.h): x32 <- the un-normalised sum, x16 <- its fp16 copy, stats <- (mean, rstd).
+// `pitch` = ints between the rows of ids (>= S_in: a length-bucketed sweep reads only the first S_in columns of wider rows).
 template <bool RAWOUT>
-__global__ __launch_bounds__(256) void embed_ln_kernel(const int32_t* __restrict__ ids, int S_in, int Sp, int n_tok,
+__global__ __launch_bounds__(256) void embed_ln_kernel(const int32_t* __restrict__ ids, int pitch, int S_in, int Sp, int n_tok,
                                                        int vocab, const float* __restrict__ wemb,
                                                        const float* __restrict__ pemb, const float* __restrict__ temb,
                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -70,7 +71,7 @@ __global__ __launch_bounds__(256) void embed_ln_kernel(const int32_t* __restrict
   const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (t >= n_tok) return;
   const int b = t / Sp, s = t - b * Sp;
-  int id = (s < S_in) ? ids[(size_t)b * S_in + s] : 0;
+  int id = (s < S_in) ? ids[(size_t)b * pitch + s] : 0;
   id = (id < 0 || id >= vocab) ? 0 : id;
   const float* w = wemb + (size_t)id * MV_HIDDEN;
   const float* p = pemb + (size_t)(s < S_in ? s : 0) * MV_HIDDEN;  // columns >= S_in are engine padding (always masked)
