@@ -256,11 +256,33 @@ class ModelMemory(Model):
         out = self.make_output_human_readable(self.forward(**batch))
         return out if isinstance(out, list) else [dict() for _ in instances]
 
+    def sweep(self, instances: List[Instance], batch_size: int = 512) -> List[List[Dict[str, Any]]]:
+        """The whole evaluation set in one resident, length-bucketed sweep (Engine.bucketed_sweep) instead of one
+        ``forward`` per pad-to-longest batch (predict_memory.py:97-110): same per-IR arithmetic, same metric updates,
+        same human-readable records in the same order and the same per-batch grouping — but every batch runs at its
+        own longest member's length, two batches are in flight on the GPU, and token ids / results cross PCIe once."""
+        if not instances:
+            return []
+        batch = collate(instances, self.vocab)
+        metadata = batch["metadata"]
+        if metadata[0]["type"] not in ["test", "unlabel"]:
+            raise NotImplementedError("sweep() serves the test / unlabel branch (model_memory.py:133-147)")
+        ids, lens = self._ids_lens(batch["sample1"])
+        best, best_idx, p_same = self.engine.bucketed_sweep(ids, lens, batch_size, with_probs=True)
+        if batch.get("label") is not None:
+            self._counts(best, _np(batch["label"]))
+        self._siamese_metric(best, metadata)
+        out = []
+        for s0 in range(0, len(instances), batch_size):
+            out.append(self.make_output_human_readable({"meta": metadata[s0:s0 + batch_size], "p_same": p_same[s0:s0 + batch_size]}))
+        return out
+
     def make_output_human_readable(self, output_dict: Dict[str, Any]):
         if "meta" not in output_dict or output_dict["meta"][0]["type"] not in ["test", "unlabel"]:
             return output_dict
         labels = self._golden_labels
-        ps = np.asarray(output_dict["probs"])[:, :, self._same_idx]  # [B,G]
+        ps = (np.asarray(output_dict["p_same"]) if "p_same" in output_dict                  # [B,G] (resident sweep)
+              else np.asarray(output_dict["probs"])[:, :, self._same_idx])
         # vote_num[golden_name] = p[idx_same] in anchor order: a later duplicate label overwrites (l.181-183)
         order = {name: i for i, name in enumerate(labels)}  # last occurrence wins
         names = list(order.keys())

@@ -44,6 +44,23 @@ def evaluate(model, data_loader, cuda_device: int = -1, batch_weight_key: str = 
     return final_metrics
 
 
+def evaluate_sweep(model, data_loader, output_file: str = None, predictions_output_file: str = None) -> Dict[str, Any]:
+    """``evaluate`` with the batches of the loader scored in ONE resident length-bucketed sweep (ModelMemory.sweep):
+    identical files and metrics, no per-batch host round trip."""
+    model.eval()
+    instances = list(data_loader.iter_instances())
+    per_batch = model.sweep(instances, data_loader.batch_size)
+    if predictions_output_file:
+        with open(predictions_output_file, "w") as pf:
+            for recs in per_batch:
+                pf.write(json.dumps(recs) + "\n")
+    final_metrics = model.get_metrics(reset=True)
+    if output_file:
+        with open(output_file, "w") as f:
+            json.dump(_jsonable(final_metrics), f, indent=4)
+    return final_metrics
+
+
 def _jsonable(x):
     if isinstance(x, dict):
         return {k: _jsonable(v) for k, v in x.items()}
@@ -56,8 +73,9 @@ def _jsonable(x):
 
 def test_siamese(archive_file, input_file, input_golden_file, test_config=None, weights_file=None, output_file=None,
                  predictions_output_file=None, batch_size=64, cuda_device=0, seed=2021, package="memvul_amd",
-                 batch_weight_key="", file_friendly_logging=False, engine_options=None) -> Dict[str, Any]:
-    """predict_memory.py:49-114."""
+                 batch_weight_key="", file_friendly_logging=False, engine_options=None, sweep=False) -> Dict[str, Any]:
+    """predict_memory.py:49-114.  ``sweep=True``: score the evaluation set in one resident length-bucketed sweep
+    (same outputs; see evaluate_sweep)."""
     overrides = test_config or ""
     archive = load_archive(archive_file, weights_file=weights_file, cuda_device=cuda_device, overrides=overrides,
                            engine_options=engine_options)
@@ -81,8 +99,11 @@ def test_siamese(archive_file, input_file, input_golden_file, test_config=None, 
         data_loader_params["batch_size"] = batch_size
     data_loader = DataLoader.from_params(params=data_loader_params, reader=dataset_reader, data_path=input_file)
     data_loader.index_with(model.vocab)
-    metrics = evaluate(model, data_loader, cuda_device, batch_weight_key, output_file=output_file,
-                       predictions_output_file=predictions_output_file)
+    if sweep:
+        metrics = evaluate_sweep(model, data_loader, output_file=output_file, predictions_output_file=predictions_output_file)
+    else:
+        metrics = evaluate(model, data_loader, cuda_device, batch_weight_key, output_file=output_file,
+                           predictions_output_file=predictions_output_file)
     logger.info("Finished evaluating.")
     return metrics
 

@@ -113,3 +113,12 @@ class OracleEngine:
         u = self.encode(ids, lens)
         logits, p, best, idx = orc.match(u, self.v, self.w[synth.KEY_MATCH_W], self.same_idx)
         return {"logits": logits, "probs": p, "best": best, "best_idx": idx.astype(np.int32), "embed": u}
+
+    def bucketed_sweep(self, ids, lens, batch, with_probs=False):
+        """binding.Engine.bucketed_sweep on the oracle: per-row results do not depend on the batching."""
+        best, idx, ps = [], [], []
+        for s0 in range(0, ids.shape[0], batch):
+            L = int(np.asarray(lens[s0:s0 + batch]).max())
+            o = self.forward(ids[s0:s0 + batch, :L], lens[s0:s0 + batch])
+            best.append(o["best"]); idx.append(o["best_idx"]); ps.append(o["probs"][:, :, self.same_idx])
+        return np.concatenate(best), np.concatenate(idx), (np.concatenate(ps) if with_probs else None)

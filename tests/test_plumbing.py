@@ -12,13 +12,13 @@ from memvul_amd import model_memory, predict_memory
 from oracle import stats_oracle as so
 
 
-def _run(fx, tag):
+def _run(fx, tag, sweep=False):
     root, arch, golden, test_path, w, dims = fx
     out_metric = os.path.join(root, "test_results", f"{tag}_metric.json")
     out_results = os.path.join(root, "test_results", f"{tag}_result.json")
     metrics = predict_memory.test_siamese(archive_file=arch, input_file=test_path, input_golden_file=golden, test_config=pu.TEST_CONFIG,
                                           output_file=out_metric, predictions_output_file=out_results, batch_size=16, cuda_device=0,
-                                          engine_options=dict(max_tokens=16 * 256, max_batch=16, max_anchors=16))
+                                          engine_options=dict(max_tokens=16 * 256, max_batch=16, max_anchors=16), sweep=sweep)
     records = []
     for line in open(out_results):
         records.extend(json.loads(line))
@@ -54,6 +54,35 @@ def test_plumbing_cpu_with_oracle_engine(monkeypatch):
     monkeypatch.setattr(model_memory, "Engine", pu.OracleEngine)
     metrics, records, _ = _run(fx, "oracle")
     _check_format_and_metrics(fx, metrics, records, "oracle")
+
+
+def test_sweep_driver_writes_the_same_files_cpu(monkeypatch):
+    """test_siamese(sweep=True): one resident length-bucketed sweep instead of a forward per batch — same records in
+    the same order with the same per-batch line grouping, same metrics (oracle-backed engine: exactly the same)."""
+    fx = pu.make_fixture()
+    monkeypatch.setattr(model_memory, "Engine", pu.OracleEngine)
+    metrics, records, path = _run(fx, "loop")
+    metrics_s, records_s, path_s = _run(fx, "sweep", sweep=True)
+    assert [len(json.loads(l)) for l in open(path)] == [len(json.loads(l)) for l in open(path_s)]
+    assert [r["Issue_Url"] for r in records] == [r["Issue_Url"] for r in records_s]
+    a = np.array([list(r["predict"].values()) for r in records])
+    b = np.array([list(r["predict"].values()) for r in records_s])
+    assert np.abs(a - b).max() < 1e-6  # the oracle pads differently per chunk: fp32 rounding only
+    for k in metrics:
+        assert metrics[k] == pytest.approx(metrics_s[k], abs=1e-6), k
+    _check_format_and_metrics(fx, metrics_s, records_s, "sweep")
+
+
+@pytest.mark.gpu
+def test_sweep_driver_gpu_matches_batch_loop():
+    fx = pu.make_fixture(n_irs=70)
+    metrics, records, _ = _run(fx, "loop")
+    metrics_s, records_s, _ = _run(fx, "sweep", sweep=True)
+    assert [r["Issue_Url"] for r in records] == [r["Issue_Url"] for r in records_s]
+    a = np.array([list(r["predict"].values()) for r in records])
+    b = np.array([list(r["predict"].values()) for r in records_s])
+    assert np.abs(a - b).max() <= 1e-3  # a row may run at a different padded length in the two drivers
+    _check_format_and_metrics(fx, metrics_s, records_s, "sweep")
 
 
 @pytest.mark.gpu
