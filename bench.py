@@ -38,9 +38,11 @@ GEMM_CLASSES = ("gemm_qkv", "gemm_attn_out", "gemm_ffn1_gelu", "gemm_ffn2")
 # HBM bytes per launch of each GEMM class at the default workload from the separate rocprofv3 --pmc passes kept
 # under profiles/ (FETCH_SIZE x 2 per the gfx950 correction + WRITE_SIZE); None where no pass has been taken
 PMC_TRAFFIC_BYTES = {
-    # profiles/r01_f_pmc_hbm.txt: gemm_pp_kernel<PP_GELU> FETCH_SIZE 2.222e5 KiB (x2) + WRITE_SIZE 3.901e5 KiB
-    "gemm_ffn1_gelu": int((2 * 2.222e5 + 3.901e5) * 1024),
-    "gemm_ffn2": None, "gemm_qkv": None, "gemm_attn_out": None,
+    # profiles/r01_j_pmc_hbm.txt (KiB per dispatch): FETCH_SIZE x 2 + WRITE_SIZE
+    "gemm_ffn1_gelu": int((2 * 2.230e5 + 3.901e5) * 1024),                          # gemm_pp<PP_GELU, RAW>
+    "gemm_ffn2": int((2 * 3.651e5 + 3.019e5) * 1024),                               # gemm_pp<PP_RESLN2> [long]
+    "gemm_attn_out": int((2 * 1.671e5 + 3.020e5) * 1024),                           # gemm_pp<PP_RESLN2> [short]
+    "gemm_qkv": int((2 * (1.295e5 + 6.906e4) + (1.870e5 + 1.072e5)) * 1024),        # gemm_pp<PP_QK, RAW> + <PP_VT, RAW>
 }
 
 
@@ -98,6 +100,7 @@ def main():
     eng = Engine(local_rank, vocab_size=dims.vocab_size, layers=dims.layers, max_tokens=max(B * S, 128 * 512),
                  max_batch=max(B, 128), max_anchors=max(G, 128))
     eng.load_state_dict(weights)
+    eng.set_streams(args.streams)
 
     # anchor memory: G synthetic CWE descriptions of up to 512 tokens, built once per process (untimed;
     # predict_memory.py:81-83 forwards them in chunks of 128)
