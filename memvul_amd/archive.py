@@ -20,6 +20,8 @@ from . import params as _params
 from .registry import DatasetReader, Model, Vocabulary
 from . import model_memory as _mm  # noqa: F401  (registers model_memory + embedders)
 from . import reader_memory as _rm  # noqa: F401  (registers reader_memory)
+from . import model_single as _ms  # noqa: F401  (registers model_single)
+from . import reader_single as _rs  # noqa: F401  (registers reader_single)
 
 
 @dataclass

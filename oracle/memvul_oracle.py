@@ -174,3 +174,9 @@ def predict(w, ids, mask, v, same_idx=0, heads=12, eps=1e-12, dtype=np.float32):
     """One hot-loop iteration (model_memory.py:133-147) on one batch."""
     u = instance_forward(w, ids, mask, heads, eps, dtype)
     return (u,) + match(u, v.astype(dtype), w["_projector.weight"], same_idx)
+
+
+def classify_single(u: np.ndarray, w_cls: np.ndarray):
+    """MemVul-m head (model_single.py:66, 92-94): logits = Linear(512, num_class, bias=False)(u), probs = softmax."""
+    logits = u @ w_cls.astype(u.dtype).T
+    return logits, _softmax(logits)
