@@ -488,6 +488,13 @@ int encode_dev(mv_handle* h, const int32_t* d_ids, const int32_t* d_lens, int B,
           case 3: hipLaunchKernelGGL((attention_v2_kernel<3>), dim3(grid), dim3(384), ATT2_LDS_BYTES(3), h->w->stream, a, items); break;
           default: hipLaunchKernelGGL((attention_v2_kernel<4>), dim3(grid), dim3(512), ATT2_LDS_BYTES(4), h->w->stream, a, items); break;
         }
+      } else if (h->attn_v2 && (Sp == 384 || Sp == 512)) {
+        // chunks of 128 keys per (row, head, 128-query block) through the same ring: 64 score registers per lane, two
+        // workgroups of 4 waves per CU; consecutive units of a workgroup are the query blocks of one head (K / V^T from L2)
+        const int nch = Sp / 128, units = B * MV_HEADS * nch;
+        const int grid = units < 2 * h->num_cu ? units : 2 * h->num_cu;
+        if (nch == 3) hipLaunchKernelGGL((attention_v2_kernel<2, 3>), dim3(grid), dim3(256), ATT2_LDS_BYTES(2), h->w->stream, a, units);
+        else hipLaunchKernelGGL((attention_v2_kernel<2, 4>), dim3(grid), dim3(256), ATT2_LDS_BYTES(2), h->w->stream, a, units);
       } else if (Sp <= 256) {
         const int qblocks = (Sp + 127) / 128;
         hipLaunchKernelGGL((attention_kernel<4>), dim3(B * MV_HEADS * qblocks), dim3(256), ATT_LDS_BYTES(Sp), h->w->stream, a);
@@ -702,6 +709,8 @@ int mv_create(int device, const mv_config* cfg, mv_handle** out) {
   hipFuncSetAttribute((const void*)attention_v2_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT2_LDS_BYTES(2));
   hipFuncSetAttribute((const void*)attention_v2_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT2_LDS_BYTES(3));
   hipFuncSetAttribute((const void*)attention_v2_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT2_LDS_BYTES(4));
+  hipFuncSetAttribute((const void*)attention_v2_kernel<2, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT2_LDS_BYTES(2));
+  hipFuncSetAttribute((const void*)attention_v2_kernel<2, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT2_LDS_BYTES(2));
   (void)hipGetLastError();
   {
     int ncu = 0;

@@ -68,12 +68,13 @@ def test_embeddings_layernorm(gu, B, S, ragged):
 
 @pytest.mark.parametrize("attn", ["1", "0"])
 @pytest.mark.parametrize("gemm_tile", [0, 512])
-@pytest.mark.parametrize("B,S,ragged", [(2, 64, False), (3, 128, True), (2, 192, True), (2, 256, True), (1, 320, True), (2, 100, True)])
+@pytest.mark.parametrize("B,S,ragged", [(2, 64, False), (3, 128, True), (2, 192, True), (2, 256, True), (1, 320, True), (2, 100, True),
+                                        (2, 384, True), (2, 512, True), (1, 500, True)])
 def test_layer0_stages(gu, B, S, ragged, gemm_tile, attn):
     """QKV projection, attention, FFN and both LayerNorms of encoder layer 0 against the oracle taps.
     Tolerances are fp16-operand level (inputs rounded to fp16, fp32 accumulation)."""
     dims, w, ids, lens, mask, taps, _ = _taps(gu, B, S, ragged)
-    # 512: every projection through the persistent ping-pong GEMM; attn 1: attention_v2.h for Sp <= 256, 0: attention.h
+    # 512: every projection through the persistent ping-pong GEMM; attn 1: attention_v2.h for Sp <= 256 and (in chunks of 128 keys) Sp = 384 / 512, 0: attention.h
     eng = gu.engine_for(L2, WK, gemm_tile=gemm_tile, env={"MEMVUL_ATTN": attn})
     eng.debug_encode(ids, lens, 1)
     q = eng.debug_read(2)[:, :, :S].astype(np.float32) * 8.0  # engine folds 1/sqrt(64) into W_q
@@ -101,7 +102,7 @@ def test_layer0_stages(gu, B, S, ragged, gemm_tile, attn):
     assert errs["layer0"] < 1e-2, errs
 
 
-@pytest.mark.parametrize("B,S", [(48, 256), (70, 128), (40, 192)])
+@pytest.mark.parametrize("B,S", [(48, 256), (70, 128), (40, 192), (26, 512), (30, 384)])
 def test_attention_persistent_item_loop(gu, B, S):
     """attention_v2 walks (batch row, head) items with a 2-deep LDS ring: more items than resident workgroups, uneven
     tails (B * 12 not a multiple of the grid) and ragged lengths; checked against the oracle's layer-0 context."""
