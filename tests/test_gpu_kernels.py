@@ -102,17 +102,19 @@ def test_layer0_stages(gu, B, S, ragged, gemm_tile, attn):
     assert errs["layer0"] < 1e-2, errs
 
 
+@pytest.mark.parametrize("attn", ["1", "0"])
 @pytest.mark.parametrize("B,S", [(48, 256), (70, 128), (40, 192), (26, 512), (30, 384)])
-def test_attention_persistent_item_loop(gu, B, S):
-    """attention_v2 walks (batch row, head) items with a 2-deep LDS ring: more items than resident workgroups, uneven
-    tails (B * 12 not a multiple of the grid) and ragged lengths; checked against the oracle's layer-0 context."""
+def test_attention_persistent_item_loop(gu, B, S, attn):
+    """attention_v2 walks (batch row, head[, query block]) units with a 2-deep LDS ring: more units than resident
+    workgroups, uneven tails, ragged lengths, one to four key chunks per unit; checked against the oracle's layer-0
+    context (attn 0: the same inputs through attention.h, whose error is the yardstick: peaked attention, fp16 P and V)."""
     dims, w, ids, lens, mask, taps, _ = _taps(gu, B, S, True)
-    eng = gu.engine_for(L2, WK, max_tokens=B * S, max_batch=B)
+    eng = gu.engine_for(L2, WK, env={"MEMVUL_ATTN": attn}, max_tokens=B * S, max_batch=B)
     eng.debug_encode(ids, lens, 1)
     ctx = eng.debug_read(5)[:, :S].astype(np.float32)
     err = float(np.abs(ctx - taps["l0_ctx"])[mask].max())
-    gu.record("attention_items", B=B, S=S, max_err=err)
-    assert err < 8e-3
+    gu.record("attention_items", B=B, S=S, attn=attn, max_err=err)
+    assert err < 1.2e-2
 
 
 def test_match_and_topk_vs_oracle(gu):
