@@ -237,3 +237,45 @@ def test_length_bucketed_sweep_matches_padded_sweep(gu):
         lg, pp, bb, ii = orc.match(u_ref, v, w[synth.KEY_MATCH_W])
         assert np.abs(ps1[r] - pp[0, :, 0]).max() < 2e-3
     eng.anchor_reset()
+
+
+@pytest.mark.parametrize("gemm_tile", [0, 512])
+def test_edge_shapes_against_the_oracle(gu, gemm_tile):
+    """The smallest and the largest inputs the path accepts: a one-token issue report, one anchor, a batch whose rows
+    are 1 / 33 / 64 tokens long, and a 512-token row (max_pos) next to a 3-token one; errors for what it must reject."""
+    dk, wk = dict(layers=2, vocab_size=2048), dict(qk_scale=3.0)
+    dims, w = gu.weights_for(dk, wk)
+    eng = gu.engine_for(dk, wk, gemm_tile=gemm_tile, max_tokens=8 * 512, max_batch=8, max_anchors=4)
+
+    def check(ids, lens, G):
+        S = ids.shape[1]
+        aids, alens = synth.make_ids(G, 40, dims.vocab_size, seed=synth.SEED + 5, ragged=True, min_len=1)
+        eng.anchor_reset(); eng.anchor_append(aids, alens)
+        out = eng.forward(ids, lens, want_embed=True)
+        v = orc.build_anchor_bank(w, [aids[i, : alens[i]].astype(np.int64) for i in range(G)])
+        u, logits, p, best, idx = orc.predict(w, ids.astype(np.int64), synth.mask_from_lens(lens, S), v)
+        assert np.abs(out["embed"] - u).max() < 2e-3
+        assert np.abs(out["logits"] - logits).max() <= LOGIT_TOL
+        assert out["logits"].shape == (ids.shape[0], G, 2)
+
+    one = np.array([[101]], np.int32)
+    check(one, np.array([1], np.int32), 1)                                   # B = 1, S = 1, G = 1
+    ids, _ = synth.make_ids(3, 64, dims.vocab_size, ragged=False)
+    lens = np.array([1, 33, 64], np.int32)
+    ids = ids * (np.arange(64)[None, :] < lens[:, None])
+    check(ids.astype(np.int32), lens, 3)
+    ids, _ = synth.make_ids(2, 512, dims.vocab_size, ragged=False)
+    lens = np.array([512, 3], np.int32)
+    ids = ids * (np.arange(512)[None, :] < lens[:, None])
+    check(ids.astype(np.int32), lens, 2)                                      # max_pos next to a 3-token row
+    with pytest.raises(RuntimeError):
+        eng.forward(np.zeros((1, 513), np.int32), np.array([513], np.int32))  # longer than max_pos
+    # more rows than max_batch / max_tokens hold: mv_forward walks them in chunks, results as for the rows alone
+    ids9, lens9 = synth.make_ids(9, 512, dims.vocab_size, ragged=True, min_len=300)
+    eng.anchor_set(synth.make_anchor_bank(3))
+    o9 = eng.forward(ids9, lens9)
+    o1 = eng.forward(ids9[8:], lens9[8:])
+    assert np.array_equal(o9["logits"][8:], o1["logits"])
+    eng.anchor_reset()
+    with pytest.raises(RuntimeError):
+        eng.forward(one, np.array([1], np.int32))                              # empty anchor bank
