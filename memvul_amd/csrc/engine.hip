@@ -118,6 +118,7 @@ struct Work {
   float *c32 = nullptr, *cq = nullptr;          // [CLS]-row buffers of the pruned last layer
   half_t *c16 = nullptr, *cctx = nullptr, *ch16 = nullptr;
   float *lnstats = nullptr, *lnpart = nullptr;  // LayerNorm row statistics / partial row sums
+  half_t* xlo = nullptr;                        // lo plane of the two-plane raw stream (PP_RESLN3)
 };
 
 struct mv_handle {
@@ -168,6 +169,7 @@ struct mv_handle {
   // ... and no LayerNorm kernel at all between the GEMMs (RAW consumers + PP_RESLN2 producers); env MEMVUL_LN_VIRTUAL=0 disables
   bool ln_virtual = true;
   int pp_stagger = 0;  // env MEMVUL_STAGGER: see GemmArgs::stagger
+  bool res_hilo = true;  // env MEMVUL_RES_HILO=0: raw stream as fp32 + fp16 copy (PP_RESLN2) instead of two fp16 planes (PP_RESLN3)
   int r16_direct = 0;  // PP_RESLN2: fp16 copy from the transposed fp32 image (1) or through its own LDS transposition (0); env MEMVUL_R16_DIRECT
 
   // profiling
@@ -338,6 +340,7 @@ int launch_pp(mv_handle* h, int cls, const GemmArgs& a) {
   } else if constexpr (EPI == EPI_GELU) {
     return a.raw ? launch_pp_raw<PP_GELU, 1>(h, a) : launch_pp_raw<PP_GELU>(h, a);
   } else if constexpr (EPI == EPI_RES) {
+    if (a.lnstats && a.lnpart && a.out16b) return launch_pp_raw<PP_RESLN3>(h, a);
     if (a.lnstats && a.lnpart) return launch_pp_raw<PP_RESLN2>(h, a);
     if (a.lnstats) return launch_pp_raw<PP_RESLN>(h, a);
     return launch_pp_raw<PP_RES>(h, a);
@@ -399,16 +402,18 @@ int encode_dev(mv_handle* h, const int32_t* d_ids, const int32_t* d_lens, int B,
   const bool fuse = !full && h->ln_fuse && pp_selected(h, Mpad, MV_HIDDEN, MV_HIDDEN);
   // virtual LayerNorm (gemm_pp.h): no LayerNorm kernel between the GEMMs; x16 then holds the RAW stream in fp16
   const bool virt = fuse && h->ln_virtual;
+  const bool hilo = virt && h->res_hilo;  // raw stream as two fp16 planes (x16 = hi, xlo = lo); xres is then unused
   const unsigned ln_grid = (unsigned)((M + 3) / 4);
   {
     ProfScope ps(h, KC_EMBED_LN);
     if (virt)
       hipLaunchKernelGGL(embed_ln_kernel<true>, dim3(ln_grid), dim3(256), 0, h->w->stream, d_ids, pitch, S_in, Sp, (int)M, c.vocab_size,
-                         h->wemb, h->pemb, h->temb, h->embg, h->embb, c.ln_eps, h->w->xres, h->w->x16, h->w->lnstats);
+                         h->wemb, h->pemb, h->temb, h->embg, h->embb, c.ln_eps, h->w->xres, h->w->x16, h->w->lnstats,
+                         hilo ? h->w->xlo : (half_t*)nullptr);
     else
       hipLaunchKernelGGL(embed_ln_kernel<false>, dim3(ln_grid), dim3(256), 0, h->w->stream, d_ids, pitch, S_in, Sp, (int)M, c.vocab_size,
                          h->wemb, h->pemb, h->temb, h->embg, h->embb, c.ln_eps, h->w->xres, h->w->x16,
-                         fuse ? h->w->lnstats : (float*)nullptr);
+                         fuse ? h->w->lnstats : (float*)nullptr, (half_t*)nullptr);
     if (int rc = launch_check(h, "embed_ln")) return rc;
   }
   // LayerNorm whose statistics are pending in lnstats (fuse only): gamma / beta the next residual consumer applies
@@ -422,6 +427,11 @@ int encode_dev(mv_handle* h, const int32_t* d_ids, const int32_t* d_lens, int B,
     else
       hipLaunchKernelGGL(ln_kernel<true>, dim3(grid), dim3(256), 0, h->w->stream, x32, x16, rows, g, b, c.ln_eps, (float*)nullptr);
     return launch_check(h, "layernorm");
+  };
+  auto materialise_f32 = [&]() -> int {  // two-plane raw stream -> fp32 rows for the final LayerNorm kernel
+    const size_t n4 = (size_t)M * MV_HIDDEN / 4;
+    hipLaunchKernelGGL(hilo_to_f32_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, h->w->stream, h->w->x16, h->w->xlo, n4, h->w->xres);
+    return launch_check(h, "hilo_to_f32");
   };
   auto run_finalize = [&]() -> int {  // virt: partial row sums of the residual GEMM -> (mean, rstd)
     ProfScope ps(h, KC_LN);
@@ -449,7 +459,8 @@ int encode_dev(mv_handle* h, const int32_t* d_ids, const int32_t* d_lens, int B,
       h->prof_mask = 0;  // the tail is one profiled span; its inner launches carry no events of their own
       auto tail_rc = [&]() -> int {
         hipLaunchKernelGGL(cls_gather_kernel, dim3((B + 3) / 4), dim3(256), 0, h->w->stream, h->w->xres, h->w->x16, Sp, B,
-                           fuse ? h->w->lnstats : (const float*)nullptr, pend_g, pend_b, h->w->c32, h->w->c16, virt ? 1 : 0);
+                           fuse ? h->w->lnstats : (const float*)nullptr, pend_g, pend_b, h->w->c32, h->w->c16, virt ? 1 : 0,
+                           hilo ? h->w->xlo : (const half_t*)nullptr);
         if (int rc = launch_check(h, "cls_gather")) return rc;
         GemmArgs t{};
         t.M = Bp; t.Mreal = B; t.S = 64;
@@ -505,26 +516,27 @@ int encode_dev(mv_handle* h, const int32_t* d_ids, const int32_t* d_lens, int B,
       if (int rc = launch_check(h, "attention")) return rc;
     }
     // K4: attention output projection + bias + residual (in place), then LayerNorm
-    g.raw = 0; g.lnstats = nullptr; g.lnpart = nullptr;
+    g.raw = 0; g.lnstats = nullptr; g.lnpart = nullptr; g.out16b = nullptr;
     g.A = h->w->ctx; g.W = w.wo; g.bias = w.bo; g.N = MV_HIDDEN; g.K = MV_HIDDEN; g.xres = h->w->xres;
     if (fuse) { g.lnstats = h->w->lnstats; g.lng = pend_g; g.lnb = pend_b; }
-    if (virt) { g.lnpart = h->w->lnpart; g.out16 = h->w->x16; g.raw = h->r16_direct; }  // + the fp16 copy of the new raw stream and its partial row sums
+    if (virt) { g.lnpart = h->w->lnpart; g.out16 = h->w->x16; g.raw = h->r16_direct; g.out16b = hilo ? h->w->xlo : nullptr; }  // + fp16 operand copy / planes, partial row sums
     if (int rc = launch_gemm<EPI_RES>(h, KC_GEMM_OUT, g)) return rc;
     if (virt) { if (int rc = run_finalize()) return rc; }
     else if (int rc = run_ln(h->w->xres, h->w->x16, (int)M, w.ln1g, w.ln1b, fuse)) return rc;
     pend_g = w.ln1g; pend_b = w.ln1b;
     // K5: FFN-1 + exact-erf GELU
-    g.lnstats = nullptr; g.lnpart = nullptr; g.raw = 0;
+    g.lnstats = nullptr; g.lnpart = nullptr; g.raw = 0; g.out16b = nullptr;
     if (virt) { g.raw = 1; g.lnstats = h->w->lnstats; }
     g.A = h->w->x16; g.W = virt ? w.w1_f : w.w1; g.bias = virt ? w.b1_f : w.b1; g.N = MV_INTER; g.K = MV_HIDDEN; g.out16 = h->w->h16;
     if (int rc = launch_gemm<EPI_GELU>(h, KC_GEMM_FFN1, g)) return rc;
     // K6: FFN-2 + bias + residual, then LayerNorm
-    g.raw = 0; g.lnstats = nullptr;
+    g.raw = 0; g.lnstats = nullptr; g.out16b = nullptr;
     g.A = h->w->h16; g.W = w.w2; g.bias = w.b2; g.N = MV_HIDDEN; g.K = MV_INTER; g.xres = h->w->xres;
     if (fuse) { g.lnstats = h->w->lnstats; g.lng = pend_g; g.lnb = pend_b; }
-    if (virt) { g.lnpart = h->w->lnpart; g.out16 = h->w->x16; g.raw = h->r16_direct; }
+    if (virt) { g.lnpart = h->w->lnpart; g.out16 = h->w->x16; g.raw = h->r16_direct; g.out16b = hilo ? h->w->xlo : nullptr; }
     if (int rc = launch_gemm<EPI_RES>(h, KC_GEMM_FFN2, g)) return rc;
     if (virt && !last) { if (int rc = run_finalize()) return rc; }
+    else if (hilo && materialise_f32() != MV_OK) return MV_ERR_HIP;
     else if (int rc = run_ln(h->w->xres, h->w->x16, (int)M, w.ln2g, w.ln2b, fuse && !last)) return rc;  // the pooler reads a normalised stream
     pend_g = w.ln2g; pend_b = w.ln2b;
   }
@@ -694,6 +706,7 @@ int mv_create(int device, const mv_config* cfg, mv_handle** out) {
   hipFuncSetAttribute((const void*)gemm_pp_kernel<PP_RES, PP_DIST, 0, PP_SCHED, PP_COAL>, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS_BYTES);
   hipFuncSetAttribute((const void*)gemm_pp_kernel<PP_RESLN, PP_DIST, 0, PP_SCHED, PP_COAL>, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS_BYTES);
   hipFuncSetAttribute((const void*)gemm_pp_kernel<PP_RESLN2, PP_DIST, 0, PP_SCHED, PP_COAL>, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS_BYTES);
+  hipFuncSetAttribute((const void*)gemm_pp_kernel<PP_RESLN3, PP_DIST, 0, PP_SCHED, PP_COAL>, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS_BYTES);
   hipFuncSetAttribute((const void*)gemm_pp_kernel<PP_QK, PP_DIST, 0, PP_SCHED, PP_COAL, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS_BYTES_RAW);
   hipFuncSetAttribute((const void*)gemm_pp_kernel<PP_VT, PP_DIST, 0, PP_SCHED, PP_COAL, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS_BYTES_RAW);
   hipFuncSetAttribute((const void*)gemm_pp_kernel<PP_GELU, PP_DIST, 0, PP_SCHED, PP_COAL, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS_BYTES_RAW);
@@ -703,6 +716,7 @@ int mv_create(int device, const mv_config* cfg, mv_handle** out) {
   if (const char* e = getenv("MEMVUL_LN_FUSE")) h->ln_fuse = atoi(e) != 0;
   if (const char* e = getenv("MEMVUL_LN_VIRTUAL")) h->ln_virtual = atoi(e) != 0;
   if (const char* e = getenv("MEMVUL_R16_DIRECT")) h->r16_direct = atoi(e) != 0;
+  if (const char* e = getenv("MEMVUL_RES_HILO")) h->res_hilo = atoi(e) != 0;
   if (const char* e = getenv("MEMVUL_STAGGER")) h->pp_stagger = atoi(e);
   if (const char* e = getenv("MEMVUL_ATTN")) h->attn_v2 = atoi(e) != 0;
   hipFuncSetAttribute((const void*)attention_v2_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT2_LDS_BYTES(1));
@@ -738,6 +752,7 @@ int mv_create(int device, const mv_config* cfg, mv_handle** out) {
     A(dev_alloc(h, &h->w->h16, T * MV_INTER));
     A(dev_alloc(h, &h->w->lnstats, T * 2));
     A(dev_alloc(h, &h->w->lnpart, T * (MV_HIDDEN / 64) * 2));
+    A(dev_alloc(h, &h->w->xlo, T * MV_HIDDEN));
     A(dev_alloc(h, &h->w->c32, Bp * MV_HIDDEN));
     A(dev_alloc(h, &h->w->cq, Bp * MV_HIDDEN));
     A(dev_alloc(h, &h->w->c16, Bp * MV_HIDDEN));

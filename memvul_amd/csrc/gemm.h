@@ -40,7 +40,8 @@ struct GemmArgs {
   int N, K;
   int GN;             // raster group width in tiles (divides N / tile)
   float* outf;        // EPI_F32: [M][N]
-  half_t* out16;      // EPI_GELU: [M][N]
+  half_t* out16;      // EPI_GELU: [M][N]; PP_RESLN2 / 3: the fp16 operand copy (hi plane) of the raw stream
+  half_t* out16b;     // PP_RESLN3: the lo plane, fp16(r - hi)
   float* xres;        // EPI_RES: [M][N] residual stream, updated in place
   half_t* q;          // EPI_QKV: [B][12][S][64]  (W_q, b_q pre-scaled by 1/8)
   half_t* k;          //          [B][12][S][64]

@@ -42,7 +42,7 @@
 
 #include "gemm.h"
 
-enum { PP_F32 = 0, PP_QK = 1, PP_VT = 2, PP_GELU = 3, PP_RES = 4, PP_F16 = 5, PP_RESLN = 6, PP_RESLN2 = 7 };
+enum { PP_F32 = 0, PP_QK = 1, PP_VT = 2, PP_GELU = 3, PP_RES = 4, PP_F16 = 5, PP_RESLN = 6, PP_RESLN2 = 7, PP_RESLN3 = 8 };
 // PP_RESLN: PP_RES whose residual tile is the PRE-LayerNorm stream: the accumulators start from
 //   LN(x) + bias = fma((x - mean) * rstd, gamma, beta) + bias   (row statistics from ln_kernel<stats>),
 // the same IEEE operations ln_row_store performs, so the result equals PP_RES on a normalised stream bit for bit
@@ -56,6 +56,10 @@ enum { PP_F32 = 0, PP_QK = 1, PP_VT = 2, PP_GELU = 3, PP_RES = 4, PP_F16 = 5, PP
 // (PP_RESLN2 = PP_RESLN that ALSO writes the fp16 copy of the raw stream and, per row and 64-column wave slice, the
 // partial (sum, sum of squares)) replaces the LayerNorm kernel's second pass over the stream; ln_finalize_kernel
 // turns the N / 64 partials of a row into (mean, rstd) in a fixed order (deterministic).
+// PP_RESLN3 = PP_RESLN2 with the raw stream kept as TWO fp16 planes instead of fp32 + an fp16 copy:
+//   hi = fp16(r)  (exactly the operand the RAW consumers read),  lo = fp16(r - hi),  r ~= hi + lo to 2^-22 relative
+// (fp32 carries 2^-24).  The residual tile is read as hi + lo (same bytes as fp32) and written as hi, lo: 100 MB less
+// per launch than fp32 + fp16 copy at the bench shape, and no fp32 transposition pass in the epilogue.
 // timing ablations (wrong results by construction; cdna_hip_programming.md §5.4 rules 8/17)
 enum { PP_ABL_NODMA = 1, PP_ABL_NOMFMA = 2, PP_ABL_NOREAD = 4, PP_ABL_NOEPI = 8, PP_ABL_NOPRIO = 16, PP_ABL_NOSTAGGER = 32 };
 
@@ -132,6 +136,22 @@ __device__ __forceinline__ void scr_f16x2(uint32_t w0, uint32_t w1, uint32_t w2,
       : "memory");
 #endif
 }
+// The reverse direction for two fp16 planes of one 32 x 32 fragment: coalesced 16-byte pieces (rows lane >> 2 and + 16, chunk
+// lane & 3) are written into the image, the C/D-layout units (row lane & 31, columns 8 g + 4 hi .. + 3) are read back.
+__device__ __forceinline__ void scr_f16_rev2(uint32_t wc, const u32x4& a0, const u32x4& a1, const u32x4& b0, const u32x4& b1, uint32_t r0,
+                                             uint32_t r1, uint32_t r2, uint32_t r3, u32x2 (&oa)[4], u32x2 (&ob)[4]) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm volatile(
+      "ds_write_b128 %8, %9\n\tds_write_b128 %8, %10 offset:1024\n\t"
+      "ds_read_b64 %0, %13\n\tds_read_b64 %1, %14\n\tds_read_b64 %2, %15\n\tds_read_b64 %3, %16\n\t"
+      "ds_write_b128 %8, %11\n\tds_write_b128 %8, %12 offset:1024\n\t"
+      "ds_read_b64 %4, %13\n\tds_read_b64 %5, %14\n\tds_read_b64 %6, %15\n\tds_read_b64 %7, %16\n\ts_waitcnt lgkmcnt(0)"
+      : "=&v"(oa[0]), "=&v"(oa[1]), "=&v"(oa[2]), "=&v"(oa[3]), "=&v"(ob[0]), "=&v"(ob[1]), "=&v"(ob[2]), "=&v"(ob[3])
+      : "v"(wc), "v"(a0), "v"(a1), "v"(b0), "v"(b1), "v"(r0), "v"(r1), "v"(r2), "v"(r3)
+      : "memory");
+  __builtin_amdgcn_sched_barrier(0);
+#endif
+}
 // Four fp32 rounds (32 rows x 16 columns each) per statement: writes at (wa, wb), reads at (ra, rb).
 __device__ __forceinline__ void scr_f32x4(uint32_t wa, uint32_t wb, const u32x4 (&d)[8], uint32_t ra, uint32_t rb,
                                           u32x4 (&o)[8]) {
@@ -167,6 +187,17 @@ __device__ __forceinline__ void lds_read_bgb(uint32_t addr, float4 (&bi)[4], flo
 #endif
 }
 
+// One float4 of each of the three images (register-lean form of lds_read_bgb for PP_RESLN3).
+__device__ __forceinline__ void lds_read_bgb1(uint32_t addr, float4& bi, float4& ga, float4& be) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm volatile("ds_read_b128 %0, %3\n\tds_read_b128 %1, %3 offset:3072\n\tds_read_b128 %2, %3 offset:6144\n\ts_waitcnt lgkmcnt(0)"
+               : "=&v"(bi), "=&v"(ga), "=&v"(be)
+               : "v"(addr)
+               : "memory");
+  __builtin_amdgcn_sched_barrier(0);
+#endif
+}
+
 // SCHED 0: two barriers per phase, the M-halves one barrier apart (DIST = issue distance in phases, 2..6).
 // SCHED 1: ONE barrier per phase; the first M-half runs [MFMA(j), read fragments(j+1)] and the second
 //          [read fragments(j), MFMA(j)] inside the same barrier interval, so each SIMD's matrix pipe is handed from
@@ -180,7 +211,9 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmArgs a) {
   static_assert(!RAW || (COAL == 1 && (EPI == PP_QK || EPI == PP_VT || EPI == PP_GELU)), "RAW: the fp16-output kernels of the transposed path");
   static_assert(SCHED == 0 ? (DIST >= 2 && DIST <= 6) : (DIST >= 2 && DIST <= 4), "half-tile issue distance");
   constexpr bool SWAP = (EPI != PP_VT);
-  constexpr bool IS_RESLN = (EPI == PP_RESLN || EPI == PP_RESLN2);
+  constexpr bool IS_RESLN = (EPI == PP_RESLN || EPI == PP_RESLN2 || EPI == PP_RESLN3);
+  constexpr bool HILO = (EPI == PP_RESLN3);        // raw stream as two fp16 planes
+  constexpr bool EMITS = (EPI == PP_RESLN2 || EPI == PP_RESLN3);  // partial row sums + fp16 operand for the RAW consumers
   constexpr bool IS_RES = (EPI == PP_RES || IS_RESLN);
   static_assert(!IS_RESLN || COAL == 1, "the LayerNorm-fused residual init is written for the transposed (COAL) path");
   constexpr int WAITN = SCHED == 0 ? 2 * (DIST - 1) : 2 * DIST;
@@ -483,6 +516,53 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmArgs a) {
 #pragma unroll
           for (int i = 0; i < 4; ++i) lnst[i] = *(const float2*)(a.lnstats + 2 * (size_t)(mw + i * 32 + l31));
         }
+        if constexpr (HILO) {
+          // the two fp16 planes of the raw stream by full-line loads (16 rows x 64 B per instruction), parked in the
+          // accumulator registers: [i][j] registers 0-3 / 4-7 = hi rows crow / crow + 16, 8-11 / 12-15 = lo
+          const int crow = lane >> 2, cchunk = lane & 3;
+          const uint32_t wbase = scr + l31 * 64 + hi * 8 + (sf << 4);
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+              for (int pl = 0; pl < 2; ++pl)
+#pragma unroll
+                for (int x = 0; x < 2; ++x) {
+                  const half_t* src = (pl ? a.out16b : a.out16) + (size_t)(mw + i * 32 + x * 16 + crow) * MV_HIDDEN + nw + j * 32 + 8 * cchunk;
+                  const float4 t = *(const float4*)src;
+                  acc[i][j][8 * pl + 4 * x + 0] = t.x; acc[i][j][8 * pl + 4 * x + 1] = t.y;
+                  acc[i][j][8 * pl + 4 * x + 2] = t.z; acc[i][j][8 * pl + 4 * x + 3] = t.w;
+                }
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+#pragma clang fp contract(off)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+              u32x4 p[4];
+#pragma unroll
+              for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) p[q][e] = f2u(acc[i][j][4 * q + e]);
+              u32x2 oh[4], ol[4];
+              scr_f16_rev2(scr_c, p[0], p[1], p[2], p[3], wbase, wbase ^ 16u, wbase ^ 32u, wbase ^ 48u, oh, ol);
+#pragma unroll
+              for (int g = 0; g < 4; ++g) {
+                float4 bi, ga, be;
+                lds_read_bgb1(baddr + j * 128 + g * 32, bi, ga, be);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                  const uint32_t wh = oh[g][e >> 1], wl = ol[g][e >> 1];  // scalar copies before the bit casts (see f2u)
+                  const half2_t h2 = __builtin_bit_cast(half2_t, wh);
+                  const half2_t l2 = __builtin_bit_cast(half2_t, wl);
+                  const float r = (float)h2[e & 1] + (float)l2[e & 1];
+                  const float t = (r - lnst[i].x) * lnst[i].y;
+                  acc[i][j][4 * g + e] = __builtin_fmaf(t, ((const float*)&ga)[e], ((const float*)&be)[e]) + ((const float*)&bi)[e];
+                }
+              }
+            }
+          }
+        } else {
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -525,6 +605,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmArgs a) {
             for (int e = 0; e < 4; ++e) acc[i][q >> 2][4 * (q & 3) + e] = u2f(o[q][e]) + ((const float*)&bv[q >> 2][q & 3])[e];
           }
         }
+        }  // !HILO
       } else {
 #pragma unroll
       for (int j = 0; j < 2; ++j)
@@ -599,7 +680,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmArgs a) {
       const uint32_t sf = (uint32_t)((l31 >> 2) & 3);
       const uint32_t scr_c = scr + (lane >> 2) * 64 + ((((uint32_t)lane & 3) ^ (((uint32_t)lane >> 4) & 3)) << 4);
       const int crow = lane >> 2, cchunk = lane & 3;  // coalesced layout: row (+16 for the second read), 16-B chunk
-      if constexpr (EPI == PP_RESLN2) {
+      if constexpr (EMITS) {
         // per-row partial LayerNorm statistics of this wave's 64 columns: lane = token row, the two half-waves hold
         // disjoint column sets; slot nw / 64 of the row's N / 64 partials (ln_finalize_kernel adds them in order)
         const int np = a.N >> 6;
@@ -622,7 +703,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmArgs a) {
           if (hi == 0) *(float2*)(a.lnpart + ((size_t)(mw + i * 32 + l31) * np + (nw >> 6)) * 2) = st;
         }
       }
-      if constexpr (EPI == PP_F32 || IS_RES) {
+      if constexpr ((EPI == PP_F32 || IS_RES) && !HILO) {
         const uint32_t scr_m32 = scr + l31 * 64 + (((uint32_t)hi ^ sf) << 4);
         float* obase = (IS_RES ? a.xres : a.outf) + (size_t)(mw + crow) * a.N + nw + 4 * cchunk;
 #pragma unroll
@@ -649,7 +730,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmArgs a) {
           }
         }
       }
-      if constexpr (!(EPI == PP_F32 || IS_RES) || EPI == PP_RESLN2)
+      if constexpr (!(EPI == PP_F32 || IS_RES) || EMITS)
       if (EPI != PP_RESLN2 || !a.raw) {
         // fp16 outputs: 8-B units (4 values) of the C/D layout -> chunk g, half hi of the row
         // (PP_RESLN2: the fp16 copy of the raw stream, the A operand of the next RAW consumer)
@@ -659,7 +740,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmArgs a) {
         size_t istride;   // elements between i blocks (32 C/D rows along the register axis or the lane axis)
         size_t jstride;   // elements between j blocks
         bool live = true;
-        if constexpr (EPI == PP_F16 || EPI == PP_GELU || EPI == PP_RESLN2) {
+        if constexpr (EPI == PP_F16 || EPI == PP_GELU || EMITS) {
           obase = a.out16 + (size_t)(mw + crow) * a.N + nw + 8 * cchunk;
           rstride = a.N; istride = (size_t)32 * a.N; jstride = 32;
         } else if constexpr (EPI == PP_QK) {  // one head per wave; S % 64 == 0 so a 128-row block may span two batch rows
@@ -755,6 +836,24 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmArgs a) {
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
               half_t* op = ob + j * jstride;
+              *(u32x4*)op = o[2 * j];
+              *(u32x4*)(op + 16 * rstride) = o[2 * j + 1];
+            }
+          }
+          if constexpr (HILO) {  // second plane: lo = fp16(r - hi), same addresses in the lo buffer
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+              for (int g = 0; g < 4; ++g) {
+                const float v0 = acc[i][j][4 * g + 0], v1 = acc[i][j][4 * g + 1], v2 = acc[i][j][4 * g + 2], v3 = acc[i][j][4 * g + 3];
+                d[j][g][0] = pack_h2(v0 - (float)(half_t)v0, v1 - (float)(half_t)v1);
+                d[j][g][1] = pack_h2(v2 - (float)(half_t)v2, v3 - (float)(half_t)v3);
+              }
+            scr_f16x2(wbase, wbase ^ 16u, wbase ^ 32u, wbase ^ 48u, d[0], d[1], scr_c, o);
+            half_t* ol = ob + (a.out16b - a.out16);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+              half_t* op = ol + j * jstride;
               *(u32x4*)op = o[2 * j];
               *(u32x4*)(op + 16 * rstride) = o[2 * j + 1];
             }

@@ -66,7 +66,7 @@ __global__ __launch_bounds__(256) void embed_ln_kernel(const int32_t* __restrict
                                                        const float* __restrict__ pemb, const float* __restrict__ temb,
                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
                                                        float eps, float* __restrict__ x32, half_t* __restrict__ x16,
-                                                       float* __restrict__ stats) {
+                                                       float* __restrict__ stats, half_t* __restrict__ xlo) {
   const int lane = threadIdx.x & 63;
   const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (t >= n_tok) return;
@@ -103,10 +103,17 @@ __global__ __launch_bounds__(256) void embed_ln_kernel(const int32_t* __restrict
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
       const int c = 4 * lane + 256 * i;
-      *(float4*)(x32 + (size_t)t * MV_HIDDEN + c) = x[i];
       half4_t h;
       h[0] = (half_t)x[i].x; h[1] = (half_t)x[i].y; h[2] = (half_t)x[i].z; h[3] = (half_t)x[i].w;
       *(half4_t*)(x16 + (size_t)t * MV_HIDDEN + c) = h;
+      if (xlo) {  // two-plane raw stream (gemm_pp PP_RESLN3): lo = fp16(x - hi) instead of the fp32 row
+        half4_t l;
+        l[0] = (half_t)(x[i].x - (float)h[0]); l[1] = (half_t)(x[i].y - (float)h[1]);
+        l[2] = (half_t)(x[i].z - (float)h[2]); l[3] = (half_t)(x[i].w - (float)h[3]);
+        *(half4_t*)(xlo + (size_t)t * MV_HIDDEN + c) = l;
+      } else {
+        *(float4*)(x32 + (size_t)t * MV_HIDDEN + c) = x[i];
+      }
     }
   } else {
     ln_row_store<true>(x, gamma, beta, eps, lane, x32 + (size_t)t * MV_HIDDEN, x16 + (size_t)t * MV_HIDDEN, nullptr);
@@ -159,13 +166,25 @@ __global__ __launch_bounds__(256) void ln_kernel(float* __restrict__ x32, half_t
   ln_row_store<W32>(x, gamma, beta, eps, lane, row, x16 + (size_t)t * MV_HIDDEN, W32 ? nullptr : stats + 2 * (size_t)t);
 }
 
+// Two-plane raw stream -> fp32 rows (only the un-pruned last layer needs them: its final LayerNorm kernel reads fp32).
+__global__ __launch_bounds__(256) void hilo_to_f32_kernel(const half_t* __restrict__ hi, const half_t* __restrict__ lo, size_t n4,
+                                                          float* __restrict__ out) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n4) return;
+  const half4_t h = *(const half4_t*)(hi + 4 * i), l = *(const half4_t*)(lo + 4 * i);
+  float4 y;
+  y.x = (float)h[0] + (float)l[0]; y.y = (float)h[1] + (float)l[1]; y.z = (float)h[2] + (float)l[2]; y.w = (float)h[3] + (float)l[3];
+  *(float4*)(out + 4 * i) = y;
+}
+
 // Last-layer pruning (only token 0 of each issue report reaches the pooler, model_memory.py:99): gather the
 // [CLS] rows of the fp32 stream and of the fp16 GEMM operand into compact [B][768] buffers.  With `stats` the
 // stream holds raw (pre-LN) rows and is normalised here (same operations as ln_row_store).
 __global__ __launch_bounds__(256) void cls_gather_kernel(const float* __restrict__ x32, const half_t* __restrict__ x16, int Sp,
                                                          int B, const float* __restrict__ stats,
                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                         float* __restrict__ c32, half_t* __restrict__ c16, int raw16) {
+                                                         float* __restrict__ c32, half_t* __restrict__ c16, int raw16,
+                                                         const half_t* __restrict__ xlo) {
 #pragma clang fp contract(off)
   const int lane = threadIdx.x & 63;
   const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -176,7 +195,14 @@ __global__ __launch_bounds__(256) void cls_gather_kernel(const float* __restrict
 #pragma unroll
   for (int i = 0; i < 3; ++i) {
     const int c = 4 * lane + 256 * i;
-    float4 y = *(const float4*)(x32 + t * MV_HIDDEN + c);
+    float4 y;
+    if (xlo) {  // two-plane raw stream: r = hi + lo
+      const half4_t hh = *(const half4_t*)(x16 + t * MV_HIDDEN + c), ll = *(const half4_t*)(xlo + t * MV_HIDDEN + c);
+      y.x = (float)hh[0] + (float)ll[0]; y.y = (float)hh[1] + (float)ll[1];
+      y.z = (float)hh[2] + (float)ll[2]; y.w = (float)hh[3] + (float)ll[3];
+    } else {
+      y = *(const float4*)(x32 + t * MV_HIDDEN + c);
+    }
     if (stats) {
       const float4 g = *(const float4*)(gamma + c);
       const float4 bb = *(const float4*)(beta + c);

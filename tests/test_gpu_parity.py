@@ -187,10 +187,11 @@ def test_layernorm_folded_into_residual_read_is_bit_identical(gu, prune):
     assert np.array_equal(u_f, u_n)
 
 
+@pytest.mark.parametrize("hilo", ["1", "0"])
 @pytest.mark.parametrize("outliers", [False, True])
 @pytest.mark.parametrize("prune", ["0", "1"])
 @pytest.mark.parametrize("B,S", [(6, 128), (3, 256), (5, 200)])
-def test_virtual_layernorm_matches_explicit_layernorm(gu, B, S, prune, outliers):
+def test_virtual_layernorm_matches_explicit_layernorm(gu, B, S, prune, outliers, hilo):
     """MEMVUL_LN_VIRTUAL (default on the persistent-GEMM path): no LayerNorm kernel between the GEMMs — the consumer
     GEMMs read the raw stream in fp16 with gamma / beta / the row mean folded into their weights and scale rows by
     rstd in the epilogue (W LN(r) + b = rstd (W'' r) + b'), the residual GEMMs emit the fp16 copy and the partial row
@@ -199,11 +200,12 @@ def test_virtual_layernorm_matches_explicit_layernorm(gu, B, S, prune, outliers)
     dk, wk = dict(layers=4, vocab_size=2048), dict(qk_scale=2.0, ln_outliers=outliers)
     dims, w = gu.weights_for(dk, wk)
     ids, lens = synth.make_ids(B, S, dims.vocab_size, ragged=True, min_len=9)
-    u_v = gu.engine_for(dk, wk, gemm_tile=512, env={"MEMVUL_CLS_PRUNE": prune}).encode(ids, lens)
+    # hilo 1 (default): the raw stream lives as two fp16 planes hi + lo (PP_RESLN3); 0: fp32 + fp16 copy (PP_RESLN2)
+    u_v = gu.engine_for(dk, wk, gemm_tile=512, env={"MEMVUL_CLS_PRUNE": prune, "MEMVUL_RES_HILO": hilo}).encode(ids, lens)
     u_e = gu.engine_for(dk, wk, gemm_tile=512, env={"MEMVUL_CLS_PRUNE": prune, "MEMVUL_LN_VIRTUAL": "0"}).encode(ids, lens)
     u_ref = orc.instance_forward(w, ids.astype(np.int64), synth.mask_from_lens(lens, S))
     ev, ee = float(np.abs(u_v - u_ref).max()), float(np.abs(u_e - u_ref).max())
-    gu.record("virtual_ln", B=B, S=S, prune=prune, outliers=outliers, virtual_vs_oracle=ev, explicit_vs_oracle=ee,
+    gu.record("virtual_ln", B=B, S=S, prune=prune, outliers=outliers, hilo=hilo, virtual_vs_oracle=ev, explicit_vs_oracle=ee,
               virtual_vs_explicit=float(np.abs(u_v - u_e).max()), u_scale=float(np.abs(u_ref).max()))
     assert ev < 2e-3 and ev < 3 * ee + 2e-4
 
