@@ -39,6 +39,7 @@ PY
 note "A/B benches"
 bench default MEMVUL_X=1
 bench attn_v1 MEMVUL_ATTN=0
+bench res_f32 MEMVUL_RES_HILO=0
 bench ln_explicit MEMVUL_LN_VIRTUAL=0
 bench no_lnfuse MEMVUL_LN_FUSE=0
 bench no_prune MEMVUL_CLS_PRUNE=0
