@@ -27,6 +27,7 @@ struct AttnArgs {
   half_t* ctx;          // [B*S][768]
   int S;                // padded length, multiple of 64, <= 512
   int B;
+  unsigned long long* clk;  // optional (development probe, tools/attn_probe.hip): per-workgroup s_memtime ticks [total, waiting at the hand-over]
 };
 
 #define ATT_KROW 144                         // bytes per K row in LDS (128 + 16 pad)

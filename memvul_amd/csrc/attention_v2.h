@@ -30,7 +30,8 @@
 #define ATT2_BUF_BYTES(NKB) ((NKB) * 16384)
 #define ATT2_LDS_BYTES(NKB) (2 * ATT2_BUF_BYTES(NKB))
 
-template <int NKB, int NCH = 1>  // chunk = 64 NKB keys = 2 NKB waves x 32 queries; padded length S = 64 NKB NCH
+// ABL (tools/attn_probe.hip only; wrong results): 1 = v_exp_f32 replaced by a move, 2 = no MFMA in QK^T / PV, 3 = both
+template <int NKB, int NCH = 1, int ABL = 0>  // chunk = 64 NKB keys = 2 NKB waves x 32 queries; padded length S = 64 NKB NCH
 __global__ __launch_bounds__(NKB * 128) __attribute__((amdgpu_waves_per_eu(2, 2))) void attention_v2_kernel(AttnArgs a, int nunits) {
   constexpr int S = NKB * 64;        // keys per chunk = queries per unit
   constexpr int ST = S * NCH;        // padded sequence length (row pitch of V^T, rows per head of Q / K)
@@ -119,6 +120,8 @@ __global__ __launch_bounds__(NKB * 128) __attribute__((amdgpu_waves_per_eu(2, 2)
 
   int pb = 0, prev = -1, len = 0;
   floatx16 o[2];
+  const unsigned long long clk0 = a.clk ? __builtin_amdgcn_s_memtime() : 0ull;
+  unsigned long long clk_wait = 0ull, clk_vm = 0ull;
   float m_run = 0.f, l_run = 0.f;  // NCH > 1: running row maximum / this lane's share of the running row sum
   for (int unit = first; unit < nunits; unit += stride) {
     const int nxt = unit + stride;
@@ -127,11 +130,14 @@ __global__ __launch_bounds__(NKB * 128) __attribute__((amdgpu_waves_per_eu(2, 2)
       char* kb = smem + pb * BUF;
       // ---- hand-over: this chunk's K / V^T (and, for j = 0, Q) have landed for every wave, and every wave has left
       // the other ring half (its last reads were the previous chunk's PV)
+      const unsigned long long tw0 = a.clk ? __builtin_amdgcn_s_memtime() : 0ull;
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __builtin_amdgcn_sched_barrier(0);
+      if (a.clk) clk_vm += __builtin_amdgcn_s_memtime() - tw0;
       __builtin_amdgcn_s_barrier();
       __builtin_amdgcn_sched_barrier(0);
       asm volatile("" ::: "memory");
+      if (a.clk) clk_wait += __builtin_amdgcn_s_memtime() - tw0;
       if (j == 0) {
         // the prefetched registers are consumed HERE (hipcc would otherwise put its own `s_waitcnt vmcnt(0)` in front
         // of their first use, i.e. after the next chunk's DMA has been issued, and drain it)
@@ -170,7 +176,10 @@ __global__ __launch_bounds__(NKB * 128) __attribute__((amdgpu_waves_per_eu(2, 2)
 #pragma unroll
           for (int r = 0; r < 16; ++r) st[t][r] = 0.f;
 #pragma unroll
-          for (int kk = 0; kk < 4; ++kk) st[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[t & 1][kk], qf[kk], st[t], 0, 0, 0);
+          for (int kk = 0; kk < 4; ++kk) {
+            if (ABL & 2) st[t][kk] += (float)kf[t & 1][kk][0] * (float)qf[kk][0];
+            else st[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[t & 1][kk], qf[kk], st[t], 0, 0, 0);
+          }
         }
         __builtin_amdgcn_sched_barrier(0);
       }
@@ -208,7 +217,8 @@ __global__ __launch_bounds__(NKB * 128) __attribute__((amdgpu_waves_per_eu(2, 2)
       for (int t = 0; t < NT; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(st[t][r], LOG2E, nm));
+          const float e = __builtin_fmaf(st[t][r], LOG2E, nm);
+          const float p = (ABL & 1) ? e : __builtin_amdgcn_exp2f(e);
           ps4[r & 3] += p;
           pf[t][r >> 3][r & 7] = (half_t)p;
         }
@@ -252,7 +262,8 @@ __global__ __launch_bounds__(NKB * 128) __attribute__((amdgpu_waves_per_eu(2, 2)
           for (int u = 0; u < 2; ++u)
 #pragma unroll
             for (int dt = 0; dt < 2; ++dt)
-              o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[t & 1][2 * dt + u], pf[t][u], o[dt], 0, 0, 0);
+              if (ABL & 2) o[dt][u] += (float)vf[t & 1][2 * dt + u][0] * (float)pf[t][u][0];
+              else o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[t & 1][2 * dt + u], pf[t][u], o[dt], 0, 0, 0);
         }
         __builtin_amdgcn_sched_barrier(0);
       }
@@ -273,4 +284,10 @@ __global__ __launch_bounds__(NKB * 128) __attribute__((amdgpu_waves_per_eu(2, 2)
   // ---- last unit's O: the K half of the slot no DMA was issued into (nothing reads it any more)
   flush_o(prev, smem + pb * BUF);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // no LDS-DMA may outlive the workgroup's LDS allocation
+  if (a.clk && lane == 0) {
+    unsigned long long* c = a.clk + (size_t)(blockIdx.x * 8 + wave) * 3;
+    c[0] = __builtin_amdgcn_s_memtime() - clk0;
+    c[1] = clk_wait;
+    c[2] = clk_vm;
+  }
 }

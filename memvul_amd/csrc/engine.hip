@@ -487,7 +487,7 @@ int encode_dev(mv_handle* h, const int32_t* d_ids, const int32_t* d_lens, int B,
     if (int rc = launch_gemm<EPI_QKV>(h, KC_GEMM_QKV, g)) return rc;
     // K3: attention
     {
-      AttnArgs a{h->w->q, h->w->k, h->w->vt, d_lens, h->w->ctx, Sp, B};
+      AttnArgs a{h->w->q, h->w->k, h->w->vt, d_lens, h->w->ctx, Sp, B, nullptr};
       ProfScope ps(h, KC_ATTENTION);
       if (h->attn_v2 && Sp <= 256) {
         const int nkb = Sp / 64, items = B * MV_HEADS;
