@@ -30,7 +30,8 @@
 #define ATT2_BUF_BYTES(NKB) ((NKB) * 16384)
 #define ATT2_LDS_BYTES(NKB) (2 * ATT2_BUF_BYTES(NKB))
 
-// ABL (tools/attn_probe.hip only; wrong results): 1 = v_exp_f32 replaced by a move, 2 = no MFMA in QK^T / PV, 3 = both
+// ABL (tools/attn_probe.hip only; wrong results), bit mask: 1 = v_exp_f32 replaced by a move, 2 = no MFMA in QK^T / PV,
+// 4 = K / V^T fragments not read from LDS (the DMA into LDS still runs)
 template <int NKB, int NCH = 1, int ABL = 0>  // chunk = 64 NKB keys = 2 NKB waves x 32 queries; padded length S = 64 NKB NCH
 __global__ __launch_bounds__(NKB * 128) __attribute__((amdgpu_waves_per_eu(2, 2))) void attention_v2_kernel(AttnArgs a, int nunits) {
   constexpr int S = NKB * 64;        // keys per chunk = queries per unit
@@ -170,7 +171,10 @@ __global__ __launch_bounds__(NKB * 128) __attribute__((amdgpu_waves_per_eu(2, 2)
           __builtin_amdgcn_sched_barrier(0);
           if (t + 1 < NT) {
 #pragma unroll
-            for (int kk = 0; kk < 4; ++kk) kf[(t + 1) & 1][kk] = *(const half8_t*)(kb + (t + 1) * 4096 + koff[kk]);
+            for (int kk = 0; kk < 4; ++kk) {
+              if (ABL & 4) kf[(t + 1) & 1][kk] = qf[(kk + t) & 3];
+              else kf[(t + 1) & 1][kk] = *(const half8_t*)(kb + (t + 1) * 4096 + koff[kk]);
+            }
           }
           __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -250,7 +254,8 @@ __global__ __launch_bounds__(NKB * 128) __attribute__((amdgpu_waves_per_eu(2, 2)
           for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
             for (int u = 0; u < 2; ++u)
-              dstf[2 * dt + u] = *(const half8_t*)(kb + VOFF + (t >> 1) * 8192 + dt * 4096 + voff[2 * (t & 1) + u]);
+              if (ABL & 4) dstf[2 * dt + u] = pf[(t + dt) % NT][u];
+              else dstf[2 * dt + u] = *(const half8_t*)(kb + VOFF + (t >> 1) * 8192 + dt * 4096 + voff[2 * (t & 1) + u]);
         };
         read_v(0, vf[0]);
 #pragma unroll

@@ -78,5 +78,21 @@ int main() {
   if (time_abl(attention_v2_kernel<4, 1, 1>, "no v_exp_f32:")) return 2;
   if (time_abl(attention_v2_kernel<4, 1, 2>, "no MFMA:")) return 2;
   if (time_abl(attention_v2_kernel<4, 1, 3>, "no v_exp_f32, no MFMA:")) return 2;
+  if (time_abl(attention_v2_kernel<4, 1, 4>, "no LDS fragment reads:")) return 2;
+  if (time_abl(attention_v2_kernel<4, 1, 7>, "none of the three:")) return 2;
+  // working set vs the 256 MB Infinity Cache: back-to-back launches over the first Bs batch rows re-read the same
+  // Q / K / V^T (0.29 MB per row and head in, 0.1 MB out), which only stay cached when they fit
+  for (int Bs : {256, 192, 128, 64}) {
+    AttnArgs a{q, k, vt, lens, ctx, S, Bs, nullptr};
+    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL((attention_v2_kernel<4>), dim3(256), dim3(512), ATT2_LDS_BYTES(4), 0, a, Bs * 12);
+    CK(hipEventRecord(e0, 0));
+    for (int i = 0; i < 10; ++i) hipLaunchKernelGGL((attention_v2_kernel<4>), dim3(256), dim3(512), ATT2_LDS_BYTES(4), 0, a, Bs * 12);
+    CK(hipEventRecord(e1, 0));
+    CK(hipEventSynchronize(e1));
+    float ms;
+    CK(hipEventElapsedTime(&ms, e0, e1));
+    const double mb = Bs * 12 * 4.0 * 32768 / 1e6;
+    printf("attention_v2<4> B=%3d (%.0f MB touched per launch): %.1f us per launch = %.2f TB/s\n", Bs, mb, ms * 100.0f, mb / (ms * 100.0f));
+  }
   return 0;
 }
