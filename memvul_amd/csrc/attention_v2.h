@@ -55,9 +55,24 @@ __global__ __launch_bounds__(NKB * 128) __attribute__((amdgpu_waves_per_eu(2, 2)
       srcV[x] = (uint32_t)(rl * (2 * ST) + c * 16);
     }
   }
-  // unit u = (bh, qb): head bh = u / NCH, query block qb = u % NCH; chunk j of its keys = keys j S .. j S + S - 1
+  // work-list position u -> unit (bh, qb): head bh, query block qb; chunk j of its keys = keys j S .. j S + S - 1.
+  // NCH > 1: the NCH query blocks of a head read the same K / V^T, so they are placed 8 list positions apart — the
+  // workgroups that hold them at the same time are 8 apart too, i.e. on the same XCD (round-robin dispatch), and the
+  // second reader finds the chunk in that XCD's L2.  Positions are permuted inside groups of 8 NCH; a tail shorter
+  // than a group keeps the plain order.
+  const int nfull = nunits - nunits % (8 * NCH);
+  auto unit_bh = [&](int u) -> int {
+    if (NCH == 1 || u >= nfull) return u / NCH;
+    const int g = u / (8 * NCH), r = u - g * (8 * NCH);
+    return 8 * g + (r & 7);
+  };
+  auto unit_qb = [&](int u) -> int {
+    if (NCH == 1) return 0;
+    if (u >= nfull) return u % NCH;
+    return (u % (8 * NCH)) >> 3;
+  };
   auto issue_chunk = [&](int u, int j, int pb) {
-    const int bh = u / NCH;
+    const int bh = unit_bh(u);
     const char* kg = (const char*)(a.k + ((size_t)bh * ST + (size_t)j * S) * MV_HEAD_DIM);
     const char* vg = (const char*)(a.vt + (size_t)bh * MV_HEAD_DIM * ST + (size_t)j * S);
     char* kb = smem + pb * BUF;
@@ -73,7 +88,7 @@ __global__ __launch_bounds__(NKB * 128) __attribute__((amdgpu_waves_per_eu(2, 2)
     }
   };
   auto load_q = [&](int u, half8_t (&qf)[4]) {  // B operand of S^T = K Q^T: lane holds Q[qb S + 32 wave + ql][16 kk + 8 hi ..+7]
-    const int bh = u / NCH, qb = u - bh * NCH;
+    const int bh = unit_bh(u), qb = unit_qb(u);
     const half_t* gq = a.q + ((size_t)bh * ST + qb * S + 32 * wave + ql) * MV_HEAD_DIM + hi * 8;
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) qf[kk] = *(const half8_t*)(gq + kk * 16);
@@ -96,7 +111,7 @@ __global__ __launch_bounds__(NKB * 128) __attribute__((amdgpu_waves_per_eu(2, 2)
   half8_t qf[4], qn[4];
   issue_chunk(first, 0, 0);
   load_q(first, qn);
-  int len_n = a.lens[first / (NCH * MV_HEADS)];  // prefetched like Q: a VGPR-destination load must never be waited for mid-unit
+  int len_n = a.lens[unit_bh(first) / MV_HEADS];  // prefetched like Q: a VGPR-destination load must never be waited for mid-unit
 
   uint32_t opk[2][4][2];  // normalised O^T of the previous unit, fp16 pairs: [dt][rg] = dims 32 dt + 8 rg + 4 hi ..+3
   auto flush_o = [&](int u, char* kb) {
@@ -109,7 +124,7 @@ __global__ __launch_bounds__(NKB * 128) __attribute__((amdgpu_waves_per_eu(2, 2)
         v[0] = opk[dt][rg][0]; v[1] = opk[dt][rg][1];
         *(u32x2*)(kb + (o_wr ^ (uint32_t)(((4 * dt + rg) ^ (ql & 7)) << 4))) = v;
       }
-    const int bh = u / NCH, qb = u - bh * NCH;
+    const int bh = unit_bh(u), qb = unit_qb(u);
     const int b = bh / MV_HEADS, h = bh - b * MV_HEADS;
     half_t* dst = a.ctx + ((size_t)b * ST + qb * S + 32 * wave + (lane >> 3)) * MV_HIDDEN + h * MV_HEAD_DIM + 8 * (lane & 7);
     u32x4 v[4];
@@ -233,7 +248,7 @@ __global__ __launch_bounds__(NKB * 128) __attribute__((amdgpu_waves_per_eu(2, 2)
       // next unit's Q fragments: issued in the unit's last chunk (the score registers are dead), they land under its PV phase
       if (j == NCH - 1 && nxt < nunits) {
         load_q(nxt, qn);
-        len_n = a.lens[nxt / (NCH * MV_HEADS)];
+        len_n = a.lens[unit_bh(nxt) / MV_HEADS];
       }
       // ---- O^T[d][q] (+)= V^T[d][keys] P^T[keys][q]
       if (j == 0) {

@@ -125,3 +125,25 @@ def test_attention_v2_index_algebra(NKB, length):
     p = np.exp(s - s.max(axis=1, keepdims=True))
     ref = (p / p.sum(axis=1, keepdims=True)) @ V
     assert np.abs(got - ref).max() < 6e-3  # fp16 rounding of P and of the stored context
+
+
+@pytest.mark.parametrize("nch", [2, 3, 4])
+@pytest.mark.parametrize("heads_total", [12, 36, 60, 128 * 12, 7 * 12])
+def test_chunked_work_list_is_a_permutation_that_co_locates_query_blocks(nch, heads_total):
+    """attention_v2_kernel<., NCH > 1>: list position -> (head, query block).  Every unit exactly once; inside full
+    groups of 8 NCH positions the NCH query blocks of a head are 8 positions apart (same XCD under round-robin dispatch)."""
+    nunits = heads_total * nch
+    nfull = nunits - nunits % (8 * nch)
+
+    def unit(u):
+        if u >= nfull:
+            return u // nch, u % nch
+        g, r = divmod(u, 8 * nch)
+        return 8 * g + (r & 7), r >> 3
+
+    seen = {unit(u) for u in range(nunits)}
+    assert len(seen) == nunits and seen == {(bh, qb) for bh in range(heads_total) for qb in range(nch)}
+    for u in range(0, nfull - 8):
+        bh, qb = unit(u)
+        if qb + 1 < nch:
+            assert unit(u + 8) == (bh, qb + 1)
