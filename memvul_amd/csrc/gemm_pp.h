@@ -61,7 +61,8 @@ enum { PP_F32 = 0, PP_QK = 1, PP_VT = 2, PP_GELU = 3, PP_RES = 4, PP_F16 = 5, PP
 // (fp32 carries 2^-24).  The residual tile is read as hi + lo (same bytes as fp32) and written as hi, lo: 100 MB less
 // per launch than fp32 + fp16 copy at the bench shape, and no fp32 transposition pass in the epilogue.
 // timing ablations (wrong results by construction; cdna_hip_programming.md §5.4 rules 8/17)
-enum { PP_ABL_NODMA = 1, PP_ABL_NOMFMA = 2, PP_ABL_NOREAD = 4, PP_ABL_NOEPI = 8, PP_ABL_NOPRIO = 16, PP_ABL_NOSTAGGER = 32 };
+enum { PP_ABL_NODMA = 1, PP_ABL_NOMFMA = 2, PP_ABL_NOREAD = 4, PP_ABL_NOEPI = 8, PP_ABL_NOPRIO = 16, PP_ABL_NOSTAGGER = 32,
+       PP_ABL_CLK = 64 };  // CLK (tools/gemm_bench.hip): per-wave s_memtime sums of accumulator init / main loop / epilogue -> a.clk[(wg 8 + wave) 4 ..]
 
 #define PP_LDS_A 0           // [par][a][wr][64 rows][128 B]
 #define PP_LDS_B 65536       // [par][b][wc][32 rows][128 B]
@@ -480,10 +481,13 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmArgs a) {
     __builtin_amdgcn_sched_barrier(0);
   }
 
+  unsigned long long c_init = 0ull, c_main = 0ull, c_epi = 0ull;
   auto run_tiles = [&](auto grpc) {
   for (int it = 0;; ++it) {
     const int L = it * G + bslot;
     if (L >= ntiles) break;
+    unsigned long long tA = 0ull, tB = 0ull, tC = 0ull;
+    if constexpr (ABL & PP_ABL_CLK) tA = __builtin_amdgcn_s_memtime();
     int tile_m, tile_n;
     raster(L, tm_count, tn_count, a.GN, tile_m, tile_n);
     const int mw = (tile_m << 8) + wr * 128;  // first token row of this wave
@@ -642,6 +646,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmArgs a) {
         }
     }
 
+    if constexpr (ABL & PP_ABL_CLK) tB = __builtin_amdgcn_s_memtime();
     if constexpr (SCHED == 1 && decltype(grpc)::value == 0) read_set(std::integral_constant<int, 0>{});
     for (int kt = 0; kt < nk; kt += 2) {
       if constexpr (RAW) {  // every wave has left the previous tile's epilogue (>= 8 barriers ago): its stats image is free
@@ -668,6 +673,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmArgs a) {
       }
     }
 
+    if constexpr (ABL & PP_ABL_CLK) tC = __builtin_amdgcn_s_memtime();
     // ---- epilogue (store only)
     if constexpr (ABL & PP_ABL_NOEPI) {
 #pragma unroll
@@ -903,6 +909,11 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmArgs a) {
         }
       }
     }
+    if constexpr (ABL & PP_ABL_CLK) {
+      c_init += tB - tA;
+      c_main += tC - tB;
+      c_epi += __builtin_amdgcn_s_memtime() - tC;
+    }
   }
 
   };  // run_tiles
@@ -914,7 +925,17 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmArgs a) {
   }
 
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // no LDS-DMA may outlive the workgroup's LDS allocation
-  if (a.clk && tid == 0) a.clk[blockIdx.x] = __builtin_amdgcn_s_memtime() - clk0;
+  if constexpr (ABL & PP_ABL_CLK) {
+    if (a.clk && (tid & 63) == 0) {
+      unsigned long long* c = a.clk + (size_t)(blockIdx.x * 8 + wave) * 4;
+      c[0] = __builtin_amdgcn_s_memtime() - clk0;
+      c[1] = c_init;
+      c[2] = c_main;
+      c[3] = c_epi;
+    }
+  } else {
+    if (a.clk && tid == 0) a.clk[blockIdx.x] = __builtin_amdgcn_s_memtime() - clk0;
+  }
   if constexpr (SCHED == 0 && STAGGER) {
     if (wr == 0) __builtin_amdgcn_s_barrier();
   }

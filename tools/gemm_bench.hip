@@ -86,6 +86,7 @@ void run_old(GemmArgs a) {
   hipLaunchKernelGGL((gemm256_kernel<EPI>), dim3((a.M / 256) * (a.N / 256)), dim3(512), G256_LDS_BYTES, st, a);
 }
 static int g_grid_override = 0;
+static bool g_only_phases = false;  // argv[4] == "phases": only the s_memtime phase timeline at the end
 template <int EPI, int DIST, int ABL, int SCHED = 0, int COAL = 0>
 void run_pp(GemmArgs a) {
   auto kern = gemm_pp_kernel<EPI, DIST, ABL, SCHED, COAL>;
@@ -107,6 +108,7 @@ struct Variant {
 };
 
 static void time_group(const char* title, std::vector<Variant>& vs, int rounds, int reps, FILE* js) {
+  if (g_only_phases) return;
   hipEvent_t e0, e1;
   CK(hipEventCreate(&e0));
   CK(hipEventCreate(&e1));
@@ -139,6 +141,7 @@ int main(int argc, char** argv) {
   const int M = argc > 1 ? atoi(argv[1]) : 65536;
   const int rounds = argc > 2 ? atoi(argv[2]) : 5;
   const int reps = argc > 3 ? atoi(argv[3]) : 5;
+  g_only_phases = argc > 4 && !strcmp(argv[4], "phases");
   const int S = 256;
   CK(hipSetDevice(0));
   hipDeviceProp_t prop;
@@ -362,6 +365,65 @@ int main(int argc, char** argv) {
       time_group(title, vs, 2, 1, js);
     }
   }
+  {  // where a workgroup's time goes: s_memtime sums of accumulator init / main loop / epilogue per wave (PP_ABL_CLK)
+    unsigned long long* dclk;
+    CK(hipMalloc(&dclk, 256 * 8 * 4 * 8));
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    GemmArgs f1 = base(A768, W1, 3072, 768);
+    f1.out16 = o16_new;
+    f1.clk = dclk;
+    GemmArgs ro = base(A768, Wo, 768, 768);
+    ro.xres = xr_new;
+    ro.clk = dclk;
+    GemmArgs r2 = base(A3072, W2, 768, 3072);
+    r2.xres = xr_new;
+    r2.clk = dclk;
+    struct Case { const char* name; std::function<void()> fn; int tiles; };
+    std::vector<Case> cases = {
+        {"ffn1 gelu  M x3072 x768 ", [=] { run_pp<PP_GELU, 4, PP_ABL_CLK, 1, 1>(f1); }, (M / 256) * 12},
+        {"attn-out res M x768 x768 ", [=] { run_pp<PP_RES, 4, PP_ABL_CLK, 1, 1>(ro); }, (M / 256) * 3},
+        {"ffn2 res   M x768 x3072", [=] { run_pp<PP_RES, 4, PP_ABL_CLK, 1, 1>(r2); }, (M / 256) * 3},
+    };
+    std::vector<Case> more;
+    for (int sg : {1, 3, 7}) {  // start-up stagger: hash(workgroup) % (sg + 1) sleeps of ~8k cycles
+      GemmArgs ros = ro, r2s = r2, f1s = f1;
+      ros.stagger = r2s.stagger = f1s.stagger = sg;
+      static char names[9][48];
+      static int ni = 0;
+      snprintf(names[ni], 48, "attn-out res, stagger %d  ", sg);
+      more.push_back({names[ni++], [=] { run_pp<PP_RES, 4, PP_ABL_CLK, 1, 1>(ros); }, (M / 256) * 3});
+      snprintf(names[ni], 48, "ffn2 res, stagger %d      ", sg);
+      more.push_back({names[ni++], [=] { run_pp<PP_RES, 4, PP_ABL_CLK, 1, 1>(r2s); }, (M / 256) * 3});
+      snprintf(names[ni], 48, "ffn1 gelu, stagger %d     ", sg);
+      more.push_back({names[ni++], [=] { run_pp<PP_GELU, 4, PP_ABL_CLK, 1, 1>(f1s); }, (M / 256) * 12});
+    }
+    for (auto& c : more) cases.push_back(c);
+    for (auto& c : cases) {
+      for (int rep = 0; rep < 3; ++rep) {
+        if (rep == 2) { CK(hipMemsetAsync(dclk, 0, 256 * 8 * 4 * 8, st)); CK(hipEventRecord(e0, st)); }
+        c.fn();
+        if (rep == 2) CK(hipEventRecord(e1, st));
+      }
+      CK(hipEventSynchronize(e1));
+      float ms;
+      CK(hipEventElapsedTime(&ms, e0, e1));
+      std::vector<unsigned long long> hc(256 * 8 * 4);
+      CK(hipMemcpy(hc.data(), dclk, hc.size() * 8, hipMemcpyDeviceToHost));
+      double tot = 0, ini = 0, mn = 0, ep = 0;
+      const int nw = NCU * 8;
+      for (int i = 0; i < nw; ++i) { tot += (double)hc[4 * i]; ini += (double)hc[4 * i + 1]; mn += (double)hc[4 * i + 2]; ep += (double)hc[4 * i + 3]; }
+      const double us_per_tick = ms * 1e3 / (tot / nw);
+      const double tiles_per_wg = (double)c.tiles / NCU;
+      printf("PHASES %s wall %7.1f us, %.1f tiles per workgroup; per tile: init %5.2f us  main loop %6.2f us  epilogue %5.2f us  (per launch: %5.1f / %6.1f / %5.1f us; %.0f %% in the main loop)\n",
+             c.name, ms * 1e3, tiles_per_wg, ini / nw * us_per_tick / tiles_per_wg, mn / nw * us_per_tick / tiles_per_wg,
+             ep / nw * us_per_tick / tiles_per_wg, ini / nw * us_per_tick, mn / nw * us_per_tick, ep / nw * us_per_tick, 100.0 * mn / (ini + mn + ep));
+      printf("       workgroup 0 waves [init main epi] ticks:");
+      for (int w = 0; w < 8; ++w) printf(" [%llu %llu %llu]", hc[4 * w + 1], hc[4 * w + 2], hc[4 * w + 3]);
+      printf("\n");
+    }
+    CK(hipFree(dclk));
+  }
   {  // effective shader clock: s_memtime ticks of each workgroup's whole run / wall time of the launch
     unsigned long long* dclk;
     CK(hipMalloc(&dclk, 256 * 8));
@@ -371,6 +433,7 @@ int main(int argc, char** argv) {
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     for (int grid : {256, 64, 8}) {
+      if (g_only_phases) break;
       for (int which = 0; which < 3; ++which) {
         g_grid_override = grid;
         CK(hipMemsetAsync(dclk, 0, 256 * 8, st));
