@@ -19,6 +19,7 @@ There is no CPU implementation here: without the HIP library / a GPU, constructi
 """
 from __future__ import annotations
 
+import json
 import logging
 from typing import Any, Dict, List, Optional
 
@@ -276,6 +277,33 @@ class ModelMemory(Model):
         for s0 in range(0, len(instances), batch_size):
             out.append(self.make_output_human_readable({"meta": metadata[s0:s0 + batch_size], "p_same": p_same[s0:s0 + batch_size]}))
         return out
+
+    def sweep_arrays(self, arrays: Dict[str, Any], first: int = 0, last: Optional[int] = None, batch_size: int = 512,
+                     with_probs: bool = False):
+        """``sweep`` on the array form of the evaluation set (ReaderMemory.read_arrays): rows ``first:last`` in one resident
+        length-bucketed sweep, metric accumulators updated exactly as ``forward`` / ``sweep`` do (model_memory.py:133-147,
+        162-167).  Returns ``(best [n, 2], best_idx [n], p_same [n, G] or None)``; no Instances, no per-IR Python objects."""
+        if arrays["type"] not in ["test", "unlabel"]:
+            raise NotImplementedError("sweep_arrays() serves the test / unlabel branch (model_memory.py:133-147)")
+        last = len(arrays["lens"]) if last is None else last
+        lens = np.ascontiguousarray(arrays["lens"][first:last], np.int32)
+        if len(lens) == 0:
+            return np.zeros((0, 2), np.float32), np.zeros((0,), np.int32), None
+        ids = arrays["ids"][first:last, :int(lens.max())]
+        best, best_idx, p_same = self.engine.bucketed_sweep(ids, lens, batch_size, with_probs=with_probs)
+        same = np.asarray(arrays["same"][first:last], bool)
+        diff_idx = self.vocab.get_token_index("diff", namespace=self._label_namespace)
+        self._counts(best, np.where(same, self._same_idx, diff_idx).astype(np.int64))
+        self._siamese_metric.add_arrays(same.astype(np.uint8), best[:, self._same_idx])
+        return best, best_idx, p_same
+
+    def format_records_json(self, labels: List[str], urls: List[str], p_same: np.ndarray) -> str:
+        """``json.dumps(make_output_human_readable(...))`` of one batch, byte for byte, built from arrays: the line
+        predict_memory.py:111 writes per batch ({"Issue_Url", "label", "predict": {cwe: P(same)}} per issue report)."""
+        from .records import format_batch, record_layout
+
+        cols, fmt, names = record_layout(self._golden_labels)
+        return format_batch(fmt, names, urls, labels, np.asarray(p_same)[:, cols].astype(np.float64))
 
     def make_output_human_readable(self, output_dict: Dict[str, Any]):
         if "meta" not in output_dict or output_dict["meta"][0]["type"] not in ["test", "unlabel"]:

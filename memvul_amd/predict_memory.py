@@ -11,7 +11,7 @@ from __future__ import annotations
 import json
 import logging
 import os
-from typing import Any, Dict, Optional
+from typing import Any, Dict, List, Optional
 
 import numpy as np
 
@@ -61,6 +61,64 @@ def evaluate_sweep(model, data_loader, output_file: str = None, predictions_outp
     return final_metrics
 
 
+def evaluate_arrays(model, arrays: Dict[str, Any], batch_size: int = 512, output_file: str = None,
+                    predictions_output_file: str = None, chunk_batches: int = 32, record_workers: Optional[int] = None) -> Dict[str, Any]:
+    """``evaluate_sweep`` on the array form of the evaluation set (ReaderMemory.read_arrays), pipelined: the set is scored
+    in chunks of ``chunk_batches`` batches, and while the engine sweeps chunk k (the GIL is released inside the library)
+    a writer thread formats and writes the JSON-lines of chunk k-1 — one line per ``batch_size`` issue reports, the
+    bytes ``evaluate`` writes (``record_workers`` / $MEMVUL_RECORD_WORKERS processes format them; 0 = in the thread).
+    Without a predictions file no per-IR Python object is created at all."""
+    import queue
+    import threading
+
+    model.eval()
+    if record_workers is None:
+        record_workers = int(os.environ.get("MEMVUL_RECORD_WORKERS", "0"))
+    n = len(arrays["lens"])
+    step = max(1, chunk_batches) * batch_size
+    q: "queue.Queue" = queue.Queue(maxsize=2)
+    err: List[BaseException] = []
+
+    def writer():
+        try:
+            from .records import RecordWriter
+
+            with RecordWriter(predictions_output_file, model._golden_labels, workers=record_workers) as rw:
+                while True:
+                    item = q.get()
+                    if item is None:
+                        return
+                    s0, p_same = item
+                    for b0 in range(0, len(p_same), batch_size):
+                        a, b = s0 + b0, s0 + min(b0 + batch_size, len(p_same))
+                        rw.submit(arrays["urls"][a:b], arrays["labels"][a:b], p_same[b0:b0 + batch_size])
+        except BaseException as e:  # surfaced on the caller's thread below
+            err.append(e)
+            while q.get() is not None:
+                pass
+
+    th = None
+    if predictions_output_file:
+        th = threading.Thread(target=writer, name="memvul-records", daemon=True)
+        th.start()
+    try:
+        for s0 in range(0, n, step):
+            _, _, p_same = model.sweep_arrays(arrays, s0, min(n, s0 + step), batch_size, with_probs=th is not None)
+            if th is not None:
+                q.put((s0, p_same))
+    finally:
+        if th is not None:
+            q.put(None)
+            th.join()
+    if err:
+        raise err[0]
+    final_metrics = model.get_metrics(reset=True)
+    if output_file:
+        with open(output_file, "w") as f:
+            json.dump(_jsonable(final_metrics), f, indent=4)
+    return final_metrics
+
+
 def _jsonable(x):
     if isinstance(x, dict):
         return {k: _jsonable(v) for k, v in x.items()}
@@ -75,7 +133,9 @@ def test_siamese(archive_file, input_file, input_golden_file, test_config=None, 
                  predictions_output_file=None, batch_size=64, cuda_device=0, seed=2021, package="memvul_amd",
                  batch_weight_key="", file_friendly_logging=False, engine_options=None, sweep=False) -> Dict[str, Any]:
     """predict_memory.py:49-114.  ``sweep=True``: score the evaluation set in one resident length-bucketed sweep
-    (same outputs; see evaluate_sweep)."""
+    (same outputs; see evaluate_sweep).  ``sweep="arrays"``: the same through the array form of the reader
+    (ReaderMemory.read_arrays -> evaluate_arrays: batched tokenisation, no Instances, records written by a thread
+    while the engine runs)."""
     overrides = test_config or ""
     archive = load_archive(archive_file, weights_file=weights_file, cuda_device=cuda_device, overrides=overrides,
                            engine_options=engine_options)
@@ -94,6 +154,12 @@ def test_siamese(archive_file, input_file, input_golden_file, test_config=None, 
         model.forward_on_instances(golden_samples[128:])
 
     logger.info("Reading evaluation data from %s", input_file)
+    if sweep == "arrays":
+        bs = batch_size or int((config.get("validation_data_loader") or config.get("data_loader") or {}).get("batch_size", 512))
+        arrays = dataset_reader.read_arrays(input_file, workers=int(os.environ.get("MEMVUL_TOKENIZER_WORKERS", "0")))
+        metrics = evaluate_arrays(model, arrays, bs, output_file=output_file, predictions_output_file=predictions_output_file)
+        logger.info("Finished evaluating.")
+        return metrics
     data_loader_params = dict(config.get("validation_data_loader") or config.get("data_loader") or {})
     if batch_size:
         data_loader_params["batch_size"] = batch_size

@@ -24,6 +24,8 @@ import logging
 import os
 from typing import Dict, Optional
 
+import numpy as np
+
 from .data import Instance, LabelField, MetadataField, TextField
 from .registry import DatasetReader, TokenIndexer, Tokenizer
 from . import tokenizer as _tok  # noqa: F401  (registers "pretrained_transformer")
@@ -80,11 +82,23 @@ class ReaderMemory(DatasetReader):
         if self._dataset.get(file_path):
             return self._dataset[file_path]
 
+        dataset = self._grouped_samples(file_path)
+        for group in dataset.values():
+            for s in group:
+                s["description"] = self._tokenizer.tokenize(self._text_of(s))
+        self._dataset[file_path] = dataset
+        return dataset
+
+    @staticmethod
+    def _text_of(s) -> str:
+        return f"{s['Issue_Title']}. {s['Issue_Body']}"
+
+    def _grouped_samples(self, file_path):
+        """reader_memory.py:82-111 without the tokenisation: samples grouped under "neg" / their CWE id, in file order."""
         with open(file_path, "r", encoding="utf-8") as f:
             samples = json.load(f)
         dataset = {"neg": list()}
         for s in samples:
-            s["description"] = self._tokenizer.tokenize(f"{s['Issue_Title']}. {s['Issue_Body']}")
             label = "pos" if str(s[self._target]) == "1" else "neg"
             s[self._target] = label
             if label == "pos":
@@ -99,8 +113,27 @@ class ReaderMemory(DatasetReader):
                 if label not in dataset:
                     dataset[label] = list()
             dataset[label].append(s)
-        self._dataset[file_path] = dataset
         return dataset
+
+    def read_arrays(self, file_path, workers: int = 0):
+        """The ``test_`` / ``validation_`` branch of ``_read`` as arrays instead of Instances (same samples, same order:
+        positives first, reader_memory.py:150-152): ``ids int32 [N, L]`` zero-padded, ``lens int32 [N]``,
+        ``same bool [N]`` (label "same" = a positive), ``labels`` (CWE id or "neg", what the records carry) and
+        ``urls``.  Feeds ``ModelMemory.sweep_arrays``; tokenisation is one batched call (``Tokenizer.batch_ids``)."""
+        if "test_" in file_path:
+            type_ = "unlabel"
+        elif "validation_" in file_path and "golden" not in file_path:
+            type_ = "test"
+        else:
+            raise NotImplementedError("read_arrays serves the 'test_' / 'validation_' branches (reader_memory.py:146-157)")
+        dataset = self._grouped_samples(file_path)
+        all_data = [s for group in dataset.values() for s in group]
+        all_data.reverse()
+        ids, lens = self._tokenizer.batch_ids([self._text_of(s) for s in all_data], workers=workers)
+        same = np.fromiter((s[self._target] == "pos" for s in all_data), dtype=bool, count=len(all_data))
+        labels = [s["CWE_ID"] if s[self._target] == "pos" else s[self._target] for s in all_data]
+        return {"type": type_, "ids": ids, "lens": lens, "same": same, "labels": labels,
+                "urls": [s["Issue_Url"] for s in all_data]}
 
     def _read(self, file_path):
         dataset = self.read_dataset(file_path)

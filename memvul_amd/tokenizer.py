@@ -42,14 +42,61 @@ class PretrainedTransformerTokenizer(Tokenizer):
         self._hf = None
         vocab = _find_vocab(model_name)
         if vocab is not None:
+            import inspect
+
             from transformers import BertTokenizerFast
 
-            self._hf = BertTokenizerFast(vocab_file=vocab, do_lower_case=True, **(tokenizer_kwargs or {}))
+            with open(vocab, "r", encoding="utf-8") as f:
+                table = {line.rstrip("\n"): i for i, line in enumerate(f)}
+            # transformers 4.x (the reference pins 4.1.0) takes ``vocab_file``; 5.x takes ``vocab`` and silently IGNORES
+            # ``vocab_file`` (a 5-token default vocabulary comes back) — so pick by signature and check the result
+            if "vocab" in inspect.signature(BertTokenizerFast.__init__).parameters:
+                self._hf = BertTokenizerFast(vocab=table, do_lower_case=True, **(tokenizer_kwargs or {}))
+            else:
+                self._hf = BertTokenizerFast(vocab_file=vocab, do_lower_case=True, **(tokenizer_kwargs or {}))
+            if self._hf.vocab_size != len(table) or self._hf.cls_token_id != table.get("[CLS]") or self._hf.sep_token_id != table.get("[SEP]"):
+                raise RuntimeError(f"WordPiece vocabulary {vocab} was not taken over by BertTokenizerFast "
+                                   f"({self._hf.vocab_size} tokens loaded, {len(table)} in the file)")
             self.vocab_size = self._hf.vocab_size
 
     def _hash_ids(self, text: str) -> List[int]:
         lo = 1000 if self.vocab_size > 2000 else 3
         return [lo + zlib.crc32(w.encode("utf-8")) % (self.vocab_size - lo) for w in _WORD_RE.findall(text.lower())]
+
+    def _hash_encode(self, text: str) -> List[int]:
+        ids = self._hash_ids(text)
+        if self._add_special:
+            if self._max_length is not None:
+                ids = ids[: max(0, self._max_length - 2)]
+            return [CLS_ID] + ids + [SEP_ID]
+        return ids[: self._max_length] if self._max_length is not None else ids
+
+    def batch_ids(self, texts: List[str], workers: int = 0):
+        """Array form of ``tokenize`` for a whole file: ``(ids int32 [N, L] zero-padded, lens int32 [N])`` with exactly the
+        ids ``tokenize`` gives text by text.  The WordPiece path is one batched call into the Rust tokenizer (parallel
+        inside); the hashing stand-in can fan out over ``workers`` forked processes."""
+        import numpy as np
+
+        if self._hf is not None:
+            rows = self._hf(list(texts), add_special_tokens=self._add_special, truncation=self._max_length is not None,
+                            max_length=self._max_length, return_attention_mask=False, return_token_type_ids=False)["input_ids"]
+        elif workers and workers > 1 and len(texts) >= 4 * workers:
+            import multiprocessing as mp
+
+            step = (len(texts) + workers - 1) // workers
+            with mp.get_context("fork").Pool(workers) as pool:
+                parts = pool.map(self._hash_encode_many, [texts[i:i + step] for i in range(0, len(texts), step)])
+            rows = [r for part in parts for r in part]
+        else:
+            rows = self._hash_encode_many(texts)
+        lens = np.fromiter((len(r) for r in rows), dtype=np.int32, count=len(rows))
+        ids = np.zeros((len(rows), int(lens.max()) if len(rows) else 0), np.int32)
+        for i, r in enumerate(rows):
+            ids[i, :len(r)] = r
+        return ids, lens
+
+    def _hash_encode_many(self, texts: List[str]) -> List[List[int]]:
+        return [self._hash_encode(t) for t in texts]
 
     def tokenize(self, text: str) -> List[Token]:
         if self._hf is not None:
@@ -58,14 +105,7 @@ class PretrainedTransformerTokenizer(Tokenizer):
             ids = enc["input_ids"]
             texts = self._hf.convert_ids_to_tokens(ids)
             return [Token(t, i, 0) for t, i in zip(texts, ids)]
-        ids = self._hash_ids(text)
-        if self._add_special:
-            if self._max_length is not None:
-                ids = ids[: max(0, self._max_length - 2)]
-            ids = [CLS_ID] + ids + [SEP_ID]
-        elif self._max_length is not None:
-            ids = ids[: self._max_length]
-        return [Token(str(i), i, 0) for i in ids]
+        return [Token(str(i), i, 0) for i in self._hash_encode(text)]
 
 
 @TokenIndexer.register("pretrained_transformer")

@@ -73,6 +73,114 @@ def test_sweep_driver_writes_the_same_files_cpu(monkeypatch):
     _check_format_and_metrics(fx, metrics_s, records_s, "sweep")
 
 
+def test_arrays_driver_writes_the_same_bytes_cpu(monkeypatch):
+    """test_siamese(sweep="arrays"): reader -> arrays (batched tokenisation, no Instances) -> chunked resident sweeps with
+    the records written by a thread.  With the oracle-backed engine and one chunk the predictions file is the sweep
+    driver's BYTE FOR BYTE (the hand-built JSON lines equal json.dumps of the records) and the metrics are equal."""
+    fx = pu.make_fixture(n_irs=75)
+    monkeypatch.setattr(model_memory, "Engine", pu.OracleEngine)
+    metrics_s, records_s, path_s = _run(fx, "sweep", sweep=True)
+    metrics_a, records_a, path_a = _run(fx, "arrays", sweep="arrays")
+    assert open(path_a, "rb").read() == open(path_s, "rb").read()
+    for k in metrics_s:
+        assert metrics_a[k] == pytest.approx(metrics_s[k], abs=1e-12), k
+    _check_format_and_metrics(fx, metrics_a, records_a, "arrays")
+
+
+def test_arrays_driver_chunked_and_without_a_predictions_file(monkeypatch):
+    """Several chunks (chunk_batches=1, a ragged last one) through the writer thread, and the metrics-only form."""
+    from memvul_amd.archive import load_archive
+
+    fx = pu.make_fixture(n_irs=53)
+    root, arch, golden, test_path, w, dims = fx
+    monkeypatch.setattr(model_memory, "Engine", pu.OracleEngine)
+    metrics_s, records_s, path_s = _run(fx, "sweep", sweep=True)
+    archive = load_archive(arch, cuda_device=0, overrides=pu.TEST_CONFIG, engine_options=dict(max_tokens=16 * 256, max_batch=16, max_anchors=16))
+    model = archive.model
+    model.eval()
+    model._golden_instances_embeddings = None
+    model._golden_instances_labels = None
+    model.forward_on_instances(list(archive.validation_dataset_reader.read(golden)))
+    arrays = archive.dataset_reader.read_arrays(test_path)
+    assert arrays["ids"].dtype == np.int32 and arrays["ids"].shape[0] == len(arrays["lens"]) == len(records_s)
+    assert arrays["urls"] == [r["Issue_Url"] for r in records_s] and arrays["labels"] == [r["label"] for r in records_s]
+    out = os.path.join(root, "test_results", "chunked_result.json")
+    m1 = predict_memory.evaluate_arrays(model, arrays, 16, predictions_output_file=out, chunk_batches=1)
+    recs = [r for line in open(out) for r in json.loads(line)]
+    assert [len(json.loads(l)) for l in open(out)] == [len(json.loads(l)) for l in open(path_s)]
+    a = np.array([list(r["predict"].values()) for r in recs])
+    b = np.array([list(r["predict"].values()) for r in records_s])
+    assert [r["Issue_Url"] for r in recs] == [r["Issue_Url"] for r in records_s] and np.abs(a - b).max() < 1e-6
+    m2 = predict_memory.evaluate_arrays(model, arrays, 16)  # no predictions file: no writer thread, no probabilities
+    for k in metrics_s:
+        assert m1[k] == pytest.approx(metrics_s[k], abs=1e-6) and m2[k] == pytest.approx(metrics_s[k], abs=1e-6), k
+
+
+def test_record_writer_bytes_equal_json_dumps_including_worker_processes(tmp_path):
+    """records.RecordWriter (in-thread and fanned out over spawned processes) == json.dumps of the reference's records:
+    duplicate anchor labels (last wins, first position), labels / urls that need escaping or contain '%'."""
+    from memvul_amd.records import RecordWriter
+
+    golden = ["CWE-79", "CWE-89", 'we"ird %d %', "CWE-79", "ünï"]
+    rng = np.random.default_rng(11)
+    batches = []
+    for n in (7, 3, 1):
+        p = rng.random((n, len(golden)), dtype=np.float32)
+        urls = [f"https://example.invalid/{i}?q=%20\"x\"" for i in range(n)]
+        labels = [golden[i % len(golden)] if i % 2 else "neg" for i in range(n)]
+        batches.append((urls, labels, p))
+    order = {name: i for i, name in enumerate(golden)}
+    want = ""
+    for urls, labels, p in batches:
+        recs = [{"Issue_Url": u, "label": lab, "predict": dict(zip(order.keys(), p[i, list(order.values())].astype(np.float64).tolist()))}
+                for i, (u, lab) in enumerate(zip(urls, labels))]
+        want += json.dumps(recs) + "\n"
+    for workers in (0, 2):
+        path = tmp_path / f"w{workers}.json"
+        with RecordWriter(str(path), golden, workers=workers) as rw:
+            for urls, labels, p in batches:
+                rw.submit(urls, labels, p)
+        assert path.read_text() == want, workers
+
+
+def test_batch_ids_equals_tokenize_text_by_text():
+    from memvul_amd.tokenizer import PretrainedTransformerTokenizer
+
+    rng = np.random.default_rng(3)
+    texts = [pu._text(rng, int(n)) for n in rng.integers(0, 400, size=40)] + ["", "Héllo, wörld! <script>alert(1)</script>"]
+    for max_length, special in ((256, True), (32, True), (None, True), (16, False)):
+        tok = PretrainedTransformerTokenizer(max_length=max_length, add_special_tokens=special)
+        ids, lens = tok.batch_ids(texts)
+        ids_mp, lens_mp = tok.batch_ids(texts, workers=3)
+        assert np.array_equal(ids, ids_mp) and np.array_equal(lens, lens_mp)
+        for i, t in enumerate(texts):
+            ref = [k.text_id for k in tok.tokenize(t)]
+            assert lens[i] == len(ref) and ids[i, :lens[i]].tolist() == ref and not ids[i, lens[i]:].any()
+
+
+def test_wordpiece_vocab_path_tokenize_and_batch_ids(tmp_path):
+    """With a vocab.txt reachable the tokenizer is the real lower-cased WordPiece (BertTokenizerFast) with the BERT
+    special ids; truncation counts [CLS] / [SEP] (max_length 256 / 512 in the reference configs), and the batched
+    array form gives the same ids as text-by-text tokenisation."""
+    from memvul_amd.tokenizer import CLS_ID, SEP_ID, UNK_ID, PretrainedTransformerTokenizer
+
+    words = sorted(set(pu.WORDS))
+    vocab = ["[PAD]"] + [f"[unused{i}]" for i in range(99)] + ["[UNK]", "[CLS]", "[SEP]", "[MASK]"] + list(".,!<>()/") + words + ["##s", "##ing", "##ed"]
+    (tmp_path / "vocab.txt").write_text("\n".join(vocab) + "\n")
+    tok = PretrainedTransformerTokenizer(model_name=str(tmp_path), max_length=12)
+    assert tok.vocab_size == len(vocab)
+    got = tok.tokenize("Buffer OVERFLOWS crashed. Zzzunknown heap")
+    assert [t.text for t in got] == ["[CLS]", "buffer", "overflow", "##s", "crash", "##ed", ".", "[UNK]", "heap", "[SEP]"]
+    assert got[0].text_id == CLS_ID and got[-1].text_id == SEP_ID and got[7].text_id == UNK_ID
+    rng = np.random.default_rng(5)
+    texts = [pu._text(rng, int(n)) for n in rng.integers(1, 40, size=25)] + [""]
+    ids, lens = tok.batch_ids(texts)
+    assert ids.shape[1] == 12 and lens.max() == 12  # truncated to max_length INCLUDING the two specials
+    for i, t in enumerate(texts):
+        ref = [k.text_id for k in tok.tokenize(t)]
+        assert ids[i, :lens[i]].tolist() == ref and ref[0] == CLS_ID and ref[-1] == SEP_ID and not ids[i, lens[i]:].any()
+
+
 @pytest.mark.gpu
 def test_sweep_driver_gpu_matches_batch_loop():
     fx = pu.make_fixture(n_irs=70)
