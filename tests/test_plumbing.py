@@ -194,6 +194,22 @@ def test_sweep_driver_gpu_matches_batch_loop():
 
 
 @pytest.mark.gpu
+def test_arrays_driver_gpu_matches_sweep_driver():
+    """The array-form driver on the real engine: same records in the same order as the Instance sweep (both length-bucketed;
+    one chunk, so the same batches at the same padded lengths -> the same bytes)."""
+    fx = pu.make_fixture(n_irs=70)
+    metrics_s, records_s, path_s = _run(fx, "sweep", sweep=True)
+    metrics_a, records_a, path_a = _run(fx, "arrays", sweep="arrays")
+    assert [r["Issue_Url"] for r in records_a] == [r["Issue_Url"] for r in records_s]
+    a = np.array([list(r["predict"].values()) for r in records_a])
+    b = np.array([list(r["predict"].values()) for r in records_s])
+    assert np.abs(a - b).max() <= 1e-6
+    for k in metrics_s:
+        assert metrics_a[k] == pytest.approx(metrics_s[k], abs=1e-6), k
+    _check_format_and_metrics(fx, metrics_a, records_a, "arrays")
+
+
+@pytest.mark.gpu
 def test_plumbing_gpu_matches_oracle_run(monkeypatch):
     fx = pu.make_fixture()
     metrics, records, _ = _run(fx, "hip")
