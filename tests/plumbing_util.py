@@ -46,7 +46,7 @@ def _text(rng, n):
     return " ".join(rng.choice(WORDS, size=n))
 
 
-def make_fixture(n_irs=40, n_anchors=8, layers=2, seed=7):
+def make_fixture(n_irs=40, n_anchors=8, layers=2, seed=7, body_words=(5, 70)):
     """Returns (dir, archive_dir, golden_path, test_path, weights, dims)."""
     rng = np.random.default_rng(seed)
     root = tempfile.mkdtemp(prefix="mvplumb")  # no "test_"/"golden" in the directory name (reader dispatches on substrings)
@@ -64,7 +64,7 @@ def make_fixture(n_irs=40, n_anchors=8, layers=2, seed=7):
     recs = []
     for i in range(n_irs):
         pos = i % 7 == 3
-        recs.append({"Issue_Title": _text(rng, 6), "Issue_Body": _text(rng, int(rng.integers(5, 70))),
+        recs.append({"Issue_Title": _text(rng, 6), "Issue_Body": _text(rng, int(rng.integers(*body_words))),
                      "Security_Issue_Full": "1" if pos else "0", "Issue_Url": f"https://example.invalid/issues/{i}",
                      "CVE_ID": f"CVE-2020-{i}" if pos else None, "CWE_ID": str(rng.choice(cwes)) if pos else None})
     test_path = os.path.join(root, "test_project.json")
