@@ -382,11 +382,12 @@ int main(int argc, char** argv) {
     struct Case { const char* name; std::function<void()> fn; int tiles; };
     std::vector<Case> cases = {
         {"ffn1 gelu  M x3072 x768 ", [=] { run_pp<PP_GELU, 4, PP_ABL_CLK, 1, 1>(f1); }, (M / 256) * 12},
+        {"ffn1 f16 (no gelu)       ", [=] { run_pp<PP_F16, 4, PP_ABL_CLK, 1, 1>(f1); }, (M / 256) * 12},
         {"attn-out res M x768 x768 ", [=] { run_pp<PP_RES, 4, PP_ABL_CLK, 1, 1>(ro); }, (M / 256) * 3},
         {"ffn2 res   M x768 x3072", [=] { run_pp<PP_RES, 4, PP_ABL_CLK, 1, 1>(r2); }, (M / 256) * 3},
     };
     std::vector<Case> more;
-    for (int sg : {1, 3, 7}) {  // start-up stagger: hash(workgroup) % (sg + 1) sleeps of ~8k cycles
+    for (int sg : {7}) {  // start-up stagger: hash(workgroup) % (sg + 1) sleeps of ~8k cycles
       GemmArgs ros = ro, r2s = r2, f1s = f1;
       ros.stagger = r2s.stagger = f1s.stagger = sg;
       static char names[9][48];
