@@ -38,7 +38,7 @@ GEMM_CLASSES = ("gemm_qkv", "gemm_attn_out", "gemm_ffn1_gelu", "gemm_ffn2")
 # HBM bytes per launch of each GEMM class at the default workload from the separate rocprofv3 --pmc passes kept
 # under profiles/ (FETCH_SIZE x 2 per the gfx950 correction + WRITE_SIZE); None where no pass has been taken
 PMC_TRAFFIC_BYTES = {
-    # profiles/r01_k_pmc_hbm.txt (KiB per dispatch): FETCH_SIZE x 2 + WRITE_SIZE
+    # profiles/r01_k_pmc_hbm.txt, re-measured in r01_m_pmc_hbm.txt (KiB per dispatch): FETCH_SIZE x 2 + WRITE_SIZE
     "gemm_ffn1_gelu": int((2 * 2.230e5 + 3.901e5) * 1024),                          # gemm_pp<PP_GELU, RAW>
     "gemm_ffn2": int((2 * 3.640e5 + 2.022e5) * 1024),                               # gemm_pp<PP_RESLN3> [long]
     "gemm_attn_out": int((2 * 1.670e5 + 2.024e5) * 1024),                           # gemm_pp<PP_RESLN3> [short]

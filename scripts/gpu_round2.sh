@@ -38,14 +38,17 @@ PY
 }
 note "A/B benches"
 bench default MEMVUL_X=1
+if [ "${MEMVUL_VISIT:-full}" = "full" ]; then  # MEMVUL_VISIT=short: default + one_stream only (saves ~2.5 GPU-minutes)
 bench attn_v1 MEMVUL_ATTN=0
 bench res_f32 MEMVUL_RES_HILO=0
 bench ln_explicit MEMVUL_LN_VIRTUAL=0
 bench no_lnfuse MEMVUL_LN_FUSE=0
 bench no_prune MEMVUL_CLS_PRUNE=0
 bench all_off MEMVUL_ATTN=0 MEMVUL_LN_FUSE=0 MEMVUL_CLS_PRUNE=0 -- --streams 1
-bench one_stream MEMVUL_X=1 -- --streams 1
 bench noprof MEMVUL_X=1 -- --no-profile
+fi
+bench one_stream MEMVUL_X=1 -- --streams 1
+bench ragged MEMVUL_X=1 -- --ragged --steps 10
 
 note "rocprofv3 kernel trace of the bench command"
 rm -rf $O/prof_stats $O/prof_fetch $O/prof_write

@@ -21,6 +21,24 @@ def stats(db):
     print(f"{'kernel':<50} {'grid_x':>9} {'calls':>6} {'avg_us':>9} {'min_us':>9} {'max_us':>9} {'vgpr':>5} {'lds':>7}")
     for name, gx, n, avg, mn, mx, vg, lds in con.execute(q):
         print(f"{name[:50]:<50} {gx:>9} {n:>6} {avg:>9.2f} {mn:>9.2f} {mx:>9.2f} {vg:>5} {lds:>7}")
+    # one symbol, two problem shapes with the same grid (the persistent residual GEMM serves the attention-output
+    # projection, K = 768, and FFN-2, K = 3072): split bimodal symbols like the pmc summary does, so that the per-use
+    # average can be compared with bench.py's HIP-event figure for that kernel class
+    by_sym = defaultdict(list)
+    for name, gx, d in con.execute("select name, grid_x, duration from kernels"):
+        by_sym[(name, gx)].append(d)
+    first = True
+    for (name, gx), ds in sorted(by_sym.items(), key=lambda kv: -sum(kv[1])):
+        ds = sorted(ds)
+        lo, hi = ds[len(ds) // 10], ds[-1 - len(ds) // 10]
+        if lo > 0 and hi / lo > 1.6:
+            cut = (lo * hi) ** 0.5
+            if first:
+                print("\n# bimodal symbols split by dispatch duration (geometric mean of the 10th / 90th percentile as the cut)")
+                print(f"{'kernel':<58} {'calls':>6} {'avg_us':>9} {'min_us':>9} {'max_us':>9}")
+                first = False
+            for tag, part in (("[long]", [d for d in ds if d > cut]), ("[short]", [d for d in ds if d <= cut])):
+                print(f"{(name[:50] + ' ' + tag):<58} {len(part):>6} {sum(part) / len(part) / 1000.0:>9.2f} {part[0] / 1000.0:>9.2f} {part[-1] / 1000.0:>9.2f}")
 
 
 def pmc(dbs):
