@@ -77,9 +77,13 @@ def encode(
     eps: float = 1e-12,
     dtype=np.float32,
     taps: Optional[dict] = None,
+    stream_round=None,
 ) -> np.ndarray:
     """BERT forward -> last_hidden_state ``[B,S,H]``.  ``taps`` (if a dict) receives the
-    intermediate tensors the per-kernel GPU tests compare against."""
+    intermediate tensors the per-kernel GPU tests compare against.  ``stream_round`` (tests only): a function applied
+    to every PRE-LayerNorm residual sum (embedding sum, attention-output + x, FFN output + x1) — the tensors the
+    engine keeps in HBM between kernels — to model the storage format of that stream (tests/test_stream_precision.py)."""
+    sr = (lambda t: t) if stream_round is None else (lambda t: stream_round(t).astype(dtype))  # noqa: E731
     W = lambda k: w[PFX + k].astype(dtype)  # noqa: E731
     B, S = ids.shape
     H = W("embeddings.word_embeddings.weight").shape[1]
@@ -89,7 +93,7 @@ def encode(
         + W("embeddings.position_embeddings.weight")[np.arange(S)][None]
         + W("embeddings.token_type_embeddings.weight")[0][None, None]
     )
-    x = _ln(x, W("embeddings.LayerNorm.weight"), W("embeddings.LayerNorm.bias"), dtype(eps))
+    x = _ln(sr(x), W("embeddings.LayerNorm.weight"), W("embeddings.LayerNorm.bias"), dtype(eps))
     if taps is not None:
         taps["embed"] = x.copy()
     addmask = ((1.0 - mask.astype(dtype)) * dtype(MASK_ADD))[:, None, None, :]
@@ -104,10 +108,10 @@ def encode(
         pr = _softmax(sc)
         ctx = (pr @ vh).transpose(0, 2, 1, 3).reshape(B, S, H)
         ao = ctx @ W(p + "attention.output.dense.weight").T + W(p + "attention.output.dense.bias")
-        x1 = _ln(ao + x, W(p + "attention.output.LayerNorm.weight"), W(p + "attention.output.LayerNorm.bias"), dtype(eps))
+        x1 = _ln(sr(ao + x), W(p + "attention.output.LayerNorm.weight"), W(p + "attention.output.LayerNorm.bias"), dtype(eps))
         h = _gelu(x1 @ W(p + "intermediate.dense.weight").T + W(p + "intermediate.dense.bias"))
         fo = h @ W(p + "output.dense.weight").T + W(p + "output.dense.bias")
-        x = _ln(fo + x1, W(p + "output.LayerNorm.weight"), W(p + "output.LayerNorm.bias"), dtype(eps))
+        x = _ln(sr(fo + x1), W(p + "output.LayerNorm.weight"), W(p + "output.LayerNorm.bias"), dtype(eps))
         if taps is not None:
             if l == 0:
                 taps["l0_q"], taps["l0_k"], taps["l0_v"] = qh.copy(), kh.copy(), vh.copy()
@@ -118,9 +122,9 @@ def encode(
     return x
 
 
-def instance_forward(w, ids, mask, heads=12, eps=1e-12, dtype=np.float32, taps=None) -> np.ndarray:
+def instance_forward(w, ids, mask, heads=12, eps=1e-12, dtype=np.float32, taps=None, stream_round=None) -> np.ndarray:
     """model_memory.py:90-103 with use_header=True -> ``u [B,512]``."""
-    h = encode(w, ids, mask, heads, eps, dtype, taps)
+    h = encode(w, ids, mask, heads, eps, dtype, taps, stream_round)
     cls = h[:, 0]
     pooled = np.tanh(cls @ w["_bert_pooler.pooler.dense.weight"].astype(dtype).T + w["_bert_pooler.pooler.dense.bias"].astype(dtype))
     u = np.maximum(
