@@ -54,35 +54,42 @@ def init_process_group(backend: Optional[str] = None):
     return dist
 
 
-def all_gather_stats(scores: np.ndarray, labels: np.ndarray, device=None) -> Tuple[np.ndarray, np.ndarray]:
-    """All-gather the per-rank ``(score, label)`` arrays; returns the rank-ordered concatenation, trimmed
-    to the true per-rank counts.  One collective on a padded ``[n_max, 2]`` fp32 block per rank (labels
-    ride along as 0.0/1.0) plus a tiny count gather."""
+def all_gather_rows(rows: np.ndarray, device=None) -> np.ndarray:
+    """All-gather per-rank fp32 row blocks ``[n_r, k]`` (n_r may differ per rank); returns the rank-ordered concatenation
+    ``[sum n_r, k]``.  One collective on a zero-padded ``[n_max, k]`` block per rank plus a tiny count gather."""
     import torch
     import torch.distributed as dist
 
-    scores = np.ascontiguousarray(scores, np.float32)
-    labels = np.ascontiguousarray(labels, np.uint8)
+    rows = np.ascontiguousarray(rows, np.float32)
+    if rows.ndim != 2:
+        raise ValueError("all_gather_rows expects [n, k]")
     if not dist.is_initialized() or dist.get_world_size() == 1:
-        return scores.copy(), labels.copy()
+        return rows.copy()
     world = dist.get_world_size()
     if device is None:
         device = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
-    n = torch.tensor([scores.shape[0]], dtype=torch.int64, device=device)
+    k = rows.shape[1]
+    n = torch.tensor([rows.shape[0]], dtype=torch.int64, device=device)
     counts = [torch.zeros_like(n) for _ in range(world)]
     dist.all_gather(counts, n)
     counts = [int(c.item()) for c in counts]
     n_max = max(max(counts), 1)
-    block = torch.zeros((n_max, 2), dtype=torch.float32)
-    block[: scores.shape[0], 0] = torch.from_numpy(scores)
-    block[: scores.shape[0], 1] = torch.from_numpy(labels.astype(np.float32))
+    block = torch.zeros((n_max, k), dtype=torch.float32)
+    block[: rows.shape[0]] = torch.from_numpy(rows)
     block = block.to(device)
-    out = torch.empty((world * n_max, 2), dtype=torch.float32, device=device)  # rank-major concatenation
+    out = torch.empty((world * n_max, k), dtype=torch.float32, device=device)  # rank-major concatenation
     dist.all_gather_into_tensor(out, block)
-    out = out.cpu().numpy().reshape(world, n_max, 2)
-    s = np.concatenate([out[r, : counts[r], 0] for r in range(world)])
-    l = np.concatenate([out[r, : counts[r], 1] for r in range(world)]).astype(np.uint8)
-    return s, l
+    out = out.cpu().numpy().reshape(world, n_max, k)
+    return np.concatenate([out[r, : counts[r]] for r in range(world)])
+
+
+def all_gather_stats(scores: np.ndarray, labels: np.ndarray, device=None) -> Tuple[np.ndarray, np.ndarray]:
+    """All-gather the per-rank ``(score, label)`` arrays; returns the rank-ordered concatenation, trimmed
+    to the true per-rank counts (labels ride along as 0.0/1.0 in the same block: one collective)."""
+    scores = np.ascontiguousarray(scores, np.float32)
+    labels = np.ascontiguousarray(labels, np.uint8)
+    out = all_gather_rows(np.stack([scores, labels.astype(np.float32)], 1) if len(scores) else np.zeros((0, 2), np.float32), device)
+    return out[:, 0].copy(), out[:, 1].astype(np.uint8)
 
 
 def barrier():

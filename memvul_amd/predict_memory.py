@@ -177,6 +177,72 @@ def test_siamese(archive_file, input_file, input_golden_file, test_config=None, 
 test_siamese.__test__ = False  # not a pytest test
 
 
+def test_siamese_sharded(archive_file, input_file, input_golden_file, test_config=None, weights_file=None, output_file=None,
+                         predictions_output_file=None, batch_size=512, seed=2021, engine_options=None, backend=None) -> Dict[str, Any]:
+    """The multi-GPU form of ``test_siamese`` (one process per GPU under torchrun): every rank loads the
+    archive on its own GPU and builds the anchor bank redundantly, scores its contiguous shard of the evaluation set
+    (array form, ``read_arrays(shard=...)`` -> ``sweep_arrays``) and writes its own JSON-lines part
+    (``<predictions_output_file>.part<rank>``); ONE all-gather of the per-IR ``(p_0, p_1, is_positive)`` rows then lets
+    every rank compute the metrics on the whole set — the numbers a single process gives on the same per-IR results.
+    Rank 0 writes ``output_file``."""
+    from . import distributed as mvdist
+
+    rank, local_rank, world = mvdist.env_world()
+    if world > 1:
+        mvdist.init_process_group(backend)
+    archive = load_archive(archive_file, weights_file=weights_file, cuda_device=local_rank, overrides=test_config or "",
+                           engine_options=engine_options)
+    model = archive.model
+    model.eval()
+    golden_samples = list(archive.validation_dataset_reader.read(input_golden_file))
+    model._golden_instances_embeddings = None
+    model._golden_instances_labels = None
+    for s0 in range(0, len(golden_samples), 128):
+        model.forward_on_instances(golden_samples[s0:s0 + 128])
+
+    arrays = archive.dataset_reader.read_arrays(input_file, workers=int(os.environ.get("MEMVUL_TOKENIZER_WORKERS", "0")),
+                                                shard=(rank, world))
+    n = len(arrays["lens"])
+    part = f"{predictions_output_file}.part{rank}" if predictions_output_file and world > 1 else predictions_output_file
+    best = np.zeros((n, 2), np.float32)
+    step = 32 * batch_size
+    writer = None
+    if part:
+        from .records import RecordWriter
+
+        writer = RecordWriter(part, model._golden_labels, workers=int(os.environ.get("MEMVUL_RECORD_WORKERS", "0")))
+    try:
+        for s0 in range(0, n, step):
+            s1 = min(n, s0 + step)
+            b, _, p_same = model.sweep_arrays(arrays, s0, s1, batch_size, with_probs=writer is not None)
+            best[s0:s1] = b
+            if writer is not None:
+                for b0 in range(s0, s1, batch_size):
+                    b1 = min(s1, b0 + batch_size)
+                    writer.submit(arrays["urls"][b0:b1], arrays["labels"][b0:b1], p_same[b0 - s0:b1 - s0])
+    finally:
+        if writer is not None:
+            writer.close()
+    rows = mvdist.all_gather_rows(np.concatenate([best, np.asarray(arrays["same"], np.float32)[:, None]], 1))
+    # metrics of the whole set from the gathered per-IR rows, through the same accumulators a single process feeds
+    model._siamese_metric.reset()
+    model._counts.reset()
+    same = rows[:, 2] > 0.5
+    diff_idx = model.vocab.get_token_index("diff", namespace=model._label_namespace)
+    model._counts(rows[:, :2], np.where(same, model._same_idx, diff_idx).astype(np.int64))
+    model._siamese_metric.add_arrays(same.astype(np.uint8), rows[:, model._same_idx])
+    metrics = model.get_metrics(reset=True)
+    if output_file and rank == 0:
+        with open(output_file, "w") as f:
+            json.dump(_jsonable(metrics), f, indent=4)
+    mvdist.barrier()
+    return metrics
+
+
+test_siamese_sharded.__test__ = False  # not a pytest test
+
+
+
 def model_measure(test_label, pred, pred_score, sample_id=None):
     """predict_memory.py:117-156 on arrays: confusion counts, P/R/F1, ROC-AUC, AP."""
     from sklearn import metrics

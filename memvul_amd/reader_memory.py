@@ -115,11 +115,13 @@ class ReaderMemory(DatasetReader):
             dataset[label].append(s)
         return dataset
 
-    def read_arrays(self, file_path, workers: int = 0):
+    def read_arrays(self, file_path, workers: int = 0, shard=None):
         """The ``test_`` / ``validation_`` branch of ``_read`` as arrays instead of Instances (same samples, same order:
         positives first, reader_memory.py:150-152): ``ids int32 [N, L]`` zero-padded, ``lens int32 [N]``,
         ``same bool [N]`` (label "same" = a positive), ``labels`` (CWE id or "neg", what the records carry) and
-        ``urls``.  Feeds ``ModelMemory.sweep_arrays``; tokenisation is one batched call (``Tokenizer.batch_ids``)."""
+        ``urls``.  Feeds ``ModelMemory.sweep_arrays``; tokenisation is one batched call (``Tokenizer.batch_ids``).
+        ``shard=(rank, world)``: only this rank's contiguous slice of that order (distributed.shard_range) is tokenised
+        and returned; ``n_total`` / ``first`` place it in the whole set."""
         if "test_" in file_path:
             type_ = "unlabel"
         elif "validation_" in file_path and "golden" not in file_path:
@@ -129,11 +131,17 @@ class ReaderMemory(DatasetReader):
         dataset = self._grouped_samples(file_path)
         all_data = [s for group in dataset.values() for s in group]
         all_data.reverse()
+        n_total, first = len(all_data), 0
+        if shard is not None:
+            from .distributed import shard_range
+
+            first, count = shard_range(n_total, int(shard[0]), int(shard[1]))
+            all_data = all_data[first:first + count]
         ids, lens = self._tokenizer.batch_ids([self._text_of(s) for s in all_data], workers=workers)
         same = np.fromiter((s[self._target] == "pos" for s in all_data), dtype=bool, count=len(all_data))
         labels = [s["CWE_ID"] if s[self._target] == "pos" else s[self._target] for s in all_data]
         return {"type": type_, "ids": ids, "lens": lens, "same": same, "labels": labels,
-                "urls": [s["Issue_Url"] for s in all_data]}
+                "urls": [s["Issue_Url"] for s in all_data], "n_total": n_total, "first": first}
 
     def _read(self, file_path):
         dataset = self.read_dataset(file_path)

@@ -44,3 +44,39 @@ def test_all_gather_stats_world2_gloo(tmp_path, n):
     if labels.min() != labels.max():
         m = cm.siamese_metrics(labels, scores)
         assert res["f1"] == m["f1"] and res["thres"] == float(m["thres"]) and res["auc"] == float(m["auc"])
+
+
+def test_sharded_driver_world2_gloo_equals_single_process(tmp_path, monkeypatch):
+    """test_siamese_sharded on two ranks (contiguous shards, one all-gather of per-IR rows) == the single-process array
+    driver: the same metrics on every rank, and the rank parts concatenate to the same records in the same order."""
+    import plumbing_util as pu
+    from memvul_amd import model_memory, predict_memory
+
+    fx = pu.make_fixture(n_irs=45)
+    root, arch, golden, test_path, w, dims = fx
+    out = str(tmp_path / "metrics.json")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
+    port = 29820 + (os.getpid() % 150)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "tests", "dist_driver_worker.py"), root, arch, golden, test_path, out]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=420)
+    assert r.returncode == 0, r.stderr[-3000:]
+    m0, m1 = json.load(open(out + ".rank0")), json.load(open(out + ".rank1"))
+    assert m0 == m1
+    monkeypatch.setattr(model_memory, "Engine", pu.OracleEngine)
+    single_pred = os.path.join(root, "test_results", "single_result.json")
+    ms = predict_memory.test_siamese(archive_file=arch, input_file=test_path, input_golden_file=golden, test_config=pu.TEST_CONFIG,
+                                     predictions_output_file=single_pred, batch_size=16, cuda_device=0,
+                                     engine_options=dict(max_tokens=16 * 256, max_batch=16, max_anchors=16), sweep="arrays")
+    for k in ms:
+        assert m0[k] == pytest.approx(ms[k], abs=1e-6), k
+    assert json.load(open(os.path.join(root, "test_results", "sharded_metric.json"))) == m0
+    parts = []
+    for rk in range(2):
+        for line in open(os.path.join(root, "test_results", f"sharded_result.json.part{rk}")):
+            parts.extend(json.loads(line))
+    single = [rec for line in open(single_pred) for rec in json.loads(line)]
+    assert [p["Issue_Url"] for p in parts] == [s["Issue_Url"] for s in single] and [p["label"] for p in parts] == [s["label"] for s in single]
+    a = np.array([list(p["predict"].values()) for p in parts])
+    b = np.array([list(s["predict"].values()) for s in single])
+    assert np.abs(a - b).max() < 1e-6  # the oracle pads a shard's batches differently: fp32 rounding only

@@ -210,6 +210,22 @@ def test_arrays_driver_gpu_matches_sweep_driver():
 
 
 @pytest.mark.gpu
+def test_sharded_driver_single_rank_gpu_equals_arrays_driver():
+    """test_siamese_sharded with world size 1 on the real engine: no collective, same predictions file and metrics as
+    test_siamese(sweep="arrays") (the 2-rank exchange itself is covered on CPU over gloo, tests/test_distributed_cpu.py)."""
+    fx = pu.make_fixture(n_irs=60)
+    root, arch, golden, test_path, w, dims = fx
+    metrics_a, records_a, path_a = _run(fx, "arrays", sweep="arrays")
+    out = os.path.join(root, "test_results", "sharded1_result.json")
+    metrics_s = predict_memory.test_siamese_sharded(archive_file=arch, input_file=test_path, input_golden_file=golden, test_config=pu.TEST_CONFIG,
+                                                    predictions_output_file=out, batch_size=16,
+                                                    engine_options=dict(max_tokens=16 * 256, max_batch=16, max_anchors=16))
+    assert open(out, "rb").read() == open(path_a, "rb").read()
+    for k in metrics_a:
+        assert metrics_s[k] == pytest.approx(metrics_a[k], abs=1e-9), k
+
+
+@pytest.mark.gpu
 def test_plumbing_gpu_matches_oracle_run(monkeypatch):
     fx = pu.make_fixture()
     metrics, records, _ = _run(fx, "hip")
