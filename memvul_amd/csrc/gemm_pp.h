@@ -62,7 +62,7 @@ enum { PP_F32 = 0, PP_QK = 1, PP_VT = 2, PP_GELU = 3, PP_RES = 4, PP_F16 = 5, PP
 // per launch than fp32 + fp16 copy at the bench shape, and no fp32 transposition pass in the epilogue.
 // timing ablations (wrong results by construction; cdna_hip_programming.md §5.4 rules 8/17)
 enum { PP_ABL_NODMA = 1, PP_ABL_NOMFMA = 2, PP_ABL_NOREAD = 4, PP_ABL_NOEPI = 8, PP_ABL_NOPRIO = 16, PP_ABL_NOSTAGGER = 32,
-       PP_ABL_CLK = 64 };  // CLK (tools/gemm_bench.hip): per-wave s_memtime sums of accumulator init / main loop / epilogue -> a.clk[(wg 8 + wave) 4 ..]
+       PP_ABL_CLK = 64, PP_ABL_B34 = 128 };  // B34 (timing only): PP_RES moves 3/4 of its residual bytes (every 4th line neither loaded nor stored)  // CLK (tools/gemm_bench.hip): per-wave s_memtime sums of accumulator init / main loop / epilogue -> a.clk[(wg 8 + wave) 4 ..]
 
 #define PP_LDS_A 0           // [par][a][wr][64 rows][128 B]
 #define PP_LDS_B 65536       // [par][b][wc][32 rows][128 B]
@@ -575,6 +575,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmArgs a) {
             for (int h = 0; h < 2; ++h)
 #pragma unroll
               for (int x = 0; x < 2; ++x) {
+                if constexpr (ABL & PP_ABL_B34) { if (j == 1 && x == 1) continue; }
                 const float4 t = *(const float4*)(a.xres + (size_t)(mw + i * 32 + x * 16 + (lane >> 2)) * MV_HIDDEN + nw + j * 32 + h * 16 + 4 * (lane & 3));
                 acc[i][j][4 * (2 * h + x) + 0] = t.x; acc[i][j][4 * (2 * h + x) + 1] = t.y;
                 acc[i][j][4 * (2 * h + x) + 2] = t.z; acc[i][j][4 * (2 * h + x) + 3] = t.w;
@@ -723,6 +724,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmArgs a) {
 #pragma unroll
           for (int q = 0; q < 8; ++q) {  // q = (j, h, x): rows 16 x + crow, columns 32 j + 16 h + 4 cchunk
             float* op = obase + (size_t)(i * 32 + (q & 1) * 16) * a.N + (q >> 2) * 32 + ((q >> 1) & 1) * 16;
+            if constexpr (ABL & PP_ABL_B34) { if ((q >> 2) == 1 && (q & 1) == 1) continue; }
             *(u32x4*)op = o[q];
             if constexpr (EPI == PP_RESLN2) {
               if (a.raw) {  // fp16 copy straight from the transposed fp32 image: 8 bytes per lane, 32-byte row pieces

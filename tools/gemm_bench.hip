@@ -385,9 +385,14 @@ int main(int argc, char** argv) {
         {"ffn1 f16 (no gelu)       ", [=] { run_pp<PP_F16, 4, PP_ABL_CLK, 1, 1>(f1); }, (M / 256) * 12},
         {"attn-out res M x768 x768 ", [=] { run_pp<PP_RES, 4, PP_ABL_CLK, 1, 1>(ro); }, (M / 256) * 3},
         {"ffn2 res   M x768 x3072", [=] { run_pp<PP_RES, 4, PP_ABL_CLK, 1, 1>(r2); }, (M / 256) * 3},
+        {"attn-out res, 3/4 of the bytes", [=] { run_pp<PP_RES, 4, PP_ABL_CLK | PP_ABL_B34, 1, 1>(ro); }, (M / 256) * 3},
+        {"ffn2 res, 3/4 of the bytes    ", [=] { run_pp<PP_RES, 4, PP_ABL_CLK | PP_ABL_B34, 1, 1>(r2); }, (M / 256) * 3},
+        {"attn-out res (again)     ", [=] { run_pp<PP_RES, 4, PP_ABL_CLK, 1, 1>(ro); }, (M / 256) * 3},
+        {"ffn2 res (again)         ", [=] { run_pp<PP_RES, 4, PP_ABL_CLK, 1, 1>(r2); }, (M / 256) * 3},
     };
     std::vector<Case> more;
     for (int sg : {7}) {  // start-up stagger: hash(workgroup) % (sg + 1) sleeps of ~8k cycles
+      if (getenv("GEMM_BENCH_NO_STAGGER")) break;
       GemmArgs ros = ro, r2s = r2, f1s = f1;
       ros.stagger = r2s.stagger = f1s.stagger = sg;
       static char names[9][48];
