@@ -8,6 +8,7 @@ predictions file is still one JSON list per batch, ``{"Issue_Url","label","predi
 """
 from __future__ import annotations
 
+import copy
 import json
 import logging
 import os
@@ -190,7 +191,11 @@ def test_siamese_sharded(archive_file, input_file, input_golden_file, test_confi
     rank, local_rank, world = mvdist.env_world()
     if world > 1:
         mvdist.init_process_group(backend)
-    archive = load_archive(archive_file, weights_file=weights_file, cuda_device=local_rank, overrides=test_config or "",
+    # the reference takes the model's device from the config (predict_memory.py:210, test_config_memory.json "cuda:0");
+    # here every rank must land on ITS GPU whatever the config says
+    overrides = json.loads(test_config) if isinstance(test_config, str) and test_config else copy.deepcopy(test_config or {})
+    overrides.setdefault("model", {})["device"] = f"cuda:{local_rank}"
+    archive = load_archive(archive_file, weights_file=weights_file, cuda_device=local_rank, overrides=overrides,
                            engine_options=engine_options)
     model = archive.model
     model.eval()

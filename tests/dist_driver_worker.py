@@ -18,7 +18,9 @@ def main():
         output_file=os.path.join(root, "test_results", "sharded_metric.json"),
         predictions_output_file=os.path.join(root, "test_results", "sharded_result.json"), batch_size=16,
         engine_options=dict(max_tokens=16 * 256, max_batch=16, max_anchors=16), backend="gloo")
-    json.dump(predict_memory._jsonable(metrics), open(f"{out}.rank{os.environ.get('RANK', '0')}", "w"))
+    m = predict_memory._jsonable(metrics)
+    m["_device_index"] = int(pu.OracleEngine.last_device)  # which GPU this rank's engine was created on
+    json.dump(m, open(f"{out}.rank{os.environ.get('RANK', '0')}", "w"))
     import torch.distributed as dist
 
     if dist.is_initialized():

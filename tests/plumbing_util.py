@@ -76,7 +76,10 @@ def make_fixture(n_irs=40, n_anchors=8, layers=2, seed=7, body_words=(5, 70)):
 class OracleEngine:
     """Test-only stand-in with the binding.Engine surface ModelMemory uses, backed by the numpy oracle."""
 
+    last_device = None  # device index the most recent instance was created for
+
     def __init__(self, device=0, **kw):
+        OracleEngine.last_device = device
         self.same_idx = kw.get("same_idx", 0)
         self.v = np.zeros((0, 512), np.float32)
         self.w = None

@@ -62,6 +62,8 @@ def test_sharded_driver_world2_gloo_equals_single_process(tmp_path, monkeypatch)
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=420)
     assert r.returncode == 0, r.stderr[-3000:]
     m0, m1 = json.load(open(out + ".rank0")), json.load(open(out + ".rank1"))
+    # every rank lands on ITS device although test_config_memory.json says "cuda:0"
+    assert (m0.pop("_device_index"), m1.pop("_device_index")) == (0, 1)
     assert m0 == m1
     monkeypatch.setattr(model_memory, "Engine", pu.OracleEngine)
     single_pred = os.path.join(root, "test_results", "single_result.json")
