@@ -91,8 +91,13 @@ def main():
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     multi = world > 1
+    # development check of the N > 1 control flow on a ONE-GPU box (not a measurement): every rank shares device 0 and the
+    # exchange runs over gloo instead of RCCL; the JSON line says so in `config.note`
+    one_gpu_smoke = multi and os.environ.get("MEMVUL_BENCH_ONE_GPU_SMOKE") == "1"
     if multi:
-        mvdist.init_process_group("nccl")
+        mvdist.init_process_group("gloo" if one_gpu_smoke else "nccl")
+    if one_gpu_smoke:
+        local_rank = 0
 
     B, S, G, K, W = args.batch, args.seq_len, args.anchors, args.steps, args.warmup
     dims = synth.BertDims(layers=args.layers)
@@ -203,6 +208,8 @@ def main():
         "stats_allgather_ms": round(gather_ms, 3),
         "stats_table_sum": int(table.sum()),
     }
+    if one_gpu_smoke:
+        out["config"]["note"] = "MEMVUL_BENCH_ONE_GPU_SMOKE: all ranks share ONE GPU, exchange over gloo: control-flow check, not a measurement"
     if prof:
         kernels = {}
         for name, (ms, n) in breakdown.items():
