@@ -116,6 +116,36 @@ def test_arrays_driver_chunked_and_without_a_predictions_file(monkeypatch):
         assert m1[k] == pytest.approx(metrics_s[k], abs=1e-6) and m2[k] == pytest.approx(metrics_s[k], abs=1e-6), k
 
 
+def test_model_tar_gz_with_torch_weights_th(monkeypatch, tmp_path):
+    """The form a trained model ships in (predict_memory.py:62): ``model.tar.gz`` holding config.json, vocabulary/ and
+    ``weights.th`` = torch.save(state_dict) — loaded through the tar + torch path, same results as the extracted
+    directory with weights.npz."""
+    import tarfile
+
+    import torch
+
+    fx = pu.make_fixture(n_irs=20)
+    root, arch, golden, test_path, w, dims = fx
+    monkeypatch.setattr(model_memory, "Engine", pu.OracleEngine)
+    metrics_d, records_d, _ = _run(fx, "dir", sweep="arrays")
+    stage = tmp_path / "stage"
+    (stage / "vocabulary").mkdir(parents=True)
+    for name in ("config.json", "vocabulary/labels.txt", "vocabulary/non_padded_namespaces.txt"):
+        (stage / name).write_bytes(open(os.path.join(arch, name), "rb").read())
+    sd = {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in w.items()}
+    sd["_text_field_embedder.token_embedder_tokens.transformer_model.embeddings.position_ids"] = torch.arange(512).unsqueeze(0)  # an int64 buffer HF checkpoints carry
+    torch.save(sd, stage / "weights.th")
+    tar_path = tmp_path / "model.tar.gz"
+    with tarfile.open(tar_path, "w:gz") as tf:
+        for name in ("config.json", "weights.th", "vocabulary"):
+            tf.add(stage / name, arcname=name)
+    fx_tar = (root, str(tar_path), golden, test_path, w, dims)
+    metrics_t, records_t, _ = _run(fx_tar, "tar", sweep="arrays")
+    assert records_t == records_d
+    for k in metrics_d:
+        assert metrics_t[k] == pytest.approx(metrics_d[k], abs=1e-12), k
+
+
 def test_record_writer_bytes_equal_json_dumps_including_worker_processes(tmp_path):
     """records.RecordWriter (in-thread and fanned out over spawned processes) == json.dumps of the reference's records:
     duplicate anchor labels (last wins, first position), labels / urls that need escaping or contain '%'."""
