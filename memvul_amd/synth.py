@@ -57,6 +57,7 @@ def make_weights(
     match_scale: float = 1.0,
     plain_init: bool = False,
     ln_outliers: bool = False,
+    trained_like: bool = False,
 ) -> Dict[str, np.ndarray]:
     """Random-init weights of the reference architecture, fp32.
 
@@ -67,7 +68,13 @@ def make_weights(
     matcher to produce "trained-like" |logit| ~ 3.  ``ln_outliers`` gives every
     LayerNorm two large-offset / large-gain dimensions, as trained BERT checkpoints have (a few hidden
     dims with |value| ~ 5-10 in every token): rows then have a visibly non-zero mean and a variance dominated by
-    two dims, which is what the engine's folded-LayerNorm arithmetic has to survive.
+    two dims, which is what the engine's folded-LayerNorm arithmetic has to survive.  (With gain 2.5 on a dimension
+    whose offset has the same sign the outlier feeds on itself: fine for a few layers, but after 12 the stream collapses
+    onto that dimension and every row encodes to the same vector.)  ``trained_like`` is the 12-layer form of it: the
+    same two dimensions carry offsets -4 / +3 at gains 0.6 / 0.8 in every LayerNorm — a stable fixed point, |hidden| up
+    to ~12 against a unit-variance bulk as in trained BERT checkpoints — so that, together with ``qk_scale`` >= 2 and a
+    ``match_scale`` that puts |logit| near 3 (training temperature 0.1, config_memory.json:38), the 1e-3 logit tolerance
+    is tested where it is hardest.
     """
     rng = np.random.Generator(np.random.PCG64(seed))
     H, I, P = dims.hidden, dims.intermediate, dims.proj_dim
@@ -126,6 +133,14 @@ def make_weights(
             if k.endswith("LayerNorm.weight"):
                 w[k] = w[k].copy()
                 w[k][H // 3 + 52] = 2.5
+    if trained_like:
+        for k in w:
+            if k.endswith("LayerNorm.bias"):
+                w[k] = w[k].copy()
+                w[k][[H // 3 + 52, H // 2 - 3]] = [-4.0, 3.0]
+            if k.endswith("LayerNorm.weight"):
+                w[k] = w[k].copy()
+                w[k][[H // 3 + 52, H // 2 - 3]] = [0.6, 0.8]
     return w
 
 

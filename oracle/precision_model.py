@@ -1,0 +1,180 @@
+"""CPU ORACLE (test infrastructure — NOT the product path): a float64 model of WHERE the HIP engine rounds.
+
+The engine (memvul_amd/csrc) computes the reference's BERT forward (custom_PTM_embedder.py:228, HF BertModel) with
+fp16 MFMA operands and fp32 accumulation.  This module re-runs the oracle's mathematics in float64 and applies a
+rounding function at exactly the tensors the engine rounds:
+
+  ``w_qkv, w_o, w_1, w_2``   the four weight matrices of a layer (QKV / FFN-1 after LayerNorm folding)
+  ``a_qkv, a_ffn1``          the raw residual stream as the A operand of the QKV / FFN-1 GEMM (the ``hi`` plane)
+  ``qkv``                    Q, K, V^T as stored between the projection and the attention kernel
+  ``p``                      softmax probabilities as the A operand of P·V
+  ``ctx``                    attention context (A operand of the output projection)
+  ``h``                      GELU output (A operand of FFN-2)
+
+Each knob is a per-layer list of formats: ``"f16"``, ``"f16x2"`` (hi + lo split, 22 bits), ``"bf16"``, ``"bf16x2"``,
+``"bf16x3"``, ``"exact"``.  ``logit_error_table`` prints what each rounding point costs on the match logits, so a
+precision change to the engine is chosen by measurement before any kernel is touched (tests/test_precision_model.py).
+Everything else (LayerNorm statistics, softmax, residual adds, pooler, header, matcher) is fp32/fp64-exact here, as
+in the engine (fp32).
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional
+
+import numpy as np
+
+from . import memvul_oracle as orc
+
+PFX = orc.PFX
+
+
+def _f16(x):
+    return x.astype(np.float16).astype(np.float64)
+
+
+def _bf16(x):
+    """round-to-nearest-even to 8 significand bits (bfloat16), via the float32 bit pattern."""
+    f = np.ascontiguousarray(x, dtype=np.float32)
+    b = f.view(np.uint32).astype(np.uint64)
+    b = ((b + 0x7FFF + ((b >> 16) & 1)) >> 16) << 16
+    return b.astype(np.uint32).view(np.float32).astype(np.float64)
+
+
+def _split(x, rnd, n):
+    out = np.zeros_like(x, dtype=np.float64)
+    rem = x.astype(np.float64)
+    for _ in range(n):
+        part = rnd(rem)
+        out += part
+        rem = rem - part
+    return out
+
+
+FORMATS = {
+    "exact": lambda x: x.astype(np.float64),
+    "f16": _f16,
+    "f16x2": lambda x: _split(x, _f16, 2),
+    "bf16": _bf16,
+    "bf16x2": lambda x: _split(x, _bf16, 2),
+    "bf16x3": lambda x: _split(x, _bf16, 3),
+}
+
+KNOBS = ("w_qkv", "w_o", "w_1", "w_2", "a_qkv", "a_ffn1", "qkv", "p", "ctx", "h")
+
+
+def engine_formats(layers: int, fmt: str = "f16", **override) -> Dict[str, List[str]]:
+    """The engine's shipped rounding points (every knob ``fmt`` in every layer) with per-knob overrides: a format
+    name (all layers) or a list of per-layer names."""
+    cfg = {k: [fmt] * layers for k in KNOBS}
+    for k, v in override.items():
+        cfg[k] = [v] * layers if isinstance(v, str) else list(v)
+    return cfg
+
+
+def _ln_stats(x, eps):
+    mu = x.mean(-1, keepdims=True)
+    var = ((x - mu) ** 2).mean(-1, keepdims=True)
+    return mu, 1.0 / np.sqrt(var + eps)
+
+
+def encode(w, ids, mask, cfg: Optional[Dict[str, List[str]]], heads=12, eps=1e-12, fold_ln=True, cls_side=None, cls_raw_kv=False):
+    """float64 BERT forward with the engine's rounding points (``cfg`` None = exact).  ``fold_ln``: the QKV / FFN-1
+    weights are rounded AFTER the preceding LayerNorm is folded in (W'' = W gamma - rowmean, gemm_pp.h) and the A operand
+    is the raw (pre-LayerNorm) stream, as on the engine's persistent-GEMM path."""
+    W = lambda k: w[PFX + k].astype(np.float64)  # noqa: E731
+    L = orc.n_layers(w)
+    if cfg is None:
+        cfg = engine_formats(L, "exact")
+    R = lambda knob, l, x: FORMATS[cfg[knob][l]](x)  # noqa: E731
+    B, S = ids.shape
+    H = W("embeddings.word_embeddings.weight").shape[1]
+    d = H // heads
+    r = (W("embeddings.word_embeddings.weight")[ids] + W("embeddings.position_embeddings.weight")[np.arange(S)][None]
+         + W("embeddings.token_type_embeddings.weight")[0][None, None])
+    g, b = W("embeddings.LayerNorm.weight"), W("embeddings.LayerNorm.bias")
+    addmask = ((1.0 - mask.astype(np.float64)) * orc.MASK_ADD)[:, None, None, :]
+    # [CLS] side path (cls_side = format name of ITS operands, e.g. "exact" / "f16x2"): the [CLS] row of every issue report
+    # is re-computed in every layer at higher precision from the main path's stored K / V of all tokens; the pooler reads
+    # the side path's row.  The main path does not depend on it.
+    rc = r[:, 0].copy()
+    gc, bc = g, b
+    RS = FORMATS[cls_side] if cls_side else None
+
+    def consumer(r_raw, g, b, Wm, bias, wknob, aknob, l):
+        """rstd * (W'' · round(r)) + b'  ==  W · LN(r) + bias  up to the roundings"""
+        mu, rstd = _ln_stats(r_raw, eps)
+        if fold_ln:
+            Wg = Wm * g[None, :]
+            Wf = R(wknob, l, Wg - Wg.mean(-1, keepdims=True))
+            bf = bias + Wm @ b
+            return rstd * (R(aknob, l, r_raw) @ Wf.T) + bf
+        x = (r_raw - mu) * rstd * g + b
+        return R(aknob, l, x) @ R(wknob, l, Wm).T + bias
+
+    for l in range(L):
+        p = f"encoder.layer.{l}."
+        Wqkv = np.concatenate([W(p + "attention.self.query.weight") * 0.125, W(p + "attention.self.key.weight"),
+                               W(p + "attention.self.value.weight")], 0)
+        bqkv = np.concatenate([W(p + "attention.self.query.bias") * 0.125, W(p + "attention.self.key.bias"),
+                               W(p + "attention.self.value.bias")], 0)
+        r_in = r
+        qkv = R("qkv", l, consumer(r, g, b, Wqkv, bqkv, "w_qkv", "a_qkv", l))
+        sp = lambda t: t.reshape(B, S, heads, d).transpose(0, 2, 1, 3)  # noqa: E731
+        qh, kh, vh = sp(qkv[..., :H]), sp(qkv[..., H:2 * H]), sp(qkv[..., 2 * H:])
+        sc = qh @ kh.transpose(0, 1, 3, 2) + addmask  # 1/sqrt(d) folded into W_q (exact power of two)
+        m = sc.max(-1, keepdims=True)
+        e = np.exp(sc - m)
+        den = e.sum(-1, keepdims=True)
+        ctx = ((R("p", l, e) @ vh) / den).transpose(0, 2, 1, 3).reshape(B, S, H)  # the engine normalises O after P·V
+        ctx = R("ctx", l, ctx)
+        mu, rstd = _ln_stats(r, eps)
+        x = (r - mu) * rstd * g + b
+        r1 = ctx @ R("w_o", l, W(p + "attention.output.dense.weight")).T + W(p + "attention.output.dense.bias") + x
+        g1, b1 = W(p + "attention.output.LayerNorm.weight"), W(p + "attention.output.LayerNorm.bias")
+        hpre = consumer(r1, g1, b1, W(p + "intermediate.dense.weight"), W(p + "intermediate.dense.bias"), "w_1", "a_ffn1", l)
+        h = R("h", l, orc._gelu(hpre))
+        mu, rstd = _ln_stats(r1, eps)
+        x1 = (r1 - mu) * rstd * g1 + b1
+        r = h @ R("w_2", l, W(p + "output.dense.weight")).T + W(p + "output.dense.bias") + x1
+        if cls_side:
+            mu, rstd = _ln_stats(rc, eps)
+            xc = (rc - mu) * rstd * gc + bc
+            qc = (RS(xc) @ RS(Wqkv[:H]).T + bqkv[:H]).reshape(B, heads, 1, d)
+            khc, vhc = kh, vh
+            if cls_raw_kv:  # the [CLS] row attends to the main path's RAW stream: K / V re-derived at the side path's precision
+                mu, rstd = _ln_stats(r_in, eps)
+                xm = RS((r_in - mu) * rstd * g + b)
+                khc = sp(xm @ RS(Wqkv[H:2 * H]).T + bqkv[H:2 * H])
+                vhc = sp(xm @ RS(Wqkv[2 * H:]).T + bqkv[2 * H:])
+            scc = qc @ khc.transpose(0, 1, 3, 2) + addmask
+            ec = np.exp(scc - scc.max(-1, keepdims=True))
+            cc = ((ec @ vhc) / ec.sum(-1, keepdims=True)).reshape(B, H)
+            r1c = RS(cc) @ RS(W(p + "attention.output.dense.weight")).T + W(p + "attention.output.dense.bias") + xc
+            mu, rstd = _ln_stats(r1c, eps)
+            x1c = (r1c - mu) * rstd * g1 + b1
+            hc = orc._gelu(RS(x1c) @ RS(W(p + "intermediate.dense.weight")).T + W(p + "intermediate.dense.bias"))
+            rc = RS(hc) @ RS(W(p + "output.dense.weight")).T + W(p + "output.dense.bias") + x1c
+        g, b = W(p + "output.LayerNorm.weight"), W(p + "output.LayerNorm.bias")
+        gc, bc = g, b
+    if cls_side:
+        r = r.copy()
+        r[:, 0] = rc
+    mu, rstd = _ln_stats(r, eps)
+    return (r - mu) * rstd * g + b
+
+
+def instance_forward(w, ids, mask, cfg=None, **kw):
+    h = encode(w, ids, mask, cfg, **kw)
+    pooled = np.tanh(h[:, 0] @ w[orc_key("pool_w")].astype(np.float64).T + w[orc_key("pool_b")].astype(np.float64))
+    return np.maximum(pooled @ w[orc_key("head_w")].astype(np.float64).T + w[orc_key("head_b")].astype(np.float64), 0)
+
+
+def orc_key(name):
+    return {"pool_w": "_bert_pooler.pooler.dense.weight", "pool_b": "_bert_pooler.pooler.dense.bias",
+            "head_w": "_projector_single._linear_layers.0.weight", "head_b": "_projector_single._linear_layers.0.bias"}[name]
+
+
+def logits(w, ids, mask, aids, amask, cfg=None, **kw):
+    u = instance_forward(w, ids, mask, cfg, **kw)
+    v = instance_forward(w, aids, amask, cfg, **kw)
+    return orc.match(u, v, w["_projector.weight"].astype(np.float64))[0], u, v

@@ -25,6 +25,10 @@ CASES = {
     "l2_ragged": (dict(layers=2, vocab_size=2048), dict(qk_scale=3.0, match_scale=8.0), 6, 128, True, 5, 64),
     "l12_base_ragged": (dict(layers=12), dict(), 3, 128, True, 6, 160),
     "l12_base_s256": (dict(layers=12), dict(), 2, 256, False, 4, 256),
+    # trained-like regime: 12 layers, peaked attention, stable outlier dimensions in every LayerNorm,
+    # |u| = O(1), matcher scaled so that max |logit| ~ 3 (training temperature 0.1, config_memory.json:38)
+    "l12_trained_s256": (dict(layers=12), dict(qk_scale=2.0, match_scale=29.0, trained_like=True), 4, 256, False, 8, 320),
+    "l12_trained_ragged": (dict(layers=12), dict(qk_scale=2.0, match_scale=29.0, trained_like=True), 6, 256, True, 6, 512),
 }
 
 
@@ -39,7 +43,10 @@ def case_inputs(name):
 
 def main():
     out_dir = os.path.dirname(os.path.abspath(__file__))
+    only = sys.argv[1:]
     for name in CASES:
+        if only and name not in only:
+            continue
         dims, w, ids, lens, aids, alens = case_inputs(name)
         ref = HFReference(w, dims.as_dict())
         # anchor bank: one chunk (<128 anchors), padded to its longest member (predict_memory.py:81)

@@ -11,6 +11,13 @@ from oracle import memvul_oracle as orc
 pytestmark = pytest.mark.gpu
 
 LOGIT_TOL = 1e-3  # north_star: logits within 1e-3 of the CPU reference
+# Trained-like regime (|logit| ~ 3 through a matcher of norm ~ 17): what fp16 MFMA operands deliver, MEASURED — 3.3e-3 ..
+# 5.7e-3 on the MI355X (profiles/r02_a_trained_like.txt), 2.5e-3 .. 3.2e-3 in the float64 rounding model
+# (tests/test_precision_model.py), i.e. the 1e-3 budget is NOT met here; DESIGN.md §2 prices what would meet it
+# (exact [CLS] rows: ~1e-3; + split weights = 2x the MFMA work: 3e-4).  The probabilities — what thresholds, decisions
+# and every metric of the path consume — stay within 1e-4 because softmax_2 is flat at |logit| ~ 3.
+TRAINED_LIKE_LOGIT_BOUND = 8e-3
+TRAINED_LIKE_P_TOL = 2e-4
 
 
 @pytest.fixture(scope="module")
@@ -45,6 +52,36 @@ def test_golden_logits(gu, golden_dir, name, gemm_tile):
     clear = (srt[:, -1] - srt[:, -2]) > 2 * LOGIT_TOL if ps.shape[1] > 1 else np.ones(len(ps), bool)
     assert np.array_equal(out["best_idx"][clear], g["idx"][clear].astype(np.int32))
     assert np.abs(out["best"] - g["best"])[clear].max() <= LOGIT_TOL if clear.any() else True
+    eng.anchor_reset()
+
+
+@pytest.mark.parametrize("gemm_tile", [0, 512])
+@pytest.mark.parametrize("name", ["l12_trained_s256", "l12_trained_ragged"])
+def test_trained_like_logits(gu, golden_dir, name, gemm_tile):
+    """The 1e-3 logit tolerance where it is hardest: 12 layers, peaked attention, outlier
+    dimensions in every LayerNorm, |u| = O(1) and a matcher scaled so that max |logit| ~ 3 (the regime a checkpoint
+    trained at temperature 0.1, config_memory.json:38, lives in).  Goldens: HF BertModel fp32 + the reference's head
+    (tests/golden/make_golden.py); issue reports of 256 tokens (cfg-2 shape) against anchors of up to 320 / 512 tokens,
+    on both GEMM paths."""
+    import make_golden
+    g = np.load(os.path.join(golden_dir, f"{name}.npz"))
+    dk, wk, B, S, ragged, G, SA = make_golden.CASES[name]
+    eng = gu.engine_for(dk, wk, gemm_tile=gemm_tile, max_tokens=16384, max_batch=64, max_anchors=64)
+    eng.anchor_reset()
+    LA = int(g["anchor_lens"].max())
+    eng.anchor_append(g["anchor_ids"][:, :LA], g["anchor_lens"])
+    v = eng.anchor_get()
+    out = eng.forward(g["ids"], g["lens"], want_embed=True)
+    errs = dict(
+        v=float(np.abs(v - g["v"]).max()), u=float(np.abs(out["embed"] - g["u"]).max()),
+        logits=float(np.abs(out["logits"] - g["logits"]).max()), p=float(np.abs(out["probs"] - g["p"]).max()),
+        logit_scale=float(np.abs(g["logits"]).max()), u_scale=float(np.abs(g["u"]).max()),
+    )
+    gu.record("trained_like", case=name, gemm_tile=gemm_tile, **errs)
+    assert errs["logit_scale"] > 2.5
+    assert errs["logits"] <= TRAINED_LIKE_LOGIT_BOUND, errs  # NOT the 1e-3 target: the measured level, see above
+    assert errs["p"] <= TRAINED_LIKE_P_TOL, errs
+    assert errs["u"] <= 1e-3 and errs["v"] <= 1e-3, errs     # embeddings of magnitude 0.8: 6e-4 relative
     eng.anchor_reset()
 
 

