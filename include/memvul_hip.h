@@ -83,8 +83,11 @@ int mv_sync(mv_handle* h);
  * ignored.  dtype MV_F32 / MV_F16 / MV_BF16; the data is copied, the caller may free it. */
 int mv_load_tensor(mv_handle* h, const char* name, const void* host_ptr, int dtype, const int64_t* shape, int ndim);
 /* Checks that every needed key is present and well-shaped, packs QKV, converts the GEMM weights to
- * `compute_dtype` (MV_F16: fp16 MFMA operands, fp32 accumulation — the parity path; MV_BF16) and
- * uploads.  Embeddings, LayerNorm, biases, pooler, header and matcher stay fp32. */
+ * `compute_dtype` and uploads.  The only compute dtype is MV_F16 (fp16 MFMA operands, fp32 accumulation); anything
+ * else returns MV_ERR_INVALID.  MV_BF16 is a STORAGE dtype of mv_load_tensor only (bf16 checkpoints load): as MFMA
+ * operand format it was measured and rejected — 8 significand bits put the match logits 1.5e-2 off at |logit| ~ 3
+ * and 2.5e-3 off even on random-init weights (oracle/precision_model.py), against a 1e-3 budget, at the
+ * same MFMA rate as fp16.  Embeddings, LayerNorm, biases, pooler, header and matcher stay fp32. */
 int mv_finalize_weights(mv_handle* h, int compute_dtype);
 
 /* ---- anchor memory (replaces ModelMemory.forward_gold_instances, model_memory.py:105-115, as

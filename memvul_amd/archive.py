@@ -57,7 +57,7 @@ def load_archive(archive_file: str, weights_file: Optional[str] = None, cuda_dev
     if os.path.isfile(archive_file):
         tmp = tempfile.TemporaryDirectory(prefix="memvul_archive_")
         with tarfile.open(archive_file, "r:*") as tf:
-            tf.extractall(tmp.name)
+            tf.extractall(tmp.name, filter="data")  # no absolute paths / links / traversal out of the temp dir
         root = tmp.name
     try:
         config = _params.with_overrides(_params.load_config(os.path.join(root, "config.json")), overrides)

@@ -12,7 +12,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIB_DIR = os.path.join(HERE, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libmemvul_hip.so")
 SOURCES = ["engine.hip"]
-HEADERS = ["common.h", "gemm.h", "gemm_pp.h", "attention.h", "attention_v2.h", "misc_kernels.h", os.path.join(ROOT, "include", "memvul_hip.h")]
+HEADERS = ["common.h", "gemm.h", "gemm_pp.h", "attention.h", "attention_v2.h", "misc_kernels.h", "match_topk.h", os.path.join(ROOT, "include", "memvul_hip.h")]
 ARCH = "gfx950"
 
 
@@ -23,22 +23,43 @@ def hipcc_path() -> str:
     raise RuntimeError("hipcc not found (need ROCm at /opt/rocm)")
 
 
-def is_stale() -> bool:
-    if not os.path.exists(LIB_PATH):
+STAMP_PATH = LIB_PATH + ".stamp"
+FLAGS = ["-O3", "-std=c++17", "-fPIC", "-shared", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function", "-Wno-unused-value"]
+
+
+def build_fingerprint(extra_flags=()) -> str:
+    """What the binary depends on: compiler identity, flags, and the CONTENT of every source / header (not mtimes —
+    a checkout or a copy to another box rewrites those)."""
+    import hashlib
+
+    h = hashlib.sha256()
+    try:
+        h.update(subprocess.run([hipcc_path(), "--version"], capture_output=True, check=True).stdout)
+    except Exception as e:  # no compiler here (GPU box without ROCm dev tools): fingerprint of the sources alone
+        h.update(repr(type(e)).encode())
+    h.update(" ".join([ARCH, *FLAGS, *extra_flags]).encode())
+    deps = [os.path.join(CSRC, s) for s in SOURCES] + [h_ if os.path.isabs(h_) else os.path.join(CSRC, h_) for h_ in HEADERS]
+    for d in deps:
+        h.update(os.path.basename(d).encode())
+        with open(d, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
+
+
+def is_stale(extra_flags=()) -> bool:
+    if not os.path.exists(LIB_PATH) or not os.path.exists(STAMP_PATH):
         return True
-    t = os.path.getmtime(LIB_PATH)
-    deps = [os.path.join(CSRC, s) for s in SOURCES] + [h if os.path.isabs(h) else os.path.join(CSRC, h) for h in HEADERS]
-    return any(os.path.getmtime(d) > t for d in deps)
+    with open(STAMP_PATH) as f:
+        return f.read().strip() != build_fingerprint(extra_flags)
 
 
 def build(force: bool = False, verbose: bool = True, extra_flags=()) -> str:
     """Compile the HIP library for gfx950; returns the .so path."""
-    if not force and not is_stale():
+    if not force and not is_stale(extra_flags):
         return LIB_PATH
     os.makedirs(LIB_DIR, exist_ok=True)
     cmd = [
-        hipcc_path(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-shared",
-        "-fno-gpu-rdc", "-Wall", "-Wno-unused-function", "-Wno-unused-value",  # hipError_t of calls checked by launch_check
+        hipcc_path(), f"--offload-arch={ARCH}", *FLAGS,  # -Wno-unused-value: hipError_t of calls checked by launch_check
         *extra_flags,
         *[os.path.join(CSRC, s) for s in SOURCES],
         "-o", LIB_PATH + ".tmp",
@@ -47,6 +68,8 @@ def build(force: bool = False, verbose: bool = True, extra_flags=()) -> str:
         print("[memvul_amd.build]", " ".join(cmd), flush=True)
     subprocess.run(cmd, check=True)
     os.replace(LIB_PATH + ".tmp", LIB_PATH)
+    with open(STAMP_PATH, "w") as f:
+        f.write(build_fingerprint(extra_flags) + "\n")
     return LIB_PATH
 
 

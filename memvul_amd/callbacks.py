@@ -24,8 +24,8 @@ class TrainerCallback(Registrable):
 
 @TrainerCallback.register("custom_validation")
 class CustomValidation(TrainerCallback):
-    def __init__(self, serialization_dir: Optional[str] = None, anchor_path: str = "CWE_anchor_golden_project.json",
-                 data_reader=None) -> None:
+    def __init__(self, anchor_path: str = "CWE_anchor_golden_project.json", data_reader=None, data_loader=None,
+                 serialization_dir: Optional[str] = None) -> None:  # the reference's order (callbacks.py:27-31); data_loader unused there too
         super().__init__(serialization_dir)
         PTM = "bert-base-uncased"
         reader = data_reader or ReaderMemory(tokenizer=PretrainedTransformerTokenizer(PTM, add_special_tokens=True, max_length=512),

@@ -20,9 +20,10 @@
 //     the NEXT item: through the K half of the other ring slot (free, and about to be refilled by this same wave's
 //     own DMA pieces — rows 32 w .. 32 w + 31 both times, so no barrier is needed) as a [S][128 B] image read back as
 //     whole 128-B rows -> full-line global stores that have the whole item to complete.  One barrier per item.
-//   * NCH = 2 (S = 512): a work unit is (batch row, head, block of 256 queries) and its keys arrive as two chunks of
-//     256 through the same ring; the second chunk rescales O and the row sums by exp2(m_old - m_new) (online softmax at
-//     chunk granularity: one rescale per unit), so 256 < S <= 512 keeps the LDS-DMA pipeline and the whole-chunk scores.
+//   * NCH = 3 / 4 (S = 384 / 512, instantiated with NKB = 2): a work unit is (batch row, head, block of 128 queries)
+//     and its keys arrive as NCH chunks of 128 through the same ring; every chunk after the first rescales O and the row
+//     sums by exp2(m_old - m_new) (online softmax at chunk granularity), so 256 < S <= 512 keeps the LDS-DMA pipeline
+//     with 64 score registers per lane and two 4-wave workgroups per CU (engine.hip: attention_v2_kernel<2, S / 128>).
 #pragma once
 #include "attention.h"
 #include "gemm.h"  // glds16

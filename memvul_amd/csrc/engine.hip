@@ -18,6 +18,7 @@
 #include "gemm_pp.h"
 #include "attention_v2.h"
 #include "misc_kernels.h"
+#include "match_topk.h"
 
 namespace {
 
@@ -114,6 +115,8 @@ struct Work {
   int32_t* best_idx = nullptr;
   float* topk_p = nullptr;
   int32_t* topk_idx = nullptr;
+  float *part_p = nullptr, *part_q = nullptr;   // per-chunk top-k candidates of the fused matcher (G > 256)
+  int32_t* part_i = nullptr;
   float* u_in = nullptr;                        // host-provided embeddings for mv_match / mv_topk
   float *c32 = nullptr, *cq = nullptr;          // [CLS]-row buffers of the pruned last layer
   half_t *c16 = nullptr, *cctx = nullptr, *ch16 = nullptr;
@@ -555,31 +558,32 @@ int max_rows_for(mv_handle* h, int S_in) {
   return (int)r;
 }
 
-// K9: 16 issue reports per workgroup when that fills the chip, otherwise 4 (same bits either way)
-int launch_match(mv_handle* h, const float* u_dev, int B, float* logits, float* probs, float* psame) {
-  const int G = h->n_anchors, gx = (G + MT_G - 1) / MT_G;
-  if ((int64_t)gx * ((B + 15) / 16) >= h->num_cu)
-    hipLaunchKernelGGL(match_kernel<4>, dim3(gx, (B + 15) / 16), dim3(256), 0, h->w->stream, u_dev, h->anchors, h->Wm, B, G,
-                       h->cfg.same_idx, logits, probs, psame);
-  else
-    hipLaunchKernelGGL(match_kernel<1>, dim3(gx, (B + 3) / 4), dim3(256), 0, h->w->stream, u_dev, h->anchors, h->Wm, B, G,
-                       h->cfg.same_idx, logits, probs, psame);
-  return launch_check(h, "match");
-}
-
-// ---- matcher on device embeddings ------------------------------------------------------------
-int match_dev(mv_handle* h, const float* u_dev, int B, float* psame_out, int k, float* best_out, int32_t* idx_out) {
+// K9 + K10 fused (match_topk.h): logits / probs / psame_out are optional full outputs; k >= 1 selects the best anchor
+// (and, with topk_p / topk_idx, the k best).  4 issue reports per workgroup when that already fills the chip, else 1
+// (the same bits either way).
+int match_dev(mv_handle* h, const float* u_dev, int B, float* logits, float* probs, float* psame_out, int k, float* best_out,
+              int32_t* idx_out, float* topk_p = nullptr, int32_t* topk_idx = nullptr) {
   const int G = h->n_anchors;
   if (G <= 0) return fail(h, MV_ERR_STATE, "anchor bank is empty (call mv_anchor_append / mv_anchor_set first)");
+  MatchArgs a{};
+  a.B = B; a.G = G; a.same_idx = h->cfg.same_idx; a.k = k;
+  a.nchunk = (G + MK_GC - 1) / MK_GC;
+  if ((int64_t)a.nchunk * k > 1024) return fail(h, MV_ERR_INVALID, "top-k: anchors / 256 * k must not exceed 1024");
+  a.logits = logits; a.probs = probs; a.psame = psame_out;
+  a.best = best_out; a.best_idx = idx_out; a.topk_p = topk_p; a.topk_idx = topk_idx;
+  a.part_p = h->w->part_p; a.part_q = h->w->part_q; a.part_i = h->w->part_i;
   {
     ProfScope ps(h, KC_MATCH);
-    if (int rc = launch_match(h, u_dev, B, h->w->logits, h->w->probs, psame_out)) return rc;
+    if ((int64_t)a.nchunk * ((B + 3) / 4) >= h->num_cu)
+      hipLaunchKernelGGL(match_topk_kernel<4>, dim3(a.nchunk, (B + 3) / 4), dim3(256), 0, h->w->stream, u_dev, h->anchors, h->Wm, a);
+    else
+      hipLaunchKernelGGL(match_topk_kernel<1>, dim3(a.nchunk, B), dim3(256), 0, h->w->stream, u_dev, h->anchors, h->Wm, a);
+    if (int rc = launch_check(h, "match_topk")) return rc;
   }
-  {
+  if (a.nchunk > 1 && k > 0) {
     ProfScope ps(h, KC_TOPK);
-    hipLaunchKernelGGL(topk_kernel, dim3((B + 3) / 4), dim3(256), 0, h->w->stream, psame_out, h->w->probs, B, G, k, best_out,
-                       idx_out, k > 1 ? h->w->topk_p : nullptr, k > 1 ? h->w->topk_idx : nullptr);
-    if (int rc = launch_check(h, "topk")) return rc;
+    hipLaunchKernelGGL(topk_merge_kernel, dim3((B + 3) / 4), dim3(256), 0, h->w->stream, a);
+    if (int rc = launch_check(h, "topk_merge")) return rc;
   }
   return MV_OK;
 }
@@ -600,6 +604,16 @@ int check_ready(mv_handle* h) {
     h->dual_pending = false;
   }
   h->w = &h->work[0];
+  return MV_OK;
+}
+
+// HF's embedding lookup raises on an id outside the table; the embedding kernel would clamp silently (a tokenizer /
+// checkpoint vocabulary mismatch would then score garbage without a sign): reject such input at the boundary.
+int check_ids(mv_handle* h, const int32_t* ids, int64_t n, const char* who) {
+  const int32_t V = h->cfg.vocab_size;
+  uint32_t bad = 0;
+  for (int64_t i = 0; i < n; ++i) bad |= (uint32_t)(ids[i] < 0) | (uint32_t)(ids[i] >= V);
+  if (bad) return fail(h, MV_ERR_INVALID, std::string(who) + ": token id outside [0, vocab_size) — tokenizer and checkpoint vocabularies differ?");
   return MV_OK;
 }
 
@@ -768,6 +782,13 @@ int mv_create(int device, const mv_config* cfg, mv_handle** out) {
     A(dev_alloc(h, &h->w->best_idx, cfg->max_batch));
     A(dev_alloc(h, &h->w->topk_p, (int64_t)cfg->max_batch * 64));
     A(dev_alloc(h, &h->w->topk_idx, (int64_t)cfg->max_batch * 64));
+    {
+      const int64_t nch = (cfg->max_anchors + MK_GC - 1) / MK_GC;
+      const int64_t per = nch > 1 ? (nch * MK_KMAX < 1024 ? nch * MK_KMAX : 1024) : 0;  // chunks x k <= 1024 (match_dev)
+      A(dev_alloc(h, &h->w->part_p, (int64_t)cfg->max_batch * per));
+      A(dev_alloc(h, &h->w->part_q, (int64_t)cfg->max_batch * per));
+      A(dev_alloc(h, &h->w->part_i, (int64_t)cfg->max_batch * per));
+    }
     if (rc == MV_OK && hipStreamSynchronize(h->w->stream) != hipSuccess) rc = MV_ERR_HIP;
   }
   h->w = &h->work[0];
@@ -832,7 +853,8 @@ int mv_finalize_weights(mv_handle* h, int compute_dtype) {
   if (!h) return MV_ERR_INVALID;
   if (h->finalized) return fail(h, MV_ERR_STATE, "weights already finalized");
   if (compute_dtype != MV_F16)
-    return fail(h, MV_ERR_INVALID, "only MV_F16 (fp16 MFMA operands, fp32 accumulation) is built in this round");
+    return fail(h, MV_ERR_INVALID, "compute_dtype must be MV_F16 (fp16 MFMA operands, fp32 accumulation); bf16 is a storage "
+                                   "dtype of mv_load_tensor only (include/memvul_hip.h)");
   HIPCHK(h, hipSetDevice(h->device));
   const mv_config& c = h->cfg;
   const std::string P = "_text_field_embedder.token_embedder_tokens.transformer_model.";
@@ -965,6 +987,7 @@ int mv_anchor_append(mv_handle* h, const int32_t* ids, const int32_t* lens, int 
   if (int rc = check_ready(h)) return rc;
   if (!ids || !lens || n <= 0 || S <= 0 || S > h->cfg.max_pos) return fail(h, MV_ERR_INVALID, "mv_anchor_append: bad argument");
   if (h->n_anchors + n > h->cfg.max_anchors) return fail(h, MV_ERR_CAPACITY, "anchor bank capacity (mv_config.max_anchors) exceeded");
+  if (int rc = check_ids(h, ids, (int64_t)n * S, "mv_anchor_append")) return rc;
   HIPCHK(h, hipSetDevice(h->device));
   const int rows = max_rows_for(h, S);
   if (rows <= 0) return fail(h, MV_ERR_CAPACITY, "mv_config.max_tokens too small for one anchor of this length");
@@ -998,6 +1021,7 @@ int mv_anchor_set(mv_handle* h, const float* v, int G) {
 int mv_encode(mv_handle* h, const int32_t* ids, const int32_t* lens, int B, int S, float* embed) {
   if (int rc = check_ready(h)) return rc;
   if (!ids || !lens || B <= 0 || S <= 0 || S > h->cfg.max_pos) return fail(h, MV_ERR_INVALID, "mv_encode: bad argument");
+  if (int rc = check_ids(h, ids, (int64_t)B * S, "mv_encode")) return rc;
   HIPCHK(h, hipSetDevice(h->device));
   const int rows = max_rows_for(h, S);
   if (rows <= 0) return fail(h, MV_ERR_CAPACITY, "mv_config.max_tokens too small for this sequence length");
@@ -1017,6 +1041,7 @@ int mv_forward(mv_handle* h, const int32_t* ids, const int32_t* lens, int B, int
   if (int rc = check_ready(h)) return rc;
   if (!ids || !lens || B <= 0 || S <= 0 || S > h->cfg.max_pos) return fail(h, MV_ERR_INVALID, "mv_forward: bad argument");
   if (h->n_anchors <= 0) return fail(h, MV_ERR_STATE, "anchor bank is empty (call mv_anchor_append / mv_anchor_set first)");
+  if (int rc = check_ids(h, ids, (int64_t)B * S, "mv_forward")) return rc;
   HIPCHK(h, hipSetDevice(h->device));
   const int rows = max_rows_for(h, S);
   if (rows <= 0) return fail(h, MV_ERR_CAPACITY, "mv_config.max_tokens too small for this sequence length");
@@ -1026,7 +1051,9 @@ int mv_forward(mv_handle* h, const int32_t* ids, const int32_t* lens, int B, int
     HIPCHK(h, hipMemcpyAsync(h->w->d_ids, ids + (size_t)off * S, (size_t)nb * S * 4, hipMemcpyHostToDevice, h->w->stream));
     HIPCHK(h, hipMemcpyAsync(h->w->d_lens, lens + off, (size_t)nb * 4, hipMemcpyHostToDevice, h->w->stream));
     if (int rc = encode_dev(h, h->w->d_ids, h->w->d_lens, nb, S, -1, h->w->u)) return rc;
-    if (int rc = match_dev(h, h->w->u, nb, h->w->psame, 1, h->w->best, h->w->best_idx)) return rc;
+    // only the outputs the caller asked for leave the kernel (the best anchor always does)
+    if (int rc = match_dev(h, h->w->u, nb, logits ? h->w->logits : nullptr, probs ? h->w->probs : nullptr, nullptr, 1, h->w->best,
+                           h->w->best_idx)) return rc;
     const size_t bg = (size_t)nb * G;
     if (logits) HIPCHK(h, hipMemcpyAsync(logits + (size_t)off * G * 2, h->w->logits, bg * 8, hipMemcpyDeviceToHost, h->w->stream));
     if (probs) HIPCHK(h, hipMemcpyAsync(probs + (size_t)off * G * 2, h->w->probs, bg * 8, hipMemcpyDeviceToHost, h->w->stream));
@@ -1045,7 +1072,8 @@ int mv_match(mv_handle* h, const float* u, int B, float* logits, float* probs, f
   HIPCHK(h, hipSetDevice(h->device));
   const int G = h->n_anchors;
   HIPCHK(h, hipMemcpyAsync(h->w->u_in, u, (size_t)B * MV_PROJ * 4, hipMemcpyHostToDevice, h->w->stream));
-  if (int rc = match_dev(h, h->w->u_in, B, h->w->psame, 1, h->w->best, h->w->best_idx)) return rc;
+  if (int rc = match_dev(h, h->w->u_in, B, logits ? h->w->logits : nullptr, probs ? h->w->probs : nullptr, nullptr, 1, h->w->best,
+                         h->w->best_idx)) return rc;
   const size_t bg = (size_t)B * G;
   if (logits) HIPCHK(h, hipMemcpyAsync(logits, h->w->logits, bg * 8, hipMemcpyDeviceToHost, h->w->stream));
   if (probs) HIPCHK(h, hipMemcpyAsync(probs, h->w->probs, bg * 8, hipMemcpyDeviceToHost, h->w->stream));
@@ -1062,20 +1090,8 @@ int mv_topk(mv_handle* h, const float* u, int B, int k, float* topk_p, int32_t* 
   if (k > h->n_anchors) return fail(h, MV_ERR_INVALID, "k exceeds the number of anchors");
   HIPCHK(h, hipSetDevice(h->device));
   HIPCHK(h, hipMemcpyAsync(h->w->u_in, u, (size_t)B * MV_PROJ * 4, hipMemcpyHostToDevice, h->w->stream));
-  // k == 1 goes through the same kernel; force the top-k outputs on
-  {
-    const int G = h->n_anchors;
-    {
-      ProfScope ps(h, KC_MATCH);
-      if (int rc = launch_match(h, h->w->u_in, B, nullptr, nullptr, h->w->psame)) return rc;
-    }
-    {
-      ProfScope ps(h, KC_TOPK);
-      hipLaunchKernelGGL(topk_kernel, dim3((B + 3) / 4), dim3(256), 0, h->w->stream, h->w->psame, (const float*)nullptr, B, G, k,
-                         (float*)nullptr, (int32_t*)nullptr, h->w->topk_p, h->w->topk_idx);
-      if (int rc = launch_check(h, "topk")) return rc;
-    }
-  }
+  // one fused pass: P(same) [B, G] never reaches HBM, only 8 B k bytes of results do
+  if (int rc = match_dev(h, h->w->u_in, B, nullptr, nullptr, nullptr, k, nullptr, nullptr, h->w->topk_p, h->w->topk_idx)) return rc;
   HIPCHK(h, hipMemcpyAsync(topk_p, h->w->topk_p, (size_t)B * k * 4, hipMemcpyDeviceToHost, h->w->stream));
   HIPCHK(h, hipMemcpyAsync(topk_idx, h->w->topk_idx, (size_t)B * k * 4, hipMemcpyDeviceToHost, h->w->stream));
   HIPCHK(h, hipStreamSynchronize(h->w->stream));
@@ -1086,6 +1102,7 @@ int mv_topk(mv_handle* h, const float* u, int B, int k, float* topk_p, int32_t* 
 int mv_corpus_upload(mv_handle* h, const int32_t* ids, const int32_t* lens, int64_t n, int S) {
   if (int rc = check_ready(h)) return rc;
   if (!ids || !lens || n <= 0 || S <= 0 || S > h->cfg.max_pos) return fail(h, MV_ERR_INVALID, "mv_corpus_upload: bad argument");
+  if (int rc = check_ids(h, ids, n * S, "mv_corpus_upload")) return rc;
   HIPCHK(h, hipSetDevice(h->device));
   HIPCHK(h, hipStreamSynchronize(h->w->stream));
   dev_free(h, h->c_ids); dev_free(h, h->c_lens); dev_free(h, h->c_best); dev_free(h, h->c_idx); dev_free(h, h->c_psame);
@@ -1118,7 +1135,10 @@ int mv_corpus_run_len(mv_handle* h, int64_t first, int64_t count, int batch, int
   if (s_eff < 0 || s_eff > h->c_S) return fail(h, MV_ERR_INVALID, "mv_corpus_run_len: s_eff must be in [0, S of the resident corpus]");
   const int S_use = s_eff > 0 ? s_eff : h->c_S;  // tokens per row actually processed (rows longer than this must not be in the range)
   const int rows = max_rows_for(h, S_use);
-  if (batch > rows) return fail(h, MV_ERR_CAPACITY, "batch exceeds mv_config.max_batch / max_tokens");
+  if (rows <= 0) return fail(h, MV_ERR_CAPACITY, "mv_config.max_tokens too small for one row of this length");
+  // a batch larger than one pass holds is walked in passes of `rows` (as mv_forward / mv_encode do): a row's result
+  // does not depend on the batch it travels in (bit-identical, tests/test_gpu_parity.py::test_full_batch_properties)
+  if (batch > rows) batch = rows;
   const int G = h->n_anchors;
   if (keep_probs && (h->c_psame_rows != h->c_n || h->c_G != G)) {
     if (int rc = sync_all(h)) return rc;
@@ -1140,8 +1160,8 @@ int mv_corpus_run_len(mv_handle* h, int64_t first, int64_t count, int batch, int
     }
     rc = encode_dev(h, h->c_ids + (size_t)off * h->c_S, h->c_lens + off, nb, S_use, -1, h->w->u, false, h->c_S);
     if (rc != MV_OK) break;
-    float* ps = keep_probs ? h->c_psame + (size_t)off * G : h->w->psame;
-    rc = match_dev(h, h->w->u, nb, ps, 1, h->c_best + (size_t)off * 2, h->c_idx + off);
+    float* ps = keep_probs ? h->c_psame + (size_t)off * G : nullptr;  // P(same) [nb, G] only when the caller keeps it
+    rc = match_dev(h, h->w->u, nb, nullptr, nullptr, ps, 1, h->c_best + (size_t)off * 2, h->c_idx + off);
   }
   h->w = &h->work[0];
   return rc;
@@ -1203,6 +1223,7 @@ int mv_debug_encode(mv_handle* h, const int32_t* ids, const int32_t* lens, int B
   if (int rc = check_ready(h)) return rc;
   if (!ids || !lens || B <= 0 || S <= 0 || S > h->cfg.max_pos) return fail(h, MV_ERR_INVALID, "mv_debug_encode: bad argument");
   if (B > max_rows_for(h, S)) return fail(h, MV_ERR_CAPACITY, "mv_debug_encode: batch too large for one pass");
+  if (int rc = check_ids(h, ids, (int64_t)B * S, "mv_debug_encode")) return rc;
   HIPCHK(h, hipSetDevice(h->device));
   HIPCHK(h, hipMemcpyAsync(h->w->d_ids, ids, (size_t)B * S * 4, hipMemcpyHostToDevice, h->w->stream));
   HIPCHK(h, hipMemcpyAsync(h->w->d_lens, lens, (size_t)B * 4, hipMemcpyHostToDevice, h->w->stream));

@@ -1,0 +1,245 @@
+// K9 + K10 fused (model_memory.py:135-147; BASELINE.json configs[4]): anchor match, softmax_2 and best-anchor / top-k
+// selection in ONE pass over the anchor bank — P(same) [B, G] never goes through HBM unless the caller asks for it.
+//
+//   logits[b,g,c] = W_a[c] . u_b  +  W_b[c] . v_g  +  W_c[c] . |u_b - v_g|        (W_m = [W_a | W_b | W_c], bias-free, l.73,141)
+//   p = softmax_2(logits)                                                          (l.142)
+//   g* = argmax_g p[b,g,same]  (first maximal g, l.144-145);  top-k: k rounds of it
+//
+// The reference materialises the [B, G, 1536] concatenation (3.1 GB at B = 512, G = 1000).  Here:
+//   * W_a . u_b is hoisted (once per issue report: lane-parallel partial sums + a fixed-order wave reduction),
+//     W_b . v_g is one fma chain per anchor (lane = anchor), so the inner loop is  d = u - v;  acc_c += W_c[c] * |d|
+//     = 3 VALU operations per (b, g, feature) instead of the 5 of the plain form (the |.| is a source modifier);
+//   * a workgroup = RB issue reports x 256 anchors (wave w <-> anchors 64 w .. 64 w + 63 of the chunk); the anchor chunk is
+//     staged through LDS 32 features at a time by coalesced 16-byte loads (row stride 36 floats: the lane = anchor
+//     ds_read_b128 is conflict-free), the next chunk's loads are in flight while the current one is consumed; the RB issue
+//     report rows sit in LDS and are read as wave-uniform (broadcast) float4; W_c, W_b are scalar (SGPR) operands;
+//   * the chunk's P(same) values go to LDS and wave r runs k rounds of (value desc, index asc) arg-max for row r; with
+//     one chunk (G <= 256: the 124-anchor CWE memory) these ARE the results; otherwise per-chunk candidate lists
+//     [B][chunks][k] (8 B k per chunk) are merged by topk_merge_kernel.
+// Algorithmic HBM bytes: 4 (B P + G P) + 8 B k = 3.1 MB at B = 256, G = 1000, k = 10, all L2-resident; the
+// bound is the fp32 vector ALU: 3 B G P operations = 0.39 G lane-ops (5.0 us at 78.6 T lane-op/s).
+// Every (b, g) result is computed by the same instruction sequence wherever it lands in the grid: results do not depend
+// on B, on the chunking or on RB (tested), and mv_match / mv_forward / mv_topk / the resident sweep share this kernel.
+#pragma once
+#include "common.h"
+
+#define MK_GC 256     // anchors per workgroup chunk
+#define MK_I 32       // features staged per step
+#define MK_STRIDE 36  // floats per staged anchor row
+#define MK_KMAX 64
+
+struct MatchArgs {  // (u, v, W_m travel as separate `const __restrict__` kernel arguments: provably read-only -> W_m by scalar loads)
+  int B, G, same_idx, k, nchunk;
+  float *logits, *probs, *psame;      // optional full outputs: [B,G,2], [B,G,2], [B,G]
+  float* best;                        // [B,2]  p[b, g*, :]      (k >= 1, final when nchunk == 1)
+  int32_t* best_idx;                  // [B]
+  float* topk_p;                      // [B,k]  (optional)
+  int32_t* topk_idx;
+  float *part_p, *part_q;             // nchunk > 1: candidates [B][nchunk][k]: P(same), P(other)
+  int32_t* part_i;
+};
+
+// rank key: NaN (non-finite weights upstream) ranks above every probability, like torch.argmax treats it
+__device__ __forceinline__ float mk_key(float x) { return x != x ? 2.0f : x; }
+
+// k rounds of arg-max over `n` candidates held 4 per lane (cand j of lane l = index l + 64 j), order (key desc, idx asc).
+// Calls emit(round, slot) with the winning candidate's slot (lane + 64 j) or -1 when the candidates are exhausted.
+template <int NJ, typename F>
+__device__ __forceinline__ void mk_select(const float (&key)[NJ], const int (&gidx)[NJ], int k, int lane, F emit) {
+  float prev_v = 3.0e38f;
+  int prev_i = -1;
+  for (int round = 0; round < k; ++round) {
+    float bv = -1.0f;
+    int bi = 0x7fffffff, bs = -1;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      const float x = key[j];
+      const int g = gidx[j];
+      const bool after = (x < prev_v) || (x == prev_v && g > prev_i);
+      if (g != 0x7fffffff && after && (x > bv || (x == bv && g < bi))) { bv = x; bi = g; bs = lane + 64 * j; }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      const float ov = __shfl_xor(bv, off, 64);
+      const int oi = __shfl_xor(bi, off, 64);
+      const int os = __shfl_xor(bs, off, 64);
+      if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; bs = os; }
+    }
+    emit(round, bi == 0x7fffffff ? -1 : bs);
+    prev_v = bv;
+    prev_i = bi;
+  }
+}
+
+template <int RB>
+__global__ __launch_bounds__(256) void match_topk_kernel(const float* __restrict__ u, const float* __restrict__ v,
+                                                         const float* __restrict__ Wm, MatchArgs a) {
+  __shared__ __attribute__((aligned(16))) float sv[MK_GC * MK_STRIDE];  // anchor chunk x 32 features; later P(same) / P(other) [2][RB][256]
+  __shared__ __attribute__((aligned(16))) float su[RB * MV_PROJ];        // the RB issue-report rows
+  __shared__ float sa[RB][2];                                            // W_a[c] . u_r
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int g0 = blockIdx.x * MK_GC, b0 = blockIdx.y * RB;
+  // ---- issue-report rows -> LDS (rows past B repeat the last valid one; never stored)
+  for (int e = tid; e < RB * (MV_PROJ / 4); e += 256) {
+    const int r = e / (MV_PROJ / 4), c4 = e % (MV_PROJ / 4);
+    const int b = b0 + r < a.B ? b0 + r : a.B - 1;
+    *(float4*)(su + r * MV_PROJ + 4 * c4) = *(const float4*)(u + (size_t)b * MV_PROJ + 4 * c4);
+  }
+  // ---- first anchor chunk in flight
+  float4 stage[8];
+  auto load_chunk = [&](int i0) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int e = tid + 256 * j, r = e >> 3, c4 = e & 7;  // 8 float4 per 32-feature row
+      stage[j] = (g0 + r < a.G) ? *(const float4*)(v + (size_t)(g0 + r) * MV_PROJ + i0 + 4 * c4) : float4{0.f, 0.f, 0.f, 0.f};
+    }
+  };
+  auto store_chunk = [&]() {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int e = tid + 256 * j, r = e >> 3, c4 = e & 7;
+      *(float4*)(sv + r * MK_STRIDE + 4 * c4) = stage[j];
+    }
+  };
+  load_chunk(0);
+  __syncthreads();
+  // ---- hoisted W_a . u_r: wave w takes rows r = w, w + 4, ..; lane-parallel partial sums (ascending i), fixed-order reduce
+  for (int r = w; r < RB; r += 4) {
+    float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+    for (int j = 0; j < MV_PROJ / 64; ++j) {
+      const float uu = su[r * MV_PROJ + lane + 64 * j];
+      s0 = fmaf(Wm[lane + 64 * j], uu, s0);
+      s1 = fmaf(Wm[3 * MV_PROJ + lane + 64 * j], uu, s1);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      s0 += __shfl_xor(s0, off, 64);
+      s1 += __shfl_xor(s1, off, 64);
+    }
+    if (lane == 0) { sa[r][0] = s0; sa[r][1] = s1; }
+  }
+  float d0[RB], d1[RB], bv0 = 0.f, bv1 = 0.f;
+#pragma unroll
+  for (int r = 0; r < RB; ++r) d0[r] = d1[r] = 0.f;
+  const float* myrow = sv + (64 * w + lane) * MK_STRIDE;
+  for (int i0 = 0; i0 < MV_PROJ; i0 += MK_I) {
+    store_chunk();
+    __syncthreads();
+    if (i0 + MK_I < MV_PROJ) load_chunk(i0 + MK_I);  // in flight while this chunk is consumed
+#pragma unroll 2
+    for (int q = 0; q < MK_I / 4; ++q) {
+      const float4 vv = *(const float4*)(myrow + 4 * q);
+      const float vx[4] = {vv.x, vv.y, vv.z, vv.w};
+      float wb0[4], wb1[4], wc0[4], wc1[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int i = i0 + 4 * q + e;
+        wb0[e] = Wm[MV_PROJ + i]; wb1[e] = Wm[4 * MV_PROJ + i];
+        wc0[e] = Wm[2 * MV_PROJ + i]; wc1[e] = Wm[5 * MV_PROJ + i];
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        bv0 = fmaf(wb0[e], vx[e], bv0);
+        bv1 = fmaf(wb1[e], vx[e], bv1);
+      }
+#pragma unroll
+      for (int r = 0; r < RB; ++r) {
+        const float4 uu = *(const float4*)(su + r * MV_PROJ + i0 + 4 * q);  // wave-uniform address: LDS broadcast
+        const float ux[4] = {uu.x, uu.y, uu.z, uu.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float dd = fabsf(ux[e] - vx[e]);
+          d0[r] = fmaf(wc0[e], dd, d0[r]);
+          d1[r] = fmaf(wc1[e], dd, d1[r]);
+        }
+      }
+    }
+    __syncthreads();  // every wave is done with this chunk before the next one overwrites it
+  }
+  // ---- logits, softmax_2, optional full outputs; P(same) / P(other) of the chunk -> LDS
+  float* sp = sv;                  // [RB][256]
+  float* sq = sv + RB * MK_GC;     // [RB][256]
+  const int gl = 64 * w + lane, g = g0 + gl;
+#pragma unroll
+  for (int r = 0; r < RB; ++r) {
+    const int b = b0 + r;
+    const float l0 = (sa[r][0] + bv0) + d0[r];
+    const float l1 = (sa[r][1] + bv1) + d1[r];
+    const float m = fmaxf(l0, l1);
+    const float e0 = expf(l0 - m), e1 = expf(l1 - m);
+    const float inv = 1.0f / (e0 + e1);
+    const float p0 = e0 * inv, p1 = e1 * inv;
+    const float ps = a.same_idx == 0 ? p0 : p1, pq = a.same_idx == 0 ? p1 : p0;
+    sp[r * MK_GC + gl] = g < a.G ? ps : -1.0f;
+    sq[r * MK_GC + gl] = pq;
+    if (b < a.B && g < a.G) {
+      const size_t o = ((size_t)b * a.G + g) * 2;
+      if (a.logits) { a.logits[o] = l0; a.logits[o + 1] = l1; }
+      if (a.probs) { a.probs[o] = p0; a.probs[o + 1] = p1; }
+      if (a.psame) a.psame[(size_t)b * a.G + g] = ps;
+    }
+  }
+  if (a.k <= 0) return;
+  __syncthreads();
+  // ---- selection: wave w ranks rows w, w + 4, ...
+  for (int r = w; r < RB; r += 4) {
+    const int b = b0 + r;
+    if (b >= a.B) continue;
+    float key[4];
+    int gi[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int gg = g0 + lane + 64 * j;
+      key[j] = mk_key(sp[r * MK_GC + lane + 64 * j]);
+      gi[j] = gg < a.G ? gg : 0x7fffffff;
+    }
+    mk_select<4>(key, gi, a.k, lane, [&](int round, int slot) {
+      if (lane != 0) return;
+      const float ps = slot >= 0 ? sp[r * MK_GC + slot] : -1.0f, pq = slot >= 0 ? sq[r * MK_GC + slot] : -1.0f;
+      const int gw = slot >= 0 ? g0 + slot : 0x7fffffff;
+      if (a.nchunk > 1) {
+        const size_t o = ((size_t)b * a.nchunk + blockIdx.x) * a.k + round;
+        a.part_p[o] = ps; a.part_q[o] = pq; a.part_i[o] = gw;
+      } else {
+        if (a.topk_p) { a.topk_p[(size_t)b * a.k + round] = ps; a.topk_idx[(size_t)b * a.k + round] = gw; }
+        if (round == 0) {
+          if (a.best_idx) a.best_idx[b] = gw;
+          if (a.best) { a.best[2 * b + a.same_idx] = ps; a.best[2 * b + 1 - a.same_idx] = pq; }
+        }
+      }
+    });
+  }
+}
+
+// G > 256: merge the per-chunk candidate lists of an issue report (each the chunk's top k, so their union holds the
+// global top k); one wave per issue report, candidates 16 per lane per pass.
+__global__ __launch_bounds__(256) void topk_merge_kernel(MatchArgs a) {
+  const int lane = threadIdx.x & 63;
+  const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (b >= a.B) return;
+  const int n = a.nchunk * a.k;
+  const float* pp = a.part_p + (size_t)b * n;
+  const float* pq = a.part_q + (size_t)b * n;
+  const int32_t* pi = a.part_i + (size_t)b * n;
+  constexpr int NJ = 16;  // 1024 candidates per pass (nchunk * k <= 1024 is enforced by the host: G <= 4096 at k = 64)
+  float key[NJ];
+  int gi[NJ];
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    const int c = lane + 64 * j;
+    key[j] = c < n ? mk_key(pp[c]) : -1.0f;
+    gi[j] = c < n ? pi[c] : 0x7fffffff;
+  }
+  mk_select<NJ>(key, gi, a.k, lane, [&](int round, int slot) {
+    if (lane != 0) return;
+    const float ps = slot >= 0 ? pp[slot] : -1.0f, q = slot >= 0 ? pq[slot] : -1.0f;
+    const int gw = slot >= 0 ? pi[slot] : 0x7fffffff;
+    if (a.topk_p) { a.topk_p[(size_t)b * a.k + round] = ps; a.topk_idx[(size_t)b * a.k + round] = gw; }
+    if (round == 0) {
+      if (a.best_idx) a.best_idx[b] = gw;
+      if (a.best) { a.best[2 * b + a.same_idx] = ps; a.best[2 * b + 1 - a.same_idx] = q; }
+    }
+  });
+}

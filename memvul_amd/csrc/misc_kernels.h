@@ -267,128 +267,4 @@ __global__ __launch_bounds__(256) void dense768_kernel(const float* __restrict__
   }
 }
 
-// K9 (model_memory.py:135-142): logits[b,g,:] = W_m [u_b ; v_g ; |u_b - v_g|], p = softmax_2.
-// W_m is [2][1536] row-major: columns 0..511 multiply u, 512..1023 v, 1024..1535 |u-v|.
-// A workgroup covers 4 RB issue reports x MT_G anchors; the 512-long feature axis is walked in chunks of MT_I with
-// the anchor tile staged through LDS (+1 pad => conflict-free column reads).  Thread (wave w, lane l) owns anchor l
-// and issue reports RB w .. RB w + RB - 1.  The six weight values and the issue-report features of a step are
-// wave-uniform: they are read with scalar loads (SGPR operands of the fmas), so a step is one LDS read + 2 + 5 RB
-// VALU operations.  RB = 4 (16 issue reports per workgroup) when that already fills the chip, else RB = 1 (4x the
-// workgroups).  Every logit is three ascending-i fma chains whatever RB is.
-#define MT_G 64
-#define MT_I 128
-template <int RB>
-__global__ __launch_bounds__(256) void match_kernel(const float* __restrict__ u, const float* __restrict__ v,
-                                                    const float* __restrict__ Wm, int B, int G, int same_idx,
-                                                    float* __restrict__ logits, float* __restrict__ probs,
-                                                    float* __restrict__ psame) {
-  constexpr int MT_B = 4 * RB;
-  __shared__ float sv[MT_G][MT_I + 1];
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int b0 = blockIdx.y * MT_B, g0 = blockIdx.x * MT_G;
-  float accc[RB][2], accu[RB][2], accv[2];
-#pragma unroll
-  for (int r = 0; r < RB; ++r) { accc[r][0] = accc[r][1] = 0.f; accu[r][0] = accu[r][1] = 0.f; }
-  accv[0] = accv[1] = 0.f;
-  const float* urow[RB];
-#pragma unroll
-  for (int r = 0; r < RB; ++r) {
-    const int b = b0 + RB * w + r;
-    urow[r] = u + (size_t)(b < B ? b : B - 1) * MV_PROJ;  // rows past B: computed on a valid row, never stored
-  }
-  for (int i0 = 0; i0 < MV_PROJ; i0 += MT_I) {
-    __syncthreads();
-    {  // anchor tile -> LDS: 8 x 16-byte loads per thread, all in flight before the first LDS write (one by one they
-       // cost a DRAM/L2 round trip each: 32 dependent trips per chunk made this kernel latency-bound)
-      float4 t[8];
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const int e = tid + 256 * j, r = e >> 5, c4 = e & 31;  // 32 float4 per 128-feature row
-        t[j] = (g0 + r < G) ? *(const float4*)(v + (size_t)(g0 + r) * MV_PROJ + i0 + 4 * c4) : float4{0.f, 0.f, 0.f, 0.f};
-      }
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const int e = tid + 256 * j, r = e >> 5, c4 = e & 31;
-        sv[r][4 * c4 + 0] = t[j].x; sv[r][4 * c4 + 1] = t[j].y; sv[r][4 * c4 + 2] = t[j].z; sv[r][4 * c4 + 3] = t[j].w;
-      }
-    }
-    __syncthreads();
-#pragma unroll 8
-    for (int i = 0; i < MT_I; ++i) {
-      const float vv = sv[lane][i];
-      const float wa0 = Wm[i0 + i], wa1 = Wm[3 * MV_PROJ + i0 + i];
-      const float wb0 = Wm[MV_PROJ + i0 + i], wb1 = Wm[4 * MV_PROJ + i0 + i];
-      const float wc0 = Wm[2 * MV_PROJ + i0 + i], wc1 = Wm[5 * MV_PROJ + i0 + i];
-      accv[0] = fmaf(wb0, vv, accv[0]);
-      accv[1] = fmaf(wb1, vv, accv[1]);
-#pragma unroll
-      for (int r = 0; r < RB; ++r) {
-        const float uu = urow[r][i0 + i];
-        const float dd = fabsf(uu - vv);
-        accu[r][0] = fmaf(wa0, uu, accu[r][0]);
-        accu[r][1] = fmaf(wa1, uu, accu[r][1]);
-        accc[r][0] = fmaf(wc0, dd, accc[r][0]);
-        accc[r][1] = fmaf(wc1, dd, accc[r][1]);
-      }
-    }
-  }
-  const int g = g0 + lane;
-  if (g >= G) return;
-#pragma unroll
-  for (int r = 0; r < RB; ++r) {
-    const int b = b0 + RB * w + r;
-    if (b >= B) continue;
-    const float l0 = accu[r][0] + accv[0] + accc[r][0];
-    const float l1 = accu[r][1] + accv[1] + accc[r][1];
-    const float m = fmaxf(l0, l1);
-    const float e0 = expf(l0 - m), e1 = expf(l1 - m);
-    const float inv = 1.0f / (e0 + e1);
-    const size_t o = ((size_t)b * G + g) * 2;
-    if (logits) { logits[o] = l0; logits[o + 1] = l1; }
-    const float p0 = e0 * inv, p1 = e1 * inv;
-    if (probs) { probs[o] = p0; probs[o + 1] = p1; }
-    psame[(size_t)b * G + g] = same_idx == 0 ? p0 : p1;
-  }
-}
-
-// K10 (model_memory.py:144-147) generalised to top-k (BASELINE configs[4]): one wave per issue report;
-// k rounds of (value, index) arg-max over the row of P(same), ties to the LOWER anchor index
-// (torch.argmax returns the first maximal element).  k = 1 is the reference's best-anchor pick.
-__global__ __launch_bounds__(256) void topk_kernel(const float* __restrict__ psame, const float* __restrict__ probs,
-                                                   int B, int G, int k, float* __restrict__ best,
-                                                   int32_t* __restrict__ best_idx, float* __restrict__ topk_p,
-                                                   int32_t* __restrict__ topk_idx) {
-  const int lane = threadIdx.x & 63;
-  const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (b >= B) return;
-  const float* row = psame + (size_t)b * G;
-  float prev_v = 3.0e38f;
-  int prev_i = -1;
-  for (int round = 0; round < k; ++round) {
-    float bv = -1.0f;
-    int bi = 0x7fffffff;
-    for (int g = lane; g < G; g += 64) {
-      const float x = row[g];
-      // candidates: strictly after (prev_v, prev_i) in (value desc, index asc) order
-      const bool after = (x < prev_v) || (x == prev_v && g > prev_i);
-      if (after && (x > bv || (x == bv && g < bi))) { bv = x; bi = g; }
-    }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-      const float ov = __shfl_xor(bv, off, 64);
-      const int oi = __shfl_xor(bi, off, 64);
-      if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
-    }
-    if (lane == 0) {
-      if (topk_p) { topk_p[(size_t)b * k + round] = bv; topk_idx[(size_t)b * k + round] = bi; }
-      if (round == 0 && best_idx) best_idx[b] = bi;
-      if (round == 0 && best && probs) {
-        best[2 * b] = probs[((size_t)b * G + bi) * 2];
-        best[2 * b + 1] = probs[((size_t)b * G + bi) * 2 + 1];
-      }
-    }
-    prev_v = bv;
-    prev_i = bi;
-  }
-}
+// K9 + K10 (anchor match, softmax_2, best anchor / top-k): match_topk.h

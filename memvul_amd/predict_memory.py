@@ -10,6 +10,7 @@ from __future__ import annotations
 
 import copy
 import json
+import shutil
 import logging
 import os
 from typing import Any, Dict, List, Optional
@@ -240,6 +241,16 @@ def test_siamese_sharded(archive_file, input_file, input_golden_file, test_confi
     if output_file and rank == 0:
         with open(output_file, "w") as f:
             json.dump(_jsonable(metrics), f, indent=4)
+    mvdist.barrier()  # every part is closed
+    if predictions_output_file and world > 1 and rank == 0:
+        # shards are contiguous: the parts in rank order are the single-process predictions file (what cal_metrics,
+        # predict_memory.py:159-165, reads); the parts are removed once they are in it
+        with open(predictions_output_file, "wb") as out:
+            for r in range(world):
+                with open(f"{predictions_output_file}.part{r}", "rb") as f:
+                    shutil.copyfileobj(f, out)
+        for r in range(world):
+            os.remove(f"{predictions_output_file}.part{r}")
     mvdist.barrier()
     return metrics
 

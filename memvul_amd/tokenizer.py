@@ -11,6 +11,7 @@ text, not for real accuracy numbers.
 """
 from __future__ import annotations
 
+import logging
 import os
 import re
 import zlib
@@ -19,6 +20,7 @@ from typing import Dict, List, Optional
 from .data import Token
 from .registry import Tokenizer, TokenIndexer
 
+logger = logging.getLogger(__name__)
 CLS_ID, SEP_ID, PAD_ID, UNK_ID = 101, 102, 0, 100
 _WORD_RE = re.compile(r"[a-z0-9]+|[^\sa-z0-9]")
 
@@ -41,6 +43,26 @@ class PretrainedTransformerTokenizer(Tokenizer):
         self.vocab_size = vocab_size
         self._hf = None
         vocab = _find_vocab(model_name)
+        if vocab is None:
+            # a cached / local HuggingFace copy of `model_name` (what AllenNLP's tokenizer loads, reader_memory.py:88)
+            try:
+                from transformers import BertTokenizerFast
+
+                hf = BertTokenizerFast.from_pretrained(model_name, local_files_only=True, **(tokenizer_kwargs or {}))
+                # transformers 5.x hands back a 5-token default vocabulary instead of raising when nothing is cached
+                if hf.vocab_size >= 1000 and hf.cls_token_id is not None and hf.sep_token_id is not None:
+                    self._hf = hf
+                    self.vocab_size = hf.vocab_size
+            except Exception:
+                self._hf = None
+            if self._hf is None:
+                if os.environ.get("MEMVUL_ALLOW_HASH_TOKENIZER") != "1":
+                    raise RuntimeError(
+                        f"no WordPiece vocabulary for {model_name!r}: point $MEMVUL_BERT_VOCAB at its vocab.txt (or make model_name "
+                        "a directory holding one, or have it in the local HuggingFace cache).  The CRC32 hashing stand-in feeds "
+                        "meaningless ids to trained weights; it is only for synthetic plumbing / throughput runs and must be "
+                        "asked for with MEMVUL_ALLOW_HASH_TOKENIZER=1.")
+                logger.warning("MEMVUL_ALLOW_HASH_TOKENIZER=1: %r is tokenised by the CRC32 hashing stand-in (synthetic runs only)", model_name)
         if vocab is not None:
             import inspect
 

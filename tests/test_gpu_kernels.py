@@ -142,3 +142,45 @@ def test_match_and_topk_vs_oracle(gu):
         rp, ri = orc.topk_match(ps, k)
         assert np.array_equal(ti, ri.astype(np.int32)) and np.array_equal(tp, rp)
     eng.anchor_reset()
+
+
+@pytest.mark.parametrize("B,G", [(256, 1000), (512, 1000), (37, 257), (300, 124), (3, 1024)])
+def test_fused_match_topk_at_configs4_size(gu, B, G):
+    """BASELINE.json configs[4]: 1000-anchor synthetic bank, fused match + top-k (k = 1, 5, 10): the k best anchors per
+    issue report against the oracle (argsort of the oracle's own P(same), ties to the lower index), the best-anchor
+    outputs of mv_match against the same kernel's full probabilities, exact duplicates in the bank (ties across chunk
+    boundaries) and a NaN row (ranks first, index stays valid)."""
+    rng = np.random.default_rng(G + B)
+    dims, w = gu.weights_for(L2, WK)
+    eng = gu.engine_for(L2, WK, max_anchors=1024, max_batch=512)
+    u = np.maximum(rng.standard_normal((B, 512)), 0).astype(np.float32) * np.float32(0.5)
+    v = synth.make_anchor_bank(G)
+    if G > 300:
+        v[290] = v[7]; v[G - 1] = v[7]   # the same anchor in three different 256-anchor chunks
+    eng.anchor_set(v)
+    out = eng.match(u)
+    logits, p, best, idx = orc.match(u, v, w[synth.KEY_MATCH_W], same_idx=0)
+    e = float(np.abs(out["logits"] - logits).max())
+    gu.record("match_topk", B=B, G=G, max_logit_err=e)
+    assert e < 2e-5 and np.abs(out["probs"] - p).max() < 1e-5
+    ps = out["probs"][:, :, 0]
+    assert np.array_equal(out["best_idx"], np.argmax(ps, axis=1).astype(np.int32))
+    assert np.array_equal(out["best"], out["probs"][np.arange(B), out["best_idx"]])
+    for k in (1, 5, 10):
+        if k > G:
+            continue
+        tp, ti = eng.topk(u, k)
+        rp, ri = orc.topk_match(ps, k)          # the GPU's own probabilities: the selection must be exact
+        assert np.array_equal(ti, ri.astype(np.int32)) and np.array_equal(tp, rp), k
+        op, oi = orc.topk_match(p[:, :, 0], k)  # and against the oracle's probabilities wherever the margins are clear
+        srt = -np.sort(-p[:, :, 0], axis=1)[:, :k + 1]
+        clear = (np.abs(np.diff(srt, axis=1)) > 1e-5).all(1) if G > k else np.ones(B, bool)
+        assert np.array_equal(ti[clear], oi[clear].astype(np.int32))
+    if G > 300:
+        assert (np.diff(np.stack([ps[:, 7], ps[:, 290], ps[:, G - 1]]), axis=0) == 0).all()  # duplicates score identically
+    # a NaN issue report: every score NaN -> torch.argmax semantics (index 0), no out-of-range index
+    un = u[:2].copy()
+    un[0, 5] = np.nan
+    o2 = eng.match(un)
+    assert o2["best_idx"][0] == 0 and np.isnan(o2["best"][0]).all() and o2["best_idx"][1] == out["best_idx"][1]
+    eng.anchor_reset()

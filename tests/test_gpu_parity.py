@@ -318,3 +318,40 @@ def test_edge_shapes_against_the_oracle(gu, gemm_tile):
     eng.anchor_reset()
     with pytest.raises(RuntimeError):
         eng.forward(one, np.array([1], np.int32))                              # empty anchor bank
+
+
+def test_sweeps_chunk_batches_larger_than_one_pass(gu):
+    """batch_size = 512 (the reference __main__ value, predict_memory.py:207) with issue reports longer than
+    max_tokens / 512 used to fail with MV_ERR_CAPACITY on the resident sweeps.  mv_corpus_run_len now walks such a batch in
+    passes of what fits (as mv_forward / mv_encode do) with bit-identical per-row results."""
+    dk, wk = dict(layers=2, vocab_size=2048), dict(qk_scale=2.0, match_scale=6.0)
+    dims, w = gu.weights_for(dk, wk)
+    eng = gu.engine_for(dk, wk, max_tokens=24 * 256, max_batch=512, max_anchors=32)  # 24 rows of 256 tokens per pass
+    ids, lens = synth.make_ids(130, 256, dims.vocab_size, ragged=True, min_len=120)
+    eng.anchor_set(synth.make_anchor_bank(9))
+    best, idx, ps = eng.bucketed_sweep(ids, lens, 512, with_probs=True)       # one "batch" of 130 rows > 24 per pass
+    eng.corpus_upload(ids, lens)
+    eng.corpus_run(0, 130, 512, keep_probs=True)
+    best2, idx2, ps2 = eng.corpus_results(0, 130, with_probs=True)
+    ref = eng.forward(ids, lens)                                              # mv_forward chunks on its own
+    assert np.array_equal(ps2, ref["probs"][:, :, 0]) and np.array_equal(idx2, ref["best_idx"]) and np.array_equal(best2, ref["best"])
+    assert np.abs(ps - ps2).max() < 1e-3 and best.shape == (130, 2)           # bucketed: rows run at other padded lengths
+    eng.anchor_reset()
+
+
+def test_rejects_token_ids_outside_the_vocabulary(gu):
+    """an id >= vocab_size (tokenizer / checkpoint vocabulary mismatch) used to be clamped silently by the
+    embedding kernel; HF raises.  Every entry point that takes ids now rejects it."""
+    dk, wk = dict(layers=2, vocab_size=2048), dict(qk_scale=3.0)
+    eng = gu.engine_for(dk, wk)
+    ids, lens = synth.make_ids(3, 64, 2048)
+    bad = ids.copy(); bad[1, 7] = 2048
+    neg = ids.copy(); neg[2, 0] = -1
+    eng.anchor_set(synth.make_anchor_bank(3))
+    for arr in (bad, neg):
+        for call in (lambda a: eng.encode(a, lens), lambda a: eng.forward(a, lens), lambda a: eng.anchor_append(a, lens),
+                     lambda a: eng.corpus_upload(a, lens)):
+            with pytest.raises(RuntimeError, match="vocab"):
+                call(arr)
+    assert np.isfinite(eng.encode(ids, lens)).all()
+    eng.anchor_reset()

@@ -134,3 +134,30 @@ def test_reader_branches_and_order():
     assert batch["label"].tolist() == [0, 0, 1] and len(batch["metadata"]) == 3
     dl = DataLoader(reader=r, data_path=str(tmp_path / "test_project.json"), batch_size=2); dl.index_with(vocab)
     assert len(dl) == 3 and [len(b["metadata"]) for b in dl] == [2, 2, 1]
+
+
+def test_hash_tokenizer_must_be_asked_for(monkeypatch):
+    """without a reachable vocab.txt the tokenizer used to fall back SILENTLY to CRC32 hashing (meaningless ids
+    for trained weights).  Now that needs MEMVUL_ALLOW_HASH_TOKENIZER=1 (tests/conftest.py sets it for the synthetic
+    fixtures) and warns; otherwise the constructor raises and says what to do."""
+    monkeypatch.delenv("MEMVUL_ALLOW_HASH_TOKENIZER", raising=False)
+    monkeypatch.delenv("MEMVUL_BERT_VOCAB", raising=False)
+    with pytest.raises(RuntimeError, match="MEMVUL_BERT_VOCAB"):
+        PretrainedTransformerTokenizer("bert-base-uncased", max_length=16)
+    monkeypatch.setenv("MEMVUL_ALLOW_HASH_TOKENIZER", "1")
+    assert len(PretrainedTransformerTokenizer("bert-base-uncased", max_length=16).tokenize("a b c")) == 5
+
+
+def test_custom_validation_takes_the_reference_argument_order(tmp_path):
+    """callbacks.py:27-31: CustomValidation(anchor_path, data_reader, data_loader, serialization_dir) — positional use and the
+    (unused) data_loader keyword must work as in the reference."""
+    import pathlib
+    import tempfile
+
+    from memvul_amd.callbacks import CustomValidation
+
+    d = pathlib.Path(tempfile.mkdtemp(prefix="mvcb"))
+    golden = d / "CWE_anchor_golden_project.json"
+    golden.write_text(json.dumps({"CWE-79": "cross site scripting", "CWE-89": "sql injection"}))
+    cb = CustomValidation(str(golden), _reader(), data_loader=None, serialization_dir=str(d))
+    assert len(cb._anchors) == 2 and cb.serialization_dir == str(d)
