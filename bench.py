@@ -83,29 +83,36 @@ def main():
     ap.add_argument("--ragged", action="store_true", help="also time a ragged corpus (lengths uniform in [16, seq_len]) swept "
                     "padded to seq_len and length-bucketed (each batch at its longest member); adds a `ragged` object")
     ap.add_argument("--streams", type=int, default=2, choices=(1, 2), help="batches of the resident sweep in flight at once")
+    ap.add_argument("--sustain-s", type=float, default=3.0, help="N = 1: also report the rate over a run of at least this many seconds (0 disables)")
+    ap.add_argument("--shard-irs", type=int, default=0, help="N > 1: issue reports per rank in the corpus-shard leg (0 = ceil(1221677 / 8), the "
+                    "8-GPU shard of the reference's corpus, README.md:8; -1 disables)")
+    ap.add_argument("--matcher-anchors", type=int, default=1000, help="N = 1: anchors of the fused match + top-k measurement (configs[4]; 0 disables)")
     args = ap.parse_args()
 
-    if args.cpu_sample > 0 or int(os.environ.get("WORLD_SIZE", "1")) > 1:
-        import torch  # noqa: F401  (torch, when used at all, is loaded BEFORE the engine: see tests/test_gpu_parity.py)
     rank, local_rank, world = mvdist.env_world()
+    if args.cpu_sample > 0 and world == 1:
+        import torch  # noqa: F401  (the CPU baseline leg only; loaded BEFORE the engine: see tests/test_gpu_parity.py)
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     multi = world > 1
     # development check of the N > 1 control flow on a ONE-GPU box (not a measurement): every rank shares device 0 and the
     # exchange runs over gloo instead of RCCL; the JSON line says so in `config.note`
     one_gpu_smoke = multi and os.environ.get("MEMVUL_BENCH_ONE_GPU_SMOKE") == "1"
-    if multi:
-        mvdist.init_process_group("gloo" if one_gpu_smoke else "nccl")
     if one_gpu_smoke:
+        mvdist.init_process_group("gloo")  # torch.distributed only in this development mode
         local_rank = 0
 
     B, S, G, K, W = args.batch, args.seq_len, args.anchors, args.steps, args.warmup
     dims = synth.BertDims(layers=args.layers)
     weights = synth.make_weights(dims)
     eng = Engine(local_rank, vocab_size=dims.vocab_size, layers=dims.layers, max_tokens=max(B * S, 128 * 512),
-                 max_batch=max(B, 128), max_anchors=max(G, 128))
+                 max_batch=max(B, 256), max_anchors=max(G, 1024))
     eng.load_state_dict(weights)
     eng.set_streams(args.streams)
+    if multi and not one_gpu_smoke:
+        # the N > 1 transport: RCCL bound inside libmemvul_hip.so (mv_comm_*), collective on the engine's stream; this
+        # process never imports torch, so there is no second HIP runtime and no load-order rule
+        mvdist.init_rccl(eng, rank, world)
 
     # anchor memory: G synthetic CWE descriptions of up to 512 tokens, built once per process (untimed;
     # predict_memory.py:81-83 forwards them in chunks of 128)
@@ -179,7 +186,15 @@ def main():
         eng.profile_select(None)
         eng.set_streams(2 if args.streams == 2 else 1)
 
+    # N > 1: the job BASELINE.json configs[3] names — a contiguous shard of the 1.22 M-IR corpus per rank, swept once, ONE
+    # all-gather of the per-IR (score, label) statistics (every rank takes part; rank 0 reports)
+    shard = corpus_shard_leg(eng, dims, B, S, rank, world, args.shard_irs) if multi else None
+    # N = 1: a sustained (>= 3 s) rate next to the K-step figure (the chip is power-limited: short bursts run hotter)
+    sustained = sustained_leg(eng, step, B, args.sustain_s) if (not multi and args.sustain_s > 0) else None
+
     if rank != 0:
+        if multi and not one_gpu_smoke:
+            mvdist.shutdown_rccl()
         return
     from memvul_amd.custom_metric import threshold_confusion_table
 
@@ -228,11 +243,100 @@ def main():
         out["value_one_batch_in_flight"] = round(world * single_rate, 2)
         out["kernels"] = kernels
         out["kernels_note"] = "per-class HIP-event breakdown from a separate untimed pass of %d steps, one batch in flight" % min(K, 4)
+    if shard is not None:
+        out["corpus_shard"] = shard
+    if sustained is not None:
+        out["value_sustained"] = sustained
     if args.ragged:
         out["ragged"] = ragged_leg(eng, dims, B, S, rank)
+    if world == 1 and args.matcher_anchors > 0:
+        out["matcher"] = matcher_leg(eng, args.matcher_anchors, B)
     if args.cpu_sample > 0 and world == 1:
-        out["cpu_baseline"], out["logit_max_abs_err_vs_cpu"] = cpu_baseline(weights, dims, eng, ids, lens, S, args.cpu_sample)
+        out["cpu_baseline"], out["logit_max_abs_err_vs_cpu"], out["anchor_max_abs_err_vs_cpu"] = cpu_baseline(
+            weights, dims, eng, ids, lens, S, args.cpu_sample, aids, alens)
     print(json.dumps(out), flush=True)
+    if multi and not one_gpu_smoke:
+        mvdist.shutdown_rccl()
+
+
+def sustained_leg(eng, step, B, seconds):
+    """The same steps for at least `seconds` of wall time: what the part sustains once it sits at its power limit."""
+    eng.sync()
+    t0 = time.perf_counter()
+    n = 0
+    while True:
+        for i in range(16):
+            step(n + i)
+        n += 16
+        eng.sync()
+        dt = time.perf_counter() - t0
+        if dt >= seconds:
+            break
+    return {"value": round(n * B / dt, 2), "unit": "issue-reports/s", "seconds": round(dt, 2), "steps": n}
+
+
+def corpus_shard_leg(eng, dims, B, S, rank, world, shard_irs):
+    """BASELINE.json configs[3]: each rank holds a contiguous shard of the corpus resident in HBM, sweeps it once (batches
+    of B, two in flight), downloads its per-IR results once, then ONE RCCL all-gather of (score, label).  Communicator
+    warm-up and the barriers sit outside the clock; the all-gather is inside it and timed on its own."""
+    if shard_irs < 0:
+        return None
+    n = shard_irs if shard_irs > 0 else -(-1221677 // 8)
+    rng_ids, lens = synth.make_ids(n, S, dims.vocab_size, seed=synth.SEED + 5000 + rank)
+    lab = synth.make_labels(n, seed=synth.SEED + 9000 + rank)
+    eng.corpus_upload(rng_ids, lens)
+    del rng_ids
+    eng.sync()
+    mvdist.barrier()
+    t0 = time.perf_counter()
+    eng.corpus_run(0, n, B, keep_probs=False)
+    best, idx, _ = eng.corpus_results(0, n)
+    t_sweep = time.perf_counter() - t0
+    tg = time.perf_counter()
+    all_s, all_l = mvdist.all_gather_stats(best[:, 0], lab)
+    gather_ms = (time.perf_counter() - tg) * 1e3
+    t_rank = time.perf_counter() - t0
+    elapsed = mvdist.all_reduce_max(t_rank)
+    rates = mvdist.all_gather_rows(np.array([[n / t_sweep]], np.float32))[:, 0]  # every rank's own sweep rate, no collective in it
+    total = int(len(all_s))
+    return {"irs_per_rank": n, "irs_total": total, "value_corpus": round(total / elapsed, 2), "unit": "issue-reports/s",
+            "seconds": round(elapsed, 3), "allgather_ms": round(gather_ms, 3), "allgather_bytes_per_rank": int(n * 8),
+            "fixed_overhead_frac": round(gather_ms * 1e-3 / elapsed, 5),
+            "sum_of_rank_sweep_rates": round(float(rates.sum()), 2),
+            "scaling_vs_sum_of_ranks": round(total / elapsed / float(rates.sum()), 4),
+            "positives_gathered": int(all_l.sum()),
+            "note": "per-rank shard = ceil(1,221,677 / 8) synthetic IRs x %d tokens unless --shard-irs says otherwise; value_corpus = all ranks' "
+                    "IRs / max-over-ranks(sweep + result download + all-gather)" % S}
+
+
+def matcher_leg(eng, G, B, k=10, reps=20):
+    """BASELINE.json configs[4]: fused match + top-k over a G-anchor synthetic bank, measured as its own roofline
+    (SURVEY.md §8d): algorithmic bytes 4 (B P + G P) + 8 B k against HBM, 3 B G P lane operations (5 B G P FLOP of the
+    plain form) against the fp32 vector ALU.  HIP events on the engine's stream around the match (+ merge) launches."""
+    bank = eng.anchor_get()
+    rng = np.random.default_rng(3)
+    u = np.maximum(rng.standard_normal((B, P)), 0).astype(np.float32) * np.float32(0.5)
+    eng.anchor_set(synth.make_anchor_bank(G))
+    eng.topk(u, k)
+    eng.profile_enable(True)
+    eng.profile_select(["match", "topk"])
+    eng.profile_read()
+    for _ in range(reps):
+        eng.topk(u, k)
+    prof = eng.profile_read()
+    eng.profile_enable(False)
+    eng.profile_select(None)
+    eng.anchor_set(bank)
+    us = (prof["match"][0] + prof["topk"][0]) / max(prof["match"][1], 1) * 1e3
+    bytes_alg = 4 * (B * P + G * P) + 8 * B * k
+    flop_plain = 5.0 * B * G * P            # sub, |.|*w (x2 classes) as the reference's concat + Linear would count them, + W_b.v
+    laneops = 3.0 * B * G * P               # what the kernel issues per (b, g, feature): sub + 2 fma
+    return {"anchors": G, "batch": B, "k": k, "avg_us": round(us, 2), "launches": {"match": prof["match"][1], "topk_merge": prof["topk"][1]},
+            "bytes_algorithmic": bytes_alg, "GB_per_s": round(bytes_alg / (us * 1e-6) / 1e9, 1), "hbm_frac": round(bytes_alg / (us * 1e-6) / 8e12, 5),
+            "valu_tflops": round(flop_plain / (us * 1e-6) / 1e12, 2), "valu_frac": round(flop_plain / (us * 1e-6) / 157.3e12, 4),
+            "lane_ops_per_s_T": round(laneops / (us * 1e-6) / 1e12, 2),
+            "note": "bound: fp32 VALU (arithmetic intensity %.0f FLOP/B >> the 20 FLOP/B vector ridge); P(same) [B, G] never reaches HBM, "
+                    "only 8 B k bytes of results do" % (flop_plain / bytes_alg)}
 
 
 def ragged_leg(eng, dims, B, S, rank, n_batches=16):
@@ -267,7 +371,7 @@ def ragged_leg(eng, dims, B, S, rank, n_batches=16):
     return res
 
 
-def cpu_baseline(weights, dims, eng, ids, lens, S, n):
+def cpu_baseline(weights, dims, eng, ids, lens, S, n, aids, alens, n_anchors_cpu=12):
     """The reference's CPU graph (HF BertModel + pooler + header + matcher, fp32, all host cores) on the
     first n IRs of the same synthetic corpus; also the GPU-vs-CPU logit error on those IRs."""
     import torch
@@ -276,7 +380,12 @@ def cpu_baseline(weights, dims, eng, ids, lens, S, n):
 
     cores = os.cpu_count() or 1
     ref = HFReference(weights, dims.as_dict(), threads=min(cores, 32))
-    v = eng.anchor_get()
+    # the CPU leg builds its OWN anchor bank: the first n_anchors_cpu anchors through the same CPU
+    # graph, in one chunk padded to its longest member (predict_memory.py:81-83); the logit comparison is over those
+    ga = min(n_anchors_cpu, len(alens))
+    LA = int(alens[:ga].max())
+    v = ref.instance_forward(aids[:ga, :LA].astype(np.int64), synth.mask_from_lens(alens[:ga], LA))
+    anchor_err = float(np.abs(eng.anchor_get()[:ga] - v).max())
     bs = 16
     ones = np.ones((bs, S), bool)
     # pick the intra-op thread count that is fastest on this host (all cores is often slower on a
@@ -306,11 +415,11 @@ def cpu_baseline(weights, dims, eng, ids, lens, S, n):
     cores_used = best_t
     logits = np.concatenate(logits)
     gpu = eng.forward(ids[:n], lens[:n])
-    err = float(np.abs(gpu["logits"] - logits).max())
+    err = float(np.abs(gpu["logits"][:, :ga] - logits).max())
     return ({"value": round(n / dt, 3), "unit": "issue-reports/s", "cores": cores_used, "host_cores": cores, "kind": "port",
              "sample": f"{n} synthetic IRs x {S} tokens, batch {bs}, fp32 torch-CPU ({torch.get_num_threads()} threads): HF BertModel "
                        "(eager attention) + tanh pooler + ReLU header + bias-free matcher = the reference's CPU path "
-                       "(AllenNLP itself is not installable here); anchor bank taken from the GPU engine"}, err)
+                       f"(AllenNLP itself is not installable here); logits compared on {ga} anchors the CPU leg encoded itself"}, err, anchor_err)
 
 
 if __name__ == "__main__":

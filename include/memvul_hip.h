@@ -139,6 +139,19 @@ int mv_set_streams(mv_handle* h, int n);
 /* best fp32 [count,2], best_idx int32 [count], p_same fp32 [count,G] (NULL unless kept). Synchronises. */
 int mv_corpus_results(mv_handle* h, int64_t first, int64_t count, float* best, int32_t* best_idx, float* p_same);
 
+/* ---- multi-GPU exchange (the reference is single-process, predict_memory.py:103) --------------------
+ * One process per GPU, contiguous corpus shards, no data-path collective; the ONE exchange is an all-gather of the
+ * per-rank (score, label) statistics.  RCCL (librccl.so, opened at run time) is bound directly: the collective runs
+ * on the engine's own stream and the process needs neither torch nor a launcher-specific runtime.
+ * mv_comm_init: ncclCommInitRank with a unique id that rank 0 writes to `id_path` (a file every rank of the node can
+ * reach; ranks != 0 wait for it).  mv_comm_allgather: `bytes_per_rank` bytes of host memory per rank ->
+ * world * bytes_per_rank bytes on every rank, in rank order (staged through device buffers the library owns).
+ * world == 1 needs no init: the gather is then a copy (world == 1 WITH an id_path builds a real one-rank communicator:
+ * the single-GPU test of this path). */
+int mv_comm_init(mv_handle* h, int rank, int world, const char* id_path);
+int mv_comm_allgather(mv_handle* h, const void* send, void* recv, int64_t bytes_per_rank);
+int mv_comm_destroy(mv_handle* h);
+
 /* ---- measurement / test hooks ---------------------------------------------------------------- */
 
 /* Per-kernel-class HIP-event timing on the engine's own stream. Classes: see mv_kernel_class_name. */

@@ -23,7 +23,7 @@ ABI_SYMBOLS = [
     "mv_anchor_reset", "mv_anchor_append", "mv_anchor_count", "mv_anchor_get", "mv_anchor_set",
     "mv_forward", "mv_encode", "mv_match", "mv_topk", "mv_corpus_upload", "mv_corpus_run", "mv_corpus_run_len",
     "mv_corpus_results", "mv_set_streams", "mv_profile_enable", "mv_profile_select", "mv_profile_read", "mv_kernel_class_name",
-    "mv_debug_encode", "mv_debug_read", "mv_test_gemm",
+    "mv_debug_encode", "mv_debug_read", "mv_test_gemm", "mv_comm_init", "mv_comm_allgather", "mv_comm_destroy",
 ]
 
 
@@ -85,6 +85,9 @@ def load_library(path: Optional[str] = None):
         "mv_debug_encode": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, C.c_int]),
         "mv_debug_read": (C.c_int, [vp, C.c_int, vp, C.c_int64]),
         "mv_test_gemm": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, C.c_int, P(C.c_float)]),
+        "mv_comm_init": (C.c_int, [vp, C.c_int, C.c_int, C.c_char_p]),
+        "mv_comm_allgather": (C.c_int, [vp, vp, vp, C.c_int64]),
+        "mv_comm_destroy": (C.c_int, [vp]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)  # AttributeError if the .so does not export a declared symbol
@@ -254,6 +257,24 @@ class Engine:
         ps = np.empty((count, self.n_anchors), np.float32) if with_probs else None
         self._check(self._lib.mv_corpus_results(self._h, first, count, _ptr(best), _ptr(idx), _ptr(ps)), "mv_corpus_results")
         return best, idx, ps
+
+    # -- multi-GPU exchange (RCCL bound inside the library; no torch in the process)
+    def comm_init(self, rank: int, world: int, id_path: Optional[str] = None):
+        self._check(self._lib.mv_comm_init(self._h, int(rank), int(world), (id_path or "").encode()), "mv_comm_init")
+        self.comm_rank, self.comm_world = int(rank), int(world)
+
+    def comm_allgather(self, block: np.ndarray) -> np.ndarray:
+        """Every rank contributes a same-shape array; returns ``[world, *block.shape]`` in rank order."""
+        block = np.ascontiguousarray(block)
+        world = getattr(self, "comm_world", 1)
+        out = np.empty((world,) + block.shape, block.dtype)
+        if block.nbytes:
+            self._check(self._lib.mv_comm_allgather(self._h, _ptr(block), _ptr(out), block.nbytes), "mv_comm_allgather")
+        return out
+
+    def comm_destroy(self):
+        self._check(self._lib.mv_comm_destroy(self._h), "mv_comm_destroy")
+        self.comm_rank, self.comm_world = 0, 1
 
     # -- measurement / debug
     def set_streams(self, n: int):

@@ -2,7 +2,11 @@
 // Host side: weight staging/packing, workspace ownership, launch sequencing on one HIP stream,
 // HIP-event profiling per kernel class, error translation.  No torch, no exceptions across the ABI.
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
+#include <rccl/rccl.h>  // types and prototypes only: librccl.so is opened at run time (mv_comm_init), never linked
+#include <unistd.h>
 
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -188,6 +192,19 @@ struct mv_handle {
 
   // debug
   int dbg_B = 0, dbg_Sp = 0;
+
+  // multi-GPU exchange (mv_comm_*): RCCL entry points resolved from librccl.so at run time
+  void* rccl_lib = nullptr;
+  ncclComm_t comm = nullptr;
+  int comm_rank = 0, comm_world = 1;
+  std::string comm_id_path;
+  decltype(&ncclGetUniqueId) p_ncclGetUniqueId = nullptr;
+  decltype(&ncclCommInitRank) p_ncclCommInitRank = nullptr;
+  decltype(&ncclAllGather) p_ncclAllGather = nullptr;
+  decltype(&ncclCommDestroy) p_ncclCommDestroy = nullptr;
+  decltype(&ncclGetErrorString) p_ncclGetErrorString = nullptr;
+  void *comm_send = nullptr, *comm_recv = nullptr;
+  int64_t comm_send_cap = 0, comm_recv_cap = 0;
 };
 
 namespace {
@@ -567,17 +584,19 @@ int match_dev(mv_handle* h, const float* u_dev, int B, float* logits, float* pro
   if (G <= 0) return fail(h, MV_ERR_STATE, "anchor bank is empty (call mv_anchor_append / mv_anchor_set first)");
   MatchArgs a{};
   a.B = B; a.G = G; a.same_idx = h->cfg.same_idx; a.k = k;
-  a.nchunk = (G + MK_GC - 1) / MK_GC;
+  const bool small = G <= 128;                      // one 128-anchor chunk, 4 long feature steps (latency-bound pass)
+  const int GC = small ? 128 : 256;
+  a.nchunk = (G + GC - 1) / GC;
   if ((int64_t)a.nchunk * k > 1024) return fail(h, MV_ERR_INVALID, "top-k: anchors / 256 * k must not exceed 1024");
   a.logits = logits; a.probs = probs; a.psame = psame_out;
   a.best = best_out; a.best_idx = idx_out; a.topk_p = topk_p; a.topk_idx = topk_idx;
   a.part_p = h->w->part_p; a.part_q = h->w->part_q; a.part_i = h->w->part_i;
   {
     ProfScope ps(h, KC_MATCH);
-    if ((int64_t)a.nchunk * ((B + 3) / 4) >= h->num_cu)
-      hipLaunchKernelGGL(match_topk_kernel<4>, dim3(a.nchunk, (B + 3) / 4), dim3(256), 0, h->w->stream, u_dev, h->anchors, h->Wm, a);
+    if (small)
+      hipLaunchKernelGGL((match_topk_kernel<2, 128, 128>), dim3(1, (B + 3) / 4), dim3(256), 0, h->w->stream, u_dev, h->anchors, h->Wm, a);
     else
-      hipLaunchKernelGGL(match_topk_kernel<1>, dim3(a.nchunk, B), dim3(256), 0, h->w->stream, u_dev, h->anchors, h->Wm, a);
+      hipLaunchKernelGGL((match_topk_kernel<4, 256, 64>), dim3(a.nchunk, (B + 3) / 4), dim3(256), 0, h->w->stream, u_dev, h->anchors, h->Wm, a);
     if (int rc = launch_check(h, "match_topk")) return rc;
   }
   if (a.nchunk > 1 && k > 0) {
@@ -783,7 +802,7 @@ int mv_create(int device, const mv_config* cfg, mv_handle** out) {
     A(dev_alloc(h, &h->w->topk_p, (int64_t)cfg->max_batch * 64));
     A(dev_alloc(h, &h->w->topk_idx, (int64_t)cfg->max_batch * 64));
     {
-      const int64_t nch = (cfg->max_anchors + MK_GC - 1) / MK_GC;
+      const int64_t nch = (cfg->max_anchors + 255) / 256;
       const int64_t per = nch > 1 ? (nch * MK_KMAX < 1024 ? nch * MK_KMAX : 1024) : 0;  // chunks x k <= 1024 (match_dev)
       A(dev_alloc(h, &h->w->part_p, (int64_t)cfg->max_batch * per));
       A(dev_alloc(h, &h->w->part_q, (int64_t)cfg->max_batch * per));
@@ -814,6 +833,7 @@ int mv_create(int device, const mv_config* cfg, mv_handle** out) {
 void mv_destroy(mv_handle* h) {
   if (!h) return;
   hipSetDevice(h->device);
+  mv_comm_destroy(h);
   for (auto& wk : h->work)
     if (wk.stream) hipStreamSynchronize(wk.stream);
   for (auto& r : h->recs) { hipEventDestroy(r.e0); hipEventDestroy(r.e1); }
@@ -1180,6 +1200,99 @@ int mv_corpus_results(mv_handle* h, int64_t first, int64_t count, float* best, i
     HIPCHK(h, hipMemcpyAsync(p_same, h->c_psame + (size_t)first * h->c_G, (size_t)count * h->c_G * 4, hipMemcpyDeviceToHost, h->w->stream));
   }
   HIPCHK(h, hipStreamSynchronize(h->w->stream));
+  return MV_OK;
+}
+
+// ---- multi-GPU exchange: RCCL bound directly ---------------------------------------------------
+int mv_comm_init(mv_handle* h, int rank, int world, const char* id_path) {
+  if (!h || world < 1 || rank < 0 || rank >= world) return fail(h, MV_ERR_INVALID, "mv_comm_init: bad rank / world");
+  if (h->comm) return fail(h, MV_ERR_STATE, "mv_comm_init: communicator already initialised");
+  h->comm_rank = rank;
+  h->comm_world = world;
+  if (world == 1 && (!id_path || !*id_path)) return MV_OK;  // no transport needed (with an id_path: a real 1-rank communicator, the GPU-box test)
+  if (!id_path || !*id_path) return fail(h, MV_ERR_INVALID, "mv_comm_init: id_path required for world > 1");
+  HIPCHK(h, hipSetDevice(h->device));
+  if (!h->rccl_lib) {
+    for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+      h->rccl_lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+      if (h->rccl_lib) break;
+    }
+    if (!h->rccl_lib) return fail(h, MV_ERR_HIP, std::string("mv_comm_init: cannot open librccl.so: ") + dlerror());
+#define RCCL_SYM(name)                                                                   \
+    h->p_##name = (decltype(&name))dlsym(h->rccl_lib, #name);                            \
+    if (!h->p_##name) return fail(h, MV_ERR_HIP, "mv_comm_init: librccl.so lacks " #name)
+    RCCL_SYM(ncclGetUniqueId);
+    RCCL_SYM(ncclCommInitRank);
+    RCCL_SYM(ncclAllGather);
+    RCCL_SYM(ncclCommDestroy);
+    RCCL_SYM(ncclGetErrorString);
+#undef RCCL_SYM
+  }
+  ncclUniqueId id;
+  const std::string path = id_path;
+  if (rank == 0) {
+    ncclResult_t r = h->p_ncclGetUniqueId(&id);
+    if (r != ncclSuccess) return fail(h, MV_ERR_HIP, std::string("ncclGetUniqueId: ") + h->p_ncclGetErrorString(r));
+    const std::string tmp = path + ".tmp";
+    FILE* f = fopen(tmp.c_str(), "wb");
+    if (!f || fwrite(&id, sizeof(id), 1, f) != 1) { if (f) fclose(f); return fail(h, MV_ERR_INVALID, "mv_comm_init: cannot write " + tmp); }
+    fclose(f);
+    if (rename(tmp.c_str(), path.c_str()) != 0) return fail(h, MV_ERR_INVALID, "mv_comm_init: cannot publish " + path);
+    h->comm_id_path = path;
+  } else {
+    const auto t0 = std::chrono::steady_clock::now();
+    for (;;) {
+      FILE* f = fopen(path.c_str(), "rb");
+      if (f) {
+        const size_t n = fread(&id, sizeof(id), 1, f);
+        fclose(f);
+        if (n == 1) break;
+      }
+      if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(180))
+        return fail(h, MV_ERR_STATE, "mv_comm_init: rank 0 did not publish the RCCL unique id at " + path + " within 180 s");
+      usleep(20000);
+    }
+  }
+  ncclResult_t r = h->p_ncclCommInitRank(&h->comm, world, id, rank);
+  if (r != ncclSuccess) { h->comm = nullptr; return fail(h, MV_ERR_HIP, std::string("ncclCommInitRank: ") + h->p_ncclGetErrorString(r)); }
+  return MV_OK;
+}
+
+int mv_comm_allgather(mv_handle* h, const void* send, void* recv, int64_t bytes_per_rank) {
+  if (!h || !send || !recv || bytes_per_rank <= 0) return fail(h, MV_ERR_INVALID, "mv_comm_allgather: bad argument");
+  if (h->comm_world == 1 && !h->comm) { std::memcpy(recv, send, (size_t)bytes_per_rank); return MV_OK; }
+  if (!h->comm) return fail(h, MV_ERR_STATE, "mv_comm_allgather: mv_comm_init first");
+  HIPCHK(h, hipSetDevice(h->device));
+  if (int rc = sync_all(h)) return rc;
+  hipStream_t st = h->work[0].stream;
+  const int64_t total = bytes_per_rank * h->comm_world;
+  if (h->comm_send_cap < bytes_per_rank) {
+    if (h->comm_send) hipFree(h->comm_send);
+    h->comm_send = nullptr; h->comm_send_cap = 0;
+    HIPCHK(h, hipMalloc(&h->comm_send, (size_t)bytes_per_rank));
+    h->comm_send_cap = bytes_per_rank;
+  }
+  if (h->comm_recv_cap < total) {
+    if (h->comm_recv) hipFree(h->comm_recv);
+    h->comm_recv = nullptr; h->comm_recv_cap = 0;
+    HIPCHK(h, hipMalloc(&h->comm_recv, (size_t)total));
+    h->comm_recv_cap = total;
+  }
+  HIPCHK(h, hipMemcpyAsync(h->comm_send, send, (size_t)bytes_per_rank, hipMemcpyHostToDevice, st));
+  ncclResult_t r = h->p_ncclAllGather(h->comm_send, h->comm_recv, (size_t)bytes_per_rank, ncclChar, h->comm, st);
+  if (r != ncclSuccess) return fail(h, MV_ERR_HIP, std::string("ncclAllGather: ") + h->p_ncclGetErrorString(r));
+  HIPCHK(h, hipMemcpyAsync(recv, h->comm_recv, (size_t)total, hipMemcpyDeviceToHost, st));
+  HIPCHK(h, hipStreamSynchronize(st));
+  return MV_OK;
+}
+
+int mv_comm_destroy(mv_handle* h) {
+  if (!h) return MV_ERR_INVALID;
+  if (h->comm) { h->p_ncclCommDestroy(h->comm); h->comm = nullptr; }
+  if (h->comm_send) { hipFree(h->comm_send); h->comm_send = nullptr; h->comm_send_cap = 0; }
+  if (h->comm_recv) { hipFree(h->comm_recv); h->comm_recv = nullptr; h->comm_recv_cap = 0; }
+  if (!h->comm_id_path.empty()) { unlink(h->comm_id_path.c_str()); h->comm_id_path.clear(); }
+  h->comm_world = 1; h->comm_rank = 0;
   return MV_OK;
 }
 

@@ -9,13 +9,13 @@
 //   * W_a . u_b is hoisted (once per issue report: lane-parallel partial sums + a fixed-order wave reduction),
 //     W_b . v_g is one fma chain per anchor (lane = anchor), so the inner loop is  d = u - v;  acc_c += W_c[c] * |d|
 //     = 3 VALU operations per (b, g, feature) instead of the 5 of the plain form (the |.| is a source modifier);
-//   * a workgroup = RB issue reports x 256 anchors (wave w <-> anchors 64 w .. 64 w + 63 of the chunk); the anchor chunk is
-//     staged through LDS 32 features at a time by coalesced 16-byte loads (row stride 36 floats: the lane = anchor
-//     ds_read_b128 is conflict-free), the next chunk's loads are in flight while the current one is consumed; the RB issue
-//     report rows sit in LDS and are read as wave-uniform (broadcast) float4; W_c, W_b are scalar (SGPR) operands;
-//   * the chunk's P(same) values go to LDS and wave r runs k rounds of (value desc, index asc) arg-max for row r; with
-//     one chunk (G <= 256: the 124-anchor CWE memory) these ARE the results; otherwise per-chunk candidate lists
-//     [B][chunks][k] (8 B k per chunk) are merged by topk_merge_kernel.
+//   * a workgroup = 4 issue reports x GC anchors (lane = anchor); the anchor chunk is staged through LDS MI features at
+//     a time by coalesced 16-byte loads (row stride MI + 4 floats: the lane = anchor ds_read_b128 is conflict-free), the
+//     next step's loads are in flight while the current one is consumed; the issue-report rows and the four weight rows
+//     W_b[c], W_c[c] sit in LDS and are read as wave-uniform (broadcast) float4;
+//   * the chunk's P(same) values go to LDS and one wave per row runs k rounds of (value desc, index asc) arg-max; with one
+//     chunk (the 124-anchor CWE memory) these ARE the results; otherwise per-chunk candidate lists [B][chunks][k]
+//     (8 B k per chunk) are merged by topk_merge_kernel.
 // Algorithmic HBM bytes: 4 (B P + G P) + 8 B k = 3.1 MB at B = 256, G = 1000, k = 10, all L2-resident; the
 // bound is the fp32 vector ALU: 3 B G P operations = 0.39 G lane-ops (5.0 us at 78.6 T lane-op/s).
 // Every (b, g) result is computed by the same instruction sequence wherever it lands in the grid: results do not depend
@@ -23,9 +23,6 @@
 #pragma once
 #include "common.h"
 
-#define MK_GC 256     // anchors per workgroup chunk
-#define MK_I 32       // features staged per step
-#define MK_STRIDE 36  // floats per staged anchor row
 #define MK_KMAX 64
 
 struct MatchArgs {  // (u, v, W_m travel as separate `const __restrict__` kernel arguments: provably read-only -> W_m by scalar loads)
@@ -71,41 +68,56 @@ __device__ __forceinline__ void mk_select(const float (&key)[NJ], const int (&gi
   }
 }
 
-template <int RB>
+// RB issue reports per row group, GC anchors per workgroup chunk (64 per wave), MI features staged per step.
+// Waves: AW = GC / 64 anchor waves x RW = 4 / AW row groups; a workgroup covers RW * RB issue reports x GC anchors.
+//   <4, 256, 64>  large banks: 4 rows x 256 anchors, 8 steps          (LDS 70 + 8 + 8 KB)
+//   <2, 128, 128> the 124-anchor CWE memory: 4 rows x 128 anchors, 4 steps: the pass is latency-bound (0.05 G lane-ops in
+//                 total), so few, long steps matter more than filling every CU                     (LDS 68 + 8 + 8 KB)
+template <int RB, int GC, int MI>
 __global__ __launch_bounds__(256) void match_topk_kernel(const float* __restrict__ u, const float* __restrict__ v,
                                                          const float* __restrict__ Wm, MatchArgs a) {
-  __shared__ __attribute__((aligned(16))) float sv[MK_GC * MK_STRIDE];  // anchor chunk x 32 features; later P(same) / P(other) [2][RB][256]
-  __shared__ __attribute__((aligned(16))) float su[RB * MV_PROJ];        // the RB issue-report rows
-  __shared__ float sa[RB][2];                                            // W_a[c] . u_r
+  constexpr int AW = GC / 64, RW = 4 / AW, NR = RW * RB, STRIDE = MI + 4;  // row stride = 4 mod 64 floats: conflict-free b128
+  static_assert(AW * RW == 4 && (MI % 4) == 0 && MV_PROJ % MI == 0, "wave split");
+  __shared__ __attribute__((aligned(16))) float sv[GC * STRIDE];      // anchor chunk x MI features; later P(same) / P(other) [2][NR][GC]
+  __shared__ __attribute__((aligned(16))) float su[NR * MV_PROJ];     // the issue-report rows of this workgroup
+  __shared__ __attribute__((aligned(16))) float sw[4 * MV_PROJ];      // W_b[0], W_b[1], W_c[0], W_c[1]
+  __shared__ float sa[NR][2];                                         // W_a[c] . u_r
+  static_assert(2 * NR * GC <= GC * STRIDE, "P(same) / P(other) reuse the staging buffer");
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int g0 = blockIdx.x * MK_GC, b0 = blockIdx.y * RB;
-  // ---- issue-report rows -> LDS (rows past B repeat the last valid one; never stored)
-  for (int e = tid; e < RB * (MV_PROJ / 4); e += 256) {
-    const int r = e / (MV_PROJ / 4), c4 = e % (MV_PROJ / 4);
-    const int b = b0 + r < a.B ? b0 + r : a.B - 1;
-    *(float4*)(su + r * MV_PROJ + 4 * c4) = *(const float4*)(u + (size_t)b * MV_PROJ + 4 * c4);
-  }
-  // ---- first anchor chunk in flight
-  float4 stage[8];
+  const int aw = w % AW, rw = w / AW;
+  const int g0 = blockIdx.x * GC, b0 = blockIdx.y * NR;
+  // ---- first anchor chunk in flight, then the small operands -> LDS
+  constexpr int NST = GC * MI / 4 / 256;  // float4 per thread per step
+  float4 stage[NST];
   auto load_chunk = [&](int i0) {
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const int e = tid + 256 * j, r = e >> 3, c4 = e & 7;  // 8 float4 per 32-feature row
+    for (int j = 0; j < NST; ++j) {
+      const int e = tid + 256 * j, r = e / (MI / 4), c4 = e % (MI / 4);
       stage[j] = (g0 + r < a.G) ? *(const float4*)(v + (size_t)(g0 + r) * MV_PROJ + i0 + 4 * c4) : float4{0.f, 0.f, 0.f, 0.f};
     }
   };
   auto store_chunk = [&]() {
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const int e = tid + 256 * j, r = e >> 3, c4 = e & 7;
-      *(float4*)(sv + r * MK_STRIDE + 4 * c4) = stage[j];
+    for (int j = 0; j < NST; ++j) {
+      const int e = tid + 256 * j, r = e / (MI / 4), c4 = e % (MI / 4);
+      *(float4*)(sv + r * STRIDE + 4 * c4) = stage[j];
     }
   };
   load_chunk(0);
+  for (int e = tid; e < NR * (MV_PROJ / 4); e += 256) {  // rows past B repeat the last valid one; never stored
+    const int r = e / (MV_PROJ / 4), c4 = e % (MV_PROJ / 4);
+    const int b = b0 + r < a.B ? b0 + r : a.B - 1;
+    *(float4*)(su + r * MV_PROJ + 4 * c4) = *(const float4*)(u + (size_t)b * MV_PROJ + 4 * c4);
+  }
+  for (int e = tid; e < 4 * (MV_PROJ / 4); e += 256) {
+    const int c = e / (MV_PROJ / 4), c4 = e % (MV_PROJ / 4);
+    const int row = c == 0 ? 1 : c == 1 ? 4 : c == 2 ? 2 : 5;  // W_m rows: [W_a | W_b | W_c] of class 0, then of class 1
+    *(float4*)(sw + c * MV_PROJ + 4 * c4) = *(const float4*)(Wm + (size_t)row * MV_PROJ + 4 * c4);
+  }
   __syncthreads();
   // ---- hoisted W_a . u_r: wave w takes rows r = w, w + 4, ..; lane-parallel partial sums (ascending i), fixed-order reduce
-  for (int r = w; r < RB; r += 4) {
+  for (int r = w; r < NR; r += 4) {
     float s0 = 0.f, s1 = 0.f;
 #pragma unroll
     for (int j = 0; j < MV_PROJ / 64; ++j) {
@@ -123,22 +135,20 @@ __global__ __launch_bounds__(256) void match_topk_kernel(const float* __restrict
   float d0[RB], d1[RB], bv0 = 0.f, bv1 = 0.f;
 #pragma unroll
   for (int r = 0; r < RB; ++r) d0[r] = d1[r] = 0.f;
-  const float* myrow = sv + (64 * w + lane) * MK_STRIDE;
-  for (int i0 = 0; i0 < MV_PROJ; i0 += MK_I) {
+  const float* myrow = sv + (64 * aw + lane) * STRIDE;
+  const float* myu = su + rw * RB * MV_PROJ;
+  for (int i0 = 0; i0 < MV_PROJ; i0 += MI) {
     store_chunk();
     __syncthreads();
-    if (i0 + MK_I < MV_PROJ) load_chunk(i0 + MK_I);  // in flight while this chunk is consumed
-#pragma unroll 2
-    for (int q = 0; q < MK_I / 4; ++q) {
+    if (i0 + MI < MV_PROJ) load_chunk(i0 + MI);  // in flight while this chunk is consumed
+#pragma unroll 4
+    for (int q = 0; q < MI / 4; ++q) {
       const float4 vv = *(const float4*)(myrow + 4 * q);
       const float vx[4] = {vv.x, vv.y, vv.z, vv.w};
-      float wb0[4], wb1[4], wc0[4], wc1[4];
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int i = i0 + 4 * q + e;
-        wb0[e] = Wm[MV_PROJ + i]; wb1[e] = Wm[4 * MV_PROJ + i];
-        wc0[e] = Wm[2 * MV_PROJ + i]; wc1[e] = Wm[5 * MV_PROJ + i];
-      }
+      const float4 b0v = *(const float4*)(sw + i0 + 4 * q), b1v = *(const float4*)(sw + MV_PROJ + i0 + 4 * q);  // wave-uniform: LDS broadcast
+      const float4 c0v = *(const float4*)(sw + 2 * MV_PROJ + i0 + 4 * q), c1v = *(const float4*)(sw + 3 * MV_PROJ + i0 + 4 * q);
+      const float wb0[4] = {b0v.x, b0v.y, b0v.z, b0v.w}, wb1[4] = {b1v.x, b1v.y, b1v.z, b1v.w};
+      const float wc0[4] = {c0v.x, c0v.y, c0v.z, c0v.w}, wc1[4] = {c1v.x, c1v.y, c1v.z, c1v.w};
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         bv0 = fmaf(wb0[e], vx[e], bv0);
@@ -146,7 +156,7 @@ __global__ __launch_bounds__(256) void match_topk_kernel(const float* __restrict
       }
 #pragma unroll
       for (int r = 0; r < RB; ++r) {
-        const float4 uu = *(const float4*)(su + r * MV_PROJ + i0 + 4 * q);  // wave-uniform address: LDS broadcast
+        const float4 uu = *(const float4*)(myu + r * MV_PROJ + i0 + 4 * q);
         const float ux[4] = {uu.x, uu.y, uu.z, uu.w};
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -159,21 +169,21 @@ __global__ __launch_bounds__(256) void match_topk_kernel(const float* __restrict
     __syncthreads();  // every wave is done with this chunk before the next one overwrites it
   }
   // ---- logits, softmax_2, optional full outputs; P(same) / P(other) of the chunk -> LDS
-  float* sp = sv;                  // [RB][256]
-  float* sq = sv + RB * MK_GC;     // [RB][256]
-  const int gl = 64 * w + lane, g = g0 + gl;
+  float* sp = sv;             // [NR][GC]
+  float* sq = sv + NR * GC;   // [NR][GC]
+  const int gl = 64 * aw + lane, g = g0 + gl;
 #pragma unroll
   for (int r = 0; r < RB; ++r) {
-    const int b = b0 + r;
-    const float l0 = (sa[r][0] + bv0) + d0[r];
-    const float l1 = (sa[r][1] + bv1) + d1[r];
+    const int rl = rw * RB + r, b = b0 + rl;
+    const float l0 = (sa[rl][0] + bv0) + d0[r];
+    const float l1 = (sa[rl][1] + bv1) + d1[r];
     const float m = fmaxf(l0, l1);
     const float e0 = expf(l0 - m), e1 = expf(l1 - m);
     const float inv = 1.0f / (e0 + e1);
     const float p0 = e0 * inv, p1 = e1 * inv;
     const float ps = a.same_idx == 0 ? p0 : p1, pq = a.same_idx == 0 ? p1 : p0;
-    sp[r * MK_GC + gl] = g < a.G ? ps : -1.0f;
-    sq[r * MK_GC + gl] = pq;
+    sp[rl * GC + gl] = g < a.G ? ps : -1.0f;
+    sq[rl * GC + gl] = pq;
     if (b < a.B && g < a.G) {
       const size_t o = ((size_t)b * a.G + g) * 2;
       if (a.logits) { a.logits[o] = l0; a.logits[o + 1] = l1; }
@@ -184,20 +194,20 @@ __global__ __launch_bounds__(256) void match_topk_kernel(const float* __restrict
   if (a.k <= 0) return;
   __syncthreads();
   // ---- selection: wave w ranks rows w, w + 4, ...
-  for (int r = w; r < RB; r += 4) {
+  for (int r = w; r < NR; r += 4) {
     const int b = b0 + r;
     if (b >= a.B) continue;
-    float key[4];
-    int gi[4];
+    float key[AW];
+    int gi[AW];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < AW; ++j) {
       const int gg = g0 + lane + 64 * j;
-      key[j] = mk_key(sp[r * MK_GC + lane + 64 * j]);
+      key[j] = mk_key(sp[r * GC + lane + 64 * j]);
       gi[j] = gg < a.G ? gg : 0x7fffffff;
     }
-    mk_select<4>(key, gi, a.k, lane, [&](int round, int slot) {
+    mk_select<AW>(key, gi, a.k, lane, [&](int round, int slot) {
       if (lane != 0) return;
-      const float ps = slot >= 0 ? sp[r * MK_GC + slot] : -1.0f, pq = slot >= 0 ? sq[r * MK_GC + slot] : -1.0f;
+      const float ps = slot >= 0 ? sp[r * GC + slot] : -1.0f, pq = slot >= 0 ? sq[r * GC + slot] : -1.0f;
       const int gw = slot >= 0 ? g0 + slot : 0x7fffffff;
       if (a.nchunk > 1) {
         const size_t o = ((size_t)b * a.nchunk + blockIdx.x) * a.k + round;

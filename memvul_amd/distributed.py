@@ -8,8 +8,12 @@ data-path collective, and ONE all-gather (RCCL over xGMI when the backend is "nc
 ``(score fp32, label u8)`` sufficient statistics at the end, after which every rank can run
 ``find_best_thres`` / ROC-AUC / AP on the concatenation (bit-identical to a single-GPU run).
 
-torch.distributed is used as plumbing only (process group + all_gather); it is imported lazily so that
-single-GPU runs never load torch.
+Two transports behind the same four functions (all_gather_rows / all_gather_stats / barrier / all_reduce_max):
+
+* RCCL bound directly inside libmemvul_hip.so (``init_rccl(engine)`` -> mv_comm_init / mv_comm_allgather): the GPU path.
+  The collective runs on the engine's stream, the unique id travels through a file every rank of the node can reach,
+  and the process never imports torch — so there is no second HIP runtime in the process and no load-order rule.
+* torch.distributed (``init_process_group``): the gloo harness of the CPU tests (world size 2 here), imported lazily.
 """
 from __future__ import annotations
 
@@ -29,6 +33,50 @@ def shard_range(n: int, rank: int, world: int) -> Tuple[int, int]:
 
 def env_world() -> Tuple[int, int, int]:
     return int(os.environ.get("RANK", 0)), int(os.environ.get("LOCAL_RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
+
+
+_rccl_engine = None  # the Engine whose communicator carries the exchange (init_rccl)
+
+
+def rccl_id_path() -> str:
+    """A path every rank of this node derives identically: launcher port + the launcher's pid (all ranks are children of
+    one torchrun / mpirun process); rank 0 publishes the RCCL unique id there and removes it when the communicator goes."""
+    import tempfile
+
+    tag = os.environ.get("MEMVUL_RCCL_ID_TAG") or f"{os.environ.get('MASTER_PORT', '0')}_{os.environ.get('TORCHELASTIC_RUN_ID', 'x')}_{os.getppid()}"
+    return os.path.join(tempfile.gettempdir(), f"memvul_rccl_{tag}.id")
+
+
+def init_rccl(engine, rank: Optional[int] = None, world: Optional[int] = None, id_path: Optional[str] = None):
+    """Make `engine`'s RCCL communicator the transport of this module (GPU runs).  world == 1: a no-op transport."""
+    global _rccl_engine
+    r, _, w = env_world()
+    rank = r if rank is None else rank
+    world = w if world is None else world
+    engine.comm_init(rank, world, id_path or (rccl_id_path() if world > 1 else None))
+    _rccl_engine = engine
+    return engine
+
+
+def shutdown_rccl():
+    global _rccl_engine
+    if _rccl_engine is not None:
+        _rccl_engine.comm_destroy()
+        _rccl_engine = None
+
+
+def _rccl_world() -> int:
+    return getattr(_rccl_engine, "comm_world", 1) if _rccl_engine is not None else 0
+
+
+def _rccl_all_gather_rows(rows: np.ndarray) -> np.ndarray:
+    world = _rccl_world()
+    counts = _rccl_engine.comm_allgather(np.array([rows.shape[0]], np.int64)).reshape(world)
+    n_max = max(int(counts.max()), 1)
+    block = np.zeros((n_max, rows.shape[1]), np.float32)
+    block[: rows.shape[0]] = rows
+    out = _rccl_engine.comm_allgather(block)  # [world, n_max, k]
+    return np.concatenate([out[r, : int(counts[r])] for r in range(world)])
 
 
 def init_process_group(backend: Optional[str] = None):
@@ -57,10 +105,14 @@ def init_process_group(backend: Optional[str] = None):
 def all_gather_rows(rows: np.ndarray, device=None) -> np.ndarray:
     """All-gather per-rank fp32 row blocks ``[n_r, k]`` (n_r may differ per rank); returns the rank-ordered concatenation
     ``[sum n_r, k]``.  One collective on a zero-padded ``[n_max, k]`` block per rank plus a tiny count gather."""
+    rows = np.ascontiguousarray(rows, np.float32)
+    if _rccl_engine is not None:
+        if rows.ndim != 2:
+            raise ValueError("all_gather_rows expects [n, k]")
+        return _rccl_all_gather_rows(rows) if _rccl_world() > 1 else rows.copy()
     import torch
     import torch.distributed as dist
 
-    rows = np.ascontiguousarray(rows, np.float32)
     if rows.ndim != 2:
         raise ValueError("all_gather_rows expects [n, k]")
     if not dist.is_initialized() or dist.get_world_size() == 1:
@@ -93,6 +145,10 @@ def all_gather_stats(scores: np.ndarray, labels: np.ndarray, device=None) -> Tup
 
 
 def barrier():
+    if _rccl_engine is not None:
+        if _rccl_world() > 1:
+            _rccl_engine.comm_allgather(np.zeros(1, np.int32))  # returns when every rank has contributed
+        return
     import torch.distributed as dist
 
     if dist.is_initialized() and dist.get_world_size() > 1:
@@ -100,6 +156,8 @@ def barrier():
 
 
 def all_reduce_max(x: float) -> float:
+    if _rccl_engine is not None:
+        return float(_rccl_engine.comm_allgather(np.array([x], np.float64)).max()) if _rccl_world() > 1 else x
     import torch
     import torch.distributed as dist
 

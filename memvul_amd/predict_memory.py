@@ -190,7 +190,8 @@ def test_siamese_sharded(archive_file, input_file, input_golden_file, test_confi
     from . import distributed as mvdist
 
     rank, local_rank, world = mvdist.env_world()
-    if world > 1:
+    use_torch = world > 1 and backend in ("gloo", "nccl")  # gloo: the CPU test harness; "nccl": torch.distributed's RCCL route
+    if use_torch:
         mvdist.init_process_group(backend)
     # the reference takes the model's device from the config (predict_memory.py:210, test_config_memory.json "cuda:0");
     # here every rank must land on ITS GPU whatever the config says
@@ -200,6 +201,9 @@ def test_siamese_sharded(archive_file, input_file, input_golden_file, test_confi
                            engine_options=engine_options)
     model = archive.model
     model.eval()
+    if world > 1 and not use_torch:
+        # the default on GPUs: RCCL bound inside libmemvul_hip.so, collective on the engine's stream, no torch.distributed
+        mvdist.init_rccl(model.engine, rank, world)
     golden_samples = list(archive.validation_dataset_reader.read(input_golden_file))
     model._golden_instances_embeddings = None
     model._golden_instances_labels = None

@@ -73,6 +73,12 @@ def pmc(dbs):
     hdr = f"{'kernel':<52} {'grid':>8} {'n':>4} {'prof_us':>8}" + "".join(f" {c[:22]:>22}" for c in counters)
     if "FETCH_SIZE" in counters:
         hdr += f" {'fetch_corr_MB':>14}"
+    derive = "GRBM_GUI_ACTIVE" in counters and "SQ_VALU_MFMA_BUSY_CYCLES" in counters
+    if derive:
+        # GRBM_GUI_ACTIVE is summed over the 8 XCDs: / 8 = shader cycles of the dispatch -> effective clock = that / wall
+        # (MI355X_MICROARCH.md "DVFS give-back"); SQ_VALU_MFMA_BUSY_CYCLES = 32 cycles per v_mfma_32x32x16 summed over the
+        # 256 CUs x 4 SIMDs -> busy fraction of the matrix pipes = it / (1024 x shader cycles)
+        hdr += f" {'eff_clock_GHz':>14} {'mfma_busy_%':>12}"
     print(hdr)
     for key, c in sorted(agg.items(), key=lambda kv: -sum(dur[kv[0]])):
         name, gx = key
@@ -86,6 +92,11 @@ def pmc(dbs):
         if "FETCH_SIZE" in counters:
             f = c.get("FETCH_SIZE", [])
             line += f" {(2 * sum(f) / len(f) / 1024 if f else float('nan')):>14.1f}"
+        if derive:
+            g, m = c.get("GRBM_GUI_ACTIVE", []), c.get("SQ_VALU_MFMA_BUSY_CYCLES", [])
+            cyc = sum(g) / len(g) / 8 if g else float("nan")
+            us = sum(dur[key]) / len(dur[key]) / 1000.0
+            line += f" {cyc / us / 1000.0:>14.3f} {(100.0 * (sum(m) / len(m)) / (1024 * cyc) if m and cyc else float('nan')):>12.2f}"
         print(line)
 
 

@@ -355,3 +355,29 @@ def test_rejects_token_ids_outside_the_vocabulary(gu):
                 call(arr)
     assert np.isfinite(eng.encode(ids, lens)).all()
     eng.anchor_reset()
+
+
+def test_rccl_bound_in_the_library_one_rank(gu, tmp_path):
+    """mv_comm_init / mv_comm_allgather: librccl.so opened at run time, unique id through a file, a real
+    one-rank communicator on the engine's stream; then the module-level transport (distributed.init_rccl) that bench.py
+    and test_siamese_sharded use for N > 1 — with no torch.distributed anywhere."""
+    from memvul_amd import distributed as mvdist
+
+    dk, wk = dict(layers=2, vocab_size=2048), dict(qk_scale=3.0)
+    eng = gu.engine_for(dk, wk)
+    idp = str(tmp_path / "rccl.id")
+    eng.comm_init(0, 1, idp)
+    assert os.path.exists(idp)
+    x = np.arange(1000, dtype=np.float32).reshape(250, 4)
+    out = eng.comm_allgather(x)
+    assert out.shape == (1, 250, 4) and np.array_equal(out[0], x)
+    ids, lens = synth.make_ids(4, 64, 2048)
+    u0 = eng.encode(ids, lens)                    # engine work and the communicator share the stream
+    assert np.array_equal(eng.comm_allgather(u0)[0], u0)
+    eng.comm_destroy()
+    assert not os.path.exists(idp)                # rank 0 removes the id file with the communicator
+    mvdist.init_rccl(eng, 0, 1)
+    s, l = mvdist.all_gather_stats(np.array([0.25, 0.75], np.float32), np.array([0, 1], np.uint8))
+    assert s.tolist() == [0.25, 0.75] and l.tolist() == [0, 1] and mvdist.all_reduce_max(3.5) == 3.5
+    mvdist.barrier()
+    mvdist.shutdown_rccl()
