@@ -338,6 +338,10 @@ int launch_pp_raw(mv_handle* h, GemmArgs a) {
   const int tiles = (a.M / 256) * (a.N / 256);
   const int grid = tiles < h->num_cu ? tiles : h->num_cu;
   a.stagger = tiles >= 2 * h->num_cu ? h->pp_stagger : 0;
+  if (a.stagger == -1) {  // two phase groups half a tile apart (tile times at the bench shape: 25 / 42 / 105 us; one unit ~ 5 us)
+    constexpr bool res = (PPEPI == PP_RES || PPEPI == PP_RESLN || PPEPI == PP_RESLN2 || PPEPI == PP_RESLN3);
+    a.stagger = res ? (a.K <= 1024 ? -4 : -10) : -2;
+  }
   hipLaunchKernelGGL((gemm_pp_kernel<PPEPI, PP_DIST, 0, PP_SCHED, PP_COAL, RAW>), dim3(grid), dim3(512),
                      RAW ? PP_LDS_BYTES_RAW : PP_LDS_BYTES, h->w->stream, a);
   return launch_check(h, "gemm_pp");
@@ -394,10 +398,10 @@ int launch_gemm(mv_handle* h, int cls, const GemmArgs& a) {
 // K7 + K8: pooler on the [CLS] rows (row_stride floats apart), then the header
 int pool_head(mv_handle* h, const float* x, size_t row_stride, int B, float* u_out) {
   const unsigned gx = (unsigned)((B + 31) / 32);
-  hipLaunchKernelGGL(dense768_kernel<0>, dim3(gx, MV_HIDDEN / 32), dim3(256), 0, h->w->stream, x, row_stride, B, h->WpT, h->bp,
+  hipLaunchKernelGGL(dense768_kernel<0>, dim3(gx, MV_HIDDEN / 32), dim3(512), 0, h->w->stream, x, row_stride, B, h->WpT, h->bp,
                      MV_HIDDEN, h->w->pooled);
   if (int rc = launch_check(h, "pooler")) return rc;
-  hipLaunchKernelGGL(dense768_kernel<1>, dim3(gx, MV_PROJ / 32), dim3(256), 0, h->w->stream, h->w->pooled, (size_t)MV_HIDDEN, B, h->WhT,
+  hipLaunchKernelGGL(dense768_kernel<1>, dim3(gx, MV_PROJ / 32), dim3(512), 0, h->w->stream, h->w->pooled, (size_t)MV_HIDDEN, B, h->WhT,
                      h->bh, MV_PROJ, u_out);
   return launch_check(h, "header");
 }

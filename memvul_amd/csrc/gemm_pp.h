@@ -234,8 +234,11 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmArgs a) {
   // ---- optional start-up stagger: all workgroups of a launch otherwise run their tiles in lockstep, so their
   // accumulator-init loads and epilogue stores hit HBM in bursts (every CU at once) with the matrix pipes idle, and
   // HBM idles during the main loops.  (Waves 1..7 wait for wave 0 at the prologue barrier.)
-  if (a.stagger > 0 && wave == 0) {
-    const int n = (int)((uint32_t)(bslot * 2654435761u) >> 16) % (a.stagger + 1);
+  // stagger < 0: TWO phase groups instead of a random spread — odd slots start -stagger x 8128 cycles late, so half of
+  // every XCD's workgroups sit in their main loops while the other half runs its epilogue / accumulator init (each phase
+  // group keeps sharing its operand panels in L2 at the same moment, which the random spread destroyed).
+  if (a.stagger != 0 && wave == 0) {
+    const int n = a.stagger > 0 ? (int)((uint32_t)(bslot * 2654435761u) >> 16) % (a.stagger + 1) : ((bslot & 1) ? -a.stagger : 0);
     for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(127);
   }
 

@@ -94,7 +94,10 @@ __global__ __launch_bounds__(256) void match_topk_kernel(const float* __restrict
 #pragma unroll
     for (int j = 0; j < NST; ++j) {
       const int e = tid + 256 * j, r = e / (MI / 4), c4 = e % (MI / 4);
-      stage[j] = (g0 + r < a.G) ? *(const float4*)(v + (size_t)(g0 + r) * MV_PROJ + i0 + 4 * c4) : float4{0.f, 0.f, 0.f, 0.f};
+      // rows past G read the last anchor (never ranked, never stored): an `in range ? load : 0` select makes hipcc branch
+      // around every load and wait for each in turn (cdna_hip_programming.md §5 trap (c): 16 dependent L2 round trips per step)
+      const int gr = g0 + r < a.G ? g0 + r : a.G - 1;
+      stage[j] = *(const float4*)(v + (size_t)gr * MV_PROJ + i0 + 4 * c4);
     }
   };
   auto store_chunk = [&]() {

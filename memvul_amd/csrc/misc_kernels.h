@@ -225,27 +225,30 @@ __global__ __launch_bounds__(256) void cls_gather_kernel(const float* __restrict
 // K7, K8 (model_memory.py:99-102): u = relu(W_h tanh(W_p h[:,0] + b_p) + b_h), all fp32, as two launches of one
 // dense kernel: out[b][n] = act(sum_k x[b][k] W^T[k][n] + bias[n]), K = 768, on the fp32-input matrix cores
 // (v_mfma_f32_32x32x2_f32: exact fp32 products and sums, MI355X_MICROARCH.md "f32-input MFMA").  A workgroup owns
-// one 32 x 32 output tile; its 4 waves split K (192 each, ascending k inside a wave) and the four partial tiles are
-// added in wave order through LDS, so the result is deterministic.  The weights are stored transposed ([k][n]): a
-// B-operand load is two 128-byte row pieces; grid = B / 32 x N / 32 (192 + 128 workgroups at B = 256).
+// one 32 x 32 output tile; its 8 waves split K (96 each, ascending k inside a wave; all of a wave's operand loads are
+// issued up front — the kernel is latency-bound: 29 -> ~12 us per launch against 4 waves x 192 with 4 steps in flight)
+// and the eight partial tiles are added in wave order through LDS, so the result is deterministic.  The weights are
+// stored transposed ([k][n]): a B-operand load is two 128-byte row pieces; grid = B / 32 x N / 32 (192 + 128
+// workgroups at B = 256).
 typedef float floatx16_t __attribute__((ext_vector_type(16)));
 template <int ACT>  // 0: tanh (BertPooler), 1: ReLU (header FeedForward)
-__global__ __launch_bounds__(256) void dense768_kernel(const float* __restrict__ x, size_t row_stride, int B,
+__global__ __launch_bounds__(512) void dense768_kernel(const float* __restrict__ x, size_t row_stride, int B,
                                                        const float* __restrict__ WT, const float* __restrict__ bias, int N,
                                                        float* __restrict__ out) {
-  __shared__ float part[4][16][64];
+  constexpr int NW = 8, KW = MV_HIDDEN / NW;  // waves, k per wave
+  __shared__ float part[NW][16][64];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int b0 = blockIdx.x * 32, n0 = blockIdx.y * 32;
   const int h = lane >> 5, l31 = lane & 31;
   const int row = (b0 + l31 < B) ? b0 + l31 : B - 1;  // rows past B: computed on a valid row, never stored
-  const float* xr = x + (size_t)row * row_stride + wave * 192;
-  const float* wc = WT + (size_t)(wave * 192 + h) * N + n0 + l31;
+  const float* xr = x + (size_t)row * row_stride + wave * KW;
+  const float* wc = WT + (size_t)(wave * KW + h) * N + n0 + l31;
   floatx16_t acc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-#pragma unroll 4
-  for (int k0 = 0; k0 < 192; k0 += 8) {
+#pragma unroll
+  for (int k0 = 0; k0 < KW; k0 += 8) {
     const float4 a0 = *(const float4*)(xr + k0), a1 = *(const float4*)(xr + k0 + 4);
     // lanes 0-31 carry k0 + 2 j, lanes 32-63 k0 + 2 j + 1
     const float s0 = h ? a0.y : a0.x, s1 = h ? a0.w : a0.z, s2 = h ? a1.y : a1.x, s3 = h ? a1.w : a1.z;
@@ -259,9 +262,11 @@ __global__ __launch_bounds__(256) void dense768_kernel(const float* __restrict__
   for (int r = 0; r < 16; ++r) part[wave][r][lane] = acc[r];
   __syncthreads();
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int idx = tid + 256 * j, r = idx >> 6, ln = idx & 63;
-    const float v = ((part[0][r][ln] + part[1][r][ln]) + part[2][r][ln]) + part[3][r][ln];
+  for (int j = 0; j < 2; ++j) {
+    const int idx = tid + 512 * j, r = idx >> 6, ln = idx & 63;
+    float v = part[0][r][ln];
+#pragma unroll
+    for (int q = 1; q < NW; ++q) v += part[q][r][ln];
     const int orow = b0 + (r & 3) + 8 * (r >> 2) + 4 * (ln >> 5), ocol = n0 + (ln & 31);
     if (orow < B) out[(size_t)orow * N + ocol] = ACT == 0 ? tanhf(v + bias[ocol]) : fmaxf(v + bias[ocol], 0.f);
   }
