@@ -588,7 +588,7 @@ int match_dev(mv_handle* h, const float* u_dev, int B, float* logits, float* pro
   if (G <= 0) return fail(h, MV_ERR_STATE, "anchor bank is empty (call mv_anchor_append / mv_anchor_set first)");
   MatchArgs a{};
   a.B = B; a.G = G; a.same_idx = h->cfg.same_idx; a.k = k;
-  const bool small = G <= 128;                      // one 128-anchor chunk, 4 long feature steps (latency-bound pass)
+  const bool small = G <= 128;                      // one 128-anchor chunk per workgroup (the pass is latency-bound at this size)
   const int GC = small ? 128 : 256;
   a.nchunk = (G + GC - 1) / GC;
   if ((int64_t)a.nchunk * k > 1024) return fail(h, MV_ERR_INVALID, "top-k: anchors / 256 * k must not exceed 1024");
@@ -598,9 +598,9 @@ int match_dev(mv_handle* h, const float* u_dev, int B, float* logits, float* pro
   {
     ProfScope ps(h, KC_MATCH);
     if (small)
-      hipLaunchKernelGGL((match_topk_kernel<2, 128, 128>), dim3(1, (B + 3) / 4), dim3(256), 0, h->w->stream, u_dev, h->anchors, h->Wm, a);
+      hipLaunchKernelGGL((match_topk_kernel<2, 128, 64>), dim3(1, (B + 3) / 4), dim3(256), 0, h->w->stream, u_dev, h->anchors, h->Wm, a);
     else
-      hipLaunchKernelGGL((match_topk_kernel<4, 256, 64>), dim3(a.nchunk, (B + 3) / 4), dim3(256), 0, h->w->stream, u_dev, h->anchors, h->Wm, a);
+      hipLaunchKernelGGL((match_topk_kernel<4, 256, 32>), dim3(a.nchunk, (B + 3) / 4), dim3(256), 0, h->w->stream, u_dev, h->anchors, h->Wm, a);
     if (int rc = launch_check(h, "match_topk")) return rc;
   }
   if (a.nchunk > 1 && k > 0) {

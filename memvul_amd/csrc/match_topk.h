@@ -39,48 +39,61 @@ struct MatchArgs {  // (u, v, W_m travel as separate `const __restrict__` kernel
 // rank key: NaN (non-finite weights upstream) ranks above every probability, like torch.argmax treats it
 __device__ __forceinline__ float mk_key(float x) { return x != x ? 2.0f : x; }
 
-// k rounds of arg-max over `n` candidates held 4 per lane (cand j of lane l = index l + 64 j), order (key desc, idx asc).
-// Calls emit(round, slot) with the winning candidate's slot (lane + 64 j) or -1 when the candidates are exhausted.
+// k rounds of arg-max over candidates held NJ per lane (candidate j of lane l = slot l + 64 j), order (key desc, index asc).
+// A candidate is ONE 64-bit word  (key bits << 32) | ~index  (keys are >= 0 as floats, so their bit patterns order like the
+// values; ~index makes the lower index win a tie), so a round is a 64-bit max: 6 xor-shuffle stages of two dwords instead
+// of three values per stage (the selection is shuffle-latency-bound).  emit(round, slot) gets the winner's slot, or -1 when
+// the candidates are exhausted; it is called by every lane with the same arguments.
 template <int NJ, typename F>
 __device__ __forceinline__ void mk_select(const float (&key)[NJ], const int (&gidx)[NJ], int k, int lane, F emit) {
-  float prev_v = 3.0e38f;
-  int prev_i = -1;
+  unsigned long long cand[NJ];
+#pragma unroll
+  for (int j = 0; j < NJ; ++j)
+    cand[j] = gidx[j] == 0x7fffffff ? 0ull : ((unsigned long long)__float_as_uint(fmaxf(key[j], 0.0f)) << 32) | (unsigned)(~gidx[j]);
+  unsigned long long prev = ~0ull;
   for (int round = 0; round < k; ++round) {
-    float bv = -1.0f;
-    int bi = 0x7fffffff, bs = -1;
+    unsigned long long best = 0ull;
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
-      const float x = key[j];
-      const int g = gidx[j];
-      const bool after = (x < prev_v) || (x == prev_v && g > prev_i);
-      if (g != 0x7fffffff && after && (x > bv || (x == bv && g < bi))) { bv = x; bi = g; bs = lane + 64 * j; }
+      const unsigned long long c = cand[j];
+      best = (c < prev && c > best) ? c : best;
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
-      const float ov = __shfl_xor(bv, off, 64);
-      const int oi = __shfl_xor(bi, off, 64);
-      const int os = __shfl_xor(bs, off, 64);
-      if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; bs = os; }
+      const unsigned long long o = __shfl_xor(best, off, 64);
+      best = o > best ? o : best;
     }
-    emit(round, bi == 0x7fffffff ? -1 : bs);
-    prev_v = bv;
-    prev_i = bi;
+    int slot = -1;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) slot = (best != 0ull && cand[j] == best) ? lane + 64 * j : slot;
+    // the winner is unique (indices differ): exactly one lane holds it; everyone learns the slot with one more shuffle round
+    const unsigned long long has = __ballot(slot >= 0);
+    const int src = has ? __ffsll((long long)has) - 1 : 0;
+    slot = __shfl(slot, src, 64);
+    emit(round, best == 0ull ? -1 : slot);
+    prev = best == 0ull ? 0ull : best;
   }
 }
 
 // RB issue reports per row group, GC anchors per workgroup chunk (64 per wave), MI features staged per step.
 // Waves: AW = GC / 64 anchor waves x RW = 4 / AW row groups; a workgroup covers RW * RB issue reports x GC anchors.
-//   <4, 256, 64>  large banks: 4 rows x 256 anchors, 8 steps          (LDS 70 + 8 + 8 KB)
-//   <2, 128, 128> the 124-anchor CWE memory: 4 rows x 128 anchors, 4 steps: the pass is latency-bound (0.05 G lane-ops in
-//                 total), so few, long steps matter more than filling every CU                     (LDS 68 + 8 + 8 KB)
+//   <4, 256, 32>  large banks: 4 rows x 256 anchors, 16 steps, 53 KB LDS / 126 VGPRs (3 workgroups per CU)
+//   <2, 128, 64>  the 124-anchor CWE memory: 4 rows x 128 anchors, 8 steps
+// Measured (tools/match_probe.hip, profiles/r02_e_match_probe.txt): ONE workgroup alone takes 24 us (128 anchors) / 40 us
+// (256 anchors) — the pass is bound by the per-wave instruction chain (about 65 VALU + 9 LDS issues per 4 features:
+// 8 k instructions per wave), not by bytes: B = 256, G = 124: 24 us (round 1: 43 + 6); B = 256, G = 1000, k = 10:
+// 42 + 13 us merge (round 1: 73 + 11); B = 512: 57 + 13 us.
 template <int RB, int GC, int MI>
 __global__ __launch_bounds__(256) void match_topk_kernel(const float* __restrict__ u, const float* __restrict__ v,
                                                          const float* __restrict__ Wm, MatchArgs a) {
   constexpr int AW = GC / 64, RW = 4 / AW, NR = RW * RB, STRIDE = MI + 4;  // row stride = 4 mod 64 floats: conflict-free b128
   static_assert(AW * RW == 4 && (MI % 4) == 0 && MV_PROJ % MI == 0, "wave split");
   __shared__ __attribute__((aligned(16))) float sv[GC * STRIDE];      // anchor chunk x MI features; later P(same) / P(other) [2][NR][GC]
-  __shared__ __attribute__((aligned(16))) float su[NR * MV_PROJ];     // the issue-report rows of this workgroup
-  __shared__ __attribute__((aligned(16))) float sw[4 * MV_PROJ];      // W_b[0], W_b[1], W_c[0], W_c[1]
+  // wave-uniform operands, interleaved per feature quad: [W_b[0] | W_b[1] | W_c[0] | W_c[1] | u_0 | .. | u_{NR-1}] x float4,
+  // so that one base address + immediate offsets serve every broadcast read of a step (separate arrays cost a
+  // v_mov + s_add per read: the pass was instruction-bound on address arithmetic)
+  constexpr int XQ = 4 + NR;
+  __shared__ __attribute__((aligned(16))) float sx[(MV_PROJ / 4) * XQ * 4];
   __shared__ float sa[NR][2];                                         // W_a[c] . u_r
   static_assert(2 * NR * GC <= GC * STRIDE, "P(same) / P(other) reuse the staging buffer");
   const int tid = threadIdx.x, lane = tid & 63;
@@ -89,34 +102,33 @@ __global__ __launch_bounds__(256) void match_topk_kernel(const float* __restrict
   const int g0 = blockIdx.x * GC, b0 = blockIdx.y * NR;
   // ---- first anchor chunk in flight, then the small operands -> LDS
   constexpr int NST = GC * MI / 4 / 256;  // float4 per thread per step
-  float4 stage[NST];
-  auto load_chunk = [&](int i0) {
-#pragma unroll
-    for (int j = 0; j < NST; ++j) {
-      const int e = tid + 256 * j, r = e / (MI / 4), c4 = e % (MI / 4);
-      // rows past G read the last anchor (never ranked, never stored): an `in range ? load : 0` select makes hipcc branch
-      // around every load and wait for each in turn (cdna_hip_programming.md §5 trap (c): 16 dependent L2 round trips per step)
-      const int gr = g0 + r < a.G ? g0 + r : a.G - 1;
-      stage[j] = *(const float4*)(v + (size_t)gr * MV_PROJ + i0 + 4 * c4);
-    }
-  };
-  auto store_chunk = [&]() {
-#pragma unroll
-    for (int j = 0; j < NST; ++j) {
-      const int e = tid + 256 * j, r = e / (MI / 4), c4 = e % (MI / 4);
-      *(float4*)(sv + r * STRIDE + 4 * c4) = stage[j];
-    }
-  };
-  load_chunk(0);
+  // (plain unrolled loops on a local array: behind lambdas the array stayed an alloca that the backend "promoted" to LDS
+  //  — 64 KB more LDS and every staged value bounced through it)
+  typedef float mk_f4 __attribute__((ext_vector_type(4)));  // (an ext-vector, not HIP's float4 struct-with-union: SROA splits it)
+  mk_f4 stage[NST];
+#define MK_LOAD_CHUNK(I0)                                                                                         \
+  _Pragma("unroll") for (int j = 0; j < NST; ++j) {                                                               \
+    const int e = tid + 256 * j, r = e / (MI / 4), c4 = e % (MI / 4);                                             \
+    /* rows past G read the last anchor (never ranked, never stored): an `in range ? load : 0` select makes hipcc */ \
+    /* branch around every load and wait for each in turn (cdna_hip_programming.md §5 trap (c))                    */ \
+    const int gr = g0 + r < a.G ? g0 + r : a.G - 1;                                                               \
+    stage[j] = *(const mk_f4*)(v + (size_t)gr * MV_PROJ + (I0) + 4 * c4);                                        \
+  }
+#define MK_STORE_CHUNK()                                                                                          \
+  _Pragma("unroll") for (int j = 0; j < NST; ++j) {                                                               \
+    const int e = tid + 256 * j, r = e / (MI / 4), c4 = e % (MI / 4);                                             \
+    *(mk_f4*)(sv + r * STRIDE + 4 * c4) = stage[j];                                                               \
+  }
+  MK_LOAD_CHUNK(0)
   for (int e = tid; e < NR * (MV_PROJ / 4); e += 256) {  // rows past B repeat the last valid one; never stored
     const int r = e / (MV_PROJ / 4), c4 = e % (MV_PROJ / 4);
     const int b = b0 + r < a.B ? b0 + r : a.B - 1;
-    *(float4*)(su + r * MV_PROJ + 4 * c4) = *(const float4*)(u + (size_t)b * MV_PROJ + 4 * c4);
+    *(float4*)(sx + (c4 * XQ + 4 + r) * 4) = *(const float4*)(u + (size_t)b * MV_PROJ + 4 * c4);
   }
   for (int e = tid; e < 4 * (MV_PROJ / 4); e += 256) {
     const int c = e / (MV_PROJ / 4), c4 = e % (MV_PROJ / 4);
     const int row = c == 0 ? 1 : c == 1 ? 4 : c == 2 ? 2 : 5;  // W_m rows: [W_a | W_b | W_c] of class 0, then of class 1
-    *(float4*)(sw + c * MV_PROJ + 4 * c4) = *(const float4*)(Wm + (size_t)row * MV_PROJ + 4 * c4);
+    *(float4*)(sx + (c4 * XQ + c) * 4) = *(const float4*)(Wm + (size_t)row * MV_PROJ + 4 * c4);
   }
   __syncthreads();
   // ---- hoisted W_a . u_r: wave w takes rows r = w, w + 4, ..; lane-parallel partial sums (ascending i), fixed-order reduce
@@ -124,7 +136,8 @@ __global__ __launch_bounds__(256) void match_topk_kernel(const float* __restrict
     float s0 = 0.f, s1 = 0.f;
 #pragma unroll
     for (int j = 0; j < MV_PROJ / 64; ++j) {
-      const float uu = su[r * MV_PROJ + lane + 64 * j];
+      const int i = lane + 64 * j;
+      const float uu = sx[((i >> 2) * XQ + 4 + r) * 4 + (i & 3)];
       s0 = fmaf(Wm[lane + 64 * j], uu, s0);
       s1 = fmaf(Wm[3 * MV_PROJ + lane + 64 * j], uu, s1);
     }
@@ -139,17 +152,17 @@ __global__ __launch_bounds__(256) void match_topk_kernel(const float* __restrict
 #pragma unroll
   for (int r = 0; r < RB; ++r) d0[r] = d1[r] = 0.f;
   const float* myrow = sv + (64 * aw + lane) * STRIDE;
-  const float* myu = su + rw * RB * MV_PROJ;
+#pragma unroll  // fully: `stage` then has only compile-time indices and no loop-carried copy (it stays in registers)
   for (int i0 = 0; i0 < MV_PROJ; i0 += MI) {
-    store_chunk();
+    MK_STORE_CHUNK()
     __syncthreads();
-    if (i0 + MI < MV_PROJ) load_chunk(i0 + MI);  // in flight while this chunk is consumed
+    if (i0 + MI < MV_PROJ) { MK_LOAD_CHUNK(i0 + MI) }  // in flight while this chunk is consumed
 #pragma unroll 4
     for (int q = 0; q < MI / 4; ++q) {
       const float4 vv = *(const float4*)(myrow + 4 * q);
       const float vx[4] = {vv.x, vv.y, vv.z, vv.w};
-      const float4 b0v = *(const float4*)(sw + i0 + 4 * q), b1v = *(const float4*)(sw + MV_PROJ + i0 + 4 * q);  // wave-uniform: LDS broadcast
-      const float4 c0v = *(const float4*)(sw + 2 * MV_PROJ + i0 + 4 * q), c1v = *(const float4*)(sw + 3 * MV_PROJ + i0 + 4 * q);
+      const float4* xq = (const float4*)sx + (size_t)(i0 / 4 + q) * XQ;  // wave-uniform: LDS broadcast reads
+      const float4 b0v = xq[0], b1v = xq[1], c0v = xq[2], c1v = xq[3];
       const float wb0[4] = {b0v.x, b0v.y, b0v.z, b0v.w}, wb1[4] = {b1v.x, b1v.y, b1v.z, b1v.w};
       const float wc0[4] = {c0v.x, c0v.y, c0v.z, c0v.w}, wc1[4] = {c1v.x, c1v.y, c1v.z, c1v.w};
 #pragma unroll
@@ -159,7 +172,7 @@ __global__ __launch_bounds__(256) void match_topk_kernel(const float* __restrict
       }
 #pragma unroll
       for (int r = 0; r < RB; ++r) {
-        const float4 uu = *(const float4*)(myu + r * MV_PROJ + i0 + 4 * q);
+        const float4 uu = xq[4 + rw * RB + r];
         const float ux[4] = {uu.x, uu.y, uu.z, uu.w};
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -225,6 +238,9 @@ __global__ __launch_bounds__(256) void match_topk_kernel(const float* __restrict
     });
   }
 }
+
+#undef MK_LOAD_CHUNK
+#undef MK_STORE_CHUNK
 
 // G > 256: merge the per-chunk candidate lists of an issue report (each the chunk's top k, so their union holds the
 // global top k); one wave per issue report, candidates 16 per lane per pass.
