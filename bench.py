@@ -93,6 +93,8 @@ def main():
     ap.add_argument("--ragged", action="store_true", help="also time a ragged corpus (lengths uniform in [16, seq_len]) swept "
                     "padded to seq_len and length-bucketed (each batch at its longest member); adds a `ragged` object")
     ap.add_argument("--streams", type=int, default=2, choices=(1, 2), help="batches of the resident sweep in flight at once")
+    ap.add_argument("--compute", default="f16", choices=("f16", "f16x2"), help="f16x2 = MV_F16X2: split (hi + lo) GEMM operands, three MFMA "
+                    "sweeps per GEMM — the mode that holds 1e-3 in the trained-like regime; not the benchmarked default")
     ap.add_argument("--sustain-s", type=float, default=3.0, help="N = 1: also report the rate over a run of at least this many seconds (0 disables)")
     ap.add_argument("--shard-irs", type=int, default=0, help="N > 1: issue reports per rank in the corpus-shard leg (0 = ceil(1221677 / 8), the "
                     "8-GPU shard of the reference's corpus, README.md:8; -1 disables)")
@@ -117,7 +119,7 @@ def main():
     weights = synth.make_weights(dims)
     eng = Engine(local_rank, vocab_size=dims.vocab_size, layers=dims.layers, max_tokens=max(B * S, 128 * 512),
                  max_batch=max(B, 256), max_anchors=max(G, 1024))
-    eng.load_state_dict(weights)
+    eng.load_state_dict(weights, 5 if args.compute == "f16x2" else 1)
     eng.set_streams(args.streams)
     if multi and not one_gpu_smoke:
         # the N > 1 transport: RCCL bound inside libmemvul_hip.so (mv_comm_*), collective on the engine's stream; this
@@ -219,7 +221,7 @@ def main():
         "metric": "issue-reports/sec at seq_len=%d (BERT-base issue encoder + %d-anchor memory match)" % (S, G),
         "value": round(value, 2), "unit": "issue-reports/s", "n_gpus": world, "steps": K, "warmup": W,
         "ms_per_step": round(elapsed / K * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "fp16", "data": "synthetic",
+        "dtype": "fp16" if args.compute == "f16" else "fp16 (split operands: 3 MFMA sweeps per GEMM, ~22-bit)", "data": "synthetic",
         "config": {"workload": "BASELINE.json configs[1]: 1xMI355X-per-rank, bert-base-uncased geometry (%d layers), "
                                "seq_len=%d, batch=%d, %d-anchor CWE memory, fp16 MFMA operands + fp32 accumulate; "
                                "seeded random-init weights, synthetic token ids resident in HBM" % (dims.layers, S, B, G),

@@ -15,6 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libmemvul_hip.so")
 
 MV_F32, MV_F16, MV_BF16, MV_I32, MV_I64 = 0, 1, 2, 3, 4
+MV_F16X2 = 5  # compute dtype only: fp16 MFMA with split (hi + lo) operands, three sweeps per GEMM (include/memvul_hip.h)
 NUM_KERNEL_CLASSES = 14
 
 # every symbol include/memvul_hip.h declares (tests check the .so exports all of them)

@@ -28,6 +28,7 @@ struct AttnArgs {
   int S;                // padded length, multiple of 64, <= 512
   int B;
   unsigned long long* clk;  // optional (development probe, tools/attn_probe.hip): per-workgroup s_memtime ticks [total, waiting at the hand-over]
+  half_t* ctx_lo;       // optional (split-operand mode, attention_kernel only): fp16(ctx - fp16(ctx)), same layout as ctx
 };
 
 #define ATT_KROW 144                         // bytes per K row in LDS (128 + 16 pad)
@@ -161,10 +162,15 @@ __global__ __launch_bounds__(NW * 64, 2) void attention_kernel(AttnArgs a) {
   for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
     for (int rg = 0; rg < 4; ++rg) {
-      half4_t v4;
+      half4_t v4, l4;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) v4[e] = (half_t)(o[dt][4 * rg + e] * inv);
+      for (int e = 0; e < 4; ++e) {
+        const float x = o[dt][4 * rg + e] * inv;
+        v4[e] = (half_t)x;
+        l4[e] = (half_t)(x - (float)v4[e]);
+      }
       *(half4_t*)(dst + dt * 32 + 8 * rg + 4 * hi) = v4;
+      if (a.ctx_lo) *(half4_t*)(a.ctx_lo + (dst - a.ctx) + dt * 32 + 8 * rg + 4 * hi) = l4;
     }
 }
 

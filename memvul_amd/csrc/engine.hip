@@ -47,6 +47,8 @@ struct LayerW {
   // virtual LayerNorm (gemm_pp.h): the preceding LayerNorm folded in: W'' = rowcentre(W gamma), b' = b + W beta
   half_t *wqkv_f = nullptr, *w1_f = nullptr;
   float *bqkv_f = nullptr, *b1_f = nullptr;
+  // split-operand mode (MV_F16X2): lo planes fp16(W - fp16(W)) of the four GEMM weights the persistent path uses
+  half_t *wqkv_f_lo = nullptr, *wo_lo = nullptr, *w1_f_lo = nullptr, *w2_lo = nullptr;
   float *ln1g = nullptr, *ln1b = nullptr, *ln2g = nullptr, *ln2b = nullptr;
 };
 
@@ -126,6 +128,7 @@ struct Work {
   half_t *c16 = nullptr, *cctx = nullptr, *ch16 = nullptr;
   float *lnstats = nullptr, *lnpart = nullptr;  // LayerNorm row statistics / partial row sums
   half_t* xlo = nullptr;                        // lo plane of the two-plane raw stream (PP_RESLN3)
+  half_t *ctx_lo = nullptr, *h_lo = nullptr;    // MV_F16X2: lo planes of the attention context / GELU output
 };
 
 struct mv_handle {
@@ -134,6 +137,7 @@ struct mv_handle {
   std::string err;
   bool finalized = false;
   int compute_dtype = MV_F16;
+  bool precise = false;    // MV_F16X2: every persistent GEMM runs three sweeps over hi / lo operand planes (gemm.h GemmArgs::nseg)
   std::map<std::string, HostTensor> staged;
   std::vector<void*> allocs;
 
@@ -342,6 +346,21 @@ int launch_pp_raw(mv_handle* h, GemmArgs a) {
     constexpr bool res = (PPEPI == PP_RES || PPEPI == PP_RESLN || PPEPI == PP_RESLN2 || PPEPI == PP_RESLN3);
     a.stagger = res ? (a.K <= 1024 ? -4 : -10) : -2;
   }
+  if (a.nseg == 3) {  // split-operand instantiation (MV_F16X2): built for the four kernel kinds the encoder's persistent path uses
+    if constexpr (PPEPI == PP_RESLN3 || (RAW && (PPEPI == PP_QK || PPEPI == PP_VT || PPEPI == PP_GELU))) {
+      auto kern = gemm_pp_kernel<PPEPI, PP_DIST, 0, PP_SCHED, PP_COAL, RAW, 1>;
+      static bool attr_set = false;
+      if (!attr_set) {
+        hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, RAW ? PP_LDS_BYTES_RAW : PP_LDS_BYTES);
+        (void)hipGetLastError();
+        attr_set = true;
+      }
+      hipLaunchKernelGGL(kern, dim3(grid), dim3(512), RAW ? PP_LDS_BYTES_RAW : PP_LDS_BYTES, h->w->stream, a);
+      return launch_check(h, "gemm_pp x2");
+    } else {
+      return fail(h, MV_ERR_STATE, "internal: split-operand GEMM requested for a kernel kind that has no such build");
+    }
+  }
   hipLaunchKernelGGL((gemm_pp_kernel<PPEPI, PP_DIST, 0, PP_SCHED, PP_COAL, RAW>), dim3(grid), dim3(512),
                      RAW ? PP_LDS_BYTES_RAW : PP_LDS_BYTES, h->w->stream, a);
   return launch_check(h, "gemm_pp");
@@ -357,6 +376,7 @@ int launch_pp(mv_handle* h, int cls, const GemmArgs& a) {
     qk.N = qk_cols;
     if (int rc = a.raw ? launch_pp_raw<PP_QK, 1>(h, qk) : launch_pp_raw<PP_QK>(h, qk)) return rc;
     GemmArgs v = a;
+    if (a.W2) v.W2 = a.W2 + (size_t)qk_cols * a.K;
     v.W = a.W + (size_t)qk_cols * a.K;
     v.bias = a.bias ? a.bias + qk_cols : nullptr;
     v.N = MV_HIDDEN;
@@ -378,7 +398,7 @@ bool pp_selected(const mv_handle* h, int64_t M, int N, int K) {
   const bool tile256 = (M % 256 == 0) && (N % 256 == 0);
   const bool big = tile256 && ((M / 256) * (N / 256) >= 256);
   const bool pp_ok = tile256 && (K % 128 == 0) && N <= MV_INTER;
-  return pp_ok && (h->gemm_tile == 512 || (h->gemm_tile == 0 && big));
+  return pp_ok && (h->gemm_tile == 512 || h->precise || (h->gemm_tile == 0 && big));
 }
 
 template <int EPI>
@@ -421,12 +441,15 @@ int encode_dev(mv_handle* h, const int32_t* d_ids, const int32_t* d_lens, int B,
   if (n_layers < 0 || n_layers > c.layers) n_layers = c.layers;
   h->dbg_B = B;
   h->dbg_Sp = Sp;
-  const bool prune = !full && h->cls_prune && u_out && n_layers == c.layers && n_layers > 0;
+  // split-operand mode: every layer goes through the persistent kernels (the [CLS] tail's skinny GEMMs are plain fp16)
+  const bool prune = !full && h->cls_prune && !h->precise && u_out && n_layers == c.layers && n_layers > 0;
   // both residual GEMMs have N = 768 and K % 128 == 0: one predicate decides the path of every RES launch of this pass
   const bool fuse = !full && h->ln_fuse && pp_selected(h, Mpad, MV_HIDDEN, MV_HIDDEN);
   // virtual LayerNorm (gemm_pp.h): no LayerNorm kernel between the GEMMs; x16 then holds the RAW stream in fp16
   const bool virt = fuse && h->ln_virtual;
   const bool hilo = virt && h->res_hilo;  // raw stream as two fp16 planes (x16 = hi, xlo = lo); xres is then unused
+  const bool x2 = h->precise;             // three sweeps over hi / lo planes in every GEMM (GemmArgs::nseg)
+  if (x2 && !hilo) return fail(h, MV_ERR_STATE, "MV_F16X2 needs the persistent two-plane path (not available for debug taps / this shape)");
   const unsigned ln_grid = (unsigned)((M + 3) / 4);
   {
     ProfScope ps(h, KC_EMBED_LN);
@@ -508,12 +531,15 @@ int encode_dev(mv_handle* h, const int32_t* d_ids, const int32_t* d_lens, int B,
     }
     // K2: QKV projection
     g.A = h->w->x16; g.W = wqkv; g.bias = bqkv; g.N = 3 * MV_HIDDEN; g.K = MV_HIDDEN;
+    g.A2 = nullptr; g.W2 = nullptr; g.nseg = 0;
+    if (x2) { g.A2 = h->w->xlo; g.W2 = w.wqkv_f_lo; g.nseg = 3; }
     if (int rc = launch_gemm<EPI_QKV>(h, KC_GEMM_QKV, g)) return rc;
     // K3: attention
     {
       AttnArgs a{h->w->q, h->w->k, h->w->vt, d_lens, h->w->ctx, Sp, B, nullptr};
+      if (x2) a.ctx_lo = h->w->ctx_lo;  // attention.h writes the context as hi + lo planes (attention_v2 has no second plane)
       ProfScope ps(h, KC_ATTENTION);
-      if (h->attn_v2 && Sp <= 256) {
+      if (h->attn_v2 && !x2 && Sp <= 256) {
         const int nkb = Sp / 64, items = B * MV_HEADS;
         const int slots = h->num_cu * (nkb == 1 ? 4 : nkb == 2 ? 2 : 1);  // resident workgroups: 8 waves and <= 128 KiB LDS per CU
         const int grid = items < slots ? items : slots;
@@ -523,7 +549,7 @@ int encode_dev(mv_handle* h, const int32_t* d_ids, const int32_t* d_lens, int B,
           case 3: hipLaunchKernelGGL((attention_v2_kernel<3>), dim3(grid), dim3(384), ATT2_LDS_BYTES(3), h->w->stream, a, items); break;
           default: hipLaunchKernelGGL((attention_v2_kernel<4>), dim3(grid), dim3(512), ATT2_LDS_BYTES(4), h->w->stream, a, items); break;
         }
-      } else if (h->attn_v2 && (Sp == 384 || Sp == 512)) {
+      } else if (h->attn_v2 && !x2 && (Sp == 384 || Sp == 512)) {
         // chunks of 128 keys per (row, head, 128-query block) through the same ring: 64 score registers per lane, two
         // workgroups of 4 waves per CU; consecutive units of a workgroup are the query blocks of one head (K / V^T from L2)
         const int nch = Sp / 128, units = B * MV_HEADS * nch;
@@ -542,6 +568,7 @@ int encode_dev(mv_handle* h, const int32_t* d_ids, const int32_t* d_lens, int B,
     // K4: attention output projection + bias + residual (in place), then LayerNorm
     g.raw = 0; g.lnstats = nullptr; g.lnpart = nullptr; g.out16b = nullptr;
     g.A = h->w->ctx; g.W = w.wo; g.bias = w.bo; g.N = MV_HIDDEN; g.K = MV_HIDDEN; g.xres = h->w->xres;
+    if (x2) { g.A2 = h->w->ctx_lo; g.W2 = w.wo_lo; g.nseg = 3; }
     if (fuse) { g.lnstats = h->w->lnstats; g.lng = pend_g; g.lnb = pend_b; }
     if (virt) { g.lnpart = h->w->lnpart; g.out16 = h->w->x16; g.raw = h->r16_direct; g.out16b = hilo ? h->w->xlo : nullptr; }  // + fp16 operand copy / planes, partial row sums
     if (int rc = launch_gemm<EPI_RES>(h, KC_GEMM_OUT, g)) return rc;
@@ -552,10 +579,12 @@ int encode_dev(mv_handle* h, const int32_t* d_ids, const int32_t* d_lens, int B,
     g.lnstats = nullptr; g.lnpart = nullptr; g.raw = 0; g.out16b = nullptr;
     if (virt) { g.raw = 1; g.lnstats = h->w->lnstats; }
     g.A = h->w->x16; g.W = virt ? w.w1_f : w.w1; g.bias = virt ? w.b1_f : w.b1; g.N = MV_INTER; g.K = MV_HIDDEN; g.out16 = h->w->h16;
+    if (x2) { g.A2 = h->w->xlo; g.W2 = w.w1_f_lo; g.nseg = 3; g.out16b = h->w->h_lo; }
     if (int rc = launch_gemm<EPI_GELU>(h, KC_GEMM_FFN1, g)) return rc;
     // K6: FFN-2 + bias + residual, then LayerNorm
     g.raw = 0; g.lnstats = nullptr; g.out16b = nullptr;
     g.A = h->w->h16; g.W = w.w2; g.bias = w.b2; g.N = MV_HIDDEN; g.K = MV_INTER; g.xres = h->w->xres;
+    if (x2) { g.A2 = h->w->h_lo; g.W2 = w.w2_lo; g.nseg = 3; }
     if (fuse) { g.lnstats = h->w->lnstats; g.lng = pend_g; g.lnb = pend_b; }
     if (virt) { g.lnpart = h->w->lnpart; g.out16 = h->w->x16; g.raw = h->r16_direct; g.out16b = hilo ? h->w->xlo : nullptr; }
     if (int rc = launch_gemm<EPI_RES>(h, KC_GEMM_FFN2, g)) return rc;
@@ -680,6 +709,19 @@ void fold_layernorm(const float* W, const float* b, const float* gamma, const fl
     for (int64_t k = 0; k < K; ++k) Wf[(size_t)(n * K + k)] = (float)((double)W[n * K + k] * (double)gamma[k] - mean);
     bf[(size_t)n] = (float)((double)b[n] + wb);
   }
+}
+
+// lo plane of a split operand: fp16(x - fp16(x))
+int upload_f16_lo(mv_handle* h, half_t** dst, const float* src, int64_t n, float scale = 1.0f) {
+  std::vector<uint16_t> tmp((size_t)n);
+  for (int64_t i = 0; i < n; ++i) {
+    const float x = src[i] * scale;
+    tmp[(size_t)i] = f32_to_f16_bits(x - f16_bits_to_f32(f32_to_f16_bits(x)));
+  }
+  if (int rc = dev_alloc(h, dst, n, false)) return rc;
+  HIPCHK(h, hipMemcpyAsync(*dst, tmp.data(), (size_t)n * 2, hipMemcpyHostToDevice, h->w->stream));
+  HIPCHK(h, hipStreamSynchronize(h->w->stream));
+  return MV_OK;
 }
 
 int upload_f16(mv_handle* h, half_t** dst, const float* src, int64_t n, float scale = 1.0f) {
@@ -876,9 +918,10 @@ int mv_load_tensor(mv_handle* h, const char* name, const void* host_ptr, int dty
 int mv_finalize_weights(mv_handle* h, int compute_dtype) {
   if (!h) return MV_ERR_INVALID;
   if (h->finalized) return fail(h, MV_ERR_STATE, "weights already finalized");
-  if (compute_dtype != MV_F16)
-    return fail(h, MV_ERR_INVALID, "compute_dtype must be MV_F16 (fp16 MFMA operands, fp32 accumulation); bf16 is a storage "
-                                   "dtype of mv_load_tensor only (include/memvul_hip.h)");
+  if (compute_dtype != MV_F16 && compute_dtype != MV_F16X2)
+    return fail(h, MV_ERR_INVALID, "compute_dtype must be MV_F16 (fp16 MFMA operands, fp32 accumulation) or MV_F16X2 (split operands); "
+                                   "bf16 is a storage dtype of mv_load_tensor only (include/memvul_hip.h)");
+  const bool precise = compute_dtype == MV_F16X2;
   HIPCHK(h, hipSetDevice(h->device));
   const mv_config& c = h->cfg;
   const std::string P = "_text_field_embedder.token_embedder_tokens.transformer_model.";
@@ -941,10 +984,12 @@ int mv_finalize_weights(mv_handle* h, int compute_dtype) {
       std::vector<float> Wf, bf;
       fold_layernorm(wqkv_host.data(), bqkv_host.data(), tg->data.data(), tb->data.data(), 3 * H, H, Wf, bf);
       if ((rc = upload_f16(h, &w.wqkv_f, Wf.data(), 3 * H * H))) return rc;
+      if (precise && (rc = upload_f16_lo(h, &w.wqkv_f_lo, Wf.data(), 3 * H * H))) return rc;
       if ((rc = upload_f32(h, &w.bqkv_f, bf.data(), 3 * H))) return rc;
     }
     NEED(q + "attention.output.dense.weight", H, H);
     if ((rc = upload_f16(h, &w.wo, t->data.data(), H * H))) return rc;
+    if (precise && (rc = upload_f16_lo(h, &w.wo_lo, t->data.data(), H * H))) return rc;
     NEED(q + "attention.output.dense.bias", H);
     if ((rc = upload_f32(h, &w.bo, t->data.data(), H))) return rc;
     NEED(q + "attention.output.LayerNorm.weight", H);
@@ -963,10 +1008,12 @@ int mv_finalize_weights(mv_handle* h, int compute_dtype) {
       std::vector<float> Wf, bf;
       fold_layernorm(tw->data.data(), t->data.data(), tg->data.data(), tb->data.data(), I, H, Wf, bf);
       if ((rc = upload_f16(h, &w.w1_f, Wf.data(), I * H))) return rc;
+      if (precise && (rc = upload_f16_lo(h, &w.w1_f_lo, Wf.data(), I * H))) return rc;
       if ((rc = upload_f32(h, &w.b1_f, bf.data(), I))) return rc;
     }
     NEED(q + "output.dense.weight", H, I);
     if ((rc = upload_f16(h, &w.w2, t->data.data(), H * I))) return rc;
+    if (precise && (rc = upload_f16_lo(h, &w.w2_lo, t->data.data(), H * I))) return rc;
     NEED(q + "output.dense.bias", H);
     if ((rc = upload_f32(h, &w.b2, t->data.data(), H))) return rc;
     NEED(q + "output.LayerNorm.weight", H);
@@ -994,6 +1041,20 @@ int mv_finalize_weights(mv_handle* h, int compute_dtype) {
   NEED("_projector.weight", 2, 3 * MV_PROJ);
   if ((rc = upload_f32(h, &h->Wm, t->data.data(), 2 * 3 * MV_PROJ))) return rc;
 #undef NEED
+  if (precise) {  // lo planes of the two activations that are GEMM operands but not part of the two-plane stream
+    for (int wi = 0; wi < h->n_alloc; ++wi) {
+      Work* keep = h->w;
+      h->w = &h->work[wi];
+      rc = dev_alloc(h, &h->work[wi].ctx_lo, h->cap_tokens * MV_HIDDEN);
+      if (rc == MV_OK) rc = dev_alloc(h, &h->work[wi].h_lo, h->cap_tokens * MV_INTER);
+      if (rc == MV_OK && hipStreamSynchronize(h->w->stream) != hipSuccess) rc = MV_ERR_HIP;
+      h->w = keep;
+      if (rc != MV_OK) return rc;
+    }
+    if (!(h->ln_fuse && h->ln_virtual && h->res_hilo))
+      return fail(h, MV_ERR_STATE, "MV_F16X2 runs on the two-plane raw stream: MEMVUL_LN_FUSE / LN_VIRTUAL / RES_HILO must stay on");
+  }
+  h->precise = precise;
   h->staged.clear();
   h->compute_dtype = compute_dtype;
   h->finalized = true;

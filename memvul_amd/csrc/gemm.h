@@ -55,6 +55,12 @@ struct GemmArgs {
   int raw;               // RAW consumer (gemm_pp.h): A is the raw fp16 stream, W / bias are the folded ones, lnstats = row statistics
   float* lnpart;         // PP_RESLN2: [M][N / 64][2] partial (sum, sum of squares) per row and 64-column slice
   unsigned long long* clk;  // optional (development probe): per-workgroup s_memtime span of the persistent kernel
+  // split-operand ("precise") mode of gemm_pp (nseg == 3): the K sweep runs three times over the same accumulators,
+  //   A_hi W_hi + A_lo W_hi + A_hi W_lo   with  A = A_hi + A_lo,  W = W_hi + W_lo  (fp16 planes; the lo x lo term is 2^-22),
+  // i.e. ~22-bit operands on the fp16 matrix cores at 3x the MFMA work.  A2 / W2 = the lo planes (same layouts as A / W).
+  const half_t* A2;
+  const half_t* W2;
+  int nseg;              // 0 / 1: plain; 3: split operands
 };
 
 // logical tile index -> (tile_m, tile_n) under the grouped raster

@@ -207,7 +207,9 @@ __device__ __forceinline__ void lds_read_bgb1(uint32_t addr, float4& bi, float4&
 //          landed for every wave at the barrier that ends interval H-3, and its LDS region was last read in
 //          interval H-8 or H-9).
 // COAL 1: epilogue stores (and the residual loads) go through the wave-private LDS transposition above.
-template <int EPI, int DIST, int ABL, int SCHED = 0, int COAL = 0, int RAW = 0>
+// X2 1: split-operand mode (GemmArgs::nseg == 3): three K sweeps A_hi W_hi + A_lo W_hi + A_hi W_lo, and PP_GELU also writes
+//       the lo plane of its output.  A separate instantiation: the plain kernels keep their register allocation.
+template <int EPI, int DIST, int ABL, int SCHED = 0, int COAL = 0, int RAW = 0, int X2 = 0>
 __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmArgs a) {
   static_assert(!RAW || (COAL == 1 && (EPI == PP_QK || EPI == PP_VT || EPI == PP_GELU)), "RAW: the fp16-output kernels of the transposed path");
   static_assert(SCHED == 0 ? (DIST >= 2 && DIST <= 6) : (DIST >= 2 && DIST <= 4), "half-tile issue distance");
@@ -224,7 +226,9 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmArgs a) {
   const int hi = lane >> 5, l31 = lane & 31;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wave >> 2, wc = wave & 3;
-  const int K = a.K, nk = K >> 6;
+  const int K = a.K, nk0 = K >> 6;                 // K-tiles of one sweep
+  constexpr int nseg = X2 ? 3 : 1;                  // split-operand mode: three sweeps (GemmArgs::nseg)
+  const int nk = nk0 * nseg;                        // K-tiles per output tile
   const int tm_count = a.M >> 8, tn_count = a.N >> 8;
   const int ntiles = tm_count * tn_count;
   const int G = gridDim.x;
@@ -266,17 +270,28 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmArgs a) {
     offB[j] = (uint32_t)(rowB * K + c * 8) * 2u;
   }
   // issue cursor (wave-uniform): output tile being staged, its operand panels and K-tile index
-  int i_it = 0, i_kt = 0;
+  int i_it = 0, i_kt = 0, i_seg = 0;
   const char* iA = (const char*)a.A;
   const char* iW = (const char*)a.W;
+  size_t tA = 0, tW = 0;  // X2: byte offsets of the issue tile's operand panels
+  auto set_issue_seg = [&]() {  // X2, sweep 0: A_hi W_hi, 1: A_lo W_hi, 2: A_hi W_lo
+    iA = (const char*)(i_seg == 1 ? a.A2 : a.A) + tA;
+    iW = (const char*)(i_seg == 2 ? a.W2 : a.W) + tW;
+  };
   auto set_issue_tile = [&](int it) {
     const int L = it * G + bslot;
     if (L < ntiles) {  // past the end: keep staging the last valid tile (never read, keeps the vmcnt ledger exact)
       int tm, tn;
       raster(L, tm_count, tn_count, a.GN, tm, tn);
-      iA = (const char*)a.A + (size_t)tm * 256 * K * 2;
-      iW = (const char*)a.W + (size_t)tn * 256 * K * 2;
+      if constexpr (X2) {
+        tA = (size_t)tm * 256 * K * 2;
+        tW = (size_t)tn * 256 * K * 2;
+      } else {
+        iA = (const char*)a.A + (size_t)tm * 256 * K * 2;
+        iW = (const char*)a.W + (size_t)tn * 256 * K * 2;
+      }
     }
+    if constexpr (X2) set_issue_seg();
   };
   set_issue_tile(0);
   // kind: 0 = a0, 1 = a1, 2 = b0, 3 = b1; issue order per K-tile: b0, a0, b1, a1 (= read order)
@@ -299,9 +314,18 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmArgs a) {
       }
     }
     if constexpr (kind == 1) {  // last half-tile of this K-tile: advance the cursor
-      if (++i_kt == nk) {
+      if (++i_kt == nk0) {
         i_kt = 0;
-        set_issue_tile(++i_it);
+        if constexpr (X2) {
+          if (++i_seg == nseg) {
+            i_seg = 0;
+            set_issue_tile(++i_it);
+          } else {
+            set_issue_seg();
+          }
+        } else {
+          set_issue_tile(++i_it);
+        }
       }
     }
   };
@@ -838,6 +862,9 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmArgs a) {
                 a01 = gelu_erf2(a01);
                 a23 = gelu_erf2(a23);
                 v0 = a01.x; v1 = a01.y; v2 = a23.x; v3 = a23.y;
+                if constexpr (X2) {  // split-operand mode: the lo plane below is taken from the activated values
+                  acc[i][j][4 * g + 0] = v0; acc[i][j][4 * g + 1] = v1; acc[i][j][4 * g + 2] = v2; acc[i][j][4 * g + 3] = v3;
+                }
               }
               d[j][g][0] = pack_h2(v0, v1);
               d[j][g][1] = pack_h2(v2, v3);
@@ -851,7 +878,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmArgs a) {
               *(u32x4*)(op + 16 * rstride) = o[2 * j + 1];
             }
           }
-          if constexpr (HILO) {  // second plane: lo = fp16(r - hi), same addresses in the lo buffer
+          if constexpr (HILO || (X2 && EPI == PP_GELU)) {  // second plane: lo = fp16(r - hi), same addresses in the lo buffer
 #pragma unroll
             for (int j = 0; j < 2; ++j)
 #pragma unroll

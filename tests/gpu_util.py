@@ -32,7 +32,7 @@ def weights_for(dims_kw: dict, w_kw: dict):
     return _weights[key]
 
 
-def engine_for(dims_kw: dict, w_kw: dict, gemm_tile: int = 0, env: dict = None, **eng_kw) -> Engine:
+def engine_for(dims_kw: dict, w_kw: dict, gemm_tile: int = 0, env: dict = None, compute_dtype: int = 1, **eng_kw) -> Engine:
     """gemm_tile: 0 = the engine's own choice, 128 / 256 = one-tile-per-workgroup kernels, 512 = persistent
     ping-pong kernel forced (MEMVUL_GEMM_TILE, read at mv_create).  env: further MEMVUL_* switches read at
     mv_create (MEMVUL_CLS_PRUNE, MEMVUL_LN_FUSE, MEMVUL_ATTN), e.g. {"MEMVUL_CLS_PRUNE": "0"}."""
@@ -41,7 +41,7 @@ def engine_for(dims_kw: dict, w_kw: dict, gemm_tile: int = 0, env: dict = None, 
         env["MEMVUL_ATTN"] = os.environ["MEMVUL_FORCE_ATTN"]
     if gemm_tile:
         env["MEMVUL_GEMM_TILE"] = str(gemm_tile)
-    key = (tuple(sorted(dims_kw.items())), tuple(sorted(w_kw.items())), tuple(sorted(eng_kw.items())), tuple(sorted(env.items())))
+    key = (tuple(sorted(dims_kw.items())), tuple(sorted(w_kw.items())), tuple(sorted(eng_kw.items())), tuple(sorted(env.items())), compute_dtype)
     if key not in _engines:
         if len(_engines) >= 2:  # keep HBM use bounded: drop the oldest engine
             k0 = next(iter(_engines))
@@ -62,6 +62,6 @@ def engine_for(dims_kw: dict, w_kw: dict, gemm_tile: int = 0, env: dict = None, 
                     os.environ.pop(k, None)
                 else:
                     os.environ[k] = v
-        e.load_state_dict(w)
+        e.load_state_dict(w, compute_dtype)  # 1 = MV_F16, 5 = MV_F16X2 (split operands)
         _engines[key] = e
     return _engines[key]

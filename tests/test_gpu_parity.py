@@ -85,6 +85,32 @@ def test_trained_like_logits(gu, golden_dir, name, gemm_tile):
     eng.anchor_reset()
 
 
+@pytest.mark.parametrize("name", ["l12_trained_s256", "l12_trained_ragged", "l12_base_ragged"])
+def test_split_operand_mode_holds_1e3_in_the_trained_like_regime(gu, golden_dir, name):
+    """MV_F16X2 (compute dtype): every GEMM of the encoder runs three MFMA sweeps over hi / lo fp16 planes of BOTH operands
+    (A_hi W_hi + A_lo W_hi + A_hi W_lo: ~22-bit operands; Q / K / V and P stay fp16) — the engine change that meets the
+    1e-3 logit tolerance where plain fp16 operands measure 3 - 6e-3 (test_trained_like_logits), at about 1 / 2.5 of the
+    issue-report rate.  oracle/precision_model.py predicts 4e-4 for this configuration."""
+    import make_golden
+    from memvul_amd.binding import MV_F16X2
+
+    g = np.load(os.path.join(golden_dir, f"{name}.npz"))
+    dk, wk, B, S, ragged, G, SA = make_golden.CASES[name]
+    eng = gu.engine_for(dk, wk, compute_dtype=MV_F16X2, max_tokens=16384, max_batch=64, max_anchors=64)
+    eng.anchor_reset()
+    LA = int(g["anchor_lens"].max())
+    eng.anchor_append(g["anchor_ids"][:, :LA], g["anchor_lens"])
+    v = eng.anchor_get()
+    out = eng.forward(g["ids"], g["lens"], want_embed=True)
+    errs = dict(v=float(np.abs(v - g["v"]).max()), u=float(np.abs(out["embed"] - g["u"]).max()),
+                logits=float(np.abs(out["logits"] - g["logits"]).max()), p=float(np.abs(out["probs"] - g["p"]).max()),
+                logit_scale=float(np.abs(g["logits"]).max()))
+    gu.record("split_operands", case=name, **errs)
+    assert errs["logits"] <= LOGIT_TOL, errs
+    assert errs["p"] <= 1e-4, errs
+    eng.anchor_reset()
+
+
 def test_anchor_chunking_and_padding_invariance(gu):
     """Anchors appended in two chunks (128 + rest in the reference, predict_memory.py:81-83) equal one
     append; extra zero padding columns do not change an embedding (masked keys)."""
