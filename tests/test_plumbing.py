@@ -271,3 +271,33 @@ def test_plumbing_gpu_matches_oracle_run(monkeypatch):
     clear = np.abs(sr - 0.5) > 1e-3
     assert np.array_equal((sg >= 0.5)[clear], (sr >= 0.5)[clear])
     assert metrics["accuracy"] == pytest.approx(metrics_o["accuracy"], abs=0.1)
+
+
+@pytest.mark.gpu
+def test_plumbing_cfg1_scale_gpu_matches_oracle_run(monkeypatch):
+    """BASELINE.json configs[0] at its stated size: 1 000 synthetic issue reports of up to 128 tokens, 32 CWE anchors, batch 64,
+    reader -> model -> metrics -> JSON-lines -> cal_metrics, the HIP engine against the oracle-backed run of the same files."""
+    fx = pu.make_fixture(n_irs=1000, n_anchors=32, body_words=(20, 120))
+    root, arch, golden, test_path, w, dims = fx
+
+    def run(tag):
+        out_metric = os.path.join(root, "test_results", f"{tag}_metric.json")
+        out_results = os.path.join(root, "test_results", f"{tag}_result.json")
+        m = predict_memory.test_siamese(archive_file=arch, input_file=test_path, input_golden_file=golden, test_config=pu.TEST_CONFIG,
+                                        output_file=out_metric, predictions_output_file=out_results, batch_size=64, cuda_device=0,
+                                        engine_options=dict(max_tokens=64 * 256, max_batch=64, max_anchors=32))
+        return m, [r for line in open(out_results) for r in json.loads(line)]
+
+    metrics, records = run("hip1k")
+    monkeypatch.setattr(model_memory, "Engine", pu.OracleEngine)
+    metrics_o, records_o = run("oracle1k")
+    assert len(records) == 1000 and [r["Issue_Url"] for r in records] == [r["Issue_Url"] for r in records_o]
+    assert all(len(r["predict"]) == 32 for r in records)
+    gpu = np.array([list(r["predict"].values()) for r in records])
+    ref = np.array([list(r["predict"].values()) for r in records_o])
+    assert np.abs(gpu - ref).max() <= 1e-3
+    sg, sr = gpu.max(1), ref.max(1)
+    clear = np.abs(sr - 0.5) > 1e-3
+    assert np.array_equal((sg >= 0.5)[clear], (sr >= 0.5)[clear])
+    for k in ("s_auc", "s_ave_precision_score", "accuracy"):
+        assert metrics[k] == pytest.approx(metrics_o[k], abs=0.02), k
