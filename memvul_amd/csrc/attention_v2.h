@@ -33,7 +33,9 @@
 
 // ABL (tools/attn_probe.hip only; wrong results), bit mask: 1 = v_exp_f32 replaced by a move, 2 = no MFMA in QK^T / PV,
 // 4 = K / V^T fragments not read from LDS (the DMA into LDS still runs)
-template <int NKB, int NCH = 1, int ABL = 0>  // chunk = 64 NKB keys = 2 NKB waves x 32 queries; padded length S = 64 NKB NCH
+// LO 1 (split-operand mode, MV_F16X2): the context is also written as a second plane fp16(O - fp16(O)) to AttnArgs::ctx_lo
+// (16 more registers across the unit boundary, a second pass through the O image); a separate instantiation.
+template <int NKB, int NCH = 1, int ABL = 0, int LO = 0>  // chunk = 64 NKB keys = 2 NKB waves x 32 queries; padded length S = 64 NKB NCH
 __global__ __launch_bounds__(NKB * 128) __attribute__((amdgpu_waves_per_eu(2, 2))) void attention_v2_kernel(AttnArgs a, int nunits) {
   constexpr int S = NKB * 64;        // keys per chunk = queries per unit
   constexpr int ST = S * NCH;        // padded sequence length (row pitch of V^T, rows per head of Q / K)
@@ -115,24 +117,33 @@ __global__ __launch_bounds__(NKB * 128) __attribute__((amdgpu_waves_per_eu(2, 2)
   int len_n = a.lens[unit_bh(first) / MV_HEADS];  // prefetched like Q: a VGPR-destination load must never be waited for mid-unit
 
   uint32_t opk[2][4][2];  // normalised O^T of the previous unit, fp16 pairs: [dt][rg] = dims 32 dt + 8 rg + 4 hi ..+3
-  auto flush_o = [&](int u, char* kb) {
+  uint32_t opl[LO ? 2 : 1][4][2];  // LO: the lo plane, fp16(O - fp16(O)), same packing
+  auto flush_plane = [&](int u, char* kb, const uint32_t (&pk)[2][4][2], half_t* base) {
     // ---- O(u) -> LDS image (this wave's 32 rows) -> whole-row global stores
 #pragma unroll
     for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
       for (int rg = 0; rg < 4; ++rg) {
         u32x2 v;
-        v[0] = opk[dt][rg][0]; v[1] = opk[dt][rg][1];
+        v[0] = pk[dt][rg][0]; v[1] = pk[dt][rg][1];
         *(u32x2*)(kb + (o_wr ^ (uint32_t)(((4 * dt + rg) ^ (ql & 7)) << 4))) = v;
       }
     const int bh = unit_bh(u), qb = unit_qb(u);
     const int b = bh / MV_HEADS, h = bh - b * MV_HEADS;
-    half_t* dst = a.ctx + ((size_t)b * ST + qb * S + 32 * wave + (lane >> 3)) * MV_HIDDEN + h * MV_HEAD_DIM + 8 * (lane & 7);
+    half_t* dst = base + ((size_t)b * ST + qb * S + 32 * wave + (lane >> 3)) * MV_HIDDEN + h * MV_HEAD_DIM + 8 * (lane & 7);
     u32x4 v[4];
 #pragma unroll
     for (int it = 0; it < 4; ++it) v[it] = *(const u32x4*)(kb + o_rd + it * 1024);
 #pragma unroll
     for (int it = 0; it < 4; ++it) *(u32x4*)(dst + (size_t)(8 * it) * MV_HIDDEN) = v[it];
+  };
+  auto flush_o = [&](int u, char* kb) {
+    flush_plane(u, kb, opk, a.ctx);
+    if constexpr (LO) {
+      // the image rows are wave-private and LDS executes a wave's instructions in order: the second plane's writes may
+      // follow the first plane's reads directly (hipcc waits for the read results before the global stores use them)
+      flush_plane(u, kb, opl, a.ctx_lo);
+    }
   };
 
   int pb = 0, prev = -1, len = 0;
@@ -295,8 +306,13 @@ __global__ __launch_bounds__(NKB * 128) __attribute__((amdgpu_waves_per_eu(2, 2)
         for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
           for (int rg = 0; rg < 4; ++rg) {
-            opk[dt][rg][0] = pack_h2(o[dt][4 * rg + 0] * inv, o[dt][4 * rg + 1] * inv);
-            opk[dt][rg][1] = pack_h2(o[dt][4 * rg + 2] * inv, o[dt][4 * rg + 3] * inv);
+            const float x0 = o[dt][4 * rg + 0] * inv, x1 = o[dt][4 * rg + 1] * inv, x2 = o[dt][4 * rg + 2] * inv, x3 = o[dt][4 * rg + 3] * inv;
+            opk[dt][rg][0] = pack_h2(x0, x1);
+            opk[dt][rg][1] = pack_h2(x2, x3);
+            if constexpr (LO) {
+              opl[dt][rg][0] = pack_h2(x0 - (float)(half_t)x0, x1 - (float)(half_t)x1);
+              opl[dt][rg][1] = pack_h2(x2 - (float)(half_t)x2, x3 - (float)(half_t)x3);
+            }
           }
         prev = unit;
       }

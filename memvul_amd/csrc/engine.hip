@@ -539,7 +539,17 @@ int encode_dev(mv_handle* h, const int32_t* d_ids, const int32_t* d_lens, int B,
       AttnArgs a{h->w->q, h->w->k, h->w->vt, d_lens, h->w->ctx, Sp, B, nullptr};
       if (x2) a.ctx_lo = h->w->ctx_lo;  // attention.h writes the context as hi + lo planes (attention_v2 has no second plane)
       ProfScope ps(h, KC_ATTENTION);
-      if (h->attn_v2 && !x2 && Sp <= 256) {
+      if (h->attn_v2 && x2 && Sp == 256) {  // the bench length in split-operand mode: attention_v2 with the second output plane
+        const int items = B * MV_HEADS, grid = items < h->num_cu ? items : h->num_cu;
+        auto kern = attention_v2_kernel<4, 1, 0, 1>;
+        static bool attr_set = false;
+        if (!attr_set) {
+          hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, ATT2_LDS_BYTES(4));
+          (void)hipGetLastError();
+          attr_set = true;
+        }
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(512), ATT2_LDS_BYTES(4), h->w->stream, a, items);
+      } else if (h->attn_v2 && !x2 && Sp <= 256) {
         const int nkb = Sp / 64, items = B * MV_HEADS;
         const int slots = h->num_cu * (nkb == 1 ? 4 : nkb == 2 ? 2 : 1);  // resident workgroups: 8 waves and <= 128 KiB LDS per CU
         const int grid = items < slots ? items : slots;
