@@ -180,6 +180,7 @@ struct mv_handle {
   // ... and no LayerNorm kernel at all between the GEMMs (RAW consumers + PP_RESLN2 producers); env MEMVUL_LN_VIRTUAL=0 disables
   bool ln_virtual = true;
   int pp_stagger = 0;  // env MEMVUL_STAGGER: see GemmArgs::stagger
+  int qkv_merge = 1;   // env MEMVUL_QKV_MERGE=0: Q,K and V^T as two launches (PP_QK + PP_VT) instead of one
   bool res_hilo = true;  // env MEMVUL_RES_HILO=0: raw stream as fp32 + fp16 copy (PP_RESLN2) instead of two fp16 planes (PP_RESLN3)
   int r16_direct = 0;  // PP_RESLN2: fp16 copy from the transposed fp32 image (1) or through its own LDS transposition (0); env MEMVUL_R16_DIRECT
 
@@ -371,6 +372,11 @@ int launch_pp(mv_handle* h, int cls, const GemmArgs& a) {
   ProfScope ps(h, cls);
   if constexpr (EPI == EPI_QKV) {  // Q,K columns (row-per-lane stores) and the V^T block (token-contiguous stores)
     // a.col0 = 768: a.W / a.bias already point at the K block and the launch covers K, V only (last-layer pruning)
+    if (h->qkv_merge) {  // one launch: the V tiles take the transposed epilogue (gemm_pp.h scr_f16x2_t)
+      GemmArgs qkv = a;
+      qkv.N = (a.col0 ? 2 : 3) * MV_HIDDEN;
+      return a.raw ? launch_pp_raw<PP_QK, 1>(h, qkv) : launch_pp_raw<PP_QK>(h, qkv);
+    }
     const int qk_cols = (a.col0 ? 1 : 2) * MV_HIDDEN;
     GemmArgs qk = a;
     qk.N = qk_cols;
@@ -807,6 +813,7 @@ int mv_create(int device, const mv_config* cfg, mv_handle** out) {
   if (const char* e = getenv("MEMVUL_R16_DIRECT")) h->r16_direct = atoi(e) != 0;
   if (const char* e = getenv("MEMVUL_RES_HILO")) h->res_hilo = atoi(e) != 0;
   if (const char* e = getenv("MEMVUL_STAGGER")) h->pp_stagger = atoi(e);
+  if (const char* e = getenv("MEMVUL_QKV_MERGE")) h->qkv_merge = atoi(e);
   if (const char* e = getenv("MEMVUL_ATTN")) h->attn_v2 = atoi(e) != 0;
   hipFuncSetAttribute((const void*)attention_v2_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT2_LDS_BYTES(1));
   hipFuncSetAttribute((const void*)attention_v2_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT2_LDS_BYTES(2));

@@ -137,6 +137,32 @@ __device__ __forceinline__ void scr_f16x2(uint32_t w0, uint32_t w1, uint32_t w2,
       : "memory");
 #endif
 }
+// The V block of a merged Q,K,V launch (PP_QK orientation: lane = token, registers = 4 consecutive head dims) goes
+// through the image TRANSPOSED - image rows = head dims, image columns = tokens - so that the read side and the
+// stores are the V^T ones: 16 two-byte writes per fragment (row 8 g + 4 hi + e at a0 / a1 = a0 ^ 32 plus
+// 512 g + 64 e; the slot swizzle (row >> 2) & 3 = (2 g + hi) & 3 alternates between hi and hi ^ 2).
+__device__ __forceinline__ void scr_f16x2_t(uint32_t a0, uint32_t a1, const u32x2 (&da)[4], const u32x2 (&db)[4], uint32_t r,
+                                            u32x4 (&o)[4]) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  const uint32_t a00 = da[0][0], a01 = da[0][1], a10 = da[1][0], a11 = da[1][1], a20 = da[2][0], a21 = da[2][1], a30 = da[3][0],
+                 a31 = da[3][1];
+  const uint32_t b00 = db[0][0], b01 = db[0][1], b10 = db[1][0], b11 = db[1][1], b20 = db[2][0], b21 = db[2][1], b30 = db[3][0],
+                 b31 = db[3][1];
+#define MV_T16(A, LO, HI, OFF)                                                                            \
+  "ds_write_b16 " A ", " LO " offset:" #OFF "+0\n\tds_write_b16_d16_hi " A ", " LO " offset:" #OFF "+64\n\t" \
+  "ds_write_b16 " A ", " HI " offset:" #OFF "+128\n\tds_write_b16_d16_hi " A ", " HI " offset:" #OFF "+192\n\t"
+  asm volatile(
+      MV_T16("%4", "%6", "%7", 0) MV_T16("%5", "%8", "%9", 512) MV_T16("%4", "%10", "%11", 1024) MV_T16("%5", "%12", "%13", 1536)
+      "ds_read_b128 %0, %22\n\tds_read_b128 %1, %22 offset:1024\n\t"
+      MV_T16("%4", "%14", "%15", 0) MV_T16("%5", "%16", "%17", 512) MV_T16("%4", "%18", "%19", 1024) MV_T16("%5", "%20", "%21", 1536)
+      "ds_read_b128 %2, %22\n\tds_read_b128 %3, %22 offset:1024\n\ts_waitcnt lgkmcnt(0)"
+      : "=&v"(o[0]), "=&v"(o[1]), "=&v"(o[2]), "=&v"(o[3])
+      : "v"(a0), "v"(a1), "v"(a00), "v"(a01), "v"(a10), "v"(a11), "v"(a20), "v"(a21), "v"(a30), "v"(a31), "v"(b00), "v"(b01),
+        "v"(b10), "v"(b11), "v"(b20), "v"(b21), "v"(b30), "v"(b31), "v"(r)
+      : "memory");
+#undef MV_T16
+#endif
+}
 // The reverse direction for two fp16 planes of one 32 x 32 fragment: coalesced 16-byte pieces (rows lane >> 2 and + 16, chunk
 // lane & 3) are written into the image, the C/D-layout units (row lane & 31, columns 8 g + 4 hi .. + 3) are read back.
 __device__ __forceinline__ void scr_f16_rev2(uint32_t wc, const u32x4& a0, const u32x4& a1, const u32x4& b0, const u32x4& b1, uint32_t r0,
@@ -775,14 +801,24 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmArgs a) {
         size_t istride;   // elements between i blocks (32 C/D rows along the register axis or the lane axis)
         size_t jstride;   // elements between j blocks
         bool live = true;
+        bool vtile = false;  // PP_QK: this tile belongs to the V block and is stored as V^T
+        const uint32_t tbase = scr + hi * 256 + (((uint32_t)(l31 >> 3) ^ (uint32_t)hi) << 4) + (uint32_t)(l31 & 7) * 2;
         if constexpr (EPI == PP_F16 || EPI == PP_GELU || EMITS) {
           obase = a.out16 + (size_t)(mw + crow) * a.N + nw + 8 * cchunk;
           rstride = a.N; istride = (size_t)32 * a.N; jstride = 32;
         } else if constexpr (EPI == PP_QK) {  // one head per wave; S % 64 == 0 so a 128-row block may span two batch rows
-          const int which = (nw + a.col0) >= MV_HIDDEN;  // col0 = 768: the launch covers the K block only
-          const int head = (nw + a.col0 - which * MV_HIDDEN) >> 6;
-          obase = (which ? a.k : a.q) + (size_t)head * a.S * MV_HEAD_DIM + (size_t)crow * MV_HEAD_DIM + 8 * cchunk;
-          rstride = MV_HEAD_DIM; istride = 0; jstride = 32;  // the batch-row part is added per i below
+          // columns [0,768) -> Q, [768,1536) -> K, [1536,2304) -> V^T (a merged launch); col0 = 768: K (and V) only
+          const int colg = nw + a.col0;
+          const int which = colg >= 2 * MV_HIDDEN ? 2 : (colg >= MV_HIDDEN ? 1 : 0);
+          const int head = (colg - which * MV_HIDDEN) >> 6;
+          vtile = which == 2;
+          if (vtile) {  // image rows = head dims, image columns = tokens (scr_f16x2_t)
+            obase = a.vt + ((size_t)head * MV_HEAD_DIM + crow) * a.S + 8 * cchunk;
+            rstride = a.S; istride = 0; jstride = (size_t)32 * a.S;
+          } else {
+            obase = (which ? a.k : a.q) + (size_t)head * a.S * MV_HEAD_DIM + (size_t)crow * MV_HEAD_DIM + 8 * cchunk;
+            rstride = MV_HEAD_DIM; istride = 0; jstride = 32;  // the batch-row part is added per i below
+          }
         } else {  // PP_VT: image rows = head dims, image columns = tokens
           const int head = nw >> 6;
           obase = a.vt + ((size_t)head * MV_HEAD_DIM + crow) * a.S + 8 * cchunk;
@@ -837,7 +873,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmArgs a) {
           if constexpr (EPI == PP_QK || EPI == PP_VT) {
             live = mb < a.Mreal;
             const int b = mb / a.S, s0 = mb - b * a.S;
-            if constexpr (EPI == PP_QK) ob = obase + ((size_t)b * MV_HEADS * a.S + s0) * MV_HEAD_DIM;
+            if (EPI == PP_QK && !vtile) ob = obase + ((size_t)b * MV_HEADS * a.S + s0) * MV_HEAD_DIM;
             else ob = obase + (size_t)b * MV_HEADS * MV_HEAD_DIM * a.S + s0;
           }
           u32x2 d[2][4];
@@ -869,7 +905,8 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmArgs a) {
               d[j][g][0] = pack_h2(v0, v1);
               d[j][g][1] = pack_h2(v2, v3);
             }
-          scr_f16x2(wbase, wbase ^ 16u, wbase ^ 32u, wbase ^ 48u, d[0], d[1], scr_c, o);
+          if (EPI == PP_QK && vtile) scr_f16x2_t(tbase, tbase ^ 32u, d[0], d[1], scr_c, o);
+          else scr_f16x2(wbase, wbase ^ 16u, wbase ^ 32u, wbase ^ 48u, d[0], d[1], scr_c, o);
           if (live) {
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
