@@ -324,8 +324,9 @@ def corpus_shard_leg(eng, dims, B, S, rank, world, shard_irs):
 
 def matcher_leg(eng, G, B, k=10, reps=20):
     """BASELINE.json configs[4]: fused match + top-k over a G-anchor synthetic bank, measured as its own roofline
-    (SURVEY.md §8d): algorithmic bytes 4 (B P + G P) + 8 B k against HBM, 3 B G P lane operations (5 B G P FLOP of the
-    plain form) against the fp32 vector ALU.  HIP events on the engine's stream around the match (+ merge) launches."""
+    (SURVEY.md §8d): algorithmic bytes 4 (B P + G P) + 8 B k against HBM, 2 B G P lane operations (the class-delta chain:
+    sub + one fma; 5 B G P FLOP of the plain form) against the fp32 vector ALU's issue rate (match_topk.h).  HIP events on
+    the engine's stream around the match (+ merge) launches."""
     bank = eng.anchor_get()
     rng = np.random.default_rng(3)
     u = np.maximum(rng.standard_normal((B, P)), 0).astype(np.float32) * np.float32(0.5)
@@ -343,7 +344,7 @@ def matcher_leg(eng, G, B, k=10, reps=20):
     us = (prof["match"][0] + prof["topk"][0]) / max(prof["match"][1], 1) * 1e3
     bytes_alg = 4 * (B * P + G * P) + 8 * B * k
     flop_plain = 5.0 * B * G * P            # sub, |.|*w (x2 classes) as the reference's concat + Linear would count them, + W_b.v
-    laneops = 3.0 * B * G * P               # what the kernel issues per (b, g, feature): sub + 2 fma
+    laneops = 2.0 * B * G * P               # what the kernel issues per (b, g, feature): sub + one fma on the class-delta chain
     return {"anchors": G, "batch": B, "k": k, "avg_us": round(us, 2), "launches": {"match": prof["match"][1], "topk_merge": prof["topk"][1]},
             "bytes_algorithmic": bytes_alg, "GB_per_s": round(bytes_alg / (us * 1e-6) / 1e9, 1), "hbm_frac": round(bytes_alg / (us * 1e-6) / 8e12, 5),
             "valu_tflops": round(flop_plain / (us * 1e-6) / 1e12, 2), "valu_frac": round(flop_plain / (us * 1e-6) / 157.3e12, 4),

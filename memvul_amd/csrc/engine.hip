@@ -642,15 +642,16 @@ int match_dev(mv_handle* h, const float* u_dev, int B, float* logits, float* pro
   a.part_p = h->w->part_p; a.part_q = h->w->part_q; a.part_i = h->w->part_i;
   {
     ProfScope ps(h, KC_MATCH);
-    if (small)
-      hipLaunchKernelGGL((match_topk_kernel<2, 128, 64>), dim3(1, (B + 3) / 4), dim3(256), 0, h->w->stream, u_dev, h->anchors, h->Wm, a);
-    else
-      hipLaunchKernelGGL((match_topk_kernel<4, 256, 32>), dim3(a.nchunk, (B + 3) / 4), dim3(256), 0, h->w->stream, u_dev, h->anchors, h->Wm, a);
+    const dim3 grid(small ? 1 : a.nchunk, (B + 3) / 4);
+    if (small && a.logits) hipLaunchKernelGGL((match_topk_kernel<2, 128, 64, 1, 2>), grid, dim3(256), 0, h->w->stream, u_dev, h->anchors, h->Wm, a);
+    else if (small) hipLaunchKernelGGL((match_topk_kernel<2, 128, 64, 0, 2>), grid, dim3(256), 0, h->w->stream, u_dev, h->anchors, h->Wm, a);
+    else if (a.logits) hipLaunchKernelGGL((match_topk_kernel<2, 256, 32, 1, 2>), grid, dim3(512), 0, h->w->stream, u_dev, h->anchors, h->Wm, a);
+    else hipLaunchKernelGGL((match_topk_kernel<2, 256, 32, 0, 2>), grid, dim3(512), 0, h->w->stream, u_dev, h->anchors, h->Wm, a);
     if (int rc = launch_check(h, "match_topk")) return rc;
   }
   if (a.nchunk > 1 && k > 0) {
     ProfScope ps(h, KC_TOPK);
-    hipLaunchKernelGGL(topk_merge_kernel, dim3((B + 3) / 4), dim3(256), 0, h->w->stream, a);
+    launch_topk_merge(a, h->w->stream);
     if (int rc = launch_check(h, "topk_merge")) return rc;
   }
   return MV_OK;
