@@ -91,3 +91,19 @@ __device__ __forceinline__ float gelu_erf(float x) {
   const float s = __builtin_fmaf(x, 0.5f, ha);
   return __builtin_fmaf(-az, e, s);
 }
+
+// Virtual LayerNorm statistics ("vstats", gemm_pp.h): three (sum, sum of squares) pairs per row — one per 256-column tile
+// of the residual GEMM whose epilogue produced the row (the embedding kernel writes one pair and two zeros).  Every
+// consumer (the RAW GEMM epilogues, the residual GEMMs' accumulator init, cls_gather_kernel) turns them into (mean, rstd)
+// with this function, so there is no statistics kernel between the GEMMs: var = E[x^2] - mean^2 in fp32 (rows are O(1),
+// clamped at 0), rstd by v_rsq_f32 (1 ulp).
+__device__ __forceinline__ float2 ln_from_partials(float2 p0, float2 p1, float2 p2, float eps) {
+#pragma clang fp contract(off)
+  const float s1 = (p0.x + p1.x) + p2.x, s2 = (p0.y + p1.y) + p2.y;
+  const float mean = s1 * (1.0f / MV_HIDDEN);
+  const float var = fmaxf(s2 * (1.0f / MV_HIDDEN) - mean * mean, 0.f);
+  float2 st;
+  st.x = mean;
+  st.y = __builtin_amdgcn_rsqf(var + eps);
+  return st;
+}

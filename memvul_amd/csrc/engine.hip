@@ -126,7 +126,8 @@ struct Work {
   float* u_in = nullptr;                        // host-provided embeddings for mv_match / mv_topk
   float *c32 = nullptr, *cq = nullptr;          // [CLS]-row buffers of the pruned last layer
   half_t *c16 = nullptr, *cctx = nullptr, *ch16 = nullptr;
-  float *lnstats = nullptr, *lnpart = nullptr;  // LayerNorm row statistics / partial row sums
+  float *lnstats = nullptr, *lnpart = nullptr;  // LayerNorm row statistics: (mean, rstd) [T][2], or the two vstats buffers [T][3][2]
+                                                // of the virtual LayerNorm (layer input / mid-layer; each residual GEMM reads one, writes the other)
   half_t* xlo = nullptr;                        // lo plane of the two-plane raw stream (PP_RESLN3)
   half_t *ctx_lo = nullptr, *h_lo = nullptr;    // MV_F16X2: lo planes of the attention context / GELU output
 };
@@ -180,7 +181,6 @@ struct mv_handle {
   // ... and no LayerNorm kernel at all between the GEMMs (RAW consumers + PP_RESLN2 producers); env MEMVUL_LN_VIRTUAL=0 disables
   bool ln_virtual = true;
   int pp_stagger = 0;  // env MEMVUL_STAGGER: see GemmArgs::stagger
-  int qkv_merge = 1;   // env MEMVUL_QKV_MERGE=0: Q,K and V^T as two launches (PP_QK + PP_VT) instead of one
   bool res_hilo = true;  // env MEMVUL_RES_HILO=0: raw stream as fp32 + fp16 copy (PP_RESLN2) instead of two fp16 planes (PP_RESLN3)
   int r16_direct = 0;  // PP_RESLN2: fp16 copy from the transposed fp32 image (1) or through its own LDS transposition (0); env MEMVUL_R16_DIRECT
 
@@ -339,6 +339,7 @@ template <int PPEPI, int RAW = 0>
 int launch_pp_raw(mv_handle* h, GemmArgs a) {
   if (a.M % 256 || a.N % 256 || a.K % 128 || a.N > MV_INTER)
     return fail(h, MV_ERR_INVALID, "gemm_pp: M,N % 256, K % 128, N <= 3072 required");
+  if (RAW && !a.bias) return fail(h, MV_ERR_STATE, "internal: RAW GEMM without the folded bias");
   a.GN = choose_gn(a.N / 256, 4);  // widths 2 / 3 / 6 / 12 measured: 4 (or the largest divisor below it) is the fastest
   const int tiles = (a.M / 256) * (a.N / 256);
   const int grid = tiles < h->num_cu ? tiles : h->num_cu;
@@ -348,7 +349,7 @@ int launch_pp_raw(mv_handle* h, GemmArgs a) {
     a.stagger = res ? (a.K <= 1024 ? -4 : -10) : -2;
   }
   if (a.nseg == 3) {  // split-operand instantiation (MV_F16X2): built for the four kernel kinds the encoder's persistent path uses
-    if constexpr (PPEPI == PP_RESLN3 || (RAW && (PPEPI == PP_QK || PPEPI == PP_VT || PPEPI == PP_GELU))) {
+    if constexpr (PPEPI == PP_RESLN3 || (RAW && (PPEPI == PP_QK || PPEPI == PP_GELU))) {
       auto kern = gemm_pp_kernel<PPEPI, PP_DIST, 0, PP_SCHED, PP_COAL, RAW, 1>;
       static bool attr_set = false;
       if (!attr_set) {
@@ -372,21 +373,10 @@ int launch_pp(mv_handle* h, int cls, const GemmArgs& a) {
   ProfScope ps(h, cls);
   if constexpr (EPI == EPI_QKV) {  // Q,K columns (row-per-lane stores) and the V^T block (token-contiguous stores)
     // a.col0 = 768: a.W / a.bias already point at the K block and the launch covers K, V only (last-layer pruning)
-    if (h->qkv_merge) {  // one launch: the V tiles take the transposed epilogue (gemm_pp.h scr_f16x2_t)
-      GemmArgs qkv = a;
-      qkv.N = (a.col0 ? 2 : 3) * MV_HIDDEN;
-      return a.raw ? launch_pp_raw<PP_QK, 1>(h, qkv) : launch_pp_raw<PP_QK>(h, qkv);
-    }
-    const int qk_cols = (a.col0 ? 1 : 2) * MV_HIDDEN;
-    GemmArgs qk = a;
-    qk.N = qk_cols;
-    if (int rc = a.raw ? launch_pp_raw<PP_QK, 1>(h, qk) : launch_pp_raw<PP_QK>(h, qk)) return rc;
-    GemmArgs v = a;
-    if (a.W2) v.W2 = a.W2 + (size_t)qk_cols * a.K;
-    v.W = a.W + (size_t)qk_cols * a.K;
-    v.bias = a.bias ? a.bias + qk_cols : nullptr;
-    v.N = MV_HIDDEN;
-    return a.raw ? launch_pp_raw<PP_VT, 1>(h, v) : launch_pp_raw<PP_VT>(h, v);
+    // one launch: the V tiles take the transposed epilogue (gemm_pp.h scr_f16x2_t)
+    GemmArgs qkv = a;
+    qkv.N = (a.col0 ? 2 : 3) * MV_HIDDEN;
+    return a.raw ? launch_pp_raw<PP_QK, 1>(h, qkv) : launch_pp_raw<PP_QK>(h, qkv);
   } else if constexpr (EPI == EPI_GELU) {
     return a.raw ? launch_pp_raw<PP_GELU, 1>(h, a) : launch_pp_raw<PP_GELU>(h, a);
   } else if constexpr (EPI == EPI_RES) {
@@ -486,19 +476,16 @@ int encode_dev(mv_handle* h, const int32_t* d_ids, const int32_t* d_lens, int B,
     hipLaunchKernelGGL(hilo_to_f32_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, h->w->stream, h->w->x16, h->w->xlo, n4, h->w->xres);
     return launch_check(h, "hilo_to_f32");
   };
-  auto run_finalize = [&]() -> int {  // virt: partial row sums of the residual GEMM -> (mean, rstd)
-    ProfScope ps(h, KC_LN);
-    hipLaunchKernelGGL(ln_finalize_kernel, dim3((unsigned)((Mpad + 255) / 256)), dim3(256), 0, h->w->stream, h->w->lnpart, MV_HIDDEN / 64,
-                       (int)Mpad, c.ln_eps, h->w->lnstats);
-    return launch_check(h, "ln_finalize");
-  };
+  // virtual LayerNorm: st_in = vstats of the layer's input rows (embedding / previous FFN-2), st_mid = of the rows after the
+  // attention-output projection; no statistics kernel in between (gemm_pp.h)
+  float *st_in = h->w->lnstats, *st_mid = h->w->lnpart;
   for (int l = 0; l < n_layers; ++l) {
     const LayerW& w = h->L[l];
     const bool last = (l == n_layers - 1);
     GemmArgs g{};
-    g.M = (int)Mpad; g.Mreal = (int)M; g.S = Sp;
+    g.M = (int)Mpad; g.Mreal = (int)M; g.S = Sp; g.ln_eps = c.ln_eps;
     g.q = h->w->q; g.k = h->w->k; g.vt = h->w->vt;
-    if (virt) { g.raw = 1; g.lnstats = h->w->lnstats; }
+    if (virt) { g.raw = 1; g.lnstats = st_in; }
     const half_t* wqkv = virt ? w.wqkv_f : w.wqkv;
     const float* bqkv = virt ? w.bqkv_f : w.bqkv;
     if (last && prune) {
@@ -512,8 +499,8 @@ int encode_dev(mv_handle* h, const int32_t* d_ids, const int32_t* d_lens, int B,
       h->prof_mask = 0;  // the tail is one profiled span; its inner launches carry no events of their own
       auto tail_rc = [&]() -> int {
         hipLaunchKernelGGL(cls_gather_kernel, dim3((B + 3) / 4), dim3(256), 0, h->w->stream, h->w->xres, h->w->x16, Sp, B,
-                           fuse ? h->w->lnstats : (const float*)nullptr, pend_g, pend_b, h->w->c32, h->w->c16, virt ? 1 : 0,
-                           hilo ? h->w->xlo : (const half_t*)nullptr);
+                           fuse ? st_in : (const float*)nullptr, pend_g, pend_b, h->w->c32, h->w->c16, virt ? 1 : 0,
+                           hilo ? h->w->xlo : (const half_t*)nullptr, virt ? 1 : 0, c.ln_eps);
         if (int rc = launch_check(h, "cls_gather")) return rc;
         GemmArgs t{};
         t.M = Bp; t.Mreal = B; t.S = 64;
@@ -585,15 +572,14 @@ int encode_dev(mv_handle* h, const int32_t* d_ids, const int32_t* d_lens, int B,
     g.raw = 0; g.lnstats = nullptr; g.lnpart = nullptr; g.out16b = nullptr;
     g.A = h->w->ctx; g.W = w.wo; g.bias = w.bo; g.N = MV_HIDDEN; g.K = MV_HIDDEN; g.xres = h->w->xres;
     if (x2) { g.A2 = h->w->ctx_lo; g.W2 = w.wo_lo; g.nseg = 3; }
-    if (fuse) { g.lnstats = h->w->lnstats; g.lng = pend_g; g.lnb = pend_b; }
-    if (virt) { g.lnpart = h->w->lnpart; g.out16 = h->w->x16; g.raw = h->r16_direct; g.out16b = hilo ? h->w->xlo : nullptr; }  // + fp16 operand copy / planes, partial row sums
+    if (fuse) { g.lnstats = st_in; g.lng = pend_g; g.lnb = pend_b; }
+    if (virt) { g.lnpart = st_mid; g.out16 = h->w->x16; g.raw = h->r16_direct; g.out16b = hilo ? h->w->xlo : nullptr; }  // + fp16 operand copy / planes, vstats
     if (int rc = launch_gemm<EPI_RES>(h, KC_GEMM_OUT, g)) return rc;
-    if (virt) { if (int rc = run_finalize()) return rc; }
-    else if (int rc = run_ln(h->w->xres, h->w->x16, (int)M, w.ln1g, w.ln1b, fuse)) return rc;
+    if (!virt) { if (int rc = run_ln(h->w->xres, h->w->x16, (int)M, w.ln1g, w.ln1b, fuse)) return rc; }
     pend_g = w.ln1g; pend_b = w.ln1b;
     // K5: FFN-1 + exact-erf GELU
     g.lnstats = nullptr; g.lnpart = nullptr; g.raw = 0; g.out16b = nullptr;
-    if (virt) { g.raw = 1; g.lnstats = h->w->lnstats; }
+    if (virt) { g.raw = 1; g.lnstats = st_mid; }
     g.A = h->w->x16; g.W = virt ? w.w1_f : w.w1; g.bias = virt ? w.b1_f : w.b1; g.N = MV_INTER; g.K = MV_HIDDEN; g.out16 = h->w->h16;
     if (x2) { g.A2 = h->w->xlo; g.W2 = w.w1_f_lo; g.nseg = 3; g.out16b = h->w->h_lo; }
     if (int rc = launch_gemm<EPI_GELU>(h, KC_GEMM_FFN1, g)) return rc;
@@ -601,10 +587,10 @@ int encode_dev(mv_handle* h, const int32_t* d_ids, const int32_t* d_lens, int B,
     g.raw = 0; g.lnstats = nullptr; g.out16b = nullptr;
     g.A = h->w->h16; g.W = w.w2; g.bias = w.b2; g.N = MV_HIDDEN; g.K = MV_INTER; g.xres = h->w->xres;
     if (x2) { g.A2 = h->w->h_lo; g.W2 = w.w2_lo; g.nseg = 3; }
-    if (fuse) { g.lnstats = h->w->lnstats; g.lng = pend_g; g.lnb = pend_b; }
-    if (virt) { g.lnpart = h->w->lnpart; g.out16 = h->w->x16; g.raw = h->r16_direct; g.out16b = hilo ? h->w->xlo : nullptr; }
+    if (fuse) { g.lnstats = virt ? st_mid : h->w->lnstats; g.lng = pend_g; g.lnb = pend_b; }
+    if (virt) { g.lnpart = st_in; g.out16 = h->w->x16; g.raw = h->r16_direct; g.out16b = hilo ? h->w->xlo : nullptr; }
     if (int rc = launch_gemm<EPI_RES>(h, KC_GEMM_FFN2, g)) return rc;
-    if (virt && !last) { if (int rc = run_finalize()) return rc; }
+    if (virt && !last) {}  // the next layer's consumers read st_in
     else if (hilo && materialise_f32() != MV_OK) return MV_ERR_HIP;
     else if (int rc = run_ln(h->w->xres, h->w->x16, (int)M, w.ln2g, w.ln2b, fuse && !last)) return rc;  // the pooler reads a normalised stream
     pend_g = w.ln2g; pend_b = w.ln2b;
@@ -797,14 +783,12 @@ int mv_create(int device, const mv_config* cfg, mv_handle** out) {
   hipFuncSetAttribute((const void*)gemm256_kernel<EPI_RES>, hipFuncAttributeMaxDynamicSharedMemorySize, G256_LDS_BYTES);
   hipFuncSetAttribute((const void*)gemm_pp_kernel<PP_F32, PP_DIST, 0, PP_SCHED, PP_COAL>, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS_BYTES);
   hipFuncSetAttribute((const void*)gemm_pp_kernel<PP_QK, PP_DIST, 0, PP_SCHED, PP_COAL>, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS_BYTES);
-  hipFuncSetAttribute((const void*)gemm_pp_kernel<PP_VT, PP_DIST, 0, PP_SCHED, PP_COAL>, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS_BYTES);
   hipFuncSetAttribute((const void*)gemm_pp_kernel<PP_GELU, PP_DIST, 0, PP_SCHED, PP_COAL>, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS_BYTES);
   hipFuncSetAttribute((const void*)gemm_pp_kernel<PP_RES, PP_DIST, 0, PP_SCHED, PP_COAL>, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS_BYTES);
   hipFuncSetAttribute((const void*)gemm_pp_kernel<PP_RESLN, PP_DIST, 0, PP_SCHED, PP_COAL>, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS_BYTES);
   hipFuncSetAttribute((const void*)gemm_pp_kernel<PP_RESLN2, PP_DIST, 0, PP_SCHED, PP_COAL>, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS_BYTES);
   hipFuncSetAttribute((const void*)gemm_pp_kernel<PP_RESLN3, PP_DIST, 0, PP_SCHED, PP_COAL>, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS_BYTES);
   hipFuncSetAttribute((const void*)gemm_pp_kernel<PP_QK, PP_DIST, 0, PP_SCHED, PP_COAL, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS_BYTES_RAW);
-  hipFuncSetAttribute((const void*)gemm_pp_kernel<PP_VT, PP_DIST, 0, PP_SCHED, PP_COAL, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS_BYTES_RAW);
   hipFuncSetAttribute((const void*)gemm_pp_kernel<PP_GELU, PP_DIST, 0, PP_SCHED, PP_COAL, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS_BYTES_RAW);
   (void)hipGetLastError();
   if (const char* e = getenv("MEMVUL_GEMM_TILE")) h->gemm_tile = atoi(e);
@@ -814,7 +798,6 @@ int mv_create(int device, const mv_config* cfg, mv_handle** out) {
   if (const char* e = getenv("MEMVUL_R16_DIRECT")) h->r16_direct = atoi(e) != 0;
   if (const char* e = getenv("MEMVUL_RES_HILO")) h->res_hilo = atoi(e) != 0;
   if (const char* e = getenv("MEMVUL_STAGGER")) h->pp_stagger = atoi(e);
-  if (const char* e = getenv("MEMVUL_QKV_MERGE")) h->qkv_merge = atoi(e);
   if (const char* e = getenv("MEMVUL_ATTN")) h->attn_v2 = atoi(e) != 0;
   hipFuncSetAttribute((const void*)attention_v2_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT2_LDS_BYTES(1));
   hipFuncSetAttribute((const void*)attention_v2_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT2_LDS_BYTES(2));
@@ -847,8 +830,8 @@ int mv_create(int device, const mv_config* cfg, mv_handle** out) {
     A(dev_alloc(h, &h->w->vt, T * MV_HIDDEN));
     A(dev_alloc(h, &h->w->ctx, T * MV_HIDDEN));
     A(dev_alloc(h, &h->w->h16, T * MV_INTER));
-    A(dev_alloc(h, &h->w->lnstats, T * 2));
-    A(dev_alloc(h, &h->w->lnpart, T * (MV_HIDDEN / 64) * 2));
+    A(dev_alloc(h, &h->w->lnstats, T * 6));
+    A(dev_alloc(h, &h->w->lnpart, T * 6));
     A(dev_alloc(h, &h->w->xlo, T * MV_HIDDEN));
     A(dev_alloc(h, &h->w->c32, Bp * MV_HIDDEN));
     A(dev_alloc(h, &h->w->cq, Bp * MV_HIDDEN));

@@ -48,12 +48,14 @@ struct GemmArgs {
   half_t* vt;         //          [B][12][64][S]
   int S;              // padded sequence length (multiple of 64)
   int col0;           // EPI_QKV / PP_QK: packed-QKV column of this launch's first output column (0, or 768 = K,V only)
-  const float* lnstats;  // PP_RESLN: [M][2] (mean, rstd) of the residual rows; lng / lnb: that LayerNorm's gamma, beta [768]
+  const float* lnstats;  // PP_RESLN: [M][2] (mean, rstd) of the residual rows; PP_RESLN2 / 3 and RAW consumers: the rows' "vstats"
+                         // [M][3][2] (misc_kernels.h ln_from_partials); lng / lnb: that LayerNorm's gamma, beta [768]
   const float* lng;
   const float* lnb;
   int stagger;           // gemm_pp: workgroup w starts (hash(w) % (stagger + 1)) x ~8k cycles late (breaks the lockstep of the memory bursts)
   int raw;               // RAW consumer (gemm_pp.h): A is the raw fp16 stream, W / bias are the folded ones, lnstats = row statistics
-  float* lnpart;         // PP_RESLN2: [M][N / 64][2] partial (sum, sum of squares) per row and 64-column slice
+  float* lnpart;         // PP_RESLN2 / 3 (N = 768): vstats of the NEW raw rows, [M][3][2] = (sum, sum of squares) per row and 256-column tile
+  float ln_eps;          // LayerNorm epsilon of the vstats consumers
   unsigned long long* clk;  // optional (development probe): per-workgroup s_memtime span of the persistent kernel
   // split-operand ("precise") mode of gemm_pp (nseg == 3): the K sweep runs three times over the same accumulators,
   //   A_hi W_hi + A_lo W_hi + A_hi W_lo   with  A = A_hi + A_lo,  W = W_hi + W_lo  (fp16 planes; the lo x lo term is 2^-22),

@@ -52,10 +52,12 @@ enum { PP_F32 = 0, PP_QK = 1, PP_VT = 2, PP_GELU = 3, PP_RES = 4, PP_F16 = 5, PP
 // (the row mean of r drops out against the row-centred weights), so a consumer GEMM (RAW = 1: PP_QK / PP_VT /
 // PP_GELU) takes the RAW stream rounded to fp16 as its A operand, the folded weights W'' (prepared once on the
 // host), starts its accumulators from zero and applies  fma(rstd_row, acc, b'_col)  in the epilogue; the 256 rows'
-// (mean, rstd) of the workgroup's next tile arrive by two LDS-DMA pieces into a 2 x 2 KiB image.  The producer
-// (PP_RESLN2 = PP_RESLN that ALSO writes the fp16 copy of the raw stream and, per row and 64-column wave slice, the
-// partial (sum, sum of squares)) replaces the LayerNorm kernel's second pass over the stream; ln_finalize_kernel
-// turns the N / 64 partials of a row into (mean, rstd) in a fixed order (deterministic).
+// statistics of the workgroup's next tile arrive by six LDS-DMA pieces (and its 256 bias' values by a seventh) into
+// 2 x 6 KiB (2 x 1 KiB) images.  The producer (PP_RESLN2 = PP_RESLN that ALSO writes the fp16 copy of the raw stream and the
+// rows' "vstats": per row and 256-column tile the (sum, sum of squares), the four column waves' shares added in wave
+// order through LDS) replaces the LayerNorm kernel's second pass over the stream, and every consumer turns the three
+// pairs of a row into (mean, rstd) itself (common.h ln_from_partials) — no statistics kernel between the GEMMs
+// (round 1 / early round 2 ran a 6 us ln_finalize launch after every residual GEMM: 22 launches per pass).
 // PP_RESLN3 = PP_RESLN2 with the raw stream kept as TWO fp16 planes instead of fp32 + an fp16 copy:
 //   hi = fp16(r)  (exactly the operand the RAW consumers read),  lo = fp16(r - hi),  r ~= hi + lo to 2^-22 relative
 // (fp32 carries 2^-24).  The residual tile is read as hi + lo (same bytes as fp32) and written as hi, lo: 100 MB less
@@ -69,8 +71,12 @@ enum { PP_ABL_NODMA = 1, PP_ABL_NOMFMA = 2, PP_ABL_NOREAD = 4, PP_ABL_NOEPI = 8,
 #define PP_LDS_BIAS 131072   // [N] fp32 (N <= 3072)
 #define PP_LDS_SCR (PP_LDS_BIAS + MV_INTER * 4)  // 8 waves x 2 KiB: wave-private transposition scratch
 #define PP_LDS_BYTES (PP_LDS_SCR + 8 * 2048)     // 159,744 of 163,840
-#define PP_LDS_STATS PP_LDS_BYTES                 // RAW kernels: [2][256 rows][mean, rstd] fp32
-#define PP_LDS_BYTES_RAW (PP_LDS_STATS + 2 * 2048)  // 163,840 = all of the CU's LDS
+// RAW kernels re-partition everything above the operand ring: [2][256] bias' of the tile | [2][256 rows][3][sum, sumsq] | scratch
+#define PP_LDS_BIAS_T PP_LDS_BIAS                  // 2 x 1 KiB
+#define PP_LDS_STATS (PP_LDS_BIAS + 2048)          // 2 x 6 KiB
+#define PP_LDS_SCR_RAW (PP_LDS_STATS + 2 * 6144)   // 8 waves x 2 KiB
+#define PP_LDS_RSTD (PP_LDS_SCR_RAW + 8 * 2048)    // 2 x 256 rstd of the tile's rows (computed once per workgroup, in the main loop)
+#define PP_LDS_BYTES_RAW (PP_LDS_RSTD + 2048)      // 163,840 = all of the CU's LDS
 
 __device__ __forceinline__ uint32_t pack_h2(float a, float b) {
   half2_t h;
@@ -237,7 +243,7 @@ __device__ __forceinline__ void lds_read_bgb1(uint32_t addr, float4& bi, float4&
 //       the lo plane of its output.  A separate instantiation: the plain kernels keep their register allocation.
 template <int EPI, int DIST, int ABL, int SCHED = 0, int COAL = 0, int RAW = 0, int X2 = 0>
 __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmArgs a) {
-  static_assert(!RAW || (COAL == 1 && (EPI == PP_QK || EPI == PP_VT || EPI == PP_GELU)), "RAW: the fp16-output kernels of the transposed path");
+  static_assert(!RAW || (COAL == 1 && (EPI == PP_QK || EPI == PP_GELU)), "RAW: the fp16-output kernels of the transposed path, token row per lane");
   static_assert(SCHED == 0 ? (DIST >= 2 && DIST <= 6) : (DIST >= 2 && DIST <= 4), "half-tile issue distance");
   constexpr bool SWAP = (EPI != PP_VT);
   constexpr bool IS_RESLN = (EPI == PP_RESLN || EPI == PP_RESLN2 || EPI == PP_RESLN3);
@@ -246,6 +252,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmArgs a) {
   constexpr bool IS_RES = (EPI == PP_RES || IS_RESLN);
   static_assert(!IS_RESLN || COAL == 1, "the LayerNorm-fused residual init is written for the transposed (COAL) path");
   constexpr int WAITN = SCHED == 0 ? 2 * (DIST - 1) : 2 * DIST;
+  constexpr int LDS_SCR = RAW ? PP_LDS_SCR_RAW : PP_LDS_SCR;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -272,8 +279,8 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmArgs a) {
     for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(127);
   }
 
-  // ---- bias -> LDS (once per workgroup)
-  {
+  // ---- bias -> LDS (once per workgroup; RAW kernels: per tile, issue_stats)
+  if constexpr (!RAW) {
     float* lb = (float*)(smem + PP_LDS_BIAS);
     for (int n = tid; n < a.N; n += 512) lb[n] = a.bias ? a.bias[n] : 0.f;
     if constexpr (IS_RESLN) {  // N == 768: gamma at [768, 1536), beta at [1536, 2304) of the same image
@@ -492,22 +499,29 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmArgs a) {
     __builtin_amdgcn_sched_barrier(0);
   };
 
-  // ---- RAW: (mean, rstd) of the 256 token rows of persistent iteration `itn` -> LDS image itn & 1 (wave 0 only; two
-  // 1-KiB LDS-DMA pieces that ride in the same vmcnt ledger: they are older than anything a later counted wait must
-  // retire, so every wait stays conservative)
-  auto issue_stats = [&](int itn) {
-    const int L = itn * G + bslot;
-    if (L < ntiles) {
-      int tm, tn;
-      raster(L, tm_count, tn_count, a.GN, tm, tn);
-      const char* src = (const char*)a.lnstats + (size_t)tm * 2048 + lane * 16;
-      char* dst = smem + PP_LDS_STATS + (itn & 1) * 2048;
-      glds16((const half_t*)src, dst);
-      glds16((const half_t*)(src + 1024), dst + 1024);
+  // ---- RAW: vstats of the 256 token rows (6 KiB) and the 256 bias' values (1 KiB) of persistent iteration `itn` -> LDS
+  // images itn & 1.  Seven 1-KiB LDS-DMA pieces, two per wave 0..3, riding in the same vmcnt ledger: a piece only pushes
+  // OLDER operand pieces out of a counted wait's window, so every wait stays conservative.  (tm, tn) = the tile's
+  // coordinates (computed at the START of the previous tile: the raster's integer divisions stay out of the main loop).
+  auto issue_stats = [&](int itn, int tm, int tn) {
+    if (itn * G + bslot < ntiles && wave < 4) {
+#pragma unroll
+      for (int pc = 0; pc < 2; ++pc) {
+        const int piece = 2 * wave + pc;  // 0..5: vstats, 6: bias', 7: none
+        if (piece < 6) {
+          const char* src = (const char*)a.lnstats + (size_t)tm * 6144 + piece * 1024 + lane * 16;
+          glds16((const half_t*)src, smem + PP_LDS_STATS + (itn & 1) * 6144 + piece * 1024);
+        } else if (piece == 6) {
+          const char* src = (const char*)a.bias + (size_t)tn * 1024 + lane * 16;
+          glds16((const half_t*)src, smem + PP_LDS_BIAS_T + (itn & 1) * 1024);
+        }
+      }
     }
   };
   if constexpr (RAW) {
-    if (wave == 0) issue_stats(0);
+    int tm = 0, tn = 0;
+    if (bslot < ntiles) raster(bslot, tm_count, tn_count, a.GN, tm, tn);
+    issue_stats(0, tm, tn);
   }
 
   // ---- prologue.  SCHED 0: half-tiles psi = 0 .. DIST in flight, psi 0 (b0 of K-tile 0) and 1 (a0) landed.
@@ -543,6 +557,11 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmArgs a) {
     if constexpr (ABL & PP_ABL_CLK) tA = __builtin_amdgcn_s_memtime();
     int tile_m, tile_n;
     raster(L, tm_count, tn_count, a.GN, tile_m, tile_n);
+    int next_m = 0, next_n = 0;  // RAW: the workgroup's next tile (issue_stats)
+    if constexpr (RAW) {
+      if (L + G < ntiles) raster(L + G, tm_count, tn_count, a.GN, next_m, next_n);
+    }
+    (void)next_m; (void)next_n;
     const int mw = (tile_m << 8) + wr * 128;  // first token row of this wave
     const int nw = (tile_n << 8) + wc * 64;   // first output column of this wave
 
@@ -552,6 +571,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmArgs a) {
     if constexpr (SWAP) {
       float4 bv[2][4];
       const uint32_t baddr = (uint32_t)(PP_LDS_BIAS + (nw + 4 * hi) * 4);
+      if constexpr (!RAW)  // (RAW: accumulators start from zero; bias' is applied in the epilogue from the per-tile image)
       asm volatile(
           "ds_read_b128 %0, %8\n\tds_read_b128 %1, %8 offset:32\n\tds_read_b128 %2, %8 offset:64\n\t"
           "ds_read_b128 %3, %8 offset:96\n\tds_read_b128 %4, %8 offset:128\n\tds_read_b128 %5, %8 offset:160\n\t"
@@ -561,7 +581,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmArgs a) {
           : "v"(baddr)
           : "memory");
       // scratch addresses of this lane: MFMA layout (row = lane & 31) and coalesced layout (row = lane >> 2)
-      const uint32_t scr = (uint32_t)(PP_LDS_SCR + wave * 2048);
+      const uint32_t scr = (uint32_t)(LDS_SCR + wave * 2048);
       const uint32_t sf = (uint32_t)((l31 >> 2) & 3);
       const uint32_t scr_m32 = scr + l31 * 64 + (((uint32_t)hi ^ sf) << 4);          // fp32 rounds: chunk 2 gg + hi -> ^ (gg * 32)
       const uint32_t scr_c = scr + (lane >> 2) * 64 + ((((uint32_t)lane & 3) ^ (((uint32_t)lane >> 4) & 3)) << 4);
@@ -569,10 +589,27 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmArgs a) {
         // residual tile by full-line loads (16 rows x 64 B per instruction), transposed into the C/D layout
         // (the raw lines are parked in the accumulator registers they will be transposed into)
         float2 lnst[4];  // PP_RESLN: (mean, rstd) of this lane's four token rows
+        float2 lnp[4][3];  // virtual LayerNorm: the rows' vstats, loaded here and turned into (mean, rstd) only AFTER the
+                           // residual tile's loads are issued (in source order hipcc waits for these loads first and the
+                           // two memory latencies add up: +1.3 us per tile)
         if constexpr (IS_RESLN) {
 #pragma unroll
-          for (int i = 0; i < 4; ++i) lnst[i] = *(const float2*)(a.lnstats + 2 * (size_t)(mw + i * 32 + l31));
+          for (int i = 0; i < 4; ++i) {
+            if constexpr (EMITS) {
+              const float2* pp = (const float2*)(a.lnstats + 6 * (size_t)(mw + i * 32 + l31));
+              lnp[i][0] = pp[0]; lnp[i][1] = pp[1]; lnp[i][2] = pp[2];
+            } else {
+              lnst[i] = *(const float2*)(a.lnstats + 2 * (size_t)(mw + i * 32 + l31));
+            }
+          }
         }
+        auto finish_stats = [&]() {
+          if constexpr (EMITS) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) lnst[i] = ln_from_partials(lnp[i][0], lnp[i][1], lnp[i][2], a.ln_eps);
+          }
+        };
+        (void)lnp;
         if constexpr (HILO) {
           // the two fp16 planes of the raw stream by full-line loads (16 rows x 64 B per instruction), parked in the
           // accumulator registers: [i][j] registers 0-3 / 4-7 = hi rows crow / crow + 16, 8-11 / 12-15 = lo
@@ -591,6 +628,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmArgs a) {
                   acc[i][j][8 * pl + 4 * x + 0] = t.x; acc[i][j][8 * pl + 4 * x + 1] = t.y;
                   acc[i][j][8 * pl + 4 * x + 2] = t.z; acc[i][j][8 * pl + 4 * x + 3] = t.w;
                 }
+          finish_stats();
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
 #pragma clang fp contract(off)
@@ -633,6 +671,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmArgs a) {
                 acc[i][j][4 * (2 * h + x) + 0] = t.x; acc[i][j][4 * (2 * h + x) + 1] = t.y;
                 acc[i][j][4 * (2 * h + x) + 2] = t.z; acc[i][j][4 * (2 * h + x) + 3] = t.w;
               }
+        finish_stats();
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           u32x4 d[8], o[8];
@@ -704,7 +743,23 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmArgs a) {
     if constexpr (SCHED == 1 && decltype(grpc)::value == 0) read_set(std::integral_constant<int, 0>{});
     for (int kt = 0; kt < nk; kt += 2) {
       if constexpr (RAW) {  // every wave has left the previous tile's epilogue (>= 8 barriers ago): its stats image is free
-        if (kt == 2 && wave == 0) issue_stats(it + 1);
+        if (kt == 2) {
+          issue_stats(it + 1, next_m, next_n);
+          // rstd of THIS tile's 256 rows -> LDS, once per workgroup (waves 4..7, one row per lane; in the epilogue, per column
+          // wave, the three pairs + rsq of four rows per lane cost 0.4 us per tile)
+          if (wave >= 4) {
+            const int row = (wave - 4) * 64 + lane;
+            const uint32_t saddr = (uint32_t)(PP_LDS_STATS + (it & 1) * 6144 + row * 24);
+            float2 p0, p1, p2;
+            asm volatile("ds_read_b64 %0, %3\n\tds_read_b64 %1, %3 offset:8\n\tds_read_b64 %2, %3 offset:16\n\ts_waitcnt lgkmcnt(0)"
+                         : "=&v"(p0), "=&v"(p1), "=&v"(p2)
+                         : "v"(saddr)
+                         : "memory");
+            const float rs = ln_from_partials(p0, p1, p2, a.ln_eps).y;
+            const uint32_t waddr = (uint32_t)(PP_LDS_RSTD + (it & 1) * 1024 + row * 4);
+            asm volatile("ds_write_b32 %0, %1" ::"v"(waddr), "v"(rs) : "memory");
+          }
+        }
       }
       if constexpr (SCHED == 0) {
         phase(std::integral_constant<int, 0>{});
@@ -736,14 +791,16 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmArgs a) {
         for (int j = 0; j < 2; ++j) keep_live(acc[i][j]);
     } else if constexpr (COAL) {
       // ---- coalesced epilogue: every 32x32 fragment goes through the wave's [32][64 B] LDS image
-      const uint32_t scr = (uint32_t)(PP_LDS_SCR + wave * 2048);
+      const uint32_t scr = (uint32_t)(LDS_SCR + wave * 2048);
       const uint32_t sf = (uint32_t)((l31 >> 2) & 3);
       const uint32_t scr_c = scr + (lane >> 2) * 64 + ((((uint32_t)lane & 3) ^ (((uint32_t)lane >> 4) & 3)) << 4);
       const int crow = lane >> 2, cchunk = lane & 3;  // coalesced layout: row (+16 for the second read), 16-B chunk
       if constexpr (EMITS) {
-        // per-row partial LayerNorm statistics of this wave's 64 columns: lane = token row, the two half-waves hold
-        // disjoint column sets; slot nw / 64 of the row's N / 64 partials (ln_finalize_kernel adds them in order)
-        const int np = a.N >> 6;
+        // vstats of the new raw rows: (sum, sum of squares) over this TILE's 256 columns.  Each wave reduces its 64 columns
+        // (lane = token row, the two half-waves hold disjoint column sets), parks the 128 pairs in its own scratch, and after
+        // a workgroup barrier the first column wave of each M-half adds the four shares in wave order (deterministic) and
+        // writes slot tile_n of the rows' three pairs.  A second barrier keeps the scratch intact until it has been read.
+        // (inline asm: compiler-visible LDS accesses would wait for the LDS-DMA in flight, see the accumulator init)
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           float s1 = 0.f, s2 = 0.f;
@@ -760,8 +817,33 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmArgs a) {
           float2 st;
           st.x = u2f(t1[0]) + u2f(t1[1]);
           st.y = u2f(t2[0]) + u2f(t2[1]);
-          if (hi == 0) *(float2*)(a.lnpart + ((size_t)(mw + i * 32 + l31) * np + (nw >> 6)) * 2) = st;
+          const uint32_t waddr = scr + (uint32_t)(i * 32 + l31) * 8;  // both half-waves write the same pair
+          asm volatile("ds_write_b64 %0, %1" ::"v"(waddr), "v"(st) : "memory");
         }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        if (wc == 0) {  // rows i * 32 + l31 of this M-half: the lower half-wave takes i = 0, 1, the upper one i = 2, 3
+#pragma unroll
+          for (int ii = 0; ii < 2; ++ii) {
+            const int row = (2 * hi + ii) * 32 + l31;
+            const uint32_t raddr = (uint32_t)(LDS_SCR + wr * 4 * 2048) + (uint32_t)row * 8;
+            float2 q0, q1, q2, q3;
+            asm volatile("ds_read_b64 %0, %4\n\tds_read_b64 %1, %4 offset:2048\n\tds_read_b64 %2, %4 offset:4096\n\t"
+                         "ds_read_b64 %3, %4 offset:6144\n\ts_waitcnt lgkmcnt(0)"
+                         : "=&v"(q0), "=&v"(q1), "=&v"(q2), "=&v"(q3)
+                         : "v"(raddr)
+                         : "memory");
+            float2 st;
+            st.x = ((q0.x + q1.x) + q2.x) + q3.x;
+            st.y = ((q0.y + q1.y) + q2.y) + q3.y;
+            *(float2*)(a.lnpart + ((size_t)(mw + row) * 3 + tile_n) * 2) = st;
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
       }
       if constexpr ((EPI == PP_F32 || IS_RES) && !HILO) {
         const uint32_t scr_m32 = scr + l31 * 64 + (((uint32_t)hi ^ sf) << 4);
@@ -824,52 +906,32 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmArgs a) {
           obase = a.vt + ((size_t)head * MV_HEAD_DIM + crow) * a.S + 8 * cchunk;
           rstride = a.S; istride = 0; jstride = (size_t)32 * a.S;
         }
-        // RAW: bias' of this wave's columns and rstd of its token rows (LDS images), applied as fma(rstd, acc, bias')
+        // RAW: bias' of this wave's columns (per-tile LDS image) and rstd of its token rows (from the vstats image, one row
+        // per lane and i), applied as fma(rstd, acc, bias')
         float4 rbv[2][4];
-        float rrs[4], rb0 = 0.f, rb1 = 0.f;
-        const uint32_t stats_img = (uint32_t)(PP_LDS_STATS + (it & 1) * 2048 + wr * 1024);  // this wave's 128 rows
-        if constexpr (RAW && SWAP) {
-          const uint32_t baddr = (uint32_t)(PP_LDS_BIAS + (nw + 4 * hi) * 4);
-          const uint32_t saddr = stats_img + l31 * 8 + 4;
+        float rrs[4];
+        if constexpr (RAW) {
+          const uint32_t baddr = (uint32_t)(PP_LDS_BIAS_T + (it & 1) * 1024 + (wc * 64 + 4 * hi) * 4);
+          const uint32_t saddr = (uint32_t)(PP_LDS_RSTD + (it & 1) * 1024 + (wr * 128 + l31) * 4);  // this wave's 128 rows
           asm volatile(
               "ds_read_b128 %0, %12\n\tds_read_b128 %1, %12 offset:32\n\tds_read_b128 %2, %12 offset:64\n\t"
               "ds_read_b128 %3, %12 offset:96\n\tds_read_b128 %4, %12 offset:128\n\tds_read_b128 %5, %12 offset:160\n\t"
               "ds_read_b128 %6, %12 offset:192\n\tds_read_b128 %7, %12 offset:224\n\t"
-              "ds_read_b32 %8, %13\n\tds_read_b32 %9, %13 offset:256\n\tds_read_b32 %10, %13 offset:512\n\t"
-              "ds_read_b32 %11, %13 offset:768\n\ts_waitcnt lgkmcnt(0)"
+              "ds_read_b32 %8, %13\n\tds_read_b32 %9, %13 offset:128\n\tds_read_b32 %10, %13 offset:256\n\t"
+              "ds_read_b32 %11, %13 offset:384\n\ts_waitcnt lgkmcnt(0)"
               : "=&v"(rbv[0][0]), "=&v"(rbv[0][1]), "=&v"(rbv[0][2]), "=&v"(rbv[0][3]), "=&v"(rbv[1][0]), "=&v"(rbv[1][1]),
                 "=&v"(rbv[1][2]), "=&v"(rbv[1][3]), "=&v"(rrs[0]), "=&v"(rrs[1]), "=&v"(rrs[2]), "=&v"(rrs[3])
               : "v"(baddr), "v"(saddr)
               : "memory");
           __builtin_amdgcn_sched_barrier(0);
         }
-        if constexpr (RAW && !SWAP) {
-          const uint32_t baddr = (uint32_t)(PP_LDS_BIAS + (nw + l31) * 4);
-          asm volatile("ds_read_b32 %0, %2\n\tds_read_b32 %1, %2 offset:128\n\ts_waitcnt lgkmcnt(0)"
-                       : "=&v"(rb0), "=&v"(rb1)
-                       : "v"(baddr)
-                       : "memory");
-          __builtin_amdgcn_sched_barrier(0);
-        }
-        (void)rbv; (void)rrs; (void)rb0; (void)rb1; (void)stats_img;
+        (void)rbv; (void)rrs;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           const int mb = mw + i * 32;
           half_t* ob = obase + i * istride;
-          float4 rst[4][2];  // RAW, lane = column: (mean, rstd) pairs of tokens 32 i + 8 g + 4 hi + 0..3
-          if constexpr (RAW && !SWAP) {
-            const uint32_t saddr = stats_img + (uint32_t)(i * 32 + 4 * hi) * 8;
-            asm volatile(
-                "ds_read_b128 %0, %8\n\tds_read_b128 %1, %8 offset:16\n\tds_read_b128 %2, %8 offset:64\n\t"
-                "ds_read_b128 %3, %8 offset:80\n\tds_read_b128 %4, %8 offset:128\n\tds_read_b128 %5, %8 offset:144\n\t"
-                "ds_read_b128 %6, %8 offset:192\n\tds_read_b128 %7, %8 offset:208\n\ts_waitcnt lgkmcnt(0)"
-                : "=&v"(rst[0][0]), "=&v"(rst[0][1]), "=&v"(rst[1][0]), "=&v"(rst[1][1]), "=&v"(rst[2][0]), "=&v"(rst[2][1]),
-                  "=&v"(rst[3][0]), "=&v"(rst[3][1])
-                : "v"(saddr)
-                : "memory");
-            __builtin_amdgcn_sched_barrier(0);
-          }
-          (void)rst;
+          const float rrs_i = RAW ? rrs[i] : 1.f;  // RAW: rstd of token row 32 i + l31
+          (void)rrs_i;
           if constexpr (EPI == PP_QK || EPI == PP_VT) {
             live = mb < a.Mreal;
             const int b = mb / a.S, s0 = mb - b * a.S;
@@ -883,14 +945,9 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmArgs a) {
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
               float v0 = acc[i][j][4 * g + 0], v1 = acc[i][j][4 * g + 1], v2 = acc[i][j][4 * g + 2], v3 = acc[i][j][4 * g + 3];
-              if constexpr (RAW && SWAP) {  // lane = token row 32 i + l31, registers = 4 consecutive columns
-                v0 = __builtin_fmaf(rrs[i], v0, rbv[j][g].x); v1 = __builtin_fmaf(rrs[i], v1, rbv[j][g].y);
-                v2 = __builtin_fmaf(rrs[i], v2, rbv[j][g].z); v3 = __builtin_fmaf(rrs[i], v3, rbv[j][g].w);
-              }
-              if constexpr (RAW && !SWAP) {  // lane = column 32 j + l31, registers = tokens 32 i + 8 g + 4 hi + 0..3
-                const float bj = j ? rb1 : rb0;
-                v0 = __builtin_fmaf(rst[g][0].y, v0, bj); v1 = __builtin_fmaf(rst[g][0].w, v1, bj);
-                v2 = __builtin_fmaf(rst[g][1].y, v2, bj); v3 = __builtin_fmaf(rst[g][1].w, v3, bj);
+              if constexpr (RAW) {  // lane = token row 32 i + l31, registers = 4 consecutive columns
+                v0 = __builtin_fmaf(rrs_i, v0, rbv[j][g].x); v1 = __builtin_fmaf(rrs_i, v1, rbv[j][g].y);
+                v2 = __builtin_fmaf(rrs_i, v2, rbv[j][g].z); v3 = __builtin_fmaf(rrs_i, v3, rbv[j][g].w);
               }
               if constexpr (EPI == PP_GELU) {
                 float2_t a01, a23;

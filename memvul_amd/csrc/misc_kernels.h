@@ -58,7 +58,8 @@ __device__ __forceinline__ void ln_row_store(const float4 (&x)[3], const float* 
 
 // K1: x = LN(word[id] + pos[s] + type[0])   (HF BertEmbeddings; token-type ids are all zero in this
 // path, custom_PTM_embedder.py:199-202).  ids are [B][S_in] (0-padded), the engine row pitch is Sp.
-// RAWOUT (virtual LayerNorm, gemm_pp.h): x32 <- the un-normalised sum, x16 <- its fp16 copy, stats <- (mean, rstd).
+// RAWOUT (virtual LayerNorm, gemm_pp.h): x32 <- the un-normalised sum, x16 <- its fp16 copy, stats <- the row's vstats
+// (the exact two-pass mean and variance, expressed as one (sum, sum of squares) pair).
 // `pitch` = ints between the rows of ids (>= S_in: a length-bucketed sweep reads only the first S_in columns of wider rows).
 template <bool RAWOUT>
 __global__ __launch_bounds__(256) void embed_ln_kernel(const int32_t* __restrict__ ids, int pitch, int S_in, int Sp, int n_tok,
@@ -94,11 +95,12 @@ __global__ __launch_bounds__(256) void embed_ln_kernel(const int32_t* __restrict
       const float a = x[i].x - mean, bb = x[i].y - mean, c = x[i].z - mean, d = x[i].w - mean;
       v = __builtin_fmaf(a, a, v); v = __builtin_fmaf(bb, bb, v); v = __builtin_fmaf(c, c, v); v = __builtin_fmaf(d, d, v);
     }
-    const float rstd = 1.0f / sqrtf(wave_sum(v) * (1.0f / MV_HIDDEN) + eps);
-    if (lane == 0) {
+    const float var = wave_sum(v) * (1.0f / MV_HIDDEN);
+    if (lane < 3) {
       float2 st;
-      st.x = mean; st.y = rstd;
-      *(float2*)(stats + 2 * (size_t)t) = st;
+      st.x = lane == 0 ? mean * MV_HIDDEN : 0.f;
+      st.y = lane == 0 ? (var + mean * mean) * MV_HIDDEN : 0.f;
+      *(float2*)(stats + 6 * (size_t)t + 2 * lane) = st;
     }
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
@@ -124,29 +126,6 @@ __global__ __launch_bounds__(256) void embed_ln_kernel(const int32_t* __restrict
       *(float2*)(stats + 2 * (size_t)t) = st;
     }
   }
-}
-
-// Virtual LayerNorm: (mean, rstd) of each row from the N / 64 partial (sum, sum of squares) pairs the PP_RESLN2
-// epilogue wrote, added in slot order (deterministic); var = E[x^2] - mean^2 in fp32 (rows are O(1): no cancellation
-// to speak of; clamped at 0).
-__global__ __launch_bounds__(256) void ln_finalize_kernel(const float* __restrict__ part, int np, int n_tok, float eps,
-                                                          float* __restrict__ stats) {
-#pragma clang fp contract(off)
-  const int t = blockIdx.x * 256 + threadIdx.x;
-  if (t >= n_tok) return;
-  const float2* p = (const float2*)(part + (size_t)t * np * 2);
-  float s1 = 0.f, s2 = 0.f;
-  for (int i = 0; i < np; ++i) {
-    const float2 v = p[i];
-    s1 += v.x;
-    s2 += v.y;
-  }
-  const float mean = s1 * (1.0f / MV_HIDDEN);
-  const float var = fmaxf(s2 * (1.0f / MV_HIDDEN) - mean * mean, 0.f);
-  float2 st;
-  st.x = mean;
-  st.y = 1.0f / sqrtf(var + eps);
-  *(float2*)(stats + 2 * (size_t)t) = st;
 }
 
 // LayerNorm of the residual stream (the GEMM epilogue already added bias + residual).
@@ -179,19 +158,26 @@ __global__ __launch_bounds__(256) void hilo_to_f32_kernel(const half_t* __restri
 
 // Last-layer pruning (only token 0 of each issue report reaches the pooler, model_memory.py:99): gather the
 // [CLS] rows of the fp32 stream and of the fp16 GEMM operand into compact [B][768] buffers.  With `stats` the
-// stream holds raw (pre-LN) rows and is normalised here (same operations as ln_row_store).
+// stream holds raw (pre-LN) rows and is normalised here (same operations as ln_row_store); vstats != 0: `stats` holds
+// the rows' vstats (virtual LayerNorm) instead of (mean, rstd).
 __global__ __launch_bounds__(256) void cls_gather_kernel(const float* __restrict__ x32, const half_t* __restrict__ x16, int Sp,
                                                          int B, const float* __restrict__ stats,
                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
                                                          float* __restrict__ c32, half_t* __restrict__ c16, int raw16,
-                                                         const half_t* __restrict__ xlo) {
+                                                         const half_t* __restrict__ xlo, int vstats, float eps) {
 #pragma clang fp contract(off)
   const int lane = threadIdx.x & 63;
   const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (b >= B) return;
   const size_t t = (size_t)b * Sp;
   float mean = 0.f, rstd = 1.f;
-  if (stats) { mean = stats[2 * t]; rstd = stats[2 * t + 1]; }
+  if (stats && vstats) {
+    const float2* p = (const float2*)(stats + 6 * t);
+    const float2 st = ln_from_partials(p[0], p[1], p[2], eps);
+    mean = st.x; rstd = st.y;
+  } else if (stats) {
+    mean = stats[2 * t]; rstd = stats[2 * t + 1];
+  }
 #pragma unroll
   for (int i = 0; i < 3; ++i) {
     const int c = 4 * lane + 256 * i;
