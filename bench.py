@@ -38,21 +38,21 @@ GEMM_CLASSES = ("gemm_qkv", "gemm_attn_out", "gemm_ffn1_gelu", "gemm_ffn2")
 # HBM bytes per launch of each GEMM class at the default workload from the separate rocprofv3 --pmc passes kept
 # under profiles/ (FETCH_SIZE x 2 per the gfx950 correction + WRITE_SIZE); None where no pass has been taken
 PMC_TRAFFIC_BYTES = {
-    # profiles/r02_c_cfg2_pmc_hbm.txt (= r01_k / r01_m, identical counts; KiB per dispatch): FETCH_SIZE x 2 + WRITE_SIZE
-    "gemm_ffn1_gelu": int((2 * 2.230e5 + 3.901e5) * 1024),                          # gemm_pp<PP_GELU, RAW>
-    "gemm_ffn2": int((2 * 3.640e5 + 2.022e5) * 1024),                               # gemm_pp<PP_RESLN3> [long]
-    "gemm_attn_out": int((2 * 1.670e5 + 2.024e5) * 1024),                           # gemm_pp<PP_RESLN3> [short]
-    "gemm_qkv": int((2 * (1.295e5 + 6.906e4) + (1.870e5 + 1.088e5)) * 1024),        # gemm_pp<PP_QK, RAW> + <PP_VT, RAW>
+    # profiles/r02_j_cfg2_pmc_hbm.txt (KiB per dispatch): FETCH_SIZE x 2 + WRITE_SIZE
+    "gemm_ffn1_gelu": int((2 * 2.247e5 + 3.901e5) * 1024),                          # gemm_pp<PP_GELU, RAW>
+    "gemm_ffn2": int((2 * 3.646e5 + 1.974e5) * 1024),                               # gemm_pp<PP_RESLN3> [long]
+    "gemm_attn_out": int((2 * 1.677e5 + 1.977e5) * 1024),                           # gemm_pp<PP_RESLN3> [short]
+    "gemm_qkv": int((2 * 1.971e5 + 2.887e5) * 1024),                                # gemm_pp<PP_QK, RAW>: Q, K and V^T in one launch
 }
 
 
 # Matrix-pipe busy fraction and effective shader clock of each GEMM class from the SQ / GRBM counter pass of the same command
-# (profiles/r02_c_cfg2_pmc_sq_grbm.txt: SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8), GRBM_GUI_ACTIVE / 8 / wall)
+# (profiles/r02_j_cfg2_pmc_sq_grbm.txt: SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8), GRBM_GUI_ACTIVE / 8 / wall)
 PMC_MFMA = {
-    "gemm_ffn1_gelu": {"mfma_busy_frac": 0.4893, "effective_clock_ghz": 1.811},
-    "gemm_ffn2": {"mfma_busy_frac": 0.4863, "effective_clock_ghz": 1.839},
-    "gemm_attn_out": {"mfma_busy_frac": 0.2300, "effective_clock_ghz": 2.168},
-    "gemm_qkv": {"mfma_busy_frac": 0.4960, "effective_clock_ghz": 1.92},  # Q,K launch 51.9 % @ 1.883 + V^T launch 45.5 % @ 1.997, time-weighted
+    "gemm_ffn1_gelu": {"mfma_busy_frac": 0.5070, "effective_clock_ghz": 1.740},
+    "gemm_ffn2": {"mfma_busy_frac": 0.4880, "effective_clock_ghz": 1.781},
+    "gemm_attn_out": {"mfma_busy_frac": 0.2283, "effective_clock_ghz": 2.099},
+    "gemm_qkv": {"mfma_busy_frac": 0.5505, "effective_clock_ghz": 1.777},  # Q, K and V^T in one launch
 }
 
 
@@ -250,7 +250,7 @@ def main():
         out["roofline"] = {"kernel": dom, "bound": "mfma", "achieved": round(achieved, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                            "frac": round(achieved / MFMA_PEAK_TFLOPS, 4), "traffic": PMC_TRAFFIC_BYTES.get(dom),
                            "flops_per_launch": gemm_flops(dom, M), "avg_launch_us": round(avg_us, 2), "launches_timed": n,
-                           **PMC_MFMA.get(dom, {}), "pmc_source": "profiles/r02_c_cfg2_pmc_sq_grbm.txt (rocprofv3 --pmc, same command, separate pass)",
+                           **PMC_MFMA.get(dom, {}), "pmc_source": "profiles/r02_j_cfg2_pmc_sq_grbm.txt (rocprofv3 --pmc, same command, separate pass)",
                            "note": "HIP events around this kernel class over a pass of the same K steps with ONE batch in flight "
                                    "(`value` runs two: a launch's span then includes time shared with the other batch's kernels)"}
         out["value_one_batch_in_flight"] = round(world * single_rate, 2)
