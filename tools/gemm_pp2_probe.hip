@@ -1,0 +1,229 @@
+// Development probe (not part of the product library): does a TWO-workgroups-per-CU persistent GEMM keep the main-loop rate of
+// gemm_pp while its tile phases (accumulator init / epilogue: HBM at ~25 GB/s per CU, matrix pipes idle) overlap the other
+// workgroup's main loop?  gemm_pp runs ONE 8-wave workgroup per CU (256 x 256 tile, 128 KB operand ring): 19 - 43 % of a tile's
+// time is outside the main loop and every attempt to overlap it inside one workgroup failed for lack of LDS.
+//
+// gemm_pp2 (prototype): 256 threads = 4 waves, tile 128 (M) x 256 (N), wave w -> columns 64 w .. + 63 of all 128 rows (the same
+// 128 x 64 wave tile as gemm_pp: 128 accumulator VGPRs, 12 ds_read_b128 per 16 MFMAs); K step 32: a stage = A [128][64 B] +
+// W [256][64 B] = 24 KB, three stages = 72 KB -> two workgroups per CU; one barrier per K step (16 MFMAs per wave); LDS-DMA
+// staging with the bank swizzle on the per-lane source address (16-B chunk c of row r at slot c ^ ((r >> 2) & 3)).
+// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/gemm_pp2_probe.hip -o tools/gemm_pp2_probe
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "../memvul_amd/csrc/gemm.h"
+#include "../memvul_amd/csrc/gemm_pp.h"
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "HIP error %s: %s\n", #x, hipGetErrorString(e_)); exit(2); } } while (0)
+
+#define PP2_STAGE 24576
+#define PP2_NSTG 3
+#define PP2_LDS (PP2_NSTG * PP2_STAGE)
+
+// EPI 0: no stores (main loop alone); 1: out16 = fp16(A W^T + bias), row-per-lane stores (16 B pieces)
+template <int EPI>
+__global__ __launch_bounds__(256, 2) void gemm_pp2_kernel(GemmArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int hi = lane >> 5, l31 = lane & 31;
+  const int K = a.K, nk = K >> 5;
+  const int tm_count = a.M >> 7, tn_count = a.N >> 8;
+  const int ntiles = tm_count * tn_count;
+  const int G = gridDim.x;
+  const int bslot = xcd_remap(blockIdx.x, G);
+  if (bslot >= ntiles) return;
+
+  // ---- staging: a stage = 24 pieces of 1 KiB (16 rows x 64 B): 0..7 A rows 16 p.., 8..23 W rows 16 (p - 8)..; wave w issues
+  // pieces w, w + 4, .., w + 20.  Lane L of a piece lands at +16 L: row L >> 2, slot L & 3 -> source chunk slot ^ ((row >> 2) & 3)
+  const uint32_t lane_src = (uint32_t)((lane >> 2) * K * 2 + (((lane & 3) ^ ((lane >> 4) & 3)) << 4));
+  int i_it = 0, i_k = 0;  // issue cursor: tile iteration and K step
+  const char *iA = nullptr, *iW = nullptr;
+  auto set_issue_tile = [&](int it) {
+    const int L = it * G + bslot;
+    if (L < ntiles) {
+      int tm, tn;
+      raster(L, tm_count, tn_count, a.GN, tm, tn);
+      iA = (const char*)a.A + (size_t)tm * 128 * K * 2;
+      iW = (const char*)a.W + (size_t)tn * 256 * K * 2;
+    }
+  };
+  set_issue_tile(0);
+  auto issue_stage = [&](int stg) {
+    char* dst = smem + stg * PP2_STAGE;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      const int p = wave + 4 * i;  // wave-uniform
+      const char* src = (p < 8 ? iA + (size_t)(16 * p) * K * 2 : iW + (size_t)(16 * (p - 8)) * K * 2) + i_k * 64 + lane_src;
+      glds16((const half_t*)src, dst + p * 1024);
+    }
+    if (++i_k == nk) { i_k = 0; set_issue_tile(++i_it); }
+  };
+
+  // ---- fragment read offsets inside a stage (A at +0, W at +8192)
+  uint32_t offA[2], offW[2];
+#pragma unroll
+  for (int kk = 0; kk < 2; ++kk) {
+    const uint32_t c = (uint32_t)(((2 * kk + hi) ^ ((l31 >> 2) & 3)) << 4);
+    offA[kk] = (uint32_t)(l31 * 64) + c;
+    offW[kk] = 8192u + (uint32_t)((64 * wave + l31) * 64) + c;
+  }
+
+  // total K steps of this workgroup
+  int my_tiles = 0;
+  for (int L = bslot; L < ntiles; L += G) ++my_tiles;
+  const int total = my_tiles * nk;
+  issue_stage(0);
+  if (total > 1) issue_stage(1);
+
+  floatx16 acc[4][2];
+  int g = 0;
+  for (int it = 0; it < my_tiles; ++it) {
+    const int L = it * G + bslot;
+    int tile_m, tile_n;
+    raster(L, tm_count, tn_count, a.GN, tile_m, tile_n);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    for (int k = 0; k < nk; ++k, ++g) {
+      // stage g has landed for this wave once at most the 6 pieces of stage g + 1 are outstanding
+      if (g + 1 < total) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();  // ... for every wave; and every wave has left stage g - 1 (= the slot of stage g + 2)
+      __builtin_amdgcn_sched_barrier(0);
+      if (g + 2 < total) issue_stage((g + 2) % PP2_NSTG);
+      const char* sb = smem + (g % PP2_NSTG) * PP2_STAGE;
+      half8_t Af[4][2], Wf[2][2];
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) Wf[j][kk] = *(const half8_t*)(sb + offW[kk] + j * 2048);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) Af[i][kk] = *(const half8_t*)(sb + offA[kk] + i * 2048);
+      }
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Wf[j][kk], Af[i][kk], acc[i][j], 0, 0, 0);
+      __builtin_amdgcn_s_setprio(0);
+    }
+    // ---- epilogue
+    if constexpr (EPI == 1) {
+      const int mw = tile_m << 7, nw = (tile_n << 8) + wave * 64;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        float4 bv[4];
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) bv[gq] = *(const float4*)(a.bias + nw + 32 * j + 8 * gq + 4 * hi);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          half_t* rowptr = a.out16 + (size_t)(mw + i * 32 + l31) * a.N + nw + 32 * j;
+#pragma unroll
+          for (int gq = 0; gq < 4; ++gq) {
+            half4_t h;
+            h[0] = (half_t)(acc[i][j][4 * gq + 0] + bv[gq].x); h[1] = (half_t)(acc[i][j][4 * gq + 1] + bv[gq].y);
+            h[2] = (half_t)(acc[i][j][4 * gq + 2] + bv[gq].z); h[3] = (half_t)(acc[i][j][4 * gq + 3] + bv[gq].w);
+            *(half4_t*)(rowptr + 8 * gq + 4 * hi) = h;
+          }
+        }
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) keep_live(acc[i][j]);
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+__device__ __forceinline__ uint32_t hash32(uint32_t x) { x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16; return x; }
+__global__ void fill_h(half_t* p, size_t n, uint32_t seed, float scale) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+    p[i] = (half_t)(((hash32((uint32_t)i * 2654435761u + seed) >> 8) * (2.0f / 16777216.0f) - 1.0f) * scale);
+}
+__global__ void fill_f(float* p, size_t n, uint32_t seed, float scale) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+    p[i] = ((hash32((uint32_t)i * 2654435761u + seed) >> 8) * (2.0f / 16777216.0f) - 1.0f) * scale;
+}
+__global__ void cmp_h(const half_t* x, const half_t* y, size_t n, unsigned* maxbits, unsigned long long* bad) {
+  float mx = 0.f; unsigned long long nb = 0;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const float d = fabsf((float)x[i] - (float)y[i]);
+    if (!(d <= 1e-3f * fmaxf(1.f, fabsf((float)x[i])))) nb++;
+    mx = fmaxf(mx, d == d ? d : 1e30f);
+  }
+  atomicMax(maxbits, __float_as_uint(mx));
+  if (nb) atomicAdd(bad, nb);
+}
+
+static int choose_gn(int tn, int gn_max) { int g = 1; for (int d = 1; d <= gn_max && d <= tn; ++d) if (tn % d == 0) g = d; return g; }
+
+int main() {
+  const int M = 65536;
+  half_t *A, *W, *o1, *o2; float* bias; unsigned* mb; unsigned long long* bad;
+  CK(hipMalloc(&A, (size_t)M * 3072 * 2)); CK(hipMalloc(&W, (size_t)3072 * 3072 * 2)); CK(hipMalloc(&o1, (size_t)M * 3072 * 2)); CK(hipMalloc(&o2, (size_t)M * 3072 * 2));
+  CK(hipMalloc(&bias, 3072 * 4)); CK(hipMalloc(&mb, 4)); CK(hipMalloc(&bad, 8));
+  hipLaunchKernelGGL(fill_h, dim3(4096), dim3(256), 0, 0, A, (size_t)M * 3072, 1u, 1.0f);
+  hipLaunchKernelGGL(fill_h, dim3(4096), dim3(256), 0, 0, W, (size_t)3072 * 3072, 2u, 0.05f);
+  hipLaunchKernelGGL(fill_f, dim3(16), dim3(256), 0, 0, bias, (size_t)3072, 3u, 0.5f);
+  CK(hipDeviceSynchronize());
+  int ncu = 256;
+  { hipDeviceProp_t p; CK(hipGetDeviceProperties(&p, 0)); ncu = p.multiProcessorCount; }
+  auto k_ref = gemm_pp_kernel<PP_F16, 4, 0, 1, 1>;
+  auto k_ref_noepi = gemm_pp_kernel<PP_F16, 4, PP_ABL_NOEPI, 1, 1>;
+  CK(hipFuncSetAttribute((const void*)k_ref, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS_BYTES));
+  CK(hipFuncSetAttribute((const void*)k_ref_noepi, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS_BYTES));
+  CK(hipFuncSetAttribute((const void*)gemm_pp2_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, PP2_LDS));
+  CK(hipFuncSetAttribute((const void*)gemm_pp2_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, PP2_LDS));
+  { int nb = 0; CK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, gemm_pp2_kernel<1>, 256, PP2_LDS)); printf("gemm_pp2: %d workgroups per CU (occupancy query)\n", nb); }
+  struct Shape { const char* name; int N, K; };
+  const Shape shapes[] = {{"FFN-1 (N 3072, K 768)", 3072, 768}, {"QKV (N 2304, K 768)", 2304, 768}, {"FFN-2 (N 768, K 3072)", 768, 3072}, {"out-proj (N 768, K 768)", 768, 768}};
+  hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  for (const Shape& s : shapes) {
+    GemmArgs a{};
+    a.A = A; a.W = W; a.bias = bias; a.M = M; a.Mreal = M; a.N = s.N; a.K = s.K;
+    GemmArgs r = a; r.out16 = o1; r.GN = choose_gn(s.N / 256, 4);
+    GemmArgs n = a; n.out16 = o2; n.GN = choose_gn(s.N / 256, 4);
+    const int tiles_ref = (M / 256) * (s.N / 256), tiles_new = (M / 128) * (s.N / 256);
+    auto run_ref = [&](bool epi) { hipLaunchKernelGGL(epi ? k_ref : k_ref_noepi, dim3(std::min(tiles_ref, ncu)), dim3(512), PP_LDS_BYTES, 0, r); };
+    auto run_new = [&](bool epi) {
+      if (epi) hipLaunchKernelGGL(gemm_pp2_kernel<1>, dim3(std::min(tiles_new, 2 * ncu)), dim3(256), PP2_LDS, 0, n);
+      else hipLaunchKernelGGL(gemm_pp2_kernel<0>, dim3(std::min(tiles_new, 2 * ncu)), dim3(256), PP2_LDS, 0, n);
+    };
+    CK(hipMemset(o1, 0, (size_t)M * s.N * 2)); CK(hipMemset(o2, 0xff, (size_t)M * s.N * 2));
+    run_ref(true); run_new(true);
+    CK(hipDeviceSynchronize());
+    CK(hipMemset(mb, 0, 4)); CK(hipMemset(bad, 0, 8));
+    hipLaunchKernelGGL(cmp_h, dim3(2048), dim3(256), 0, 0, o1, o2, (size_t)M * s.N, mb, bad);
+    unsigned mbh; unsigned long long badh; CK(hipMemcpy(&mbh, mb, 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(&badh, bad, 8, hipMemcpyDeviceToHost));
+    float mx; memcpy(&mx, &mbh, 4);
+    printf("%-26s check: max|diff| %.3e, bad %llu %s\n", s.name, mx, badh, badh ? "FAIL" : "OK");
+    const double fl = 2.0 * M * s.N * s.K;
+    for (int which = 0; which < 4; ++which) {
+      float best = 1e9f;
+      for (int rep = 0; rep < 4; ++rep) {
+        CK(hipEventRecord(e0, 0));
+        for (int i = 0; i < 5; ++i) { if (which == 0) run_ref(true); else if (which == 1) run_ref(false); else if (which == 2) run_new(true); else run_new(false); }
+        CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
+        float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+        best = std::min(best, ms / 5);
+      }
+      const char* nm[] = {"gemm_pp  256x256 1 wg/CU", "gemm_pp  no epilogue", "gemm_pp2 128x256 2 wg/CU", "gemm_pp2 no epilogue"};
+      printf("   %-28s %8.1f us  %7.1f TF\n", nm[which], best * 1e3, fl / (best * 1e-3) / 1e12);
+    }
+  }
+  return 0;
+}
