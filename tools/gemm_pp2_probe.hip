@@ -6,7 +6,7 @@
 // gemm_pp2 (prototype): 256 threads = 4 waves, tile 128 (M) x 256 (N), wave w -> columns 64 w .. + 63 of all 128 rows (the same
 // 128 x 64 wave tile as gemm_pp: 128 accumulator VGPRs, 12 ds_read_b128 per 16 MFMAs); K step 32: a stage = A [128][64 B] +
 // W [256][64 B] = 24 KB, three stages = 72 KB -> two workgroups per CU; one barrier per K step (16 MFMAs per wave); LDS-DMA
-// staging with the bank swizzle on the per-lane source address (16-B chunk c of row r at slot c ^ ((r >> 2) & 3)).
+// fragments register-double-buffered across the barrier; staging with the bank swizzle on the per-lane source address (16-B chunk c of row r at slot c ^ ((r >> 2) & 3)).
 // Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/gemm_pp2_probe.hip -o tools/gemm_pp2_probe
 #include <hip/hip_runtime.h>
 
@@ -78,11 +78,54 @@ __global__ __launch_bounds__(256, 2) void gemm_pp2_kernel(GemmArgs a) {
   int my_tiles = 0;
   for (int L = bslot; L < ntiles; L += G) ++my_tiles;
   const int total = my_tiles * nk;
+  // Fragments are register-double-buffered ACROSS the barrier: step g's MFMAs run on the set read during step g - 1 while
+  // the set of step g + 1 is read.  Ring: stage g + 1 (landed, being read), g + 2 and g + 3 in flight (slot of g + 3 = slot of g,
+  // whose reads ended before this step's barrier).
   issue_stage(0);
   if (total > 1) issue_stage(1);
+  if (total > 2) issue_stage(2);
+  half8_t Af[2][4][2], Wf[2][2][2];
+  auto read_frags = [&](int gstep, int set) {
+    const char* sb = smem + (gstep % PP2_NSTG) * PP2_STAGE;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j) Wf[set][j][kk] = *(const half8_t*)(sb + offW[kk] + j * 2048);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) Af[set][i][kk] = *(const half8_t*)(sb + offA[kk] + i * 2048);
+    }
+  };
+  // stage 0 landed for everyone, then its fragments
+  if (total > 2) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+  else if (total > 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_sched_barrier(0);
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_sched_barrier(0);
+  read_frags(0, 0);
 
   floatx16 acc[4][2];
   int g = 0;
+  auto step = [&](auto setc) {
+    constexpr int set = decltype(setc)::value;
+    // stage g + 1 has landed for this wave once at most the 6 pieces of stage g + 2 are outstanding
+    if (g + 2 < total) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();  // ... for every wave; and every wave has finished reading stage g
+    __builtin_amdgcn_sched_barrier(0);
+    if (g + 3 < total) issue_stage((g + 3) % PP2_NSTG);
+    if (g + 1 < total) read_frags(g + 1, set ^ 1);
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Wf[set][j][kk], Af[set][i][kk], acc[i][j], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+    ++g;
+  };
   for (int it = 0; it < my_tiles; ++it) {
     const int L = it * G + bslot;
     int tile_m, tile_n;
@@ -93,31 +136,9 @@ __global__ __launch_bounds__(256, 2) void gemm_pp2_kernel(GemmArgs a) {
       for (int j = 0; j < 2; ++j)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    for (int k = 0; k < nk; ++k, ++g) {
-      // stage g has landed for this wave once at most the 6 pieces of stage g + 1 are outstanding
-      if (g + 1 < total) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __builtin_amdgcn_sched_barrier(0);
-      __builtin_amdgcn_s_barrier();  // ... for every wave; and every wave has left stage g - 1 (= the slot of stage g + 2)
-      __builtin_amdgcn_sched_barrier(0);
-      if (g + 2 < total) issue_stage((g + 2) % PP2_NSTG);
-      const char* sb = smem + (g % PP2_NSTG) * PP2_STAGE;
-      half8_t Af[4][2], Wf[2][2];
-#pragma unroll
-      for (int kk = 0; kk < 2; ++kk) {
-#pragma unroll
-        for (int j = 0; j < 2; ++j) Wf[j][kk] = *(const half8_t*)(sb + offW[kk] + j * 2048);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) Af[i][kk] = *(const half8_t*)(sb + offA[kk] + i * 2048);
-      }
-      __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-      for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-          for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Wf[j][kk], Af[i][kk], acc[i][j], 0, 0, 0);
-      __builtin_amdgcn_s_setprio(0);
+    for (int k = 0; k < nk; k += 2) {  // nk is even (K % 64 == 0): the register sets alternate with compile-time indices
+      step(std::integral_constant<int, 0>{});
+      step(std::integral_constant<int, 1>{});
     }
     // ---- epilogue
     if constexpr (EPI == 1) {
