@@ -402,6 +402,23 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmArgs a) {
   }
 
   floatx16 acc[4][2];
+  // PP_RESLN3: the two fp16 planes of fragment pair i of the residual tile at (mw0, nw0) by full-line loads (16 rows x 64 B per
+  // instruction), parked in the accumulator registers they will be transposed into: [i][j] registers 0-3 / 4-7 = hi rows
+  // crow / crow + 16, 8-11 / 12-15 = lo
+  auto park_residual = [&](int i, int mw0, int nw0) {
+    const int crow = lane >> 2, cchunk = lane & 3;
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int pl = 0; pl < 2; ++pl)
+#pragma unroll
+        for (int x = 0; x < 2; ++x) {
+          const half_t* src = (pl ? a.out16b : a.out16) + (size_t)(mw0 + i * 32 + x * 16 + crow) * MV_HIDDEN + nw0 + j * 32 + 8 * cchunk;
+          const float4 t = *(const float4*)src;
+          acc[i][j][8 * pl + 4 * x + 0] = t.x; acc[i][j][8 * pl + 4 * x + 1] = t.y;
+          acc[i][j][8 * pl + 4 * x + 2] = t.z; acc[i][j][8 * pl + 4 * x + 3] = t.w;
+        }
+  };
   auto mma_quadrant = [&](auto asubc, auto bc, const half8_t (&Wf)[4]) {
     constexpr int asub = decltype(asubc)::value;
     constexpr int b = decltype(bc)::value;
@@ -557,11 +574,12 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmArgs a) {
     if constexpr (ABL & PP_ABL_CLK) tA = __builtin_amdgcn_s_memtime();
     int tile_m, tile_n;
     raster(L, tm_count, tn_count, a.GN, tile_m, tile_n);
-    int next_m = 0, next_n = 0;  // RAW: the workgroup's next tile (issue_stats)
-    if constexpr (RAW) {
-      if (L + G < ntiles) raster(L + G, tm_count, tn_count, a.GN, next_m, next_n);
+    int next_m = 0, next_n = 0;  // RAW: the workgroup's next tile (issue_stats); PP_RESLN3: its residual tile is requested
+    const bool has_next = L + G < ntiles;  // during this tile's epilogue
+    if constexpr (RAW || HILO) {
+      if (has_next) raster(L + G, tm_count, tn_count, a.GN, next_m, next_n);
     }
-    (void)next_m; (void)next_n;
+    (void)next_m; (void)next_n; (void)has_next;
     const int mw = (tile_m << 8) + wr * 128;  // first token row of this wave
     const int nw = (tile_n << 8) + wc * 64;   // first output column of this wave
 
@@ -613,21 +631,14 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmArgs a) {
         if constexpr (HILO) {
           // the two fp16 planes of the raw stream by full-line loads (16 rows x 64 B per instruction), parked in the
           // accumulator registers: [i][j] registers 0-3 / 4-7 = hi rows crow / crow + 16, 8-11 / 12-15 = lo
-          const int crow = lane >> 2, cchunk = lane & 3;
           const uint32_t wbase = scr + l31 * 64 + hi * 8 + (sf << 4);
+          // (tiles after the workgroup's first: the lines were requested fragment pair by fragment pair during the PREVIOUS
+          //  tile's epilogue, each as soon as its accumulator registers had been stored — park_residual below — so the read
+          //  phase of this tile runs under the write phase of the last one instead of after it)
+          if (it == 0) {
 #pragma unroll
-          for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-              for (int pl = 0; pl < 2; ++pl)
-#pragma unroll
-                for (int x = 0; x < 2; ++x) {
-                  const half_t* src = (pl ? a.out16b : a.out16) + (size_t)(mw + i * 32 + x * 16 + crow) * MV_HIDDEN + nw + j * 32 + 8 * cchunk;
-                  const float4 t = *(const float4*)src;
-                  acc[i][j][8 * pl + 4 * x + 0] = t.x; acc[i][j][8 * pl + 4 * x + 1] = t.y;
-                  acc[i][j][8 * pl + 4 * x + 2] = t.z; acc[i][j][8 * pl + 4 * x + 3] = t.w;
-                }
+            for (int i = 0; i < 4; ++i) park_residual(i, mw, nw);
+          }
           finish_stats();
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
@@ -988,6 +999,9 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmArgs a) {
               half_t* op = ol + j * jstride;
               *(u32x4*)op = o[2 * j];
               *(u32x4*)(op + 16 * rstride) = o[2 * j + 1];
+            }
+            if constexpr (HILO) {  // fragment pair i is out: request pair i of the NEXT tile's residual into its registers
+              if (has_next) park_residual(i, (next_m << 8) + wr * 128, (next_n << 8) + wc * 64);
             }
           }
         }
