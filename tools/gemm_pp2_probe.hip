@@ -170,6 +170,144 @@ __global__ __launch_bounds__(256, 2) void gemm_pp2_kernel(GemmArgs a) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// gemm_pp3 (prototype): ONE wave per SIMD with a 128 x 128 wave tile — 256 accumulator registers (the unified 512-register
+// file: hipcc puts the MFMA C/D operands in AGPRs), 4 waves = 2 (M) x 2 (N) on a 256 x 256 tile, K tile 64, two 64 KB stages
+// (as gemm_pp).  32 fragment reads per 64 MFMAs instead of 24 per 32: a third fewer LDS bytes per FLOP; the fragments of K
+// sub-step kk + 1 are read while the 16 MFMAs of sub-step kk run (the wave has nobody to hand the pipe to).
+#define PP3_STAGE 65536
+#define PP3_LDS (2 * PP3_STAGE)
+template <int EPI>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void gemm_pp3_kernel(GemmArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 1, wc = wave & 1;
+  const int hi = lane >> 5, l31 = lane & 31;
+  const int K = a.K, nk = K >> 6;
+  const int tm_count = a.M >> 8, tn_count = a.N >> 8;
+  const int ntiles = tm_count * tn_count;
+  const int G = gridDim.x;
+  const int bslot = xcd_remap(blockIdx.x, G);
+  if (bslot >= ntiles) return;
+  // staging: a stage = 64 pieces of 1 KiB (8 rows x 128 B): 0..31 A rows 8 p.., 32..63 W rows; wave w issues pieces w + 4 i.
+  // lane L: row L >> 3, slot L & 7 -> source chunk slot ^ ((row_in_tile >> 1) & 7), row_in_tile = 8 p + (L >> 3)
+  uint32_t lane_src[2];
+#pragma unroll
+  for (int x = 0; x < 2; ++x) lane_src[x] = (uint32_t)((lane >> 3) * K * 2 + (((lane & 7) ^ (((lane >> 4) + 4 * x) & 7)) << 4));
+  int i_it = 0, i_k = 0;
+  const char *iA = nullptr, *iW = nullptr;
+  auto set_issue_tile = [&](int it) {
+    const int L = it * G + bslot;
+    if (L < ntiles) {
+      int tm, tn;
+      raster(L, tm_count, tn_count, a.GN, tm, tn);
+      iA = (const char*)a.A + (size_t)tm * 256 * K * 2;
+      iW = (const char*)a.W + (size_t)tn * 256 * K * 2;
+    }
+  };
+  set_issue_tile(0);
+  auto issue_stage = [&](int stg) {
+    char* dst = smem + stg * PP3_STAGE;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int p = wave + 4 * i;  // piece parity = wave parity
+      const char* src = (p < 32 ? iA + (size_t)(8 * p) * K * 2 : iW + (size_t)(8 * (p - 32)) * K * 2) + i_k * 128;
+      glds16((const half_t*)(src + ((wave & 1) ? lane_src[1] : lane_src[0])), dst + p * 1024);
+    }
+    if (++i_k == nk) { i_k = 0; set_issue_tile(++i_it); }
+  };
+  const uint32_t swz = (uint32_t)((l31 >> 1) & 7);
+  const uint32_t rowA = (uint32_t)((wr * 128 + l31) * 128), rowW = 32768u + (uint32_t)((wc * 128 + l31) * 128);
+  int my_tiles = 0;
+  for (int L = bslot; L < ntiles; L += G) ++my_tiles;
+  const int total = my_tiles * nk;
+  issue_stage(0);
+  floatx16 acc[4][4];
+  int g = 0;
+  for (int it = 0; it < my_tiles; ++it) {
+    const int L = it * G + bslot;
+    int tile_m, tile_n;
+    raster(L, tm_count, tn_count, a.GN, tile_m, tile_n);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    for (int k = 0; k < nk; ++k, ++g) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // K tile g has landed for this wave (the only thing in flight)
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();  // ... for every wave; and every wave has left K tile g - 1 (the slot of g + 1)
+      __builtin_amdgcn_sched_barrier(0);
+      if (g + 1 < total) issue_stage((g + 1) & 1);
+      const char* sb = smem + (g & 1) * PP3_STAGE;
+      // Fragment reads as inline asm with their waits placed by hand: hipcc's own schedule reads one fragment, waits for it
+      // and issues four MFMAs, sixteen times per K tile — with one wave per SIMD every one of those waits is exposed.  Here the
+      // eight reads of sub-step kk + 1 are issued, then `lgkmcnt(8)` (LDS returns in order: sub-step kk's eight are in) and
+      // only then the sixteen MFMAs of sub-step kk run, under which the newer reads complete.
+      half8_t Af[2][4], Wf[2][4];
+      const uint32_t sbo = (uint32_t)((g & 1) * PP3_STAGE);
+#define PP3_READ(KK, SET, TAIL)                                                                                          \
+  {                                                                                                                      \
+    const uint32_t c = (((uint32_t)(2 * (KK) + hi)) ^ swz) << 4;                                                         \
+    const uint32_t aa = sbo + rowA + c, ww = sbo + rowW + c;                                                             \
+    asm volatile("ds_read_b128 %0, %8\n\tds_read_b128 %1, %8 offset:4096\n\tds_read_b128 %2, %8 offset:8192\n\t"          \
+                 "ds_read_b128 %3, %8 offset:12288\n\tds_read_b128 %4, %9\n\tds_read_b128 %5, %9 offset:4096\n\t"         \
+                 "ds_read_b128 %6, %9 offset:8192\n\tds_read_b128 %7, %9 offset:12288\n\t" TAIL                          \
+                 : "=&v"(Af[SET][0]), "=&v"(Af[SET][1]), "=&v"(Af[SET][2]), "=&v"(Af[SET][3]), "=&v"(Wf[SET][0]),         \
+                   "=&v"(Wf[SET][1]), "=&v"(Wf[SET][2]), "=&v"(Wf[SET][3])                                                \
+                 : "v"(aa), "v"(ww)                                                                                      \
+                 : "memory");                                                                                            \
+    __builtin_amdgcn_sched_barrier(0);                                                                                   \
+  }
+#define PP3_MMA(SET)                                                                                                     \
+  _Pragma("unroll") for (int i = 0; i < 4; ++i) _Pragma("unroll") for (int j = 0; j < 4; ++j)                            \
+      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Wf[SET][j], Af[SET][i], acc[i][j], 0, 0, 0);                     \
+  __builtin_amdgcn_sched_barrier(0);
+      PP3_READ(0, 0, "")
+      PP3_READ(1, 1, "s_waitcnt lgkmcnt(8)")
+      PP3_MMA(0)
+      PP3_READ(2, 0, "s_waitcnt lgkmcnt(8)")
+      PP3_MMA(1)
+      PP3_READ(3, 1, "s_waitcnt lgkmcnt(8)")
+      PP3_MMA(0)
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      PP3_MMA(1)
+#undef PP3_READ
+#undef PP3_MMA
+    }
+    if constexpr (EPI == 1) {
+      const int mw = (tile_m << 8) + wr * 128, nw = (tile_n << 8) + wc * 128;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float4 bv[4];
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) bv[gq] = *(const float4*)(a.bias + nw + 32 * j + 8 * gq + 4 * hi);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          half_t* rowptr = a.out16 + (size_t)(mw + i * 32 + l31) * a.N + nw + 32 * j;
+#pragma unroll
+          for (int gq = 0; gq < 4; ++gq) {
+            half4_t h;
+            h[0] = (half_t)(acc[i][j][4 * gq + 0] + bv[gq].x); h[1] = (half_t)(acc[i][j][4 * gq + 1] + bv[gq].y);
+            h[2] = (half_t)(acc[i][j][4 * gq + 2] + bv[gq].z); h[3] = (half_t)(acc[i][j][4 * gq + 3] + bv[gq].w);
+            *(half4_t*)(rowptr + 8 * gq + 4 * hi) = h;
+          }
+        }
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) keep_live(acc[i][j]);
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
 __device__ __forceinline__ uint32_t hash32(uint32_t x) { x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16; return x; }
 __global__ void fill_h(half_t* p, size_t n, uint32_t seed, float scale) {
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
@@ -209,6 +347,8 @@ int main() {
   CK(hipFuncSetAttribute((const void*)k_ref_noepi, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS_BYTES));
   CK(hipFuncSetAttribute((const void*)gemm_pp2_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, PP2_LDS));
   CK(hipFuncSetAttribute((const void*)gemm_pp2_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, PP2_LDS));
+  CK(hipFuncSetAttribute((const void*)gemm_pp3_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, PP3_LDS));
+  CK(hipFuncSetAttribute((const void*)gemm_pp3_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, PP3_LDS));
   { int nb = 0; CK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, gemm_pp2_kernel<1>, 256, PP2_LDS)); printf("gemm_pp2: %d workgroups per CU (occupancy query)\n", nb); }
   struct Shape { const char* name; int N, K; };
   const Shape shapes[] = {{"FFN-1 (N 3072, K 768)", 3072, 768}, {"QKV (N 2304, K 768)", 2304, 768}, {"FFN-2 (N 768, K 3072)", 768, 3072}, {"out-proj (N 768, K 768)", 768, 768}};
@@ -224,6 +364,20 @@ int main() {
       if (epi) hipLaunchKernelGGL(gemm_pp2_kernel<1>, dim3(std::min(tiles_new, 2 * ncu)), dim3(256), PP2_LDS, 0, n);
       else hipLaunchKernelGGL(gemm_pp2_kernel<0>, dim3(std::min(tiles_new, 2 * ncu)), dim3(256), PP2_LDS, 0, n);
     };
+    auto run_pp3 = [&](bool epi) {
+      if (epi) hipLaunchKernelGGL(gemm_pp3_kernel<1>, dim3(std::min(tiles_ref, ncu)), dim3(256), PP3_LDS, 0, n);
+      else hipLaunchKernelGGL(gemm_pp3_kernel<0>, dim3(std::min(tiles_ref, ncu)), dim3(256), PP3_LDS, 0, n);
+    };
+    {  // gemm_pp3 against the reference first
+      CK(hipMemset(o1, 0, (size_t)M * s.N * 2)); CK(hipMemset(o2, 0xff, (size_t)M * s.N * 2));
+      run_ref(true); run_pp3(true);
+      CK(hipDeviceSynchronize());
+      CK(hipMemset(mb, 0, 4)); CK(hipMemset(bad, 0, 8));
+      hipLaunchKernelGGL(cmp_h, dim3(2048), dim3(256), 0, 0, o1, o2, (size_t)M * s.N, mb, bad);
+      unsigned mbh; unsigned long long badh; CK(hipMemcpy(&mbh, mb, 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(&badh, bad, 8, hipMemcpyDeviceToHost));
+      float mx; memcpy(&mx, &mbh, 4);
+      printf("%-26s gemm_pp3 check: max|diff| %.3e, bad %llu %s\n", s.name, mx, badh, badh ? "FAIL" : "OK");
+    }
     CK(hipMemset(o1, 0, (size_t)M * s.N * 2)); CK(hipMemset(o2, 0xff, (size_t)M * s.N * 2));
     run_ref(true); run_new(true);
     CK(hipDeviceSynchronize());
@@ -233,16 +387,16 @@ int main() {
     float mx; memcpy(&mx, &mbh, 4);
     printf("%-26s check: max|diff| %.3e, bad %llu %s\n", s.name, mx, badh, badh ? "FAIL" : "OK");
     const double fl = 2.0 * M * s.N * s.K;
-    for (int which = 0; which < 4; ++which) {
+    for (int which = 0; which < 6; ++which) {
       float best = 1e9f;
       for (int rep = 0; rep < 4; ++rep) {
         CK(hipEventRecord(e0, 0));
-        for (int i = 0; i < 5; ++i) { if (which == 0) run_ref(true); else if (which == 1) run_ref(false); else if (which == 2) run_new(true); else run_new(false); }
+        for (int i = 0; i < 5; ++i) { if (which == 0) run_ref(true); else if (which == 1) run_ref(false); else if (which == 2) run_new(true); else if (which == 3) run_new(false); else if (which == 4) run_pp3(true); else run_pp3(false); }
         CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
         float ms; CK(hipEventElapsedTime(&ms, e0, e1));
         best = std::min(best, ms / 5);
       }
-      const char* nm[] = {"gemm_pp  256x256 1 wg/CU", "gemm_pp  no epilogue", "gemm_pp2 128x256 2 wg/CU", "gemm_pp2 no epilogue"};
+      const char* nm[] = {"gemm_pp  256x256 1 wg/CU", "gemm_pp  no epilogue", "gemm_pp2 128x256 2 wg/CU", "gemm_pp2 no epilogue", "gemm_pp3 128x128 wave tile", "gemm_pp3 no epilogue"};
       printf("   %-28s %8.1f us  %7.1f TF\n", nm[which], best * 1e3, fl / (best * 1e-3) / 1e12);
     }
   }
