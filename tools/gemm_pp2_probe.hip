@@ -176,6 +176,15 @@ __global__ __launch_bounds__(256, 2) void gemm_pp2_kernel(GemmArgs a) {
 // file: hipcc puts the MFMA C/D operands in AGPRs), 4 waves = 2 (M) x 2 (N) on a 256 x 256 tile, K tile 64, two 64 KB stages
 // (as gemm_pp).  32 fragment reads per 64 MFMAs instead of 24 per 32: a third fewer LDS bytes per FLOP; the fragments of K
 // sub-step kk + 1 are read while the 16 MFMAs of sub-step kk run (the wave has nobody to hand the pipe to).
+// Measured variants of this pipeline (main loop alone, FFN-1 / QKV / FFN-2 / output-projection shapes):
+//   this form (vmcnt(0) + barrier at the K-tile boundary, one K tile in flight)                         1.00 - 1.08 PF
+//   arrival barrier moved before the last sub-step + first fragments of the next K tile read under it    0.95 - 1.02 PF
+//   four-deep ring of half-K sub-stages with 64-byte rows (prefetch distance 3, barrier mid sub-step)    0.83 - 0.89 PF
+//     (half-line DMA rows double the vector-memory requests; gemm_pp2 above shares that layout)
+// i.e. the K-tile boundary bubble is not what holds it back; with two 64 KB stages only ONE K tile (64 KB per CU) can be in
+// flight for the ~1.1 us of a step, which is exactly the demand at 1.2 PF (58 GB/s per CU) with no slack — gemm_pp keeps the
+// same 64 KB in flight but in 16 KB half-tiles issued every interval.  Next: stage units of 16 KB (A / W half-tiles, as
+// gemm_pp) in a 10-unit ring (2.5 K tiles) so that 1.5 K tiles are in flight.
 #define PP3_STAGE 65536
 #define PP3_LDS (2 * PP3_STAGE)
 template <int EPI>
