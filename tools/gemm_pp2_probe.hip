@@ -181,6 +181,9 @@ __global__ __launch_bounds__(256, 2) void gemm_pp2_kernel(GemmArgs a) {
 //   arrival barrier moved before the last sub-step + first fragments of the next K tile read under it    0.95 - 1.02 PF
 //   four-deep ring of half-K sub-stages with 64-byte rows (prefetch distance 3, barrier mid sub-step)    0.83 - 0.89 PF
 //     (half-line DMA rows double the vector-memory requests; gemm_pp2 above shares that layout)
+// Timing ablations of this form (EPI 2 / 3): without the operand DMA the same loop runs at 1.31 - 1.44 PF; with the DMA issued but
+// never waited for it is back at the shipped 1.00 - 1.13 PF — neither the wait nor the latency costs the 25 %, the LDS-DMA WRITES
+// do (64 KB per K tile at the LDS's 64 - 85 B/clk store rate = ~40 % of the LDS's cycles, shared with the fragment reads).
 // i.e. the K-tile boundary bubble is not what holds it back; with two 64 KB stages only ONE K tile (64 KB per CU) can be in
 // flight for the ~1.1 us of a step, which is exactly the demand at 1.2 PF (58 GB/s per CU) with no slack — gemm_pp keeps the
 // same 64 KB in flight but in 16 KB half-tiles issued every interval.  Next: stage units of 16 KB (A / W half-tiles, as
@@ -246,11 +249,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
     for (int k = 0; k < nk; ++k, ++g) {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // K tile g has landed for this wave (the only thing in flight)
+      if (EPI != 3) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // K tile g has landed for this wave (the only thing in flight)
+      else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");          // EPI 3 (timing ablation, wrong results): the DMA is issued but a whole extra K tile may stay in flight
       __builtin_amdgcn_sched_barrier(0);
       __builtin_amdgcn_s_barrier();  // ... for every wave; and every wave has left K tile g - 1 (the slot of g + 1)
       __builtin_amdgcn_sched_barrier(0);
-      if (g + 1 < total) issue_stage((g + 1) & 1);
+      if (EPI != 2 && g + 1 < total) issue_stage((g + 1) & 1);  // EPI 2 (timing ablation, wrong results): no operand DMA after the first tile
       const char* sb = smem + (g & 1) * PP3_STAGE;
       // Fragment reads as inline asm with their waits placed by hand: hipcc's own schedule reads one fragment, waits for it
       // and issues four MFMAs, sixteen times per K tile — with one wave per SIMD every one of those waits is exposed.  Here the
@@ -358,6 +362,8 @@ int main() {
   CK(hipFuncSetAttribute((const void*)gemm_pp2_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, PP2_LDS));
   CK(hipFuncSetAttribute((const void*)gemm_pp3_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, PP3_LDS));
   CK(hipFuncSetAttribute((const void*)gemm_pp3_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, PP3_LDS));
+  CK(hipFuncSetAttribute((const void*)gemm_pp3_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, PP3_LDS));
+  CK(hipFuncSetAttribute((const void*)gemm_pp3_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, PP3_LDS));
   { int nb = 0; CK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, gemm_pp2_kernel<1>, 256, PP2_LDS)); printf("gemm_pp2: %d workgroups per CU (occupancy query)\n", nb); }
   struct Shape { const char* name; int N, K; };
   const Shape shapes[] = {{"FFN-1 (N 3072, K 768)", 3072, 768}, {"QKV (N 2304, K 768)", 2304, 768}, {"FFN-2 (N 768, K 3072)", 768, 3072}, {"out-proj (N 768, K 768)", 768, 768}};
@@ -396,16 +402,16 @@ int main() {
     float mx; memcpy(&mx, &mbh, 4);
     printf("%-26s check: max|diff| %.3e, bad %llu %s\n", s.name, mx, badh, badh ? "FAIL" : "OK");
     const double fl = 2.0 * M * s.N * s.K;
-    for (int which = 0; which < 6; ++which) {
+    for (int which = 0; which < 8; ++which) {
       float best = 1e9f;
       for (int rep = 0; rep < 4; ++rep) {
         CK(hipEventRecord(e0, 0));
-        for (int i = 0; i < 5; ++i) { if (which == 0) run_ref(true); else if (which == 1) run_ref(false); else if (which == 2) run_new(true); else if (which == 3) run_new(false); else if (which == 4) run_pp3(true); else run_pp3(false); }
+        for (int i = 0; i < 5; ++i) { if (which == 0) run_ref(true); else if (which == 1) run_ref(false); else if (which == 2) run_new(true); else if (which == 3) run_new(false); else if (which == 4) run_pp3(true); else if (which == 5) run_pp3(false); else if (which == 6) hipLaunchKernelGGL(gemm_pp3_kernel<2>, dim3(std::min(tiles_ref, ncu)), dim3(256), PP3_LDS, 0, n); else hipLaunchKernelGGL(gemm_pp3_kernel<3>, dim3(std::min(tiles_ref, ncu)), dim3(256), PP3_LDS, 0, n); }
         CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
         float ms; CK(hipEventElapsedTime(&ms, e0, e1));
         best = std::min(best, ms / 5);
       }
-      const char* nm[] = {"gemm_pp  256x256 1 wg/CU", "gemm_pp  no epilogue", "gemm_pp2 128x256 2 wg/CU", "gemm_pp2 no epilogue", "gemm_pp3 128x128 wave tile", "gemm_pp3 no epilogue"};
+      const char* nm[] = {"gemm_pp  256x256 1 wg/CU", "gemm_pp  no epilogue", "gemm_pp2 128x256 2 wg/CU", "gemm_pp2 no epilogue", "gemm_pp3 128x128 wave tile", "gemm_pp3 no epilogue", "gemm_pp3 no epi, no DMA", "gemm_pp3 no epi, late wait"};
       printf("   %-28s %8.1f us  %7.1f TF\n", nm[which], best * 1e3, fl / (best * 1e-3) / 1e12);
     }
   }
