@@ -109,9 +109,13 @@ def main():
     multi = world > 1
     # development check of the N > 1 control flow on a ONE-GPU box (not a measurement): every rank shares device 0 and the
     # exchange runs over gloo instead of RCCL; the JSON line says so in `config.note`
-    one_gpu_smoke = multi and os.environ.get("MEMVUL_BENCH_ONE_GPU_SMOKE") == "1"
+    smoke_mode = os.environ.get("MEMVUL_BENCH_ONE_GPU_SMOKE", "")  # "1": gloo, "tcp": the socket-hub fallback transport
+    one_gpu_smoke = multi and smoke_mode in ("1", "tcp")
     if one_gpu_smoke:
-        mvdist.init_process_group("gloo")  # torch.distributed only in this development mode
+        if smoke_mode == "tcp":
+            mvdist.init_tcp(rank, world)
+        else:
+            mvdist.init_process_group("gloo")  # torch.distributed only in this development mode
         local_rank = 0
 
     B, S, G, K, W = args.batch, args.seq_len, args.anchors, args.steps, args.warmup
@@ -121,10 +125,16 @@ def main():
                  max_batch=max(B, 256), max_anchors=max(G, 1024))
     eng.load_state_dict(weights, 5 if args.compute == "f16x2" else 1)
     eng.set_streams(args.streams)
+    transport = "none (one rank)" if not multi else ("tcp hub (one-GPU smoke)" if smoke_mode == "tcp" else "gloo (one-GPU smoke)") if one_gpu_smoke else "rccl (bound in libmemvul_hip.so, engine stream)"
     if multi and not one_gpu_smoke:
         # the N > 1 transport: RCCL bound inside libmemvul_hip.so (mv_comm_*), collective on the engine's stream; this
         # process never imports torch, so there is no second HIP runtime and no load-order rule
-        mvdist.init_rccl(eng, rank, world)
+        try:
+            mvdist.init_rccl(eng, rank, world)
+        except Exception as e:  # e.g. librccl not loadable / IPC mode: the same on every rank of the node
+            sys.stderr.write(f"[bench rank {rank}] RCCL init failed ({e}); statistics exchange falls back to the TCP hub\n")
+            mvdist.init_tcp(rank, world)
+            transport = "tcp-fallback (RCCL init failed: %s)" % str(e)[:120]
 
     # anchor memory: G synthetic CWE descriptions of up to 512 tokens, built once per process (untimed;
     # predict_memory.py:81-83 forwards them in chunks of 128)
@@ -226,7 +236,7 @@ def main():
                                "seq_len=%d, batch=%d, %d-anchor CWE memory, fp16 MFMA operands + fp32 accumulate; "
                                "seeded random-init weights, synthetic token ids resident in HBM" % (dims.layers, S, B, G),
                    "global_batch": world * B, "seq_len": S, "anchors": G, "parallelism": "dp%d (corpus shards, one "
-                   "all-gather of (score,label) stats)" % world},
+                   "all-gather of (score,label) stats)" % world, "stats_transport": transport},
         # executed FLOPs (with last-layer [CLS] pruning the fraction is priced on what runs)
         "e2e_tflops_per_gpu": round(value / world * fpi_exec / 1e12, 2),
         "e2e_mfma_frac": round(value / world * fpi_exec / 1e12 / MFMA_PEAK_TFLOPS, 4),
@@ -236,7 +246,7 @@ def main():
         "stats_table_sum": int(table.sum()),
     }
     if one_gpu_smoke:
-        out["config"]["note"] = "MEMVUL_BENCH_ONE_GPU_SMOKE: all ranks share ONE GPU, exchange over gloo: control-flow check, not a measurement"
+        out["config"]["note"] = "MEMVUL_BENCH_ONE_GPU_SMOKE: all ranks share ONE GPU, exchange over %s: control-flow check, not a measurement" % ("the TCP hub" if smoke_mode == "tcp" else "gloo")
     if prof:
         kernels = {}
         for name, (ms, n) in breakdown.items():

@@ -14,6 +14,11 @@ Two transports behind the same four functions (all_gather_rows / all_gather_stat
   The collective runs on the engine's stream, the unique id travels through a file every rank of the node can reach,
   and the process never imports torch — so there is no second HIP runtime in the process and no load-order rule.
 * torch.distributed (``init_process_group``): the gloo harness of the CPU tests (world size 2 here), imported lazily.
+
+A third, ``init_tcp``, is the fallback of the RCCL one: a rank-0 socket hub that serves the same ``comm_allgather`` call with
+the launcher's MASTER_ADDR / MASTER_PORT, so that a node whose RCCL cannot be initialised (library missing, IPC mode) still
+gets its whole-job measurement — the data path has no collective, only the 8 B per issue report of statistics cross ranks.
+bench.py says which transport carried a run.
 """
 from __future__ import annotations
 
@@ -56,6 +61,93 @@ def init_rccl(engine, rank: Optional[int] = None, world: Optional[int] = None, i
     engine.comm_init(rank, world, id_path or (rccl_id_path() if world > 1 else None))
     _rccl_engine = engine
     return engine
+
+
+class _TcpComm:
+    """``comm_allgather`` over sockets: every rank sends its block to rank 0, rank 0 returns the rank-ordered stack.  Same call
+    surface as the Engine's RCCL methods (comm_world / comm_allgather / comm_destroy), torch-free."""
+
+    def __init__(self, rank: int, world: int, addr: str, port: int, timeout_s: float = 120.0):
+        import socket
+        import time
+
+        self.rank, self.comm_world = rank, world
+        self.peers = []
+        self.sock = None
+        if world <= 1:
+            return
+        if rank == 0:
+            srv = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
+            srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+            srv.bind((addr, port))
+            srv.listen(world)
+            srv.settimeout(timeout_s)
+            by_rank = {}
+            while len(by_rank) < world - 1:
+                c, _ = srv.accept()
+                c.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
+                by_rank[int.from_bytes(self._recvn(c, 4), "little")] = c
+            srv.close()
+            self.peers = [by_rank[r] for r in range(1, world)]
+        else:
+            t0 = time.time()
+            while True:
+                try:
+                    c = socket.create_connection((addr, port), timeout=5.0)
+                    break
+                except OSError:
+                    if time.time() - t0 > timeout_s:
+                        raise
+                    time.sleep(0.05)
+            c.settimeout(None)
+            c.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
+            c.sendall(int(rank).to_bytes(4, "little"))
+            self.sock = c
+
+    @staticmethod
+    def _recvn(c, n: int) -> bytes:
+        buf = bytearray()
+        while len(buf) < n:
+            part = c.recv(min(1 << 20, n - len(buf)))
+            if not part:
+                raise ConnectionError("peer closed the statistics socket")
+            buf += part
+        return bytes(buf)
+
+    def comm_allgather(self, arr: np.ndarray) -> np.ndarray:
+        arr = np.ascontiguousarray(arr)
+        if self.comm_world <= 1:
+            return arr[None].copy()
+        nb = arr.nbytes
+        if self.rank == 0:
+            blocks = [arr.tobytes()] + [self._recvn(c, nb) for c in self.peers]
+            whole = b"".join(blocks)
+            for c in self.peers:
+                c.sendall(whole)
+        else:
+            self.sock.sendall(arr.tobytes())
+            whole = self._recvn(self.sock, nb * self.comm_world)
+        return np.frombuffer(whole, arr.dtype).reshape((self.comm_world,) + arr.shape).copy()
+
+    def comm_destroy(self):
+        for c in self.peers + ([self.sock] if self.sock is not None else []):
+            try:
+                c.close()
+            except OSError:
+                pass
+        self.peers, self.sock = [], None
+
+
+def init_tcp(rank: Optional[int] = None, world: Optional[int] = None, addr: Optional[str] = None, port: Optional[int] = None):
+    """Fallback transport (see the module docstring): rank 0 listens on MASTER_ADDR : MASTER_PORT + 1."""
+    global _rccl_engine
+    r, _, w = env_world()
+    rank = r if rank is None else rank
+    world = w if world is None else world
+    addr = addr or os.environ.get("MASTER_ADDR", "127.0.0.1")
+    port = port if port is not None else int(os.environ.get("MASTER_PORT", "29500")) + 1
+    _rccl_engine = _TcpComm(rank, world, addr, port)
+    return _rccl_engine
 
 
 def shutdown_rccl():

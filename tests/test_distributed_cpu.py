@@ -81,3 +81,20 @@ def test_sharded_driver_world2_gloo_equals_single_process(tmp_path, monkeypatch)
     a = np.array([list(p["predict"].values()) for p in parts])
     b = np.array([list(s["predict"].values()) for s in single])
     assert np.abs(a - b).max() < 1e-6  # the oracle pads a shard's batches differently: fp32 rounding only
+
+
+def test_tcp_fallback_transport_world3(tmp_path):
+    """The socket-hub fallback of the RCCL transport (distributed.init_tcp; bench.py uses it when mv_comm_init fails): three
+    torch-free processes, ragged row blocks — every rank gets the rank-ordered concatenation, the maximum and the statistics."""
+    world, port, out = 3, 30100 + (os.getpid() % 500), str(tmp_path / "tcp")
+    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "tcp_worker.py"), str(r), str(world), str(port), out],
+                              stderr=subprocess.PIPE, text=True) for r in range(world)]
+    for p in procs:
+        _, err = p.communicate(timeout=120)
+        assert p.returncode == 0, err[-2000:]
+    want_rows = np.concatenate([np.arange((r + 2) * 3, dtype=np.float32).reshape(r + 2, 3) + 100 * r for r in range(world)])
+    for r in range(world):
+        res = json.load(open(f"{out}.rank{r}"))
+        assert np.array_equal(np.array(res["rows"], np.float32), want_rows)
+        assert res["max"] == world - 0.5
+        assert res["scores"] == [0.0, 0.5, 0.25, 0.5, 0.5, 0.5] and res["labels"] == [0, 1, 1, 1, 0, 1]
