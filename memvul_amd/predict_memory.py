@@ -203,7 +203,16 @@ def test_siamese_sharded(archive_file, input_file, input_golden_file, test_confi
     model.eval()
     if world > 1 and not use_torch:
         # the default on GPUs: RCCL bound inside libmemvul_hip.so, collective on the engine's stream, no torch.distributed
-        mvdist.init_rccl(model.engine, rank, world)
+        # (backend="tcp", or an RCCL that cannot be initialised on this node: the torch-free socket hub, distributed.init_tcp)
+        if backend == "tcp":
+            mvdist.init_tcp(rank, world)
+        else:
+            try:
+                mvdist.init_rccl(model.engine, rank, world)
+            except RuntimeError as e:
+                import sys
+                sys.stderr.write(f"[test_siamese_sharded rank {rank}] RCCL init failed ({e}); falling back to the TCP hub\n")
+                mvdist.init_tcp(rank, world)
     golden_samples = list(archive.validation_dataset_reader.read(input_golden_file))
     model._golden_instances_embeddings = None
     model._golden_instances_labels = None
