@@ -114,6 +114,9 @@ int mv_anchor_set(mv_handle* h, const float* v, int G);
  *   best   fp32 [B,2]     probs[b, argmax_g probs[b,g,same_idx]]  (l.144-147)
  *   best_idx int32 [B]    that argmax (first maximal g)
  *   embed  fp32 [B,512]   u = header(pooler(BERT(ids)[:,0]))      (l.133)
+ * (The matcher accumulates delta = logit_0 - logit_1 as one fp32 chain with the class-difference weights and derives probs from
+ *  it — softmax_2 depends on nothing else — on every entry point; when `logits` is requested the class-0 chain runs too and
+ *  logit_1 = logit_0 - delta.  Both agree with the reference's two separate sums to fp32 rounding: ~1e-6 on the logits.)
  * Returns after the results are in host memory. */
 int mv_forward(mv_handle* h, const int32_t* ids, const int32_t* lens, int B, int S,
                float* logits, float* probs, float* best, int32_t* best_idx, float* embed);
