@@ -31,7 +31,8 @@
 #define ATT2_BUF_BYTES(NKB) ((NKB) * 16384)
 #define ATT2_LDS_BYTES(NKB) (2 * ATT2_BUF_BYTES(NKB))
 
-// ABL (tools/attn_probe.hip only; wrong results), bit mask: 1 = v_exp_f32 replaced by a move, 2 = no MFMA in QK^T / PV,
+// ABL (tools/attn_probe.hip only; wrong results), bit mask: 8 = no Q loads, 16 = no O stores, 32 = no K / V^T LDS-DMA,
+// 1 = v_exp_f32 replaced by a move, 2 = no MFMA in QK^T / PV,
 // 4 = K / V^T fragments not read from LDS (the DMA into LDS still runs)
 // LO 1 (split-operand mode, MV_F16X2): the context is also written as a second plane fp16(O - fp16(O)) to AttnArgs::ctx_lo
 // (16 more registers across the unit boundary, a second pass through the O image); a separate instantiation.
@@ -79,6 +80,7 @@ __global__ __launch_bounds__(NKB * 128) __attribute__((amdgpu_waves_per_eu(2, 2)
     const char* kg = (const char*)(a.k + ((size_t)bh * ST + (size_t)j * S) * MV_HEAD_DIM);
     const char* vg = (const char*)(a.vt + (size_t)bh * MV_HEAD_DIM * ST + (size_t)j * S);
     char* kb = smem + pb * BUF;
+    if (ABL & 32) return;
 #pragma unroll
     for (int x = 0; x < 4; ++x) {
       const int p = 4 * wave + x;
@@ -93,6 +95,7 @@ __global__ __launch_bounds__(NKB * 128) __attribute__((amdgpu_waves_per_eu(2, 2)
   auto load_q = [&](int u, half8_t (&qf)[4]) {  // B operand of S^T = K Q^T: lane holds Q[qb S + 32 wave + ql][16 kk + 8 hi ..+7]
     const int bh = unit_bh(u), qb = unit_qb(u);
     const half_t* gq = a.q + ((size_t)bh * ST + qb * S + 32 * wave + ql) * MV_HEAD_DIM + hi * 8;
+    if (ABL & 8) gq = a.q + (size_t)(32 * wave + ql) * MV_HEAD_DIM + hi * 8;  // the same (cached) 32 KB every time
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) qf[kk] = *(const half8_t*)(gq + kk * 16);
   };
@@ -134,6 +137,7 @@ __global__ __launch_bounds__(NKB * 128) __attribute__((amdgpu_waves_per_eu(2, 2)
     u32x4 v[4];
 #pragma unroll
     for (int it = 0; it < 4; ++it) v[it] = *(const u32x4*)(kb + o_rd + it * 1024);
+    if (ABL & 16) dst = base + (size_t)(32 * wave + (lane >> 3)) * MV_HIDDEN + 8 * (lane & 7);  // the same lines every time
 #pragma unroll
     for (int it = 0; it < 4; ++it) *(u32x4*)(dst + (size_t)(8 * it) * MV_HIDDEN) = v[it];
   };

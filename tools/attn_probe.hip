@@ -80,6 +80,12 @@ int main() {
   if (time_abl(attention_v2_kernel<4, 1, 3>, "no v_exp_f32, no MFMA:")) return 2;
   if (time_abl(attention_v2_kernel<4, 1, 4>, "no LDS fragment reads:")) return 2;
   if (time_abl(attention_v2_kernel<4, 1, 7>, "none of the three:")) return 2;
+  // memory streams (round 2): which of the four costs what
+  if (time_abl(attention_v2_kernel<4, 1, 8>, "Q loads from one cached tile:")) return 2;
+  if (time_abl(attention_v2_kernel<4, 1, 16>, "O stores to one cached tile:")) return 2;
+  if (time_abl(attention_v2_kernel<4, 1, 32>, "no K / V^T LDS-DMA:")) return 2;
+  if (time_abl(attention_v2_kernel<4, 1, 24>, "Q and O cached:")) return 2;
+  if (time_abl(attention_v2_kernel<4, 1, 56>, "no memory streams at all:")) return 2;
   // working set vs the 256 MB Infinity Cache: back-to-back launches over the first Bs batch rows re-read the same
   // Q / K / V^T (0.29 MB per row and head in, 0.1 MB out), which only stay cached when they fit
   for (int Bs : {256, 192, 128, 64}) {
