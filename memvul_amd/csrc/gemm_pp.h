@@ -49,8 +49,8 @@ enum { PP_F32 = 0, PP_QK = 1, PP_VT = 2, PP_GELU = 3, PP_RES = 4, PP_F16 = 5, PP
 // while the LayerNorm kernel no longer writes the fp32 stream back (201 MB per LayerNorm at the bench shape).
 // PP_RESLN2 + RAW consumers ("virtual LayerNorm": no LayerNorm kernel at all).  By linearity
 //   W LN(r) + b = rstd * (W'' r) + b',  W''[n][k] = W[n][k] gamma[k] - mean_k(W[n][.] gamma[.]),  b' = b + W beta
-// (the row mean of r drops out against the row-centred weights), so a consumer GEMM (RAW = 1: PP_QK / PP_VT /
-// PP_GELU) takes the RAW stream rounded to fp16 as its A operand, the folded weights W'' (prepared once on the
+// (the row mean of r drops out against the row-centred weights), so a consumer GEMM (RAW = 1: PP_QK — Q, K and V^T in
+// one launch — and PP_GELU; PP_VT, the separate V^T launch of round 1, survives for tools/gemm_bench.hip only) takes the RAW stream rounded to fp16 as its A operand, the folded weights W'' (prepared once on the
 // host), starts its accumulators from zero and applies  fma(rstd_row, acc, b'_col)  in the epilogue; the 256 rows'
 // statistics of the workgroup's next tile arrive by six LDS-DMA pieces (and its 256 bias' values by a seventh) into
 // 2 x 6 KiB (2 x 1 KiB) images.  The producer (PP_RESLN2 = PP_RESLN that ALSO writes the fp16 copy of the raw stream and the
