@@ -77,7 +77,8 @@ def _ln_stats(x, eps):
     return mu, 1.0 / np.sqrt(var + eps)
 
 
-def encode(w, ids, mask, cfg: Optional[Dict[str, List[str]]], heads=12, eps=1e-12, fold_ln=True, cls_side=None, cls_raw_kv=False):
+def encode(w, ids, mask, cfg: Optional[Dict[str, List[str]]], heads=12, eps=1e-12, fold_ln=True, cls_side=None, cls_raw_kv=False,
+           cls_from_layer=0):
     """float64 BERT forward with the engine's rounding points (``cfg`` None = exact).  ``fold_ln``: the QKV / FFN-1
     weights are rounded AFTER the preceding LayerNorm is folded in (W'' = W gamma - rowmean, gemm_pp.h) and the A operand
     is the raw (pre-LayerNorm) stream, as on the engine's persistent-GEMM path."""
@@ -95,7 +96,8 @@ def encode(w, ids, mask, cfg: Optional[Dict[str, List[str]]], heads=12, eps=1e-1
     addmask = ((1.0 - mask.astype(np.float64)) * orc.MASK_ADD)[:, None, None, :]
     # [CLS] side path (cls_side = format name of ITS operands, e.g. "exact" / "f16x2"): the [CLS] row of every issue report
     # is re-computed in every layer at higher precision from the main path's stored K / V of all tokens; the pooler reads
-    # the side path's row.  The main path does not depend on it.
+    # the side path's row.  The main path does not depend on it.  ``cls_from_layer``: the side path starts at that layer from the
+    # main path's [CLS] row (L - 1 = only the last layer's [CLS] work at the higher precision: the engine's pruned tail).
     rc = r[:, 0].copy()
     gc, bc = g, b
     RS = FORMATS[cls_side] if cls_side else None
@@ -118,6 +120,8 @@ def encode(w, ids, mask, cfg: Optional[Dict[str, List[str]]], heads=12, eps=1e-1
         bqkv = np.concatenate([W(p + "attention.self.query.bias") * 0.125, W(p + "attention.self.key.bias"),
                                W(p + "attention.self.value.bias")], 0)
         r_in = r
+        if cls_side and l == cls_from_layer and l > 0:
+            rc, gc, bc = r[:, 0].copy(), g, b
         qkv = R("qkv", l, consumer(r, g, b, Wqkv, bqkv, "w_qkv", "a_qkv", l))
         sp = lambda t: t.reshape(B, S, heads, d).transpose(0, 2, 1, 3)  # noqa: E731
         qh, kh, vh = sp(qkv[..., :H]), sp(qkv[..., H:2 * H]), sp(qkv[..., 2 * H:])
@@ -136,7 +140,7 @@ def encode(w, ids, mask, cfg: Optional[Dict[str, List[str]]], heads=12, eps=1e-1
         mu, rstd = _ln_stats(r1, eps)
         x1 = (r1 - mu) * rstd * g1 + b1
         r = h @ R("w_2", l, W(p + "output.dense.weight")).T + W(p + "output.dense.bias") + x1
-        if cls_side:
+        if cls_side and l >= cls_from_layer:
             mu, rstd = _ln_stats(rc, eps)
             xc = (rc - mu) * rstd * gc + bc
             qc = (RS(xc) @ RS(Wqkv[:H]).T + bqkv[:H]).reshape(B, heads, 1, d)
