@@ -37,7 +37,8 @@ def main():
     t["read + tokenise (hashing stand-in tokenizer)"] = time.perf_counter() - t0
     lens = arrays["lens"]
     out = os.path.join(root, "test_results", "e2e_result.json")
-    pm.evaluate_arrays(model, {k: (v[:2048] if k != "type" else v) for k, v in arrays.items()}, 512)  # warm-up
+    pm.evaluate_arrays(model, {k: (v[:2048] if hasattr(v, "__len__") and not isinstance(v, str) and len(v) == len(lens) else v)
+                               for k, v in arrays.items()}, 512)  # warm-up on the first 2048 issue reports
     res = {}
     for name, kw in (("sweep + metrics (no predictions file)", {}),
                      ("sweep + JSON-lines in the writer thread + metrics", dict(predictions_output_file=out, record_workers=0)),
