@@ -69,6 +69,19 @@ __device__ __forceinline__ unsigned long long mk_wave_max64(unsigned long long x
   return ((unsigned long long)hi << 32) | lo;
 }
 
+// Wave-wide sum (same ladder, every lane gets the total): the order of the additions is fixed by the ladder, the same for every row.
+__device__ __forceinline__ float mk_wave_sum(float x) {
+#define MK_SUM_STEP(CTRL, ROWS) x += __uint_as_float((unsigned)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(x), CTRL, ROWS, 0xf, false));
+  MK_SUM_STEP(0x111, 0xf)
+  MK_SUM_STEP(0x112, 0xf)
+  MK_SUM_STEP(0x114, 0xf)
+  MK_SUM_STEP(0x118, 0xf)
+  MK_SUM_STEP(0x142, 0xa)
+  MK_SUM_STEP(0x143, 0xc)
+#undef MK_SUM_STEP
+  return __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(x), 63));
+}
+
 // k rounds of arg-max over candidates held NJ per lane (candidate j of lane l = slot l + 64 j), order (key desc, index asc).
 // A candidate is ONE 64-bit word  (key bits << 32) | ~index  (keys are >= 0 as floats, so their bit patterns order like the
 // values; ~index makes the lower index win a tie), so a round is one 64-bit wave maximum.  emit(round, slot) gets the winner's
@@ -145,7 +158,7 @@ __device__ __forceinline__ void mk_merge_row_any(const MatchArgs& a, int b, int 
 //   <2, 256, 32, L, 2>  large banks: 8 waves, 4 rows x 256 anchors, 16 steps (two waves per SIMD already at 256 workgroups)
 //   <2, 128, 64, L, 2>  the 124-anchor CWE memory: 4 waves, 4 rows x 128 anchors, 8 steps
 // Measured (tools/match_probe.hip, profiles/r02_i_match_probe.txt): B = 256, G = 124: 15.7 us (round 1: 43 + 6; start of
-// round 2: 24); B = 256, G = 1000, k = 10: 26.0 + 5.1 us merge (round 1: 73 + 11; start of round 2: 42 + 13).  What the
+// round 2: 24); B = 256, G = 1000, k = 10: 24.7 + 5.0 us merge (round 1: 73 + 11; start of round 2: 42 + 13).  What the
 // probe's in-kernel stamps and ablations ruled out on the way is recorded at the main loop below.
 template <int RB, int GC, int MI, int LOGITS, int RW>
 __global__ __launch_bounds__(GC * RW) void match_topk_kernel(const float* __restrict__ u, const float* __restrict__ v,
@@ -216,11 +229,8 @@ __global__ __launch_bounds__(GC * RW) void match_topk_kernel(const float* __rest
       s0 = fmaf(wa0 - Wm[3 * MV_PROJ + lane + 64 * j], uu, s0);  // delta chain
       s1 = fmaf(wa0, uu, s1);                                     // class-0 chain (LOGITS)
     }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-      s0 += __shfl_xor(s0, off, 64);
-      s1 += __shfl_xor(s1, off, 64);
-    }
+    s0 = mk_wave_sum(s0);
+    s1 = mk_wave_sum(s1);
     if (lane == 0) { sa[r][0] = s0; sa[r][1] = s1; }
   }
   // ---- main loop.  What tools/match_probe.hip (in-kernel stamps, ablations) and tools/valu_rate.hip showed: at one wave per
@@ -366,8 +376,12 @@ __global__ __launch_bounds__(GC * RW) void match_topk_kernel(const float* __rest
       key[j] = mk_key(sp[r * GC + lane + 64 * j]);
       gi[j] = gg < a.G ? gg : 0x7fffffff;
     }
-    mk_select<AW>(key, gi, a.k, lane, [&](int round, int slot) {
-      if (lane != 0) return;
+    // lane `round` remembers the round's winner; the k results are then fetched and written by k lanes at once (a round does not
+    // wait for an LDS read + three global stores of lane 0)
+    int won = -1;
+    mk_select<AW>(key, gi, a.k, lane, [&](int round, int slot) { won = lane == round ? slot : won; });
+    if (lane < a.k) {
+      const int round = lane, slot = won;
       const float ps = slot >= 0 ? sp[r * GC + slot] : -1.0f, pq = slot >= 0 ? sq[r * GC + slot] : -1.0f;
       const int gw = slot >= 0 ? g0 + slot : 0x7fffffff;
       if (a.nchunk > 1) {
@@ -380,7 +394,7 @@ __global__ __launch_bounds__(GC * RW) void match_topk_kernel(const float* __rest
           if (a.best) { a.best[2 * b + a.same_idx] = ps; a.best[2 * b + 1 - a.same_idx] = pq; }
         }
       }
-    });
+    }
   }
   if (stamp) a.clk[4] = __builtin_amdgcn_s_memtime();
 }
