@@ -1,0 +1,56 @@
+"""Numerical safety of the virtual LayerNorm's one-pass statistics ("vstats", common.h ln_from_partials / gemm_pp.h): the
+residual GEMMs emit per row three fp32 (sum, sum of squares) pairs — each the fixed-order sum of four 64-column wave shares —
+and every consumer forms  mean = S1 / 768,  var = S2 / 768 - mean^2,  rstd = rsq(var + eps).  E[x^2] - mean^2 cancels when
+|mean| >> std; this emulates the arithmetic in float32 on rows like the encoder's (O(1) values, trained-checkpoint-like outlier
+dimensions, a large common offset) and bounds the error of (mean, rstd) against float64 two-pass statistics."""
+import numpy as np
+import pytest
+
+H, EPS = 768, 1e-12
+
+
+def vstats_f32(x):
+    """x [rows, 768] float32 -> (mean, rstd) the way the kernels compute them."""
+    x = x.astype(np.float32)
+    parts = []
+    for t in range(3):  # 256-column tile
+        waves = []
+        for w in range(4):  # 64-column wave share: per lane 32 values (two fragments), then the two half-waves are added
+            blk = x[:, t * 256 + w * 64: t * 256 + (w + 1) * 64]
+            s1 = np.zeros(len(x), np.float32)
+            s2 = np.zeros(len(x), np.float32)
+            for half in range(2):
+                h1 = np.zeros(len(x), np.float32)
+                h2 = np.zeros(len(x), np.float32)
+                for c in range(32):
+                    v = blk[:, half * 32 + c]
+                    h1 = (h1 + v).astype(np.float32)
+                    h2 = (v.astype(np.float64) * v + h2).astype(np.float32)  # fma: one rounding
+                s1, s2 = (s1 + h1).astype(np.float32), (s2 + h2).astype(np.float32)
+            waves.append((s1, s2))
+        p1 = ((waves[0][0] + waves[1][0]).astype(np.float32) + waves[2][0]).astype(np.float32) + waves[3][0]
+        p2 = ((waves[0][1] + waves[1][1]).astype(np.float32) + waves[2][1]).astype(np.float32) + waves[3][1]
+        parts.append((p1.astype(np.float32), p2.astype(np.float32)))
+    S1 = ((parts[0][0] + parts[1][0]).astype(np.float32) + parts[2][0]).astype(np.float32)
+    S2 = ((parts[0][1] + parts[1][1]).astype(np.float32) + parts[2][1]).astype(np.float32)
+    mean = (S1 * np.float32(1.0 / H)).astype(np.float32)
+    var = np.maximum((S2 * np.float32(1.0 / H)).astype(np.float32) - (mean * mean).astype(np.float32), np.float32(0))
+    rstd = (1.0 / np.sqrt(var.astype(np.float64) + EPS)).astype(np.float32)  # v_rsq_f32: 1 ulp, not modelled
+    return mean, rstd
+
+
+@pytest.mark.parametrize("kind,tol", [("unit", 2e-6), ("outliers", 2e-6), ("offset3", 2e-5)])
+def test_one_pass_statistics_hold_on_encoder_like_rows(kind, tol):
+    rng = np.random.default_rng(7)
+    x = rng.standard_normal((512, H))
+    if kind == "outliers":  # two dimensions carry +-20 sigma, as trained BERT checkpoints do (synth trained_like: -4 / +3 after LN)
+        x[:, H // 3 + 52] += 20.0
+        x[:, H // 2 - 3] -= 15.0
+    if kind == "offset3":  # a common offset of 3 sigma: the cancellation case, an order of magnitude looser but still far below fp16's 5e-4
+        x += 3.0
+    mean, rstd = vstats_f32(x)
+    x64 = x.astype(np.float32).astype(np.float64)
+    m64 = x64.mean(1)
+    r64 = 1.0 / np.sqrt(x64.var(1) + EPS)
+    assert np.abs(mean - m64).max() <= tol * max(1.0, np.abs(m64).max())
+    assert (np.abs(rstd - r64) / r64).max() <= tol
