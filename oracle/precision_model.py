@@ -40,6 +40,43 @@ def _bf16(x):
     return b.astype(np.uint32).view(np.float32).astype(np.float64)
 
 
+def _e4m3(x):
+    """round-to-nearest-even to OCP e4m3fn (4 significant bits, normal range 2^-6 .. 448, subnormal step 2^-9), saturating —
+    what ``v_cvt_pk_fp8_f32`` after a clamp to +-448 produces on gfx950."""
+    x = np.asarray(x, np.float64)
+    a = np.abs(x)
+    e = np.clip(np.floor(np.log2(np.maximum(a, 1e-300))), -6, 8)
+    q = 2.0 ** (e - 3)
+    return np.sign(x) * np.minimum(np.round(a / q) * q, 448.0)
+
+
+# static power-of-two pre-scales of the fp8 planes (engine: MV_F16X8; the E8M0 scale operands of the MX instruction undo them
+# exactly): activations 2^2 (|x| up to 112 representable), weights per matrix from max |W|
+X8_ACT_SHIFT = 2
+
+
+def _x8_planes(x, shift):
+    """hi = fp16(x); hi8 = e4m3(hi 2^shift); lo8 = e4m3((x - hi) 2^(11 + shift)), returned de-scaled."""
+    hi = _f16(x)
+    s = 2.0 ** shift
+    return hi, _e4m3(hi * s) / s, _e4m3((x - hi) * (2048.0 * s)) / (2048.0 * s)
+
+
+def _w_shift(w):
+    m = float(np.abs(w).max())
+    return int(np.floor(np.log2(448.0 / m))) if m > 0 else 0
+
+
+def _mm(afmt, wfmt, A, W):
+    """A @ W^T as the engine forms it.  Both operands "f16x8" (MV_F16X8): ONE fp16 sweep + two fp8 (e4m3) correction sweeps
+    into the same fp32 accumulators,  A_hi W_hi + A_lo8 W_hi8 + A_hi8 W_lo8;  otherwise each operand is rounded on its own."""
+    if afmt == "f16x8" and wfmt == "f16x8":
+        ah, ah8, al8 = _x8_planes(A, X8_ACT_SHIFT)
+        wh, wh8, wl8 = _x8_planes(W, _w_shift(W))
+        return ah @ wh.T + al8 @ wh8.T + ah8 @ wl8.T
+    return FORMATS[afmt](A) @ FORMATS[wfmt](W).T
+
+
 def _split(x, rnd, n):
     out = np.zeros_like(x, dtype=np.float64)
     rem = x.astype(np.float64)
@@ -57,6 +94,8 @@ FORMATS = {
     "bf16": _bf16,
     "bf16x2": lambda x: _split(x, _bf16, 2),
     "bf16x3": lambda x: _split(x, _bf16, 3),
+    # one-sided use of the MV_F16X8 planes (the other operand in another format): hi + the de-scaled fp8 lo plane
+    "f16x8": lambda x: (lambda p: p[0] + p[2])(_x8_planes(x, X8_ACT_SHIFT)),
 }
 
 KNOBS = ("w_qkv", "w_o", "w_1", "w_2", "a_qkv", "a_ffn1", "qkv", "p", "ctx", "h")
@@ -107,11 +146,10 @@ def encode(w, ids, mask, cfg: Optional[Dict[str, List[str]]], heads=12, eps=1e-1
         mu, rstd = _ln_stats(r_raw, eps)
         if fold_ln:
             Wg = Wm * g[None, :]
-            Wf = R(wknob, l, Wg - Wg.mean(-1, keepdims=True))
             bf = bias + Wm @ b
-            return rstd * (R(aknob, l, r_raw) @ Wf.T) + bf
+            return rstd * _mm(cfg[aknob][l], cfg[wknob][l], r_raw, Wg - Wg.mean(-1, keepdims=True)) + bf
         x = (r_raw - mu) * rstd * g + b
-        return R(aknob, l, x) @ R(wknob, l, Wm).T + bias
+        return _mm(cfg[aknob][l], cfg[wknob][l], x, Wm) + bias
 
     for l in range(L):
         p = f"encoder.layer.{l}."
@@ -130,16 +168,15 @@ def encode(w, ids, mask, cfg: Optional[Dict[str, List[str]]], heads=12, eps=1e-1
         e = np.exp(sc - m)
         den = e.sum(-1, keepdims=True)
         ctx = ((R("p", l, e) @ vh) / den).transpose(0, 2, 1, 3).reshape(B, S, H)  # the engine normalises O after P·V
-        ctx = R("ctx", l, ctx)
         mu, rstd = _ln_stats(r, eps)
         x = (r - mu) * rstd * g + b
-        r1 = ctx @ R("w_o", l, W(p + "attention.output.dense.weight")).T + W(p + "attention.output.dense.bias") + x
+        r1 = _mm(cfg["ctx"][l], cfg["w_o"][l], ctx, W(p + "attention.output.dense.weight")) + W(p + "attention.output.dense.bias") + x
         g1, b1 = W(p + "attention.output.LayerNorm.weight"), W(p + "attention.output.LayerNorm.bias")
         hpre = consumer(r1, g1, b1, W(p + "intermediate.dense.weight"), W(p + "intermediate.dense.bias"), "w_1", "a_ffn1", l)
-        h = R("h", l, orc._gelu(hpre))
+        h = orc._gelu(hpre)
         mu, rstd = _ln_stats(r1, eps)
         x1 = (r1 - mu) * rstd * g1 + b1
-        r = h @ R("w_2", l, W(p + "output.dense.weight")).T + W(p + "output.dense.bias") + x1
+        r = _mm(cfg["h"][l], cfg["w_2"][l], h, W(p + "output.dense.weight")) + W(p + "output.dense.bias") + x1
         if cls_side and l >= cls_from_layer:
             mu, rstd = _ln_stats(rc, eps)
             xc = (rc - mu) * rstd * gc + bc

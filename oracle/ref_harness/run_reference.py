@@ -104,8 +104,12 @@ def structured_matcher(w_random: np.ndarray) -> np.ndarray:
     return wm
 
 
-def make_fixture(root: str, layers: int = 2, n_irs: int = 70, n_anchors: int = 9, seed: int = 11) -> Dict:
-    """Synthetic archive + data files under `root` (file names carry the substrings the reader dispatches on)."""
+def make_fixture(root: str, layers: int = 2, n_irs: int = 70, n_anchors: int = 9, seed: int = 11, weight_kwargs: Dict = None,
+                 structured: bool = True, long_texts: bool = False) -> Dict:
+    """Synthetic archive + data files under `root` (file names carry the substrings the reader dispatches on).
+    Defaults = tests/golden/ref (2 layers, a discriminating matcher).  tests/golden/ref12: ``layers=12``, the trained-like
+    weights of SURVEY.md §8(d) (``weight_kwargs``), synth's own x29 matcher (``structured=False``: |logit| ~ 3) and
+    ``long_texts`` (most issue reports reach the 256-token truncation, anchors run up to 512 tokens)."""
     import torch
     from transformers import BertConfig, BertModel
 
@@ -120,9 +124,10 @@ def make_fixture(root: str, layers: int = 2, n_irs: int = 70, n_anchors: int = 9
     os.makedirs(os.path.join(root, "test_results"))
     V = make_vocab(os.path.join(hf_dir, "vocab.txt"))
     dims = synth.BertDims(layers=layers, vocab_size=V)
-    wk = dict(qk_scale=2.0, match_scale=2.0)
+    wk = dict(weight_kwargs) if weight_kwargs else dict(qk_scale=2.0, match_scale=2.0)
     w = synth.make_weights(dims, **wk)
-    w[synth.KEY_MATCH_W] = structured_matcher(w[synth.KEY_MATCH_W])
+    if structured:
+        w[synth.KEY_MATCH_W] = structured_matcher(w[synth.KEY_MATCH_W])
     cfg = BertConfig(vocab_size=V, hidden_size=dims.hidden, num_hidden_layers=layers, num_attention_heads=dims.heads,
                      intermediate_size=dims.intermediate, max_position_embeddings=dims.max_pos, type_vocab_size=dims.type_vocab,
                      layer_norm_eps=dims.ln_eps, hidden_act="gelu")
@@ -140,12 +145,14 @@ def make_fixture(root: str, layers: int = 2, n_irs: int = 70, n_anchors: int = 9
     open(os.path.join(arch, "vocabulary", "non_padded_namespaces.txt"), "w").write("*tags\n*labels\n")
     cwes = [f"CWE-{100 + 7 * i}" for i in range(n_anchors)]
     golden = os.path.join(root, "CWE_anchor_golden_project.json")
-    anchors = {c: _text(rng, int(rng.integers(12, 90))) for c in cwes}
+    anchors = {c: _text(rng, int(rng.integers(60, 420) if long_texts else rng.integers(12, 90))) for c in cwes}
     json.dump(anchors, open(golden, "w"), indent=0)
     recs, cve = [], {}
     for i in range(n_irs):
         pos = i % 6 == 2
-        rec = {"Issue_Title": _text(rng, int(rng.integers(3, 9))), "Issue_Body": _text(rng, int(rng.integers(4, 140 if i % 9 else 400))),
+        title = _text(rng, int(rng.integers(3, 9)))
+        nbody = int(rng.integers(90, 330)) if long_texts else int(rng.integers(4, 140 if i % 9 else 400))
+        rec = {"Issue_Title": title, "Issue_Body": _text(rng, nbody),
                "Security_Issue_Full": "1" if pos else "0", "Issue_Url": f"https://example.invalid/repo/issues/{i}"}
         if pos:
             cid = f"CVE-2020-{1000 + i}"
@@ -165,7 +172,7 @@ def make_fixture(root: str, layers: int = 2, n_irs: int = 70, n_anchors: int = 9
     json.dump(recs, open(test_path, "w"), indent=0)
     json.dump(cve, open(os.path.join(root, "xxxCVE_dict.json"), "w"), indent=0)  # data_path = "xxx" + 'CVE_dict.json' (reader_memory.py:62-64)
     return dict(root=root, archive=arch, hf_dir=hf_dir, golden=golden, test=test_path, dims=dims, weights=w, weight_kwargs=wk,
-                vocab_size=V, seed=seed, layers=layers)
+                vocab_size=V, seed=seed, layers=layers, structured=structured)
 
 
 def _prepare_imports(hf_dir: str):
@@ -230,7 +237,7 @@ def run(fx: Dict, batch_size: int = 16) -> Dict:
         skipped = []
         import_module_and_submodules("MemVul", skipped)
         write_weights_th(fx)
-        captured = {"probs": [], "meta": []}
+        captured = {"probs": [], "meta": [], "logits": []}
         orig_load = pm.load_archive
 
         def load_and_hook(*a, **kw):
@@ -245,6 +252,8 @@ def run(fx: Dict, batch_size: int = 16) -> Dict:
                     captured["meta"].extend(out["meta"])
 
             archive.model.register_forward_hook(hook)
+            # the match logits (model_memory.py:141, `self._projector(torch.cat([...]))`): output_dict carries only their softmax
+            archive.model._projector.register_forward_hook(lambda _m, _i, out: captured["logits"].append(out.detach().numpy().copy()))
             return archive
 
         pm.load_archive = load_and_hook
@@ -280,7 +289,8 @@ def run(fx: Dict, batch_size: int = 16) -> Dict:
             predictions_text=open(out_result).read(), metrics_file_text=open(out_metric).read(),
             anchors=model._golden_instances_embeddings.detach().numpy().astype(np.float32),
             anchor_labels=list(model._golden_instances_labels),
-            probs=np.asarray(captured["probs"], np.float32), meta=captured["meta"], reader=reader_dump, same_idx=int(model._same_idx),
+            probs=np.asarray(captured["probs"], np.float32), logits=np.concatenate(captured["logits"], 0).astype(np.float32),
+            meta=captured["meta"], reader=reader_dump, same_idx=int(model._same_idx),
             skipped_submodules=skipped, state_dict_keys=fx["state_dict_keys"],
         )
         res["stats_cases"] = stats_cases(pm)
@@ -350,7 +360,7 @@ def generate(out_dir: str, **fixture_kw) -> Dict:
     json.dump(res["metric_all"], open(os.path.join(out_dir, "ref_metric_all.json"), "w"), indent=1)
     json.dump(res["reader"], open(os.path.join(out_dir, "ref_reader.json"), "w"))
     json.dump(res["stats_cases"], open(os.path.join(out_dir, "ref_stats_cases.json"), "w"))
-    np.savez_compressed(os.path.join(out_dir, "ref_tensors.npz"), anchors=res["anchors"], probs=res["probs"])
+    np.savez_compressed(os.path.join(out_dir, "ref_tensors.npz"), anchors=res["anchors"], probs=res["probs"], logits=res["logits"])
     import transformers
     import torch
     meta = dict(
@@ -359,7 +369,8 @@ def generate(out_dir: str, **fixture_kw) -> Dict:
                          "MemVul/custom_PTM_embedder.py", "MemVul/util.py"],
         skipped_submodules=res["skipped_submodules"], transformers=transformers.__version__, torch=torch.__version__,
         numpy=np.__version__, layers=fx["layers"], vocab_size=fx["vocab_size"], weight_seed=2021,
-        weight_kwargs=fx["weight_kwargs"], matcher="oracle.ref_harness.run_reference.structured_matcher(synth matcher)", fixture_seed=fx["seed"], batch_size=16, thres=res["thres"], same_idx=res["same_idx"],
+        weight_kwargs=fx["weight_kwargs"], structured_matcher=bool(fx["structured"]),
+        matcher="oracle.ref_harness.run_reference.structured_matcher(synth matcher)" if fx["structured"] else "synth matcher (match_scale)", fixture_seed=fx["seed"], batch_size=16, thres=res["thres"], same_idx=res["same_idx"],
         anchor_labels=res["anchor_labels"], issue_urls=[m["instance"][0]["Issue_Url"] for m in res["meta"]],
         issue_labels=[m["instance"][0]["label"] for m in res["meta"]], state_dict_keys=res["state_dict_keys"],
     )

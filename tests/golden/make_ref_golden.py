@@ -20,7 +20,18 @@ sys.path.insert(0, ROOT)
 
 from oracle.ref_harness import run_reference  # noqa: E402
 
+# tests/golden/ref12: the 12-layer TRAINED-LIKE regime (stable LayerNorm outlier dimensions, peaked attention,
+# matcher x29 -> |logit| ~ 3) through the reference's own code; adds `logits` (a hook on ModelMemory._projector) to the tensors
+REF12 = dict(layers=12, n_irs=20, n_anchors=6, seed=12, weight_kwargs=dict(qk_scale=2.0, match_scale=29.0, trained_like=True),
+             structured=False, long_texts=True)
+
 if __name__ == "__main__":
-    out = os.path.join(ROOT, "tests", "golden", "ref")
-    res = run_reference.generate(out)
-    print({k: res["metrics"][k] for k in ("accuracy", "f1-score", "s_f1-score", "s_thres", "s_auc")})
+    which = sys.argv[1:] or ["ref", "ref12"]
+    if "ref" in which:
+        res = run_reference.generate(os.path.join(ROOT, "tests", "golden", "ref"))
+        print({k: res["metrics"][k] for k in ("accuracy", "f1-score", "s_f1-score", "s_thres", "s_auc")})
+    if "ref12" in which:
+        res = run_reference.generate(os.path.join(ROOT, "tests", "golden", "ref12"), **REF12)
+        import numpy as np
+        print("ref12: max |logit|", float(np.abs(res["logits"]).max()), "probs", res["probs"].shape,
+              {k: res["metrics"][k] for k in ("accuracy", "s_f1-score", "s_thres", "s_auc")})

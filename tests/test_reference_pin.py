@@ -24,22 +24,46 @@ from oracle import memvul_oracle as orc
 from oracle import stats_oracle as so
 from oracle.ref_harness.run_reference import structured_matcher
 
-REF = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref")
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
-@pytest.fixture(scope="module")
-def ref():
+def load_ref(name):
+    """tests/golden/ref: 2 layers, 69 issue reports, a discriminating matcher.  tests/golden/ref12 (round 3): 12 layers in the
+    TRAINED-LIKE regime (LayerNorm outlier dimensions, peaked attention, matcher x29 -> max |logit| 2.5),
+    19 issue reports of up to 256 tokens, 6 anchors of up to 512; carries the match LOGITS too (a forward hook on the
+    reference model's `_projector`, model_memory.py:141)."""
+    REF = os.path.join(GOLDEN, name)
     meta = json.load(open(os.path.join(REF, "meta.json")))
     t = np.load(os.path.join(REF, "ref_tensors.npz"))
     dims = synth.BertDims(layers=meta["layers"], vocab_size=meta["vocab_size"])
     w = synth.make_weights(dims, seed=meta["weight_seed"], **meta["weight_kwargs"])
-    w[synth.KEY_MATCH_W] = structured_matcher(w[synth.KEY_MATCH_W])
-    return dict(meta=meta, anchors=t["anchors"], probs=t["probs"], dims=dims, w=w,
+    if meta.get("structured_matcher", True):
+        w[synth.KEY_MATCH_W] = structured_matcher(w[synth.KEY_MATCH_W])
+    return dict(meta=meta, anchors=t["anchors"], probs=t["probs"], logits=t["logits"], dims=dims, w=w, dir=REF, name=name,
                 reader=json.load(open(os.path.join(REF, "ref_reader.json"))),
                 metrics=json.load(open(os.path.join(REF, "ref_metrics.json"))),
                 metric_all=json.load(open(os.path.join(REF, "ref_metric_all.json"))),
                 stats=json.load(open(os.path.join(REF, "ref_stats_cases.json"))),
                 records=[r for line in open(os.path.join(REF, "ref_predictions.jsonl")) for r in json.loads(line)])
+
+
+_refs = {}
+
+
+def get_ref(name):
+    if name not in _refs:
+        _refs[name] = load_ref(name)
+    return _refs[name]
+
+
+@pytest.fixture(scope="module")
+def ref():
+    return get_ref("ref")
+
+
+@pytest.fixture(scope="module")
+def ref12():
+    return get_ref("ref12")
 
 
 def _pad(rows):
@@ -52,10 +76,14 @@ def _pad(rows):
     return ids, mask
 
 
-def test_numeric_oracle_equals_the_reference_run(ref):
+@pytest.mark.parametrize("which", ["ref", "ref12"])
+def test_numeric_oracle_equals_the_reference_run(which):
     """oracle/memvul_oracle.py (numpy restatement of model_memory.py:90-147 + HF BERT) against what the reference's
     ModelMemory computed: the anchor bank (forward_gold_instances in one chunk of 9 < 128) and every batch's
-    probabilities (batches of 16, each padded to its own longest member as allennlp_collate does)."""
+    probabilities (batches of 16, each padded to its own longest member as allennlp_collate does) and match logits —
+    on the 2-layer fixture and on the 12-layer trained-like one (measured there: anchors 7.7e-7, probabilities 1.7e-6,
+    logits 6.6e-6 at |logit| <= 2.5)."""
+    ref = get_ref(which)
     w = ref["w"]
     aids, amask = _pad(ref["reader"]["golden"])
     v = orc.instance_forward(w, aids, amask)
@@ -65,6 +93,7 @@ def test_numeric_oracle_equals_the_reference_run(ref):
         ids, mask = _pad(rows[s:s + 16])
         u, logits, p, best, idx = orc.predict(w, ids, mask, ref["anchors"], same_idx=ref["meta"]["same_idx"])
         assert np.abs(p - ref["probs"][s:s + 16]).max() < 5e-6
+        assert np.abs(logits - ref["logits"][s:s + 16]).max() < 2e-5
     assert ref["probs"].shape == (len(rows), len(ref["meta"]["anchor_labels"]), 2)
 
 
@@ -109,6 +138,7 @@ def _stage(tmp_path, ref, monkeypatch):
     arch = os.path.join(root, "archive")
     os.makedirs(os.path.join(arch, "vocabulary"))
     os.makedirs(os.path.join(root, "test_results"))
+    REF = ref["dir"]
     for name in ("CWE_anchor_golden_project.json", "test_project.json"):
         shutil.copy(os.path.join(REF, name), os.path.join(root, name))
     shutil.copy(os.path.join(REF, "xxxCVE_dict.json"), os.path.join(root, "CVE_dict.json"))
@@ -140,7 +170,7 @@ def _run_product(root, arch, tag, **kw):
 def _check_against_reference(ref, metrics, lines, tol, root, tag):
     records = [r for line in lines for r in line]
     want = ref["records"]
-    ref_lines = [json.loads(line) for line in open(os.path.join(REF, "ref_predictions.jsonl"))]
+    ref_lines = [json.loads(line) for line in open(os.path.join(ref["dir"], "ref_predictions.jsonl"))]
     assert [len(x) for x in lines] == [len(x) for x in ref_lines]          # one JSON line per batch of 16
     assert [r["Issue_Url"] for r in records] == [r["Issue_Url"] for r in want]  # positives first, reversed order
     assert [r["label"] for r in records] == [r["label"] for r in want]
@@ -188,11 +218,12 @@ def test_product_reader_emits_the_reference_instances(ref, tmp_path, monkeypatch
         assert arrays["ids"][i, :arrays["lens"][i]].tolist() == w_["ids"]
 
 
-@pytest.mark.parametrize("sweep", [False, True, "arrays"])
-def test_product_drivers_reproduce_the_reference_run_cpu(ref, tmp_path, monkeypatch, sweep):
+@pytest.mark.parametrize("which,sweep", [("ref", False), ("ref", True), ("ref", "arrays"), ("ref12", "arrays")])
+def test_product_drivers_reproduce_the_reference_run_cpu(which, tmp_path, monkeypatch, sweep):
     """memvul_amd.predict_memory.test_siamese (all three driver forms) on the reference's fixture with the oracle-backed
     engine: the reference's predictions file, its metrics (per-class precision / recall / F1 of AllenNLP's FBetaMeasure
-    included) and its cal_metrics output."""
+    included) and its cal_metrics output.  (ref12, the 12-layer trained-like run: the array driver.)"""
+    ref = get_ref(which)
     root, arch = _stage(tmp_path, ref, monkeypatch)
     monkeypatch.setattr(model_memory, "Engine", pu.OracleEngine)
     metrics, lines, _ = _run_product(root, arch, "prod", sweep=sweep)
