@@ -15,7 +15,21 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libmemvul_hip.so")
 
 MV_F32, MV_F16, MV_BF16, MV_I32, MV_I64 = 0, 1, 2, 3, 4
-MV_F16X2 = 5  # compute dtype only: fp16 MFMA with split (hi + lo) operands, three sweeps per GEMM (include/memvul_hip.h)
+MV_F16X8 = 6  # compute dtype only ("precise"): fp16 MFMA sweep + one fp8 (e4m3) correction sweep per GEMM (include/memvul_hip.h)
+COMPUTE_DTYPES = {"f16": MV_F16, "f16x8": MV_F16X8, "precise": MV_F16X8}
+
+
+def compute_dtype_of(name_or_code) -> int:
+    """"f16" | "f16x8" (alias "precise") or the numeric mv_dtype -> the code mv_finalize_weights takes; anything else raises."""
+    if isinstance(name_or_code, str):
+        if name_or_code.lower() not in COMPUTE_DTYPES:
+            raise ValueError(f"unknown compute dtype {name_or_code!r}: expected one of {sorted(COMPUTE_DTYPES)}")
+        return COMPUTE_DTYPES[name_or_code.lower()]
+    if int(name_or_code) not in (MV_F16, MV_F16X8):
+        raise ValueError(f"unknown compute dtype code {name_or_code!r}: MV_F16 = {MV_F16} or MV_F16X8 = {MV_F16X8}")
+    return int(name_or_code)
+
+
 NUM_KERNEL_CLASSES = 14
 
 # every symbol include/memvul_hip.h declares (tests check the .so exports all of them)
@@ -24,7 +38,7 @@ ABI_SYMBOLS = [
     "mv_anchor_reset", "mv_anchor_append", "mv_anchor_count", "mv_anchor_get", "mv_anchor_set",
     "mv_forward", "mv_encode", "mv_match", "mv_topk", "mv_corpus_upload", "mv_corpus_run", "mv_corpus_run_len",
     "mv_corpus_results", "mv_set_streams", "mv_profile_enable", "mv_profile_select", "mv_profile_read", "mv_kernel_class_name",
-    "mv_debug_encode", "mv_debug_read", "mv_test_gemm", "mv_comm_init", "mv_comm_allgather", "mv_comm_destroy",
+    "mv_debug_encode", "mv_debug_read", "mv_test_gemm", "mv_test_gemm_pp", "mv_test_e4m3", "mv_comm_init", "mv_comm_allgather", "mv_comm_destroy",
 ]
 
 
@@ -86,6 +100,8 @@ def load_library(path: Optional[str] = None):
         "mv_debug_encode": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, C.c_int]),
         "mv_debug_read": (C.c_int, [vp, C.c_int, vp, C.c_int64]),
         "mv_test_gemm": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, C.c_int, P(C.c_float)]),
+        "mv_test_gemm_pp": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, C.c_int, P(C.c_float)]),
+        "mv_test_e4m3": (C.c_int, [vp, vp, C.c_int64]),
         "mv_comm_init": (C.c_int, [vp, C.c_int, C.c_int, C.c_char_p]),
         "mv_comm_allgather": (C.c_int, [vp, vp, vp, C.c_int64]),
         "mv_comm_destroy": (C.c_int, [vp]),
@@ -156,14 +172,14 @@ class Engine:
         shape = (C.c_int64 * arr.ndim)(*arr.shape)
         self._check(self._lib.mv_load_tensor(self._h, name.encode(), _ptr(arr), dt, shape, arr.ndim), f"mv_load_tensor({name})")
 
-    def load_state_dict(self, sd: Dict[str, np.ndarray], compute_dtype: int = MV_F16):
+    def load_state_dict(self, sd: Dict[str, np.ndarray], compute_dtype=MV_F16):
         """``sd``: reference ``state_dict`` keys -> arrays (torch tensors are converted by the caller)."""
         for k, v in sd.items():
             a = np.asarray(v)
             if a.ndim == 0:
                 continue
             self.load_tensor(k, a)
-        self._check(self._lib.mv_finalize_weights(self._h, compute_dtype), "mv_finalize_weights")
+        self._check(self._lib.mv_finalize_weights(self._h, compute_dtype_of(compute_dtype)), "mv_finalize_weights")
 
     # -- anchors
     def anchor_reset(self):
@@ -305,7 +321,8 @@ class Engine:
     def debug_encode(self, ids, lens, n_layers: int):
         ids, lens = _as(ids, np.int32), _as(lens, np.int32)
         self._check(self._lib.mv_debug_encode(self._h, _ptr(ids), _ptr(lens), ids.shape[0], ids.shape[1], n_layers), "mv_debug_encode")
-        self._dbg = (ids.shape[0], (ids.shape[1] + 63) // 64 * 64)
+        S = ids.shape[1]
+        self._dbg = (ids.shape[0], (S + 63) // 64 * 64 if S <= 256 else (S + 127) // 128 * 128)  # engine.hip padded_len
 
     def debug_read(self, buffer: int) -> np.ndarray:
         B, Sp = self._dbg
@@ -329,3 +346,36 @@ class Engine:
         self._check(self._lib.mv_test_gemm(self._h, variant, M, N, K, _ptr(A16), _ptr(W16), _ptr(bias), _ptr(out), iters,
                                            C.byref(ms)), "mv_test_gemm")
         return out, float(ms.value)
+
+    def test_gemm_pp(self, A: np.ndarray, W: np.ndarray, bias: np.ndarray, x8: bool = False, iters: int = 1):
+        """The persistent FFN-1 kernel on fp32 operands (unit row statistics): fp16 gelu(A W^T + bias) [M][N]; x8: the MV_F16X8
+        build, also returning the [lo8 | hi8] e4m3 planes of the output as uint8 [M][2 N]."""
+        A, W, bias = _as(A, np.float32), _as(W, np.float32), _as(bias, np.float32)
+        M, K = A.shape
+        N = W.shape[0]
+        out = np.empty((M, N), np.float16)
+        out8 = np.empty((M, 2 * N), np.uint8) if x8 else None
+        ms = C.c_float(0)
+        self._check(self._lib.mv_test_gemm_pp(self._h, int(x8), M, N, K, _ptr(A), _ptr(W), _ptr(bias), _ptr(out), _ptr(out8), iters,
+                                              C.byref(ms)), "mv_test_gemm_pp")
+        return out, out8, float(ms.value)
+
+
+def e4m3_bits(x: np.ndarray) -> np.ndarray:
+    """OCP e4m3fn bits of fp32 values through the library's host-side encoder (the one that builds the MV_F16X8 weight planes)."""
+    lib = load_library()
+    x = _as(x, np.float32)
+    out = np.empty(x.shape, np.uint8)
+    rc = lib.mv_test_e4m3(_ptr(x), _ptr(out), x.size)
+    if rc != 0:
+        raise RuntimeError("mv_test_e4m3 failed")
+    return out
+
+
+def e4m3_decode(b: np.ndarray) -> np.ndarray:
+    """fp32 value of OCP e4m3fn bits (0x7f / 0xff = NaN)."""
+    b = np.asarray(b, np.uint8).astype(np.int32)
+    e, m = (b >> 3) & 15, b & 7
+    v = np.where(e == 0, m * 2.0 ** -9, (8 + m) * 2.0 ** (e - 10))
+    v = np.where((e == 15) & (m == 7), np.nan, v)
+    return (np.where(b & 0x80, -v, v)).astype(np.float32)

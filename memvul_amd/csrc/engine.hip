@@ -16,10 +16,10 @@
 #include <vector>
 
 #include "../../include/memvul_hip.h"
-#include "attention.h"
 #include "common.h"
 #include "gemm.h"
 #include "gemm_pp.h"
+#include "attention.h"
 #include "attention_v2.h"
 #include "misc_kernels.h"
 #include "match_topk.h"
@@ -47,8 +47,10 @@ struct LayerW {
   // virtual LayerNorm (gemm_pp.h): the preceding LayerNorm folded in: W'' = rowcentre(W gamma), b' = b + W beta
   half_t *wqkv_f = nullptr, *w1_f = nullptr;
   float *bqkv_f = nullptr, *b1_f = nullptr;
-  // split-operand mode (MV_F16X2): lo planes fp16(W - fp16(W)) of the four GEMM weights the persistent path uses
-  half_t *wqkv_f_lo = nullptr, *wo_lo = nullptr, *w1_f_lo = nullptr, *w2_lo = nullptr;
+  // MV_F16X8 (gemm_pp.h): fp8 planes [hi8 | lo8] of the four GEMM weights the persistent path uses, rows of 2 K bytes, and the
+  // E8M0 scale word of each GEMM's correction sweep (2^-(11 + MV_X8_ACT_SHIFT + the matrix' own shift))
+  uint8_t *wqkv_f8 = nullptr, *wo8 = nullptr, *w1_f8 = nullptr, *w28 = nullptr;
+  int sc_qkv = 0, sc_o = 0, sc_1 = 0, sc_2 = 0;
   float *ln1g = nullptr, *ln1b = nullptr, *ln2g = nullptr, *ln2b = nullptr;
 };
 
@@ -126,10 +128,11 @@ struct Work {
   float* u_in = nullptr;                        // host-provided embeddings for mv_match / mv_topk
   float *c32 = nullptr, *cq = nullptr;          // [CLS]-row buffers of the pruned last layer
   half_t *c16 = nullptr, *cctx = nullptr, *ch16 = nullptr;
-  float *lnstats = nullptr, *lnpart = nullptr;  // LayerNorm row statistics: (mean, rstd) [T][2], or the two vstats buffers [T][3][2]
-                                                // of the virtual LayerNorm (layer input / mid-layer; each residual GEMM reads one, writes the other)
+  float *lnstats = nullptr, *lnpart = nullptr;  // the two vstats buffers [T][3][2] of the virtual LayerNorm (layer input / mid-layer;
+                                                // each residual GEMM reads one, writes the other)
   half_t* xlo = nullptr;                        // lo plane of the two-plane raw stream (PP_RESLN3)
-  half_t *ctx_lo = nullptr, *h_lo = nullptr;    // MV_F16X2: lo planes of the attention context / GELU output
+  uint8_t *x8 = nullptr, *ctx8 = nullptr, *h8 = nullptr;  // MV_F16X8: [lo8 | hi8] planes of the raw stream [T][1536], the attention
+                                                          // context [T][1536] and the GELU output [T][6144]
 };
 
 struct mv_handle {
@@ -138,7 +141,7 @@ struct mv_handle {
   std::string err;
   bool finalized = false;
   int compute_dtype = MV_F16;
-  bool precise = false;    // MV_F16X2: every persistent GEMM runs three sweeps over hi / lo operand planes (gemm.h GemmArgs::nseg)
+  bool precise = false;    // MV_F16X8: every persistent GEMM adds the fp8 correction sweep (gemm_pp.h X8)
   std::map<std::string, HostTensor> staged;
   std::vector<void*> allocs;
 
@@ -173,16 +176,6 @@ struct mv_handle {
 
   // last-layer pruning ([CLS] rows only after the last layer's K / V projection) and its compact buffers
   bool cls_prune = true;   // env MEMVUL_CLS_PRUNE=0 disables
-  // LayerNorm folded into the consumer's residual read (gemm_pp PP_RESLN); env MEMVUL_LN_FUSE=0 disables
-  bool ln_fuse = true;
-  // persistent LDS-DMA attention kernel for padded lengths <= 256 (attention_v2.h); env MEMVUL_ATTN=0 selects attention.h
-  bool attn_v2 = true;
-  float *ones = nullptr, *zeros = nullptr;
-  // ... and no LayerNorm kernel at all between the GEMMs (RAW consumers + PP_RESLN2 producers); env MEMVUL_LN_VIRTUAL=0 disables
-  bool ln_virtual = true;
-  int pp_stagger = 0;  // env MEMVUL_STAGGER: see GemmArgs::stagger
-  bool res_hilo = true;  // env MEMVUL_RES_HILO=0: raw stream as fp32 + fp16 copy (PP_RESLN2) instead of two fp16 planes (PP_RESLN3)
-  int r16_direct = 0;  // PP_RESLN2: fp16 copy from the transposed fp32 image (1) or through its own LDS transposition (0); env MEMVUL_R16_DIRECT
 
   // profiling
   uint32_t prof_mask = 0xffffffffu;  // kernel classes that get HIP events while profiling is on
@@ -190,8 +183,8 @@ struct mv_handle {
   std::vector<ProfRec> recs;
   std::vector<hipEvent_t> free_events;
 
-  // GEMM path (env MEMVUL_GEMM_TILE): 0 auto (persistent ping-pong kernel when the launch fills the chip, else the
-  // 128^2 tile), 128 / 256 force the one-tile-per-workgroup kernels, 512 forces the ping-pong kernel.
+  // GEMM path (env MEMVUL_GEMM_TILE): 0 auto (persistent ping-pong kernels when the pass fills the chip, else the
+  // one-tile-per-workgroup kernels on an fp32 stream), 128 forces the small path, 512 the persistent one.
   int gemm_tile = 0;
   int num_cu = 256;
 
@@ -291,124 +284,65 @@ int choose_gn(int tn, int gn_max) {
   return g;
 }
 
-template <int EPI, bool GLDS>
+template <int EPI>
 int launch_gemm128(mv_handle* h, int cls, GemmArgs a) {
   if (a.M % 128 || a.N % 128 || a.K % 64) return fail(h, MV_ERR_INVALID, "gemm128: M,N % 128, K % 64 required");
   a.GN = choose_gn(a.N / 128, 8);
   const int grid = (a.M / 128) * (a.N / 128);
   ProfScope ps(h, cls);
-  hipLaunchKernelGGL((gemm128_kernel<EPI, GLDS>), dim3(grid), dim3(256), G128_LDS_BYTES, h->w->stream, a);
+  hipLaunchKernelGGL((gemm128_kernel<EPI>), dim3(grid), dim3(256), G128_LDS_BYTES, h->w->stream, a);
   return launch_check(h, "gemm128");
 }
 
+// skinny problems (the [CLS] tail of the pruned last layer: M = batch rows): 64 x 64 tiles on a 4-stage LDS ring,
+// 4x the workgroups of the 128^2 kernel and a K loop that is DMA-latency-bound per step rather than per tile
+constexpr int RING64_LDS = 4 * (64 + 64) * 64 * 2;
 template <int EPI>
-int launch_gemm256(mv_handle* h, int cls, GemmArgs a) {
-  if (a.M % 256 || a.N % 256 || a.K % 64) return fail(h, MV_ERR_INVALID, "gemm256: M,N % 256, K % 64 required");
-  a.GN = choose_gn(a.N / 256, 4);
-  const int grid = (a.M / 256) * (a.N / 256);
+int launch_ring64(mv_handle* h, int cls, GemmArgs a) {
+  if (a.M % 64 || a.N % 64 || a.K % 64) return fail(h, MV_ERR_INVALID, "gemm_ring: shape not a multiple of the 64 x 64 x 64 tile");
+  a.GN = choose_gn(a.N / 64, 8);
+  const int grid = (a.M / 64) * (a.N / 64);
   ProfScope ps(h, cls);
-  hipLaunchKernelGGL((gemm256_kernel<EPI>), dim3(grid), dim3(512), G256_LDS_BYTES, h->w->stream, a);
-  return launch_check(h, "gemm256");
-}
-
-template <int EPI, int FR_M, int FR_N, int WM, int WN, int BK, int ST, int MINW, int ABL = 0>
-int launch_ring(mv_handle* h, int cls, GemmArgs a, int gn_max) {
-  constexpr int BM = WM * FR_M * 32, BN = WN * FR_N * 32;
-  constexpr int LDS = ST * (BM + BN) * BK * 2;
-  static_assert(LDS <= 160 * 1024, "LDS ring exceeds 160 KiB");
-  if (a.M % BM || a.N % BN || a.K % BK) return fail(h, MV_ERR_INVALID, "gemm_ring: shape not a multiple of the tile");
-  auto kern = gemm_ring_kernel<EPI, FR_M, FR_N, WM, WN, BK, ST, MINW, ABL>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-    (void)hipGetLastError();
-    attr_set = true;
-  }
-  a.GN = choose_gn(a.N / BN, gn_max);
-  const int grid = (a.M / BM) * (a.N / BN);
-  ProfScope ps(h, cls);
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * WM * WN), LDS, h->w->stream, a);
+  hipLaunchKernelGGL((gemm_ring_kernel<EPI, 1, 1, 2, 2, 64, 4, 2>), dim3(grid), dim3(256), RING64_LDS, h->w->stream, a);
   return launch_check(h, "gemm_ring");
 }
 
-// production configuration of the ping-pong GEMM (tools/gemm_bench.hip sweeps the alternatives): one barrier per
-// phase (SCHED 1), 4 half-tiles in flight across each barrier, epilogue / residual I/O through the LDS transposition
-constexpr int PP_DIST = 4, PP_SCHED = 1, PP_COAL = 1;
-
-template <int PPEPI, int RAW = 0>
-int launch_pp_raw(mv_handle* h, GemmArgs a) {
-  if (a.M % 256 || a.N % 256 || a.K % 128 || a.N > MV_INTER)
-    return fail(h, MV_ERR_INVALID, "gemm_pp: M,N % 256, K % 128, N <= 3072 required");
-  if (RAW && !a.bias) return fail(h, MV_ERR_STATE, "internal: RAW GEMM without the folded bias");
+// The persistent ping-pong GEMM (gemm_pp.h): one workgroup per CU walks the 256^2 output tiles.  a.A8 set = the
+// MV_F16X8 build (a second, fp8 sweep over [A8 | W8]).
+template <int PPEPI>
+int launch_pp(mv_handle* h, int cls, GemmArgs a) {
+  constexpr int RAW = PPEPI != PP_RESLN3;
+  if (a.M % 256 || a.N % 256 || a.K % 128 || a.K < 256 || a.N > MV_INTER)
+    return fail(h, MV_ERR_INVALID, "gemm_pp: M,N % 256, K % 128, K >= 256, N <= 3072 required");  // K >= 256: the RAW kernels stage the
+                                                                                              // next tile's statistics at K-tile 2
+  if (!a.bias || !a.lnstats) return fail(h, MV_ERR_STATE, "internal: gemm_pp without bias / row statistics");
   a.GN = choose_gn(a.N / 256, 4);  // widths 2 / 3 / 6 / 12 measured: 4 (or the largest divisor below it) is the fastest
   const int tiles = (a.M / 256) * (a.N / 256);
   const int grid = tiles < h->num_cu ? tiles : h->num_cu;
-  a.stagger = tiles >= 2 * h->num_cu ? h->pp_stagger : 0;
-  if (a.stagger == -1) {  // two phase groups half a tile apart (tile times at the bench shape: 25 / 42 / 105 us; one unit ~ 5 us)
-    constexpr bool res = (PPEPI == PP_RES || PPEPI == PP_RESLN || PPEPI == PP_RESLN2 || PPEPI == PP_RESLN3);
-    a.stagger = res ? (a.K <= 1024 ? -4 : -10) : -2;
+  const int lds = RAW ? PP_LDS_BYTES_RAW : PP_LDS_BYTES;
+  ProfScope ps(h, cls);
+  if (a.A8) {
+    if (!a.W8 || (PPEPI != PP_QK && !a.out8)) return fail(h, MV_ERR_STATE, "internal: MV_F16X8 GEMM without its fp8 planes");
+    hipLaunchKernelGGL((gemm_pp_kernel<PPEPI, RAW, 1>), dim3(grid), dim3(512), lds, h->w->stream, a);
+  } else {
+    hipLaunchKernelGGL((gemm_pp_kernel<PPEPI, RAW, 0>), dim3(grid), dim3(512), lds, h->w->stream, a);
   }
-  if (a.nseg == 3) {  // split-operand instantiation (MV_F16X2): built for the four kernel kinds the encoder's persistent path uses
-    if constexpr (PPEPI == PP_RESLN3 || (RAW && (PPEPI == PP_QK || PPEPI == PP_GELU))) {
-      auto kern = gemm_pp_kernel<PPEPI, PP_DIST, 0, PP_SCHED, PP_COAL, RAW, 1>;
-      static bool attr_set = false;
-      if (!attr_set) {
-        hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, RAW ? PP_LDS_BYTES_RAW : PP_LDS_BYTES);
-        (void)hipGetLastError();
-        attr_set = true;
-      }
-      hipLaunchKernelGGL(kern, dim3(grid), dim3(512), RAW ? PP_LDS_BYTES_RAW : PP_LDS_BYTES, h->w->stream, a);
-      return launch_check(h, "gemm_pp x2");
-    } else {
-      return fail(h, MV_ERR_STATE, "internal: split-operand GEMM requested for a kernel kind that has no such build");
-    }
-  }
-  hipLaunchKernelGGL((gemm_pp_kernel<PPEPI, PP_DIST, 0, PP_SCHED, PP_COAL, RAW>), dim3(grid), dim3(512),
-                     RAW ? PP_LDS_BYTES_RAW : PP_LDS_BYTES, h->w->stream, a);
   return launch_check(h, "gemm_pp");
 }
 
-template <int EPI>
-int launch_pp(mv_handle* h, int cls, const GemmArgs& a) {
-  ProfScope ps(h, cls);
-  if constexpr (EPI == EPI_QKV) {  // Q,K columns (row-per-lane stores) and the V^T block (token-contiguous stores)
-    // a.col0 = 768: a.W / a.bias already point at the K block and the launch covers K, V only (last-layer pruning)
-    // one launch: the V tiles take the transposed epilogue (gemm_pp.h scr_f16x2_t)
-    GemmArgs qkv = a;
-    qkv.N = (a.col0 ? 2 : 3) * MV_HIDDEN;
-    return a.raw ? launch_pp_raw<PP_QK, 1>(h, qkv) : launch_pp_raw<PP_QK>(h, qkv);
-  } else if constexpr (EPI == EPI_GELU) {
-    return a.raw ? launch_pp_raw<PP_GELU, 1>(h, a) : launch_pp_raw<PP_GELU>(h, a);
-  } else if constexpr (EPI == EPI_RES) {
-    if (a.lnstats && a.lnpart && a.out16b) return launch_pp_raw<PP_RESLN3>(h, a);
-    if (a.lnstats && a.lnpart) return launch_pp_raw<PP_RESLN2>(h, a);
-    if (a.lnstats) return launch_pp_raw<PP_RESLN>(h, a);
-    return launch_pp_raw<PP_RES>(h, a);
-  } else {
-    return launch_pp_raw<PP_F32>(h, a);
-  }
+// path choice: the persistent kernels need enough 256^2 tiles to fill the CUs (one workgroup each); both residual GEMMs
+// have N = 768 and every K is a multiple of 128, so ONE predicate (on the padded token count) decides the path of a pass
+bool pp_selected(const mv_handle* h, int64_t M) {
+  if (M % 256) return false;
+  if (h->gemm_tile == 128) return false;
+  return h->gemm_tile == 512 || h->precise || (M / 256) * (MV_HIDDEN / 256) >= 256;
 }
 
-// path choice: the persistent kernels need enough 256^2 tiles to fill the CUs (one workgroup each)
-bool pp_selected(const mv_handle* h, int64_t M, int N, int K) {
-  const bool tile256 = (M % 256 == 0) && (N % 256 == 0);
-  const bool big = tile256 && ((M / 256) * (N / 256) >= 256);
-  const bool pp_ok = tile256 && (K % 128 == 0) && N <= MV_INTER;
-  return pp_ok && (h->gemm_tile == 512 || h->precise || (h->gemm_tile == 0 && big));
-}
-
+// the mid-size / skinny GEMMs of a pass that does not fill the chip (and of the [CLS] tail)
 template <int EPI>
-int launch_gemm(mv_handle* h, int cls, const GemmArgs& a) {
-  const bool tile256 = (a.M % 256 == 0) && (a.N % 256 == 0);
-  const bool big = tile256 && ((int64_t)(a.M / 256) * (a.N / 256) >= 256);
-  if (pp_selected(h, a.M, a.N, a.K)) return launch_pp<EPI>(h, cls, a);
-  if (a.lnstats || a.raw) return fail(h, MV_ERR_STATE, "internal: LayerNorm-fused GEMM requested on a non-persistent GEMM path");
-  if (tile256 && (h->gemm_tile == 256 || (h->gemm_tile == 0 && big))) return launch_gemm256<EPI>(h, cls, a);
-  // skinny problems (the [CLS] tail of the pruned last layer: M = batch rows): 64 x 64 tiles on a 4-stage LDS ring,
-  // 4x the workgroups of the 128^2 kernel and a K loop that is DMA-latency-bound per step rather than per tile
-  if (h->gemm_tile == 0 && a.M <= 512 && a.M % 64 == 0 && a.N % 64 == 0)
-    return launch_ring<EPI, 1, 1, 2, 2, 64, 4, 2>(h, cls, a, 8);
-  return launch_gemm128<EPI, true>(h, cls, a);
+int launch_small(mv_handle* h, int cls, const GemmArgs& a) {
+  if (h->gemm_tile == 0 && a.M <= 512 && a.M % 64 == 0 && a.N % 64 == 0) return launch_ring64<EPI>(h, cls, a);
+  return launch_gemm128<EPI>(h, cls, a);
 }
 
 // K7 + K8: pooler on the [CLS] rows (row_stride floats apart), then the header
@@ -422,61 +356,92 @@ int pool_head(mv_handle* h, const float* x, size_t row_stride, int B, float* u_o
   return launch_check(h, "header");
 }
 
+// padded sequence length of a pass: attention_v2 runs 64-key blocks up to 256 and 128-key chunks above
+inline int padded_len(int S_in) { return (int)round_up(S_in, S_in <= 256 ? 64 : 128); }
+
+int launch_attention(mv_handle* h, const int32_t* d_lens, int B, int Sp, bool x8) {
+  AttnArgs a{h->w->q, h->w->k, h->w->vt, d_lens, h->w->ctx, Sp, B, x8 ? h->w->ctx8 : nullptr};
+  ProfScope ps(h, KC_ATTENTION);
+  if (Sp <= 256) {
+    const int nkb = Sp / 64, items = B * MV_HEADS;
+    const int slots = h->num_cu * (nkb == 1 ? 4 : nkb == 2 ? 2 : 1);  // resident workgroups: 8 waves and <= 128 KiB LDS per CU
+    const int grid = items < slots ? items : slots;
+#define MV_ATT(NKB)                                                                                                              \
+    if (x8) hipLaunchKernelGGL((attention_v2_kernel<NKB, 1, 1>), dim3(grid), dim3(NKB * 128), ATT2_LDS_BYTES(NKB), h->w->stream, a, items); \
+    else hipLaunchKernelGGL((attention_v2_kernel<NKB, 1, 0>), dim3(grid), dim3(NKB * 128), ATT2_LDS_BYTES(NKB), h->w->stream, a, items)
+    switch (nkb) {
+      case 1: MV_ATT(1); break;
+      case 2: MV_ATT(2); break;
+      case 3: MV_ATT(3); break;
+      default: MV_ATT(4); break;
+    }
+#undef MV_ATT
+  } else if (Sp == 384 || Sp == 512) {
+    // chunks of 128 keys per (row, head, 128-query block) through the same ring: 64 score registers per lane, two
+    // workgroups of 4 waves per CU; consecutive units of a workgroup are the query blocks of one head (K / V^T from L2)
+    const int nch = Sp / 128, units = B * MV_HEADS * nch;
+    const int grid = units < 2 * h->num_cu ? units : 2 * h->num_cu;
+    if (nch == 3 && x8) hipLaunchKernelGGL((attention_v2_kernel<2, 3, 1>), dim3(grid), dim3(256), ATT2_LDS_BYTES(2), h->w->stream, a, units);
+    else if (nch == 3) hipLaunchKernelGGL((attention_v2_kernel<2, 3, 0>), dim3(grid), dim3(256), ATT2_LDS_BYTES(2), h->w->stream, a, units);
+    else if (x8) hipLaunchKernelGGL((attention_v2_kernel<2, 4, 1>), dim3(grid), dim3(256), ATT2_LDS_BYTES(2), h->w->stream, a, units);
+    else hipLaunchKernelGGL((attention_v2_kernel<2, 4, 0>), dim3(grid), dim3(256), ATT2_LDS_BYTES(2), h->w->stream, a, units);
+  } else {
+    return fail(h, MV_ERR_INVALID, "internal: attention at a padded length other than 64 .. 256 / 384 / 512");
+  }
+  return launch_check(h, "attention");
+}
+
 // ---- encoder: ids (device) -> u (device, [B][512]); stops after n_layers (<0: all) ------------
-// `full`: every layer over every token and the normalised fp32 stream left in xres (debug taps); otherwise the
-// last layer is pruned to the [CLS] rows when the pooler follows (cls_prune), and on the persistent-GEMM path the
-// LayerNorm kernels write only the fp16 operand + row statistics, the residual consumers normalise (ln_fuse).
+// Two paths, chosen by the size of the pass (pp_selected):
+//   * bench scale: the persistent GEMMs on the two-plane raw stream with the virtual LayerNorm (gemm_pp.h), five launches per
+//     layer; compute dtype MV_F16X8 adds the fp8 correction sweep to each GEMM and the [lo8 | hi8] planes to each producer;
+//   * small passes: one-tile-per-workgroup GEMMs (gemm.h) on an fp32 stream with explicit LayerNorm kernels.
+// The last layer is pruned to the [CLS] rows when the pooler follows (cls_prune); `full` (debug taps) disables that and
+// leaves the normalised fp32 stream of the last layer run in xres.
 int encode_dev(mv_handle* h, const int32_t* d_ids, const int32_t* d_lens, int B, int S_in, int n_layers, float* u_out,
                bool full = false, int pitch = 0) {
   if (pitch <= 0) pitch = S_in;  // ints between the rows of d_ids
   const mv_config& c = h->cfg;
-  const int Sp = (int)round_up(S_in, 64);
+  const int Sp = padded_len(S_in);
   const int64_t M = (int64_t)B * Sp, Mpad = round_up(M, 256);
-  if (Sp > c.max_pos && S_in > c.max_pos) return fail(h, MV_ERR_INVALID, "sequence longer than max_pos");
+  if (S_in > c.max_pos) return fail(h, MV_ERR_INVALID, "sequence longer than max_pos");
   if (Mpad > h->cap_tokens) return fail(h, MV_ERR_CAPACITY, "B*S exceeds mv_config.max_tokens");
   if (n_layers < 0 || n_layers > c.layers) n_layers = c.layers;
   h->dbg_B = B;
   h->dbg_Sp = Sp;
-  // split-operand mode: every layer goes through the persistent kernels (the [CLS] tail's skinny GEMMs are plain fp16)
-  const bool prune = !full && h->cls_prune && !h->precise && u_out && n_layers == c.layers && n_layers > 0;
-  // both residual GEMMs have N = 768 and K % 128 == 0: one predicate decides the path of every RES launch of this pass
-  const bool fuse = !full && h->ln_fuse && pp_selected(h, Mpad, MV_HIDDEN, MV_HIDDEN);
-  // virtual LayerNorm (gemm_pp.h): no LayerNorm kernel between the GEMMs; x16 then holds the RAW stream in fp16
-  const bool virt = fuse && h->ln_virtual;
-  const bool hilo = virt && h->res_hilo;  // raw stream as two fp16 planes (x16 = hi, xlo = lo); xres is then unused
-  const bool x2 = h->precise;             // three sweeps over hi / lo planes in every GEMM (GemmArgs::nseg)
-  if (x2 && !hilo) return fail(h, MV_ERR_STATE, "MV_F16X2 needs the persistent two-plane path (not available for debug taps / this shape)");
+  const bool big = pp_selected(h, Mpad);  // persistent GEMMs, raw two-plane stream (x16 = hi, xlo = lo), virtual LayerNorm
+  const bool x8 = h->precise;             // MV_F16X8: + fp8 correction sweeps (forces the persistent path, pp_selected)
+  // MV_F16X8: every layer goes through the persistent kernels (the [CLS] tail's skinny GEMMs are plain fp16)
+  const bool prune = !full && h->cls_prune && !x8 && u_out && n_layers == c.layers && n_layers > 0;
   const unsigned ln_grid = (unsigned)((M + 3) / 4);
   {
     ProfScope ps(h, KC_EMBED_LN);
-    if (virt)
+    if (big)
       hipLaunchKernelGGL(embed_ln_kernel<true>, dim3(ln_grid), dim3(256), 0, h->w->stream, d_ids, pitch, S_in, Sp, (int)M, c.vocab_size,
-                         h->wemb, h->pemb, h->temb, h->embg, h->embb, c.ln_eps, h->w->xres, h->w->x16, h->w->lnstats,
-                         hilo ? h->w->xlo : (half_t*)nullptr);
+                         h->wemb, h->pemb, h->temb, h->embg, h->embb, c.ln_eps, h->w->xres, h->w->x16, h->w->lnstats, h->w->xlo,
+                         x8 ? h->w->x8 : (uint8_t*)nullptr);
     else
       hipLaunchKernelGGL(embed_ln_kernel<false>, dim3(ln_grid), dim3(256), 0, h->w->stream, d_ids, pitch, S_in, Sp, (int)M, c.vocab_size,
-                         h->wemb, h->pemb, h->temb, h->embg, h->embb, c.ln_eps, h->w->xres, h->w->x16,
-                         fuse ? h->w->lnstats : (float*)nullptr, (half_t*)nullptr);
+                         h->wemb, h->pemb, h->temb, h->embg, h->embb, c.ln_eps, h->w->xres, h->w->x16, (float*)nullptr,
+                         (half_t*)nullptr, (uint8_t*)nullptr);
     if (int rc = launch_check(h, "embed_ln")) return rc;
   }
-  // LayerNorm whose statistics are pending in lnstats (fuse only): gamma / beta the next residual consumer applies
-  // (virt: the embedding LayerNorm itself is pending; otherwise the embedding kernel already applied it)
-  const float *pend_g = virt ? h->embg : h->ones, *pend_b = virt ? h->embb : h->zeros;
-  auto run_ln = [&](float* x32, half_t* x16, int rows, const float* g, const float* b, bool stats_only) -> int {
+  // big: the LayerNorm whose statistics are pending in the vstats buffers — gamma / beta the next residual GEMM applies
+  const float *pend_g = h->embg, *pend_b = h->embb;
+  auto run_ln = [&](float* x32, half_t* x16, int rows, const float* g, const float* b) -> int {
     ProfScope ps(h, KC_LN);
-    const unsigned grid = (unsigned)((rows + 3) / 4);
-    if (stats_only)
-      hipLaunchKernelGGL(ln_kernel<false>, dim3(grid), dim3(256), 0, h->w->stream, x32, x16, rows, g, b, c.ln_eps, h->w->lnstats);
-    else
-      hipLaunchKernelGGL(ln_kernel<true>, dim3(grid), dim3(256), 0, h->w->stream, x32, x16, rows, g, b, c.ln_eps, (float*)nullptr);
+    hipLaunchKernelGGL(ln_kernel<true>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, h->w->stream, x32, x16, rows, g, b, c.ln_eps,
+                       (float*)nullptr);
     return launch_check(h, "layernorm");
   };
-  auto materialise_f32 = [&]() -> int {  // two-plane raw stream -> fp32 rows for the final LayerNorm kernel
+  auto final_ln = [&](const float* g, const float* b) -> int {  // two-plane raw stream -> normalised fp32 rows (pooler / debug taps)
     const size_t n4 = (size_t)M * MV_HIDDEN / 4;
     hipLaunchKernelGGL(hilo_to_f32_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, h->w->stream, h->w->x16, h->w->xlo, n4, h->w->xres);
-    return launch_check(h, "hilo_to_f32");
+    if (int rc = launch_check(h, "hilo_to_f32")) return rc;
+    return run_ln(h->w->xres, h->w->x16, (int)M, g, b);
   };
-  // virtual LayerNorm: st_in = vstats of the layer's input rows (embedding / previous FFN-2), st_mid = of the rows after the
+  if (big && n_layers == 0) { if (int rc = final_ln(h->embg, h->embb)) return rc; }
+  // big: st_in = vstats of the layer's input rows (embedding / previous FFN-2), st_mid = of the rows after the
   // attention-output projection; no statistics kernel in between (gemm_pp.h)
   float *st_in = h->w->lnstats, *st_mid = h->w->lnpart;
   for (int l = 0; l < n_layers; ++l) {
@@ -485,115 +450,81 @@ int encode_dev(mv_handle* h, const int32_t* d_ids, const int32_t* d_lens, int B,
     GemmArgs g{};
     g.M = (int)Mpad; g.Mreal = (int)M; g.S = Sp; g.ln_eps = c.ln_eps;
     g.q = h->w->q; g.k = h->w->k; g.vt = h->w->vt;
-    if (virt) { g.raw = 1; g.lnstats = st_in; }
-    const half_t* wqkv = virt ? w.wqkv_f : w.wqkv;
-    const float* bqkv = virt ? w.bqkv_f : w.bqkv;
+    const half_t* wqkv = big ? w.wqkv_f : w.wqkv;
+    const float* bqkv = big ? w.bqkv_f : w.bqkv;
     if (last && prune) {
       // ---- last layer, [CLS] rows only: K and V of every token, everything else on B rows
       const int Bp = (int)round_up(B, 128);
       g.A = h->w->x16; g.W = wqkv + (size_t)MV_HIDDEN * MV_HIDDEN; g.bias = bqkv + MV_HIDDEN; g.N = 2 * MV_HIDDEN; g.K = MV_HIDDEN;
       g.col0 = MV_HIDDEN;
-      if (int rc = launch_gemm<EPI_QKV>(h, KC_GEMM_KV_LAST, g)) return rc;
+      if (big) { g.lnstats = st_in; if (int rc = launch_pp<PP_QK>(h, KC_GEMM_KV_LAST, g)) return rc; }
+      else if (int rc = launch_small<EPI_QKV>(h, KC_GEMM_KV_LAST, g)) return rc;
       ProfScope tail(h, KC_CLS_TAIL);
       const uint32_t keep_mask = h->prof_mask;
       h->prof_mask = 0;  // the tail is one profiled span; its inner launches carry no events of their own
       auto tail_rc = [&]() -> int {
         hipLaunchKernelGGL(cls_gather_kernel, dim3((B + 3) / 4), dim3(256), 0, h->w->stream, h->w->xres, h->w->x16, Sp, B,
-                           fuse ? st_in : (const float*)nullptr, pend_g, pend_b, h->w->c32, h->w->c16, virt ? 1 : 0,
-                           hilo ? h->w->xlo : (const half_t*)nullptr, virt ? 1 : 0, c.ln_eps);
+                           big ? st_in : (const float*)nullptr, pend_g, pend_b, h->w->c32, h->w->c16, big ? 1 : 0,
+                           big ? h->w->xlo : (const half_t*)nullptr, big ? 1 : 0, c.ln_eps);
         if (int rc = launch_check(h, "cls_gather")) return rc;
         GemmArgs t{};
         t.M = Bp; t.Mreal = B; t.S = 64;
         t.A = h->w->c16; t.W = w.wqkv; t.bias = w.bqkv; t.N = MV_HIDDEN; t.K = MV_HIDDEN; t.outf = h->w->cq;
-        if (int rc = launch_gemm<EPI_F32>(h, KC_CLS_TAIL, t)) return rc;
+        if (int rc = launch_small<EPI_F32>(h, KC_CLS_TAIL, t)) return rc;
         hipLaunchKernelGGL(attention_cls_kernel, dim3((B * MV_HEADS + 3) / 4), dim3(256), 0, h->w->stream, h->w->cq, h->w->k, h->w->vt,
                            d_lens, h->w->cctx, Sp, B * MV_HEADS);
         if (int rc = launch_check(h, "attention_cls")) return rc;
         t.A = h->w->cctx; t.W = w.wo; t.bias = w.bo; t.N = MV_HIDDEN; t.K = MV_HIDDEN; t.xres = h->w->c32; t.outf = nullptr;
-        if (int rc = launch_gemm<EPI_RES>(h, KC_CLS_TAIL, t)) return rc;
-        if (int rc = run_ln(h->w->c32, h->w->c16, B, w.ln1g, w.ln1b, false)) return rc;
+        if (int rc = launch_small<EPI_RES>(h, KC_CLS_TAIL, t)) return rc;
+        if (int rc = run_ln(h->w->c32, h->w->c16, B, w.ln1g, w.ln1b)) return rc;
         t.A = h->w->c16; t.W = w.w1; t.bias = w.b1; t.N = MV_INTER; t.K = MV_HIDDEN; t.out16 = h->w->ch16;
-        if (int rc = launch_gemm<EPI_GELU>(h, KC_CLS_TAIL, t)) return rc;
+        if (int rc = launch_small<EPI_GELU>(h, KC_CLS_TAIL, t)) return rc;
         t.A = h->w->ch16; t.W = w.w2; t.bias = w.b2; t.N = MV_HIDDEN; t.K = MV_INTER; t.xres = h->w->c32;
-        if (int rc = launch_gemm<EPI_RES>(h, KC_CLS_TAIL, t)) return rc;
-        if (int rc = run_ln(h->w->c32, h->w->c16, B, w.ln2g, w.ln2b, false)) return rc;
+        if (int rc = launch_small<EPI_RES>(h, KC_CLS_TAIL, t)) return rc;
+        if (int rc = run_ln(h->w->c32, h->w->c16, B, w.ln2g, w.ln2b)) return rc;
         return pool_head(h, h->w->c32, MV_HIDDEN, B, u_out);
       }();
       h->prof_mask = keep_mask;
       return tail_rc;
     }
-    // K2: QKV projection
-    g.A = h->w->x16; g.W = wqkv; g.bias = bqkv; g.N = 3 * MV_HIDDEN; g.K = MV_HIDDEN;
-    g.A2 = nullptr; g.W2 = nullptr; g.nseg = 0;
-    if (x2) { g.A2 = h->w->xlo; g.W2 = w.wqkv_f_lo; g.nseg = 3; }
-    if (int rc = launch_gemm<EPI_QKV>(h, KC_GEMM_QKV, g)) return rc;
-    // K3: attention
-    {
-      AttnArgs a{h->w->q, h->w->k, h->w->vt, d_lens, h->w->ctx, Sp, B, nullptr};
-      if (x2) a.ctx_lo = h->w->ctx_lo;  // attention.h writes the context as hi + lo planes (attention_v2 has no second plane)
-      ProfScope ps(h, KC_ATTENTION);
-      if (h->attn_v2 && x2 && Sp == 256) {  // the bench length in split-operand mode: attention_v2 with the second output plane
-        const int items = B * MV_HEADS, grid = items < h->num_cu ? items : h->num_cu;
-        auto kern = attention_v2_kernel<4, 1, 0, 1>;
-        static bool attr_set = false;
-        if (!attr_set) {
-          hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, ATT2_LDS_BYTES(4));
-          (void)hipGetLastError();
-          attr_set = true;
-        }
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(512), ATT2_LDS_BYTES(4), h->w->stream, a, items);
-      } else if (h->attn_v2 && !x2 && Sp <= 256) {
-        const int nkb = Sp / 64, items = B * MV_HEADS;
-        const int slots = h->num_cu * (nkb == 1 ? 4 : nkb == 2 ? 2 : 1);  // resident workgroups: 8 waves and <= 128 KiB LDS per CU
-        const int grid = items < slots ? items : slots;
-        switch (nkb) {
-          case 1: hipLaunchKernelGGL((attention_v2_kernel<1>), dim3(grid), dim3(128), ATT2_LDS_BYTES(1), h->w->stream, a, items); break;
-          case 2: hipLaunchKernelGGL((attention_v2_kernel<2>), dim3(grid), dim3(256), ATT2_LDS_BYTES(2), h->w->stream, a, items); break;
-          case 3: hipLaunchKernelGGL((attention_v2_kernel<3>), dim3(grid), dim3(384), ATT2_LDS_BYTES(3), h->w->stream, a, items); break;
-          default: hipLaunchKernelGGL((attention_v2_kernel<4>), dim3(grid), dim3(512), ATT2_LDS_BYTES(4), h->w->stream, a, items); break;
-        }
-      } else if (h->attn_v2 && !x2 && (Sp == 384 || Sp == 512)) {
-        // chunks of 128 keys per (row, head, 128-query block) through the same ring: 64 score registers per lane, two
-        // workgroups of 4 waves per CU; consecutive units of a workgroup are the query blocks of one head (K / V^T from L2)
-        const int nch = Sp / 128, units = B * MV_HEADS * nch;
-        const int grid = units < 2 * h->num_cu ? units : 2 * h->num_cu;
-        if (nch == 3) hipLaunchKernelGGL((attention_v2_kernel<2, 3>), dim3(grid), dim3(256), ATT2_LDS_BYTES(2), h->w->stream, a, units);
-        else hipLaunchKernelGGL((attention_v2_kernel<2, 4>), dim3(grid), dim3(256), ATT2_LDS_BYTES(2), h->w->stream, a, units);
-      } else if (Sp <= 256) {
-        const int qblocks = (Sp + 127) / 128;
-        hipLaunchKernelGGL((attention_kernel<4>), dim3(B * MV_HEADS * qblocks), dim3(256), ATT_LDS_BYTES(Sp), h->w->stream, a);
-      } else {
-        const int qblocks = (Sp + 255) / 256;
-        hipLaunchKernelGGL((attention_kernel<8>), dim3(B * MV_HEADS * qblocks), dim3(512), ATT_LDS_BYTES(Sp), h->w->stream, a);
-      }
-      if (int rc = launch_check(h, "attention")) return rc;
+    if (big) {
+      // K2: Q, K, V^T projection of the raw stream (LayerNorm folded into W'' / b')
+      g.A = h->w->x16; g.W = wqkv; g.bias = bqkv; g.N = 3 * MV_HIDDEN; g.K = MV_HIDDEN; g.lnstats = st_in;
+      if (x8) { g.A8 = h->w->x8; g.W8 = w.wqkv_f8; g.x8_scale = w.sc_qkv; }
+      if (int rc = launch_pp<PP_QK>(h, KC_GEMM_QKV, g)) return rc;
+      // K3: attention
+      if (int rc = launch_attention(h, d_lens, B, Sp, x8)) return rc;
+      // K4: attention output projection + bias + LayerNorm(residual), in place on the raw stream; + vstats of the new rows
+      g.A = h->w->ctx; g.W = w.wo; g.bias = w.bo; g.N = MV_HIDDEN; g.K = MV_HIDDEN;
+      g.lnstats = st_in; g.lng = pend_g; g.lnb = pend_b; g.lnpart = st_mid; g.out16 = h->w->x16; g.out16b = h->w->xlo;
+      if (x8) { g.A8 = h->w->ctx8; g.W8 = w.wo8; g.x8_scale = w.sc_o; g.out8 = h->w->x8; }
+      if (int rc = launch_pp<PP_RESLN3>(h, KC_GEMM_OUT, g)) return rc;
+      pend_g = w.ln1g; pend_b = w.ln1b;
+      // K5: FFN-1 + exact-erf GELU
+      g.A = h->w->x16; g.W = w.w1_f; g.bias = w.b1_f; g.N = MV_INTER; g.K = MV_HIDDEN; g.lnstats = st_mid; g.out16 = h->w->h16;
+      g.out16b = nullptr; g.lnpart = nullptr;
+      if (x8) { g.A8 = h->w->x8; g.W8 = w.w1_f8; g.x8_scale = w.sc_1; g.out8 = h->w->h8; }
+      if (int rc = launch_pp<PP_GELU>(h, KC_GEMM_FFN1, g)) return rc;
+      // K6: FFN-2 + bias + LayerNorm(residual)
+      g.A = h->w->h16; g.W = w.w2; g.bias = w.b2; g.N = MV_HIDDEN; g.K = MV_INTER;
+      g.lnstats = st_mid; g.lng = pend_g; g.lnb = pend_b; g.lnpart = st_in; g.out16 = h->w->x16; g.out16b = h->w->xlo;
+      if (x8) { g.A8 = h->w->h8; g.W8 = w.w28; g.x8_scale = w.sc_2; g.out8 = h->w->x8; }
+      if (int rc = launch_pp<PP_RESLN3>(h, KC_GEMM_FFN2, g)) return rc;
+      pend_g = w.ln2g; pend_b = w.ln2b;
+      if (last) { if (int rc = final_ln(w.ln2g, w.ln2b)) return rc; }  // the pooler reads a normalised stream
+    } else {
+      g.A = h->w->x16; g.W = wqkv; g.bias = bqkv; g.N = 3 * MV_HIDDEN; g.K = MV_HIDDEN;
+      if (int rc = launch_small<EPI_QKV>(h, KC_GEMM_QKV, g)) return rc;
+      if (int rc = launch_attention(h, d_lens, B, Sp, false)) return rc;
+      g.A = h->w->ctx; g.W = w.wo; g.bias = w.bo; g.N = MV_HIDDEN; g.K = MV_HIDDEN; g.xres = h->w->xres;
+      if (int rc = launch_small<EPI_RES>(h, KC_GEMM_OUT, g)) return rc;
+      if (int rc = run_ln(h->w->xres, h->w->x16, (int)M, w.ln1g, w.ln1b)) return rc;
+      g.A = h->w->x16; g.W = w.w1; g.bias = w.b1; g.N = MV_INTER; g.K = MV_HIDDEN; g.out16 = h->w->h16;
+      if (int rc = launch_small<EPI_GELU>(h, KC_GEMM_FFN1, g)) return rc;
+      g.A = h->w->h16; g.W = w.w2; g.bias = w.b2; g.N = MV_HIDDEN; g.K = MV_INTER; g.xres = h->w->xres;
+      if (int rc = launch_small<EPI_RES>(h, KC_GEMM_FFN2, g)) return rc;
+      if (int rc = run_ln(h->w->xres, h->w->x16, (int)M, w.ln2g, w.ln2b)) return rc;
     }
-    // K4: attention output projection + bias + residual (in place), then LayerNorm
-    g.raw = 0; g.lnstats = nullptr; g.lnpart = nullptr; g.out16b = nullptr;
-    g.A = h->w->ctx; g.W = w.wo; g.bias = w.bo; g.N = MV_HIDDEN; g.K = MV_HIDDEN; g.xres = h->w->xres;
-    if (x2) { g.A2 = h->w->ctx_lo; g.W2 = w.wo_lo; g.nseg = 3; }
-    if (fuse) { g.lnstats = st_in; g.lng = pend_g; g.lnb = pend_b; }
-    if (virt) { g.lnpart = st_mid; g.out16 = h->w->x16; g.raw = h->r16_direct; g.out16b = hilo ? h->w->xlo : nullptr; }  // + fp16 operand copy / planes, vstats
-    if (int rc = launch_gemm<EPI_RES>(h, KC_GEMM_OUT, g)) return rc;
-    if (!virt) { if (int rc = run_ln(h->w->xres, h->w->x16, (int)M, w.ln1g, w.ln1b, fuse)) return rc; }
-    pend_g = w.ln1g; pend_b = w.ln1b;
-    // K5: FFN-1 + exact-erf GELU
-    g.lnstats = nullptr; g.lnpart = nullptr; g.raw = 0; g.out16b = nullptr;
-    if (virt) { g.raw = 1; g.lnstats = st_mid; }
-    g.A = h->w->x16; g.W = virt ? w.w1_f : w.w1; g.bias = virt ? w.b1_f : w.b1; g.N = MV_INTER; g.K = MV_HIDDEN; g.out16 = h->w->h16;
-    if (x2) { g.A2 = h->w->xlo; g.W2 = w.w1_f_lo; g.nseg = 3; g.out16b = h->w->h_lo; }
-    if (int rc = launch_gemm<EPI_GELU>(h, KC_GEMM_FFN1, g)) return rc;
-    // K6: FFN-2 + bias + residual, then LayerNorm
-    g.raw = 0; g.lnstats = nullptr; g.out16b = nullptr;
-    g.A = h->w->h16; g.W = w.w2; g.bias = w.b2; g.N = MV_HIDDEN; g.K = MV_INTER; g.xres = h->w->xres;
-    if (x2) { g.A2 = h->w->h_lo; g.W2 = w.w2_lo; g.nseg = 3; }
-    if (fuse) { g.lnstats = virt ? st_mid : h->w->lnstats; g.lng = pend_g; g.lnb = pend_b; }
-    if (virt) { g.lnpart = st_in; g.out16 = h->w->x16; g.raw = h->r16_direct; g.out16b = hilo ? h->w->xlo : nullptr; }
-    if (int rc = launch_gemm<EPI_RES>(h, KC_GEMM_FFN2, g)) return rc;
-    if (virt && !last) {}  // the next layer's consumers read st_in
-    else if (hilo && materialise_f32() != MV_OK) return MV_ERR_HIP;
-    else if (int rc = run_ln(h->w->xres, h->w->x16, (int)M, w.ln2g, w.ln2b, fuse && !last)) return rc;  // the pooler reads a normalised stream
-    pend_g = w.ln2g; pend_b = w.ln2b;
   }
   if (u_out) {
     ProfScope ps(h, KC_POOL_HEAD);
@@ -604,7 +535,7 @@ int encode_dev(mv_handle* h, const int32_t* d_ids, const int32_t* d_lens, int B,
 
 // largest batch one encoder pass can take at padded length Sp
 int max_rows_for(mv_handle* h, int S_in) {
-  const int Sp = (int)round_up(S_in, 64);
+  const int Sp = padded_len(S_in);
   int64_t r = (h->cap_tokens - 256) / Sp;
   if (r > h->cfg.max_batch) r = h->cfg.max_batch;
   return (int)r;
@@ -714,15 +645,63 @@ void fold_layernorm(const float* W, const float* b, const float* gamma, const fl
   }
 }
 
-// lo plane of a split operand: fp16(x - fp16(x))
-int upload_f16_lo(mv_handle* h, half_t** dst, const float* src, int64_t n, float scale = 1.0f) {
-  std::vector<uint16_t> tmp((size_t)n);
-  for (int64_t i = 0; i < n; ++i) {
-    const float x = src[i] * scale;
-    tmp[(size_t)i] = f32_to_f16_bits(x - f16_bits_to_f32(f32_to_f16_bits(x)));
+// fp32 -> OCP e4m3fn bits (bias 7, 3 mantissa bits, subnormal step 2^-9, max 448, no infinities), round-to-nearest-even,
+// saturating: the host-side twin of v_cvt_pk_fp8_f32 behind a clamp (common.h pack_fp8x4)
+inline uint8_t f32_to_e4m3_bits(float f) {
+  uint32_t x;
+  std::memcpy(&x, &f, 4);
+  const uint8_t sign = (uint8_t)((x >> 24) & 0x80u);
+  x &= 0x7fffffffu;
+  if (x > 0x7f800000u) return (uint8_t)(sign | 0x7fu);  // NaN
+  float a;
+  std::memcpy(&a, &x, 4);
+  if (a >= 448.f) return (uint8_t)(sign | 0x7eu);        // saturate (0x7e = 448)
+  if (a < 0.0009765625f) return sign;                    // < 2^-10: rounds to zero (2^-10 itself ties to even = 0)
+  int e;
+  (void)std::frexp(a, &e);                               // a = m 2^e, m in [0.5, 1)  ->  binade 2^(e-1)
+  int be = e - 1;                                        // unbiased exponent
+  if (be < -6) be = -6;                                  // subnormal range shares the exponent of the smallest normal
+  const float q = std::ldexp(1.0f, be - 3);              // spacing of representable values in this binade
+  const float r = std::nearbyint(a / q);                 // default rounding mode: to nearest, ties to even
+  int mant = (int)r;                                     // 0..16 (8..16 for normals)
+  int exp_field = be + 7;
+  if (be == -6 && mant < 8) return (uint8_t)(sign | (uint8_t)mant);  // subnormal (exp field 0)
+  if (mant == 16) { mant = 8; exp_field += 1; }
+  if (exp_field > 15 || (exp_field == 15 && mant > 14)) return (uint8_t)(sign | 0x7eu);
+  return (uint8_t)(sign | (uint8_t)(exp_field << 3) | (uint8_t)(mant - 8));
+}
+
+// MV_F16X8 planes of a weight matrix W [N][K] (gemm_pp.h): rows [hi8 | lo8] of 2 K bytes with hi8 = e4m3(fp16(W) 2^sw),
+// lo8 = e4m3((W - fp16(W)) 2^(11 + sw)); sw = the largest shift that keeps max |W| inside e4m3's 448.  *scale_word = the E8M0
+// byte of 2^-(11 + MV_X8_ACT_SHIFT + sw), replicated (the MFMA's scale operand of this GEMM's correction sweep).
+void make_x8_weight_planes(const float* W, int64_t N, int64_t K, std::vector<uint8_t>& out, int* scale_word) {
+  float mx = 0.f;
+  for (int64_t i = 0; i < N * K; ++i) mx = std::fmax(mx, std::fabs(W[i]));
+  int sw = 0;
+  if (mx > 0.f) {
+    sw = (int)std::floor(std::log2(448.0 / (double)mx));
+    if (sw > 24) sw = 24;
+    if (sw < -24) sw = -24;
   }
-  if (int rc = dev_alloc(h, dst, n, false)) return rc;
-  HIPCHK(h, hipMemcpyAsync(*dst, tmp.data(), (size_t)n * 2, hipMemcpyHostToDevice, h->w->stream));
+  const float sh = std::ldexp(1.0f, sw), sl = std::ldexp(1.0f, 11 + sw);
+  out.resize((size_t)(N * 2 * K));
+  for (int64_t n = 0; n < N; ++n) {
+    uint8_t* row = out.data() + (size_t)(n * 2 * K);
+    for (int64_t k = 0; k < K; ++k) {
+      const float w = W[n * K + k], hi = f16_bits_to_f32(f32_to_f16_bits(w));
+      row[k] = f32_to_e4m3_bits(hi * sh);
+      row[K + k] = f32_to_e4m3_bits((w - hi) * sl);
+    }
+  }
+  const int e8 = 127 - (11 + MV_X8_ACT_SHIFT + sw);
+  *scale_word = e8 * 0x01010101;
+}
+
+int upload_x8_weight(mv_handle* h, uint8_t** dst, int* scale_word, const float* W, int64_t N, int64_t K) {
+  std::vector<uint8_t> tmp;
+  make_x8_weight_planes(W, N, K, tmp, scale_word);
+  if (int rc = dev_alloc(h, dst, (int64_t)tmp.size(), false)) return rc;
+  HIPCHK(h, hipMemcpyAsync(*dst, tmp.data(), tmp.size(), hipMemcpyHostToDevice, h->w->stream));
   HIPCHK(h, hipStreamSynchronize(h->w->stream));
   return MV_OK;
 }
@@ -774,38 +753,25 @@ int mv_create(int device, const mv_config* cfg, mv_handle** out) {
       return MV_ERR_HIP;
     }
   }
-  // dynamic LDS above 64 KiB needs an explicit opt-in
-  hipFuncSetAttribute((const void*)attention_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  hipFuncSetAttribute((const void*)attention_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  hipFuncSetAttribute((const void*)gemm256_kernel<EPI_F32>, hipFuncAttributeMaxDynamicSharedMemorySize, G256_LDS_BYTES);
-  hipFuncSetAttribute((const void*)gemm256_kernel<EPI_QKV>, hipFuncAttributeMaxDynamicSharedMemorySize, G256_LDS_BYTES);
-  hipFuncSetAttribute((const void*)gemm256_kernel<EPI_GELU>, hipFuncAttributeMaxDynamicSharedMemorySize, G256_LDS_BYTES);
-  hipFuncSetAttribute((const void*)gemm256_kernel<EPI_RES>, hipFuncAttributeMaxDynamicSharedMemorySize, G256_LDS_BYTES);
-  hipFuncSetAttribute((const void*)gemm_pp_kernel<PP_F32, PP_DIST, 0, PP_SCHED, PP_COAL>, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS_BYTES);
-  hipFuncSetAttribute((const void*)gemm_pp_kernel<PP_QK, PP_DIST, 0, PP_SCHED, PP_COAL>, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS_BYTES);
-  hipFuncSetAttribute((const void*)gemm_pp_kernel<PP_GELU, PP_DIST, 0, PP_SCHED, PP_COAL>, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS_BYTES);
-  hipFuncSetAttribute((const void*)gemm_pp_kernel<PP_RES, PP_DIST, 0, PP_SCHED, PP_COAL>, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS_BYTES);
-  hipFuncSetAttribute((const void*)gemm_pp_kernel<PP_RESLN, PP_DIST, 0, PP_SCHED, PP_COAL>, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS_BYTES);
-  hipFuncSetAttribute((const void*)gemm_pp_kernel<PP_RESLN2, PP_DIST, 0, PP_SCHED, PP_COAL>, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS_BYTES);
-  hipFuncSetAttribute((const void*)gemm_pp_kernel<PP_RESLN3, PP_DIST, 0, PP_SCHED, PP_COAL>, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS_BYTES);
-  hipFuncSetAttribute((const void*)gemm_pp_kernel<PP_QK, PP_DIST, 0, PP_SCHED, PP_COAL, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS_BYTES_RAW);
-  hipFuncSetAttribute((const void*)gemm_pp_kernel<PP_GELU, PP_DIST, 0, PP_SCHED, PP_COAL, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS_BYTES_RAW);
+  // dynamic LDS above 64 KiB needs an explicit opt-in — per device, so here and not behind a process-wide flag
+  hipFuncSetAttribute((const void*)gemm_ring_kernel<EPI_F32, 1, 1, 2, 2, 64, 4, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, RING64_LDS);
+  hipFuncSetAttribute((const void*)gemm_ring_kernel<EPI_QKV, 1, 1, 2, 2, 64, 4, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, RING64_LDS);
+  hipFuncSetAttribute((const void*)gemm_ring_kernel<EPI_GELU, 1, 1, 2, 2, 64, 4, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, RING64_LDS);
+  hipFuncSetAttribute((const void*)gemm_ring_kernel<EPI_RES, 1, 1, 2, 2, 64, 4, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, RING64_LDS);
+  hipFuncSetAttribute((const void*)gemm_pp_kernel<PP_QK, 1, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS_BYTES_RAW);
+  hipFuncSetAttribute((const void*)gemm_pp_kernel<PP_GELU, 1, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS_BYTES_RAW);
+  hipFuncSetAttribute((const void*)gemm_pp_kernel<PP_RESLN3, 0, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS_BYTES);
+  hipFuncSetAttribute((const void*)gemm_pp_kernel<PP_QK, 1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS_BYTES_RAW);
+  hipFuncSetAttribute((const void*)gemm_pp_kernel<PP_GELU, 1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS_BYTES_RAW);
+  hipFuncSetAttribute((const void*)gemm_pp_kernel<PP_RESLN3, 0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS_BYTES);
+#define MV_ATT_ATTR(NKB, NCH)                                                                                                     \
+  hipFuncSetAttribute((const void*)attention_v2_kernel<NKB, NCH, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT2_LDS_BYTES(NKB)); \
+  hipFuncSetAttribute((const void*)attention_v2_kernel<NKB, NCH, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT2_LDS_BYTES(NKB))
+  MV_ATT_ATTR(1, 1); MV_ATT_ATTR(2, 1); MV_ATT_ATTR(3, 1); MV_ATT_ATTR(4, 1); MV_ATT_ATTR(2, 3); MV_ATT_ATTR(2, 4);
+#undef MV_ATT_ATTR
   (void)hipGetLastError();
   if (const char* e = getenv("MEMVUL_GEMM_TILE")) h->gemm_tile = atoi(e);
   if (const char* e = getenv("MEMVUL_CLS_PRUNE")) h->cls_prune = atoi(e) != 0;
-  if (const char* e = getenv("MEMVUL_LN_FUSE")) h->ln_fuse = atoi(e) != 0;
-  if (const char* e = getenv("MEMVUL_LN_VIRTUAL")) h->ln_virtual = atoi(e) != 0;
-  if (const char* e = getenv("MEMVUL_R16_DIRECT")) h->r16_direct = atoi(e) != 0;
-  if (const char* e = getenv("MEMVUL_RES_HILO")) h->res_hilo = atoi(e) != 0;
-  if (const char* e = getenv("MEMVUL_STAGGER")) h->pp_stagger = atoi(e);
-  if (const char* e = getenv("MEMVUL_ATTN")) h->attn_v2 = atoi(e) != 0;
-  hipFuncSetAttribute((const void*)attention_v2_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT2_LDS_BYTES(1));
-  hipFuncSetAttribute((const void*)attention_v2_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT2_LDS_BYTES(2));
-  hipFuncSetAttribute((const void*)attention_v2_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT2_LDS_BYTES(3));
-  hipFuncSetAttribute((const void*)attention_v2_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT2_LDS_BYTES(4));
-  hipFuncSetAttribute((const void*)attention_v2_kernel<2, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT2_LDS_BYTES(2));
-  hipFuncSetAttribute((const void*)attention_v2_kernel<2, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT2_LDS_BYTES(2));
-  (void)hipGetLastError();
   {
     int ncu = 0;
     if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && ncu > 0) h->num_cu = ncu;
@@ -859,14 +825,6 @@ int mv_create(int device, const mv_config* cfg, mv_handle** out) {
   }
   h->w = &h->work[0];
   A(dev_alloc(h, &h->anchors, (int64_t)cfg->max_anchors * MV_PROJ));
-  A(dev_alloc(h, &h->zeros, MV_HIDDEN));
-  A(dev_alloc(h, &h->ones, MV_HIDDEN, false));
-  if (rc == MV_OK) {
-    const std::vector<float> one(MV_HIDDEN, 1.0f);
-    if (hipMemcpyAsync(h->ones, one.data(), MV_HIDDEN * 4, hipMemcpyHostToDevice, h->w->stream) != hipSuccess ||
-        hipStreamSynchronize(h->w->stream) != hipSuccess)
-      rc = MV_ERR_HIP;
-  }
   if (rc == MV_OK && hipStreamSynchronize(h->w->stream) != hipSuccess) rc = MV_ERR_HIP;
   if (rc != MV_OK) {
     g_create_error = h->err.empty() ? "workspace allocation failed" : h->err;
@@ -919,10 +877,10 @@ int mv_load_tensor(mv_handle* h, const char* name, const void* host_ptr, int dty
 int mv_finalize_weights(mv_handle* h, int compute_dtype) {
   if (!h) return MV_ERR_INVALID;
   if (h->finalized) return fail(h, MV_ERR_STATE, "weights already finalized");
-  if (compute_dtype != MV_F16 && compute_dtype != MV_F16X2)
-    return fail(h, MV_ERR_INVALID, "compute_dtype must be MV_F16 (fp16 MFMA operands, fp32 accumulation) or MV_F16X2 (split operands); "
-                                   "bf16 is a storage dtype of mv_load_tensor only (include/memvul_hip.h)");
-  const bool precise = compute_dtype == MV_F16X2;
+  if (compute_dtype != MV_F16 && compute_dtype != MV_F16X8)
+    return fail(h, MV_ERR_INVALID, "compute_dtype must be MV_F16 (fp16 MFMA operands, fp32 accumulation) or MV_F16X8 (+ fp8 correction "
+                                   "sweeps); bf16 is a storage dtype of mv_load_tensor only (include/memvul_hip.h)");
+  const bool precise = compute_dtype == MV_F16X8;
   HIPCHK(h, hipSetDevice(h->device));
   const mv_config& c = h->cfg;
   const std::string P = "_text_field_embedder.token_embedder_tokens.transformer_model.";
@@ -985,12 +943,12 @@ int mv_finalize_weights(mv_handle* h, int compute_dtype) {
       std::vector<float> Wf, bf;
       fold_layernorm(wqkv_host.data(), bqkv_host.data(), tg->data.data(), tb->data.data(), 3 * H, H, Wf, bf);
       if ((rc = upload_f16(h, &w.wqkv_f, Wf.data(), 3 * H * H))) return rc;
-      if (precise && (rc = upload_f16_lo(h, &w.wqkv_f_lo, Wf.data(), 3 * H * H))) return rc;
+      if (precise && (rc = upload_x8_weight(h, &w.wqkv_f8, &w.sc_qkv, Wf.data(), 3 * H, H))) return rc;
       if ((rc = upload_f32(h, &w.bqkv_f, bf.data(), 3 * H))) return rc;
     }
     NEED(q + "attention.output.dense.weight", H, H);
     if ((rc = upload_f16(h, &w.wo, t->data.data(), H * H))) return rc;
-    if (precise && (rc = upload_f16_lo(h, &w.wo_lo, t->data.data(), H * H))) return rc;
+    if (precise && (rc = upload_x8_weight(h, &w.wo8, &w.sc_o, t->data.data(), H, H))) return rc;
     NEED(q + "attention.output.dense.bias", H);
     if ((rc = upload_f32(h, &w.bo, t->data.data(), H))) return rc;
     NEED(q + "attention.output.LayerNorm.weight", H);
@@ -1009,12 +967,12 @@ int mv_finalize_weights(mv_handle* h, int compute_dtype) {
       std::vector<float> Wf, bf;
       fold_layernorm(tw->data.data(), t->data.data(), tg->data.data(), tb->data.data(), I, H, Wf, bf);
       if ((rc = upload_f16(h, &w.w1_f, Wf.data(), I * H))) return rc;
-      if (precise && (rc = upload_f16_lo(h, &w.w1_f_lo, Wf.data(), I * H))) return rc;
+      if (precise && (rc = upload_x8_weight(h, &w.w1_f8, &w.sc_1, Wf.data(), I, H))) return rc;
       if ((rc = upload_f32(h, &w.b1_f, bf.data(), I))) return rc;
     }
     NEED(q + "output.dense.weight", H, I);
     if ((rc = upload_f16(h, &w.w2, t->data.data(), H * I))) return rc;
-    if (precise && (rc = upload_f16_lo(h, &w.w2_lo, t->data.data(), H * I))) return rc;
+    if (precise && (rc = upload_x8_weight(h, &w.w28, &w.sc_2, t->data.data(), H, I))) return rc;
     NEED(q + "output.dense.bias", H);
     if ((rc = upload_f32(h, &w.b2, t->data.data(), H))) return rc;
     NEED(q + "output.LayerNorm.weight", H);
@@ -1042,18 +1000,18 @@ int mv_finalize_weights(mv_handle* h, int compute_dtype) {
   NEED("_projector.weight", 2, 3 * MV_PROJ);
   if ((rc = upload_f32(h, &h->Wm, t->data.data(), 2 * 3 * MV_PROJ))) return rc;
 #undef NEED
-  if (precise) {  // lo planes of the two activations that are GEMM operands but not part of the two-plane stream
+  if (precise) {  // fp8 planes [lo8 | hi8] of the three activations that are GEMM A operands
+    if (h->gemm_tile == 128) return fail(h, MV_ERR_STATE, "MV_F16X8 runs on the persistent GEMM path: MEMVUL_GEMM_TILE=128 excludes it");
     for (int wi = 0; wi < h->n_alloc; ++wi) {
       Work* keep = h->w;
       h->w = &h->work[wi];
-      rc = dev_alloc(h, &h->work[wi].ctx_lo, h->cap_tokens * MV_HIDDEN);
-      if (rc == MV_OK) rc = dev_alloc(h, &h->work[wi].h_lo, h->cap_tokens * MV_INTER);
+      rc = dev_alloc(h, &h->work[wi].x8, h->cap_tokens * 2 * MV_HIDDEN);
+      if (rc == MV_OK) rc = dev_alloc(h, &h->work[wi].ctx8, h->cap_tokens * 2 * MV_HIDDEN);
+      if (rc == MV_OK) rc = dev_alloc(h, &h->work[wi].h8, h->cap_tokens * 2 * MV_INTER);
       if (rc == MV_OK && hipStreamSynchronize(h->w->stream) != hipSuccess) rc = MV_ERR_HIP;
       h->w = keep;
       if (rc != MV_OK) return rc;
     }
-    if (!(h->ln_fuse && h->ln_virtual && h->res_hilo))
-      return fail(h, MV_ERR_STATE, "MV_F16X2 runs on the two-plane raw stream: MEMVUL_LN_FUSE / LN_VIRTUAL / RES_HILO must stay on");
   }
   h->precise = precise;
   h->staged.clear();
@@ -1436,9 +1394,8 @@ int mv_debug_read(mv_handle* h, int buffer, void* dst, int64_t bytes) {
 int mv_test_gemm(mv_handle* h, int variant, int M, int N, int K, const uint16_t* A, const uint16_t* W, const float* bias,
                  float* C, int iters, float* ms) {
   if (!h || !A || !W || M <= 0 || N <= 0 || K <= 0) return fail(h, MV_ERR_INVALID, "mv_test_gemm: bad argument");
-  if (M % 128 || N % 128 || K % 64) return fail(h, MV_ERR_INVALID, "mv_test_gemm: M,N % 128 and K % 64 required");
-  if (variant >= 2 && variant != 19 && (M % 256 || N % 256)) return fail(h, MV_ERR_INVALID, "mv_test_gemm: this variant needs M,N % 256");
-  if (variant == 30 && K % 128) return fail(h, MV_ERR_INVALID, "mv_test_gemm: variant 30 needs K % 128");
+  if (variant != 0 && variant != 19) return fail(h, MV_ERR_INVALID, "mv_test_gemm: variant 0 (128^2 tile) or 19 (64^2 ring)");
+  if (variant == 0 && (M % 128 || N % 128 || K % 64)) return fail(h, MV_ERR_INVALID, "mv_test_gemm: M,N % 128 and K % 64 required");
   HIPCHK(h, hipSetDevice(h->device));
   half_t *dA = nullptr, *dW = nullptr;
   float *dB = nullptr, *dC = nullptr;
@@ -1456,30 +1413,7 @@ int mv_test_gemm(mv_handle* h, int variant, int M, int N, int K, const uint16_t*
   hipEvent_t e0, e1;
   hipEventCreate(&e0);
   hipEventCreate(&e1);
-  auto run = [&]() -> int {
-    switch (variant) {
-      case 0: return launch_gemm128<EPI_F32, true>(h, KC_TEST_GEMM, g);
-      case 1: return launch_gemm128<EPI_F32, false>(h, KC_TEST_GEMM, g);
-      case 2: return launch_gemm256<EPI_F32>(h, KC_TEST_GEMM, g);
-      case 30: { ProfScope ps(h, KC_TEST_GEMM); return launch_pp_raw<PP_F32>(h, g); }  // persistent ping-pong kernel
-      //                       EPI     FR_M FR_N WM WN BK ST minw            raster group
-      case 10: return launch_ring<EPI_F32, 4, 2, 2, 4, 64, 2, 2>(h, KC_TEST_GEMM, g, 4);  // 256x256, 8 waves, 128 KB
-      case 11: return launch_ring<EPI_F32, 4, 2, 2, 4, 32, 4, 2>(h, KC_TEST_GEMM, g, 4);  // 256x256, 8 waves, 128 KB
-      case 12: return launch_ring<EPI_F32, 4, 2, 2, 2, 32, 3, 2>(h, KC_TEST_GEMM, g, 8);  // 256x128, 4 waves, 72 KB (2 WG/CU)
-      case 13: return launch_ring<EPI_F32, 4, 2, 2, 2, 64, 3, 2>(h, KC_TEST_GEMM, g, 8);  // 256x128, 4 waves, 144 KB
-      case 14: return launch_ring<EPI_F32, 2, 2, 2, 2, 32, 4, 2>(h, KC_TEST_GEMM, g, 8);  // 128x128, 4 waves, 64 KB (2 WG/CU)
-      case 15: return launch_ring<EPI_F32, 4, 2, 2, 4, 32, 5, 2>(h, KC_TEST_GEMM, g, 4);  // 256x256, 8 waves, 160 KB
-      case 16: return launch_ring<EPI_F32, 4, 4, 2, 2, 32, 3, 1>(h, KC_TEST_GEMM, g, 4);  // 256x256, 4 waves x 128x128, 96 KB
-      case 17: return launch_ring<EPI_F32, 4, 2, 2, 2, 32, 4, 2>(h, KC_TEST_GEMM, g, 8);  // 256x128, 4 waves, 96 KB
-      case 18: return launch_ring<EPI_F32, 2, 4, 4, 2, 32, 4, 2>(h, KC_TEST_GEMM, g, 4);  // 256x256, 8 waves x 64x128, 128 KB
-      case 19: return launch_ring<EPI_F32, 1, 1, 2, 2, 64, 4, 2>(h, KC_TEST_GEMM, g, 8);  // 64x64, 4 waves, 64 KB: the skinny-M path
-      // timing ablations of variant 10 (results are wrong by construction)
-      case 21: return launch_ring<EPI_F32, 4, 2, 2, 4, 64, 2, 2, 1>(h, KC_TEST_GEMM, g, 4);  // no LDS-DMA in the loop
-      case 22: return launch_ring<EPI_F32, 4, 2, 2, 4, 64, 2, 2, 2>(h, KC_TEST_GEMM, g, 4);  // no MFMA
-      case 23: return launch_ring<EPI_F32, 4, 2, 2, 4, 64, 2, 2, 3>(h, KC_TEST_GEMM, g, 4);  // no fragment reads
-      default: return fail(h, MV_ERR_INVALID, "mv_test_gemm: unknown variant");
-    }
-  };
+  auto run = [&]() -> int { return variant == 0 ? launch_gemm128<EPI_F32>(h, KC_TEST_GEMM, g) : launch_ring64<EPI_F32>(h, KC_TEST_GEMM, g); };
   rc = run();  // warm-up / correctness launch
   if (rc == MV_OK) {
     hipEventRecord(e0, h->w->stream);
@@ -1499,6 +1433,91 @@ int mv_test_gemm(mv_handle* h, int variant, int M, int N, int K, const uint16_t*
   }
   dev_free(h, dA); dev_free(h, dW); dev_free(h, dB); dev_free(h, dC);
   return rc;
+}
+
+// The FFN-1 kernel of the persistent path (gemm_pp_kernel<PP_GELU, RAW>) on caller-provided fp32 operands with unit row
+// statistics: out16 = fp16(gelu(A W^T + bias)) [M][N]; x8 != 0: the MV_F16X8 build (fp16 sweep + fp8 correction sweep) and, with
+// out8, the [lo8 | hi8] planes of the output [M][2 N].  A / W are split into their planes on the host exactly as
+// mv_finalize_weights does for weights (W) and as the producing epilogues do for activations (A: shift MV_X8_ACT_SHIFT).
+int mv_test_gemm_pp(mv_handle* h, int x8, int M, int N, int K, const float* A, const float* W, const float* bias, uint16_t* out16,
+                    uint8_t* out8, int iters, float* ms) {
+  if (!h || !A || !W || !bias || !out16 || M <= 0 || N <= 0 || K <= 0) return fail(h, MV_ERR_INVALID, "mv_test_gemm_pp: bad argument");
+  if (M % 256 || N % 256 || K % 128 || K < 256 || N > MV_INTER)
+    return fail(h, MV_ERR_INVALID, "mv_test_gemm_pp: M,N % 256, K % 128, K >= 256, N <= 3072 required");
+  HIPCHK(h, hipSetDevice(h->device));
+  std::vector<uint16_t> a16((size_t)M * K), w16((size_t)N * K);
+  for (size_t i = 0; i < a16.size(); ++i) a16[i] = f32_to_f16_bits(A[i]);
+  for (size_t i = 0; i < w16.size(); ++i) w16[i] = f32_to_f16_bits(W[i]);
+  std::vector<uint8_t> a8, w8;
+  int scale_word = 0;
+  if (x8) {
+    make_x8_weight_planes(W, N, K, w8, &scale_word);
+    a8.resize((size_t)M * 2 * K);
+    const float sh = std::ldexp(1.0f, MV_X8_ACT_SHIFT), sl = std::ldexp(1.0f, 11 + MV_X8_ACT_SHIFT);
+    for (int64_t m = 0; m < M; ++m)
+      for (int64_t k = 0; k < K; ++k) {
+        const float v = A[m * K + k], hi = f16_bits_to_f32(a16[(size_t)(m * K + k)]);
+        a8[(size_t)(m * 2 * K + k)] = f32_to_e4m3_bits((v - hi) * sl);   // [lo8 | hi8]
+        a8[(size_t)(m * 2 * K + K + k)] = f32_to_e4m3_bits(v * sh);
+      }
+  }
+  std::vector<float> st((size_t)M * 6, 0.f);
+  for (int64_t m = 0; m < M; ++m) st[(size_t)m * 6 + 1] = (float)MV_HIDDEN;  // (sum, sumsq) = (0, 768): mean 0, rstd 1
+  half_t *dA = nullptr, *dW = nullptr, *dO = nullptr;
+  uint8_t *dA8 = nullptr, *dW8 = nullptr, *dO8 = nullptr;
+  float *dB = nullptr, *dS = nullptr;
+  int rc;
+  if ((rc = dev_alloc(h, &dA, (int64_t)M * K, false))) return rc;
+  if ((rc = dev_alloc(h, &dW, (int64_t)N * K, false))) return rc;
+  if ((rc = dev_alloc(h, &dO, (int64_t)M * N))) return rc;
+  if ((rc = dev_alloc(h, &dB, N, false))) return rc;
+  if ((rc = dev_alloc(h, &dS, (int64_t)M * 6, false))) return rc;
+  HIPCHK(h, hipMemcpyAsync(dA, a16.data(), a16.size() * 2, hipMemcpyHostToDevice, h->w->stream));
+  HIPCHK(h, hipMemcpyAsync(dW, w16.data(), w16.size() * 2, hipMemcpyHostToDevice, h->w->stream));
+  HIPCHK(h, hipMemcpyAsync(dB, bias, (size_t)N * 4, hipMemcpyHostToDevice, h->w->stream));
+  HIPCHK(h, hipMemcpyAsync(dS, st.data(), st.size() * 4, hipMemcpyHostToDevice, h->w->stream));
+  GemmArgs g{};
+  g.A = dA; g.W = dW; g.bias = dB; g.M = M; g.Mreal = M; g.N = N; g.K = K; g.out16 = dO; g.S = 64; g.lnstats = dS; g.ln_eps = 0.f;
+  if (x8) {
+    if ((rc = dev_alloc(h, &dA8, (int64_t)a8.size(), false))) return rc;
+    if ((rc = dev_alloc(h, &dW8, (int64_t)w8.size(), false))) return rc;
+    if ((rc = dev_alloc(h, &dO8, (int64_t)M * 2 * N))) return rc;
+    HIPCHK(h, hipMemcpyAsync(dA8, a8.data(), a8.size(), hipMemcpyHostToDevice, h->w->stream));
+    HIPCHK(h, hipMemcpyAsync(dW8, w8.data(), w8.size(), hipMemcpyHostToDevice, h->w->stream));
+    g.A8 = dA8; g.W8 = dW8; g.out8 = dO8; g.x8_scale = scale_word;
+  }
+  if (iters < 1) iters = 1;
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0);
+  hipEventCreate(&e1);
+  rc = launch_pp<PP_GELU>(h, KC_TEST_GEMM, g);
+  if (rc == MV_OK) {
+    hipEventRecord(e0, h->w->stream);
+    for (int i = 0; i < iters && rc == MV_OK; ++i) rc = launch_pp<PP_GELU>(h, KC_TEST_GEMM, g);
+    hipEventRecord(e1, h->w->stream);
+  }
+  hipError_t se = hipStreamSynchronize(h->w->stream);
+  float t = 0.f;
+  hipEventElapsedTime(&t, e0, e1);
+  hipEventDestroy(e0);
+  hipEventDestroy(e1);
+  if (ms) *ms = t / (float)iters;
+  if (rc == MV_OK && se != hipSuccess) rc = fail(h, MV_ERR_HIP, std::string("test gemm_pp: ") + hipGetErrorString(se));
+  if (rc == MV_OK) {
+    se = hipMemcpy(out16, dO, (size_t)M * N * 2, hipMemcpyDeviceToHost);
+    if (se == hipSuccess && x8 && out8) se = hipMemcpy(out8, dO8, (size_t)M * 2 * N, hipMemcpyDeviceToHost);
+    if (se != hipSuccess) rc = fail(h, MV_ERR_HIP, std::string("test gemm_pp copy: ") + hipGetErrorString(se));
+  }
+  dev_free(h, dA); dev_free(h, dW); dev_free(h, dO); dev_free(h, dB); dev_free(h, dS);
+  dev_free(h, dA8); dev_free(h, dW8); dev_free(h, dO8);
+  return rc;
+}
+
+// host-side e4m3 encoder of the MV_F16X8 weight planes (no GPU needed): tests pin it to the oracle's rounding model
+int mv_test_e4m3(const float* in, uint8_t* out, int64_t n) {
+  if (!in || !out || n < 0) return MV_ERR_INVALID;
+  for (int64_t i = 0; i < n; ++i) out[i] = f32_to_e4m3_bits(in[i]);
+  return MV_OK;
 }
 
 }  // extern "C"

@@ -8,67 +8,68 @@
 //     v_mfma_f32_32x32x16_f16, ONE workgroup per CU, grid = #CUs, each workgroup walks a strided list of
 //     output tiles (persistent): the K-tile stream never drains between output tiles, so the next tile's
 //     operands are already in flight while the epilogue stores.
-//   * The two M-halves of the workgroup (waves 0-3 / 4-7: one wave of each per SIMD) run the same phase
-//     sequence ONE s_barrier apart: while one wave of a SIMD issues its 8 MFMAs of a phase (256 matrix-pipe
-//     cycles) its partner reads the next fragments from LDS and issues its LDS-DMA, then they swap.  Every
-//     s_barrier is workgroup-wide; a phase is [ds_read + DMA issue] barrier [MFMA] barrier.
-//   * A K-tile is 4 phases = the 4 quadrants (64 x 32) of the wave's C block in the order (a0,b0) (a0,b1)
-//     (a1,b1) (a1,b0'): each phase reads at most ONE operand half-tile (8 or 4 ds_read_b128 per wave), and
-//     the 4th reads b0 of the NEXT K-tile into the register set b1 just vacated (the two W register sets swap
-//     roles every K-tile; the loop is unrolled by two K-tiles so this is static).
-//   * Operand half-tiles (128 rows x 64 halfs = 16 KiB = 2 LDS-DMA instructions per wave) are the unit of
-//     staging: LDS holds two K-tiles x {a0,a1,b0,b1} = 128 KiB, half-tile h(phi) is read in phase phi only and
-//     re-issued for the K-tile two ahead DIST phases before its read (DIST <= 6: a region is rewritten no
-//     sooner than two phases after its last read, which covers the one-barrier skew between the wave halves).
-//     One counted `s_waitcnt vmcnt(2 (DIST-1))` per phase retires exactly the half-tile the NEXT phase reads;
-//     loads stay in flight across barriers (raw s_barrier, never __syncthreads), 2 DIST KiB x 8 per CU.
+//   * ONE s_barrier per phase; the first M-half of the workgroup (waves 0-3) runs [MFMA(j), read fragments(j+1)] and
+//     the second (waves 4-7: one wave of each half per SIMD) [read fragments(j), MFMA(j)] inside the same barrier
+//     interval, so each SIMD's matrix pipe is handed from one wave to the other in the middle of the interval.
+//   * A K-tile is 4 phases = the 4 quadrants (64 x 32) of the wave's C block in the order (a0,b0) (a0,b1) (a1,b1)
+//     (a1,b0): each phase reads at most ONE operand half-tile (8 or 4 ds_read_b128 per wave).
+//   * Operand half-tiles (128 rows x 128 B = 16 KiB = 2 LDS-DMA instructions per wave) are the unit of staging: LDS
+//     holds two K-tiles x {a0,a1,b0,b1} = 128 KiB; F = 4 half-tiles are kept in flight across every barrier (half-tile
+//     H is issued in interval H-3-F, is landed for every wave at the barrier that ends interval H-3, and its LDS region
+//     was last read in interval H-8 or H-9) with one counted `s_waitcnt vmcnt(2 F)` per interval; loads stay in
+//     flight across barriers (raw s_barrier, never __syncthreads).
 //   * LDS image of a half-tile is lane-linear per DMA instruction (1 KiB = 8 rows x 128 B); the bank swizzle
 //     (16-B chunk c of row r at slot c ^ ((r >> 1) & 7)) is applied on the per-lane SOURCE address and on the
 //     ds_read_b128 (rule 21).  The DMA uses the SGPR-base + 32-bit-VGPR-offset form.
-//   * Orientation: SWAP computes C^T fragments (W rows as the MFMA A operand), so a lane holds 4 CONSECUTIVE
-//     output columns of one token row per register group -> 16-byte epilogue stores (fp32 directly, fp16 after
-//     one v_permlane32_swap per dword, T21).  The V^T epilogue uses the other orientation (lane = head dim,
-//     registers = consecutive tokens) for the same reason.
-//   * bias is staged once per workgroup into LDS and the accumulators START from it (and, for the residual
-//     epilogue, from x + bias), so the epilogue has no loads; non-residual kernels have no VGPR-destination
-//     VMEM load anywhere in the persistent loop (hipcc would drain the DMA queue with vmcnt(0) at each one).
+//   * Orientation: C^T fragments (W rows as the MFMA A operand), so a lane holds 4 CONSECUTIVE output columns of one
+//     token row per register group; every 32x32 fragment goes through a wave-private LDS transposition so that each
+//     global store / residual load instruction covers 16 rows x 64 contiguous bytes.
 //   * Tile order: logical tile sequence = (column group of GN tiles) > tile_m > tile_n-in-group; per persistent
 //     iteration the 256 concurrent tiles are consecutive in it and each XCD takes a contiguous run of 32 (the
 //     group's W panels stay in that XCD's L2 while it sweeps the A row panels).
-//   * K accumulation order per output element is ascending 16-wide MFMA steps, the same as gemm128/gemm256.
+//
+// Three kernel kinds (the encoder layer's four GEMMs; everything else the round-1/2 builds carried — fp32-stream
+// epilogues, the two-barrier schedule, timing ablations — lives in tools/legacy/ with its A/B records in profiles/):
+//   PP_QK   (RAW)  Q, K (head-major) and V^T in ONE launch: the V tiles go through the wave's LDS image transposed.
+//   PP_GELU (RAW)  FFN-1 + exact-erf GELU.
+//   PP_RESLN3      attention-output projection / FFN-2: + bias + LayerNorm(residual), in place on the raw stream.
+// "Virtual LayerNorm": no LayerNorm kernel between the GEMMs.  By linearity
+//   W LN(r) + b = rstd * (W'' r) + b',  W''[n][k] = W[n][k] gamma[k] - mean_k(W[n][.] gamma[.]),  b' = b + W beta
+// (the row mean of r drops out against the row-centred weights), so a RAW consumer takes the raw stream rounded to fp16 as
+// its A operand, the folded weights W'' (prepared once on the host), starts its accumulators from zero and applies
+// fma(rstd_row, acc, b'_col) in the epilogue; the 256 rows' statistics of the workgroup's next tile arrive by six LDS-DMA
+// pieces (and its 256 bias' values by a seventh) into 2 x 6 KiB (2 x 1 KiB) images.  The producer (PP_RESLN3) normalises
+// the residual tile it loads anyway (fma((x - mean) rstd, gamma, beta) + bias while initialising the accumulators) and
+// writes the new raw stream as TWO fp16 planes  hi = fp16(r)  (exactly the operand the RAW consumers read),
+// lo = fp16(r - hi)  (r ~= hi + lo to 2^-22 relative) plus the rows' "vstats": per row and 256-column tile the
+// (sum, sum of squares), the four column waves' shares added in wave order through LDS; every consumer turns the three
+// pairs of a row into (mean, rstd) itself (common.h ln_from_partials).
+//
+// X8 = 1 (compute dtype MV_F16X8, "precise"): every GEMM adds a SECOND sweep on the fp8 matrix path into the same fp32
+// accumulators,
+//   A W  ~=  A_hi W_hi  +  2^-s ( A_lo8 W_hi8 + A_hi8 W_lo8 ),     A_hi = fp16(A), A_lo8 = e4m3((A - A_hi) 2^(11 + sa)),
+//   A_hi8 = e4m3(A_hi 2^sa), W likewise with its own shift sw, s = 11 + sa + sw,
+// i.e. the two first-order correction terms of the split-operand product, which only need ~4 significant bits, run as ONE
+// v_mfma_scale_f32_32x32x64_f8f6f4 sweep (OCP e4m3, uniform E8M0 scales = the exact power of two 2^-s) over a virtual K of
+// 2 K elements: the fp8 operands are stored as rows [lo8 (K bytes) | hi8 (K bytes)] for A and [hi8 | lo8] for W, so row
+// pitch (2 K bytes), K-tile width (128 bytes) and K-tile count (K / 64) equal the fp16 sweep's and the staging code is
+// shared; an fp8 K-tile covers 128 products per row pair in the matrix-pipe time the fp16 tile needs for 64.  Cost: 2x
+// the main loop (a three-sweep fp16 split is 3x); error: operand rounding 2^-12 -> ~2^-15.5 (oracle/precision_model.py
+// "f16x8": 3.4e-4 on the trained-like logits against 2.5e-3 for MV_F16 — the same as the full 22-bit split, because
+// Q, K, V and P stay fp16).  The producing epilogues (PP_GELU, PP_RESLN3; embedding and attention kernels) write the
+// [lo8 | hi8] planes of their outputs next to the fp16 ones.
 #pragma once
 #include "common.h"
 #include <type_traits>
 
 #include "gemm.h"
 
-enum { PP_F32 = 0, PP_QK = 1, PP_VT = 2, PP_GELU = 3, PP_RES = 4, PP_F16 = 5, PP_RESLN = 6, PP_RESLN2 = 7, PP_RESLN3 = 8 };
-// PP_RESLN: PP_RES whose residual tile is the PRE-LayerNorm stream: the accumulators start from
-//   LN(x) + bias = fma((x - mean) * rstd, gamma, beta) + bias   (row statistics from ln_kernel<stats>),
-// the same IEEE operations ln_row_store performs, so the result equals PP_RES on a normalised stream bit for bit
-// while the LayerNorm kernel no longer writes the fp32 stream back (201 MB per LayerNorm at the bench shape).
-// PP_RESLN2 + RAW consumers ("virtual LayerNorm": no LayerNorm kernel at all).  By linearity
-//   W LN(r) + b = rstd * (W'' r) + b',  W''[n][k] = W[n][k] gamma[k] - mean_k(W[n][.] gamma[.]),  b' = b + W beta
-// (the row mean of r drops out against the row-centred weights), so a consumer GEMM (RAW = 1: PP_QK — Q, K and V^T in
-// one launch — and PP_GELU; PP_VT, the separate V^T launch of round 1, survives for tools/gemm_bench.hip only) takes the RAW stream rounded to fp16 as its A operand, the folded weights W'' (prepared once on the
-// host), starts its accumulators from zero and applies  fma(rstd_row, acc, b'_col)  in the epilogue; the 256 rows'
-// statistics of the workgroup's next tile arrive by six LDS-DMA pieces (and its 256 bias' values by a seventh) into
-// 2 x 6 KiB (2 x 1 KiB) images.  The producer (PP_RESLN2 = PP_RESLN that ALSO writes the fp16 copy of the raw stream and the
-// rows' "vstats": per row and 256-column tile the (sum, sum of squares), the four column waves' shares added in wave
-// order through LDS) replaces the LayerNorm kernel's second pass over the stream, and every consumer turns the three
-// pairs of a row into (mean, rstd) itself (common.h ln_from_partials) — no statistics kernel between the GEMMs
-// (round 1 / early round 2 ran a 6 us ln_finalize launch after every residual GEMM: 22 launches per pass).
-// PP_RESLN3 = PP_RESLN2 with the raw stream kept as TWO fp16 planes instead of fp32 + an fp16 copy:
-//   hi = fp16(r)  (exactly the operand the RAW consumers read),  lo = fp16(r - hi),  r ~= hi + lo to 2^-22 relative
-// (fp32 carries 2^-24).  The residual tile is read as hi + lo (same bytes as fp32) and written as hi, lo: 100 MB less
-// per launch than fp32 + fp16 copy at the bench shape, and no fp32 transposition pass in the epilogue.
-// timing ablations (wrong results by construction; cdna_hip_programming.md §5.4 rules 8/17)
-enum { PP_ABL_NODMA = 1, PP_ABL_NOMFMA = 2, PP_ABL_NOREAD = 4, PP_ABL_NOEPI = 8, PP_ABL_NOPRIO = 16, PP_ABL_NOSTAGGER = 32,
-       PP_ABL_CLK = 64, PP_ABL_B34 = 128 };  // B34 (timing only): PP_RES moves 3/4 of its residual bytes (every 4th line neither loaded nor stored)  // CLK (tools/gemm_bench.hip): per-wave s_memtime sums of accumulator init / main loop / epilogue -> a.clk[(wg 8 + wave) 4 ..]
+enum { PP_QK = 1, PP_GELU = 3, PP_RESLN3 = 8 };
+constexpr int PP_F = 4;  // half-tiles kept in flight across each barrier
 
 #define PP_LDS_A 0           // [par][a][wr][64 rows][128 B]
 #define PP_LDS_B 65536       // [par][b][wc][32 rows][128 B]
-#define PP_LDS_BIAS 131072   // [N] fp32 (N <= 3072)
+#define PP_LDS_BIAS 131072   // PP_RESLN3: bias | gamma | beta, 3 x 768 fp32
 #define PP_LDS_SCR (PP_LDS_BIAS + MV_INTER * 4)  // 8 waves x 2 KiB: wave-private transposition scratch
 #define PP_LDS_BYTES (PP_LDS_SCR + 8 * 2048)     // 159,744 of 163,840
 // RAW kernels re-partition everything above the operand ring: [2][256] bias' of the tile | [2][256 rows][3][sum, sumsq] | scratch
@@ -85,40 +86,14 @@ __device__ __forceinline__ uint32_t pack_h2(float a, float b) {
   return __builtin_bit_cast(uint32_t, h);
 }
 
-// 16 fp32 of one 32x32 fragment in the "4 consecutive elements per register group" orientation ->
-// two 16-byte stores per lane: after the swaps lanes 0-31 hold elements 16p..16p+7 and lanes 32-63 hold
-// 16p+8..16p+15 of the fragment's 32-wide contiguous axis.  `rowptr` = this lane's row start (fp16).
-template <typename T>
-__device__ __forceinline__ void keep_live(const T& v) {
-#if defined(__HIP_DEVICE_COMPILE__)  // the host pass of hipcc parses kernel bodies too and rejects the VGPR constraint
-  asm volatile("" ::"v"(v));
-#endif
-}
-
-template <typename F>
-__device__ __forceinline__ void store_frag_f16(const floatx16& v, half_t* rowptr, int hi, F f) {
-  uint32_t d[4][2];
-#pragma unroll
-  for (int g = 0; g < 4; ++g) {
-    d[g][0] = pack_h2(f(v[4 * g + 0]), f(v[4 * g + 1]));
-    d[g][1] = pack_h2(f(v[4 * g + 2]), f(v[4 * g + 3]));
-  }
-#pragma unroll
-  for (int p = 0; p < 2; ++p) {
-    auto rx = __builtin_amdgcn_permlane32_swap(d[2 * p][0], d[2 * p + 1][0], false, false);
-    auto ry = __builtin_amdgcn_permlane32_swap(d[2 * p][1], d[2 * p + 1][1], false, false);
-    uint4 o;
-    o.x = rx[0]; o.y = ry[0]; o.z = rx[1]; o.w = ry[1];
-    *(uint4*)(rowptr + 16 * p + 8 * hi) = o;
-  }
-}
-
 // (hipcc/ROCm 7.2: __builtin_bit_cast applied directly to an ext_vector ELEMENT expression reads element 0 —
 // always go through a scalar copy)
 __device__ __forceinline__ uint32_t f2u(float x) { return __float_as_uint(x); }
 __device__ __forceinline__ float u2f(uint32_t x) { return __uint_as_float(x); }
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef int intx4 __attribute__((ext_vector_type(4)));
+typedef int intx8 __attribute__((ext_vector_type(8)));
 
 // Wave-private transposition through a [32 rows][64 B] LDS image (16-B chunk c of row r at slot c ^ ((r >> 2) & 3)):
 // the MFMA C/D layout gives a lane 8 or 16 contiguous bytes of ONE row (lane = row), so storing it directly makes
@@ -143,7 +118,27 @@ __device__ __forceinline__ void scr_f16x2(uint32_t w0, uint32_t w1, uint32_t w2,
       : "memory");
 #endif
 }
-// The V block of a merged Q,K,V launch (PP_QK orientation: lane = token, registers = 4 consecutive head dims) goes
+// Two fp8 planes (MV_F16X8: lo8, then hi8) of one 32-row x 64-column block (fragments j = 0, 1) through the same image:
+// a plane is [32 rows][64 B], the lane's dword (j, g) = columns 32 j + 8 g + 4 hi ..+3 goes to slot 2 j + (g >> 1) of its
+// row (swizzled like the fp16 image) at byte 8 (g & 1) + 4 hi; w0..w3 = the lane's slot addresses (+ 4 hi), da / db index
+// 4 j + g.  The read side is the fp16 one: rows lane >> 2 and + 16, 16-B chunk lane & 3.
+__device__ __forceinline__ void scr_f8x2(uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3, const uint32_t (&da)[8],
+                                         const uint32_t (&db)[8], uint32_t r, u32x4 (&o)[4]) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm volatile(
+      "ds_write_b32 %4, %8\n\tds_write_b32 %4, %9 offset:8\n\tds_write_b32 %5, %10\n\tds_write_b32 %5, %11 offset:8\n\t"
+      "ds_write_b32 %6, %12\n\tds_write_b32 %6, %13 offset:8\n\tds_write_b32 %7, %14\n\tds_write_b32 %7, %15 offset:8\n\t"
+      "ds_read_b128 %0, %24\n\tds_read_b128 %1, %24 offset:1024\n\t"
+      "ds_write_b32 %4, %16\n\tds_write_b32 %4, %17 offset:8\n\tds_write_b32 %5, %18\n\tds_write_b32 %5, %19 offset:8\n\t"
+      "ds_write_b32 %6, %20\n\tds_write_b32 %6, %21 offset:8\n\tds_write_b32 %7, %22\n\tds_write_b32 %7, %23 offset:8\n\t"
+      "ds_read_b128 %2, %24\n\tds_read_b128 %3, %24 offset:1024\n\ts_waitcnt lgkmcnt(0)"
+      : "=&v"(o[0]), "=&v"(o[1]), "=&v"(o[2]), "=&v"(o[3])
+      : "v"(w0), "v"(w1), "v"(w2), "v"(w3), "v"(da[0]), "v"(da[1]), "v"(da[2]), "v"(da[3]), "v"(da[4]), "v"(da[5]), "v"(da[6]),
+        "v"(da[7]), "v"(db[0]), "v"(db[1]), "v"(db[2]), "v"(db[3]), "v"(db[4]), "v"(db[5]), "v"(db[6]), "v"(db[7]), "v"(r)
+      : "memory");
+#endif
+}
+// The V block of a merged Q,K,V launch (lane = token, registers = 4 consecutive head dims) goes
 // through the image TRANSPOSED - image rows = head dims, image columns = tokens - so that the read side and the
 // stores are the V^T ones: 16 two-byte writes per fragment (row 8 g + 4 hi + e at a0 / a1 = a0 ^ 32 plus
 // 512 g + 64 e; the slot swizzle (row >> 2) & 3 = (2 g + hi) & 3 alternates between hi and hi ^ 2).
@@ -185,42 +180,8 @@ __device__ __forceinline__ void scr_f16_rev2(uint32_t wc, const u32x4& a0, const
   __builtin_amdgcn_sched_barrier(0);
 #endif
 }
-// Four fp32 rounds (32 rows x 16 columns each) per statement: writes at (wa, wb), reads at (ra, rb).
-__device__ __forceinline__ void scr_f32x4(uint32_t wa, uint32_t wb, const u32x4 (&d)[8], uint32_t ra, uint32_t rb,
-                                          u32x4 (&o)[8]) {
-#if defined(__HIP_DEVICE_COMPILE__)
-  asm volatile(
-      "ds_write_b128 %8, %10\n\tds_write_b128 %9, %11\n\tds_read_b128 %0, %18\n\tds_read_b128 %1, %19\n\t"
-      "ds_write_b128 %8, %12\n\tds_write_b128 %9, %13\n\tds_read_b128 %2, %18\n\tds_read_b128 %3, %19\n\t"
-      "ds_write_b128 %8, %14\n\tds_write_b128 %9, %15\n\tds_read_b128 %4, %18\n\tds_read_b128 %5, %19\n\t"
-      "ds_write_b128 %8, %16\n\tds_write_b128 %9, %17\n\tds_read_b128 %6, %18\n\tds_read_b128 %7, %19\n\t"
-      "s_waitcnt lgkmcnt(0)"
-      : "=&v"(o[0]), "=&v"(o[1]), "=&v"(o[2]), "=&v"(o[3]), "=&v"(o[4]), "=&v"(o[5]), "=&v"(o[6]), "=&v"(o[7])
-      : "v"(wa), "v"(wb), "v"(d[0]), "v"(d[1]), "v"(d[2]), "v"(d[3]), "v"(d[4]), "v"(d[5]), "v"(d[6]), "v"(d[7]), "v"(ra),
-        "v"(rb)
-      : "memory");
-#endif
-}
 
-// PP_RESLN accumulator init: the 4 float4 (columns 8 g + 4 hi .. + 3, g = 0..3, of one 32-column block) of the
-// bias, gamma and beta images (gamma at +3072 B, beta at +6144 B of the bias image) in one statement.
-__device__ __forceinline__ void lds_read_bgb(uint32_t addr, float4 (&bi)[4], float4 (&ga)[4], float4 (&be)[4]) {
-#if defined(__HIP_DEVICE_COMPILE__)
-  asm volatile(
-      "ds_read_b128 %0, %12\n\tds_read_b128 %1, %12 offset:32\n\tds_read_b128 %2, %12 offset:64\n\t"
-      "ds_read_b128 %3, %12 offset:96\n\tds_read_b128 %4, %12 offset:3072\n\tds_read_b128 %5, %12 offset:3104\n\t"
-      "ds_read_b128 %6, %12 offset:3136\n\tds_read_b128 %7, %12 offset:3168\n\tds_read_b128 %8, %12 offset:6144\n\t"
-      "ds_read_b128 %9, %12 offset:6176\n\tds_read_b128 %10, %12 offset:6208\n\tds_read_b128 %11, %12 offset:6240\n\t"
-      "s_waitcnt lgkmcnt(0)"
-      : "=&v"(bi[0]), "=&v"(bi[1]), "=&v"(bi[2]), "=&v"(bi[3]), "=&v"(ga[0]), "=&v"(ga[1]), "=&v"(ga[2]), "=&v"(ga[3]),
-        "=&v"(be[0]), "=&v"(be[1]), "=&v"(be[2]), "=&v"(be[3])
-      : "v"(addr)
-      : "memory");
-  __builtin_amdgcn_sched_barrier(0);
-#endif
-}
-
-// One float4 of each of the three images (register-lean form of lds_read_bgb for PP_RESLN3).
+// PP_RESLN3 accumulator init: one float4 of each of the bias, gamma and beta images (gamma at +3072 B, beta at +6144 B).
 __device__ __forceinline__ void lds_read_bgb1(uint32_t addr, float4& bi, float4& ga, float4& be) {
 #if defined(__HIP_DEVICE_COMPILE__)
   asm volatile("ds_read_b128 %0, %3\n\tds_read_b128 %1, %3 offset:3072\n\tds_read_b128 %2, %3 offset:6144\n\ts_waitcnt lgkmcnt(0)"
@@ -231,27 +192,12 @@ __device__ __forceinline__ void lds_read_bgb1(uint32_t addr, float4& bi, float4&
 #endif
 }
 
-// SCHED 0: two barriers per phase, the M-halves one barrier apart (DIST = issue distance in phases, 2..6).
-// SCHED 1: ONE barrier per phase; the first M-half runs [MFMA(j), read fragments(j+1)] and the second
-//          [read fragments(j), MFMA(j)] inside the same barrier interval, so each SIMD's matrix pipe is handed from
-//          one wave to the other in the middle of the interval without a barrier in between (DIST = F, the number
-//          of half-tiles kept in flight across each barrier, 2..4: half-tile H is issued in interval H-3-F, is
-//          landed for every wave at the barrier that ends interval H-3, and its LDS region was last read in
-//          interval H-8 or H-9).
-// COAL 1: epilogue stores (and the residual loads) go through the wave-private LDS transposition above.
-// X2 1: split-operand mode (GemmArgs::nseg == 3): three K sweeps A_hi W_hi + A_lo W_hi + A_hi W_lo, and PP_GELU also writes
-//       the lo plane of its output.  A separate instantiation: the plain kernels keep their register allocation.
-template <int EPI, int DIST, int ABL, int SCHED = 0, int COAL = 0, int RAW = 0, int X2 = 0>
+template <int EPI, int RAW = 0, int X8 = 0>
 __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmArgs a) {
-  static_assert(!RAW || (COAL == 1 && (EPI == PP_QK || EPI == PP_GELU)), "RAW: the fp16-output kernels of the transposed path, token row per lane");
-  static_assert(SCHED == 0 ? (DIST >= 2 && DIST <= 6) : (DIST >= 2 && DIST <= 4), "half-tile issue distance");
-  constexpr bool SWAP = (EPI != PP_VT);
-  constexpr bool IS_RESLN = (EPI == PP_RESLN || EPI == PP_RESLN2 || EPI == PP_RESLN3);
-  constexpr bool HILO = (EPI == PP_RESLN3);        // raw stream as two fp16 planes
-  constexpr bool EMITS = (EPI == PP_RESLN2 || EPI == PP_RESLN3);  // partial row sums + fp16 operand for the RAW consumers
-  constexpr bool IS_RES = (EPI == PP_RES || IS_RESLN);
-  static_assert(!IS_RESLN || COAL == 1, "the LayerNorm-fused residual init is written for the transposed (COAL) path");
-  constexpr int WAITN = SCHED == 0 ? 2 * (DIST - 1) : 2 * DIST;
+  static_assert(EPI == PP_QK || EPI == PP_GELU || EPI == PP_RESLN3, "kernel kinds of the encoder layer");
+  static_assert(RAW == (EPI != PP_RESLN3), "PP_QK / PP_GELU consume the raw stream (virtual LayerNorm), PP_RESLN3 produces it");
+  constexpr bool IS_RES = (EPI == PP_RESLN3);
+  constexpr int WAITN = 2 * PP_F;
   constexpr int LDS_SCR = RAW ? PP_LDS_SCR_RAW : PP_LDS_SCR;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
@@ -260,34 +206,20 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmArgs a) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wave >> 2, wc = wave & 3;
   const int K = a.K, nk0 = K >> 6;                 // K-tiles of one sweep
-  constexpr int nseg = X2 ? 3 : 1;                  // split-operand mode: three sweeps (GemmArgs::nseg)
+  constexpr int nseg = X8 ? 2 : 1;                  // X8: the fp16 sweep, then the fp8 correction sweep (same K-tile count)
   const int nk = nk0 * nseg;                        // K-tiles per output tile
   const int tm_count = a.M >> 8, tn_count = a.N >> 8;
   const int ntiles = tm_count * tn_count;
   const int G = gridDim.x;
   const int bslot = xcd_remap(blockIdx.x, G);
-  const unsigned long long clk0 = a.clk ? __builtin_amdgcn_s_memtime() : 0ull;
-
-  // ---- optional start-up stagger: all workgroups of a launch otherwise run their tiles in lockstep, so their
-  // accumulator-init loads and epilogue stores hit HBM in bursts (every CU at once) with the matrix pipes idle, and
-  // HBM idles during the main loops.  (Waves 1..7 wait for wave 0 at the prologue barrier.)
-  // stagger < 0: TWO phase groups instead of a random spread — odd slots start -stagger x 8128 cycles late, so half of
-  // every XCD's workgroups sit in their main loops while the other half runs its epilogue / accumulator init (each phase
-  // group keeps sharing its operand panels in L2 at the same moment, which the random spread destroyed).
-  if (a.stagger != 0 && wave == 0) {
-    const int n = a.stagger > 0 ? (int)((uint32_t)(bslot * 2654435761u) >> 16) % (a.stagger + 1) : ((bslot & 1) ? -a.stagger : 0);
-    for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(127);
-  }
 
   // ---- bias -> LDS (once per workgroup; RAW kernels: per tile, issue_stats)
   if constexpr (!RAW) {
     float* lb = (float*)(smem + PP_LDS_BIAS);
     for (int n = tid; n < a.N; n += 512) lb[n] = a.bias ? a.bias[n] : 0.f;
-    if constexpr (IS_RESLN) {  // N == 768: gamma at [768, 1536), beta at [1536, 2304) of the same image
-      for (int n = tid; n < MV_HIDDEN; n += 512) {
-        lb[MV_HIDDEN + n] = a.lng[n];
-        lb[2 * MV_HIDDEN + n] = a.lnb[n];
-      }
+    for (int n = tid; n < MV_HIDDEN; n += 512) {  // N == 768: gamma at [768, 1536), beta at [1536, 2304) of the same image
+      lb[MV_HIDDEN + n] = a.lng[n];
+      lb[2 * MV_HIDDEN + n] = a.lnb[n];
     }
   }
 
@@ -306,17 +238,17 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmArgs a) {
   int i_it = 0, i_kt = 0, i_seg = 0;
   const char* iA = (const char*)a.A;
   const char* iW = (const char*)a.W;
-  size_t tA = 0, tW = 0;  // X2: byte offsets of the issue tile's operand panels
-  auto set_issue_seg = [&]() {  // X2, sweep 0: A_hi W_hi, 1: A_lo W_hi, 2: A_hi W_lo
-    iA = (const char*)(i_seg == 1 ? a.A2 : a.A) + tA;
-    iW = (const char*)(i_seg == 2 ? a.W2 : a.W) + tW;
+  size_t tA = 0, tW = 0;  // X8: byte offsets of the issue tile's operand panels (the fp8 panels have the same row pitch, 2 K bytes)
+  auto set_issue_seg = [&]() {  // X8, sweep 0: A_hi W_hi (fp16), 1: [A_lo8 | A_hi8] x [W_hi8 | W_lo8] (fp8)
+    iA = (i_seg ? (const char*)a.A8 : (const char*)a.A) + tA;
+    iW = (i_seg ? (const char*)a.W8 : (const char*)a.W) + tW;
   };
   auto set_issue_tile = [&](int it) {
     const int L = it * G + bslot;
     if (L < ntiles) {  // past the end: keep staging the last valid tile (never read, keeps the vmcnt ledger exact)
       int tm, tn;
       raster(L, tm_count, tn_count, a.GN, tm, tn);
-      if constexpr (X2) {
+      if constexpr (X8) {
         tA = (size_t)tm * 256 * K * 2;
         tW = (size_t)tn * 256 * K * 2;
       } else {
@@ -324,32 +256,30 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmArgs a) {
         iW = (const char*)a.W + (size_t)tn * 256 * K * 2;
       }
     }
-    if constexpr (X2) set_issue_seg();
+    if constexpr (X8) set_issue_seg();
   };
   set_issue_tile(0);
   // kind: 0 = a0, 1 = a1, 2 = b0, 3 = b1; issue order per K-tile: b0, a0, b1, a1 (= read order)
   auto issue = [&](auto kindc, auto parc) {
     constexpr int kind = decltype(kindc)::value;
     constexpr int par = decltype(parc)::value;
-    if constexpr (!(ABL & PP_ABL_NODMA)) {
-      const char* src;
-      char* dst;
-      if constexpr (kind < 2) {
-        src = iA + (size_t)(kind * 64) * K * 2 + i_kt * 128;
-        dst = smem + PP_LDS_A + par * 32768 + kind * 16384 + wave * 2048;
-        glds16((const half_t*)(src + offA[0]), dst);
-        glds16((const half_t*)(src + offA[1]), dst + 1024);
-      } else {
-        src = iW + (size_t)((kind - 2) * 32) * K * 2 + i_kt * 128;
-        dst = smem + PP_LDS_B + par * 32768 + (kind - 2) * 16384 + wave * 2048;
-        glds16((const half_t*)(src + offB[0]), dst);
-        glds16((const half_t*)(src + offB[1]), dst + 1024);
-      }
+    const char* src;
+    char* dst;
+    if constexpr (kind < 2) {
+      src = iA + (size_t)(kind * 64) * K * 2 + i_kt * 128;
+      dst = smem + PP_LDS_A + par * 32768 + kind * 16384 + wave * 2048;
+      glds16((const half_t*)(src + offA[0]), dst);
+      glds16((const half_t*)(src + offA[1]), dst + 1024);
+    } else {
+      src = iW + (size_t)((kind - 2) * 32) * K * 2 + i_kt * 128;
+      dst = smem + PP_LDS_B + par * 32768 + (kind - 2) * 16384 + wave * 2048;
+      glds16((const half_t*)(src + offB[0]), dst);
+      glds16((const half_t*)(src + offB[1]), dst + 1024);
     }
     if constexpr (kind == 1) {  // last half-tile of this K-tile: advance the cursor
       if (++i_kt == nk0) {
         i_kt = 0;
-        if constexpr (X2) {
+        if constexpr (X8) {
           if (++i_seg == nseg) {
             i_seg = 0;
             set_issue_tile(++i_it);
@@ -379,30 +309,44 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmArgs a) {
     rdA[ks] = PP_LDS_A + wr * 8192 + o;
     rdB[ks] = PP_LDS_B + wc * 4096 + o;
   }
-  half8_t Xf[2][4], Wx[4], Wy[4];
+  // fragment registers.  X8 builds hold each PAIR of 16-byte chunks (2 kk, 2 kk + 1) as one 8-dword value, because the fp8
+  // matrix instruction takes 32 K-bytes per lane as a 256-bit operand (left as separate 128-bit values hipcc copies them
+  // into fresh 8-register tuples in front of every MFMA and spills); the fp16 instruction reads the halves in place.
+  half8_t Xf[X8 ? 1 : 2][X8 ? 1 : 4], Wx[X8 ? 1 : 4], Wy[X8 ? 1 : 4];
+  intx8 Xp[X8 ? 2 : 1][X8 ? 2 : 1], Wxp[X8 ? 2 : 1], Wyp[X8 ? 2 : 1];
+  auto ld16 = [&](int off) -> intx4 { return *(const intx4*)(smem + off); };
   auto read_a = [&](int par, int asub) {
+    if constexpr (X8) {
 #pragma unroll
-    for (int ii = 0; ii < 2; ++ii)
+      for (int ii = 0; ii < 2; ++ii)
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks)
-        Xf[ii][ks] = *(const half8_t*)(smem + rdA[ks] + par * 32768 + asub * 16384 + ii * 4096);
-  };
-  auto read_b = [&](half8_t (&Wf)[4], int par, int bsub) {
+        for (int kk = 0; kk < 2; ++kk) {
+          const int o = par * 32768 + asub * 16384 + ii * 4096;
+          Xp[ii][kk] = __builtin_shufflevector(ld16(rdA[2 * kk] + o), ld16(rdA[2 * kk + 1] + o), 0, 1, 2, 3, 4, 5, 6, 7);
+        }
+    } else {
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) Wf[ks] = *(const half8_t*)(smem + rdB[ks] + par * 32768 + bsub * 16384);
-  };
-  if constexpr (ABL & PP_ABL_NOREAD) {
+      for (int ii = 0; ii < 2; ++ii)
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-      Xf[0][ks] = *(const half8_t*)(a.A + (size_t)l31 * K + ks * 16 + hi * 8);
-      Xf[1][ks] = *(const half8_t*)(a.A + (size_t)(32 + l31) * K + ks * 16 + hi * 8);
-      Wx[ks] = *(const half8_t*)(a.W + (size_t)l31 * K + ks * 16 + hi * 8);
-      Wy[ks] = *(const half8_t*)(a.W + (size_t)(32 + l31) * K + ks * 16 + hi * 8);
+        for (int ks = 0; ks < 4; ++ks)
+          Xf[ii][ks] = *(const half8_t*)(smem + rdA[ks] + par * 32768 + asub * 16384 + ii * 4096);
     }
-  }
+  };
+  auto read_b = [&](half8_t (&Wf)[X8 ? 1 : 4], intx8 (&Wp)[X8 ? 2 : 1], int par, int bsub) {
+    if constexpr (X8) {
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        const int o = par * 32768 + bsub * 16384;
+        Wp[kk] = __builtin_shufflevector(ld16(rdB[2 * kk] + o), ld16(rdB[2 * kk + 1] + o), 0, 1, 2, 3, 4, 5, 6, 7);
+      }
+    } else {
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) Wf[ks] = *(const half8_t*)(smem + rdB[ks] + par * 32768 + bsub * 16384);
+    }
+  };
 
   floatx16 acc[4][2];
-  // PP_RESLN3: the two fp16 planes of fragment pair i of the residual tile at (mw0, nw0) by full-line loads (16 rows x 64 B per
+  // the two fp16 planes of fragment pair i of the residual tile at (mw0, nw0) by full-line loads (16 rows x 64 B per
   // instruction), parked in the accumulator registers they will be transposed into: [i][j] registers 0-3 / 4-7 = hi rows
   // crow / crow + 16, 8-11 / 12-15 = lo
   auto park_residual = [&](int i, int mw0, int nw0) {
@@ -419,96 +363,84 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmArgs a) {
           acc[i][j][8 * pl + 4 * x + 2] = t.z; acc[i][j][8 * pl + 4 * x + 3] = t.w;
         }
   };
-  auto mma_quadrant = [&](auto asubc, auto bc, const half8_t (&Wf)[4]) {
+  // One quadrant of a K-tile.  F8 (X8, the correction sweep): the same fragment registers hold fp8 bytes — a lane's four
+  // 16-byte chunks 2 ks + hi (ks = 0..3) of its 128-byte row; MFMA kk takes chunks 4 kk + hi and 4 kk + 2 + hi as its 32
+  // K-bytes, the same assignment for both operands, so every byte column of the tile meets its partner exactly once.
+  auto mma_quadrant = [&](auto asubc, auto bc, auto f8c, const half8_t (&Wf)[X8 ? 1 : 4], const intx8 (&Wp)[X8 ? 2 : 1]) {
     constexpr int asub = decltype(asubc)::value;
     constexpr int b = decltype(bc)::value;
-    if constexpr (ABL & PP_ABL_NOMFMA) {
+    if constexpr (X8) {
+      if constexpr (decltype(f8c)::value) {
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        keep_live(Wf[ks]);
-        keep_live(Xf[0][ks]);
-        keep_live(Xf[1][ks]);
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+          for (int ii = 0; ii < 2; ++ii)
+            acc[asub * 2 + ii][b] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(Wp[kk], Xp[ii][kk], acc[asub * 2 + ii][b], 0, 0, 0,
+                                                                                    a.x8_scale, 0, 0x7f7f7f7f);
+      } else {
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+          const intx4 w4 = (ks & 1) ? __builtin_shufflevector(Wp[ks >> 1], Wp[ks >> 1], 4, 5, 6, 7)
+                                    : __builtin_shufflevector(Wp[ks >> 1], Wp[ks >> 1], 0, 1, 2, 3);
+#pragma unroll
+          for (int ii = 0; ii < 2; ++ii) {
+            const intx4 x4 = (ks & 1) ? __builtin_shufflevector(Xp[ii][ks >> 1], Xp[ii][ks >> 1], 4, 5, 6, 7)
+                                      : __builtin_shufflevector(Xp[ii][ks >> 1], Xp[ii][ks >> 1], 0, 1, 2, 3);
+            acc[asub * 2 + ii][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8_t, w4), __builtin_bit_cast(half8_t, x4),
+                                                                           acc[asub * 2 + ii][b], 0, 0, 0);
+          }
+        }
       }
     } else {
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
-        for (int ii = 0; ii < 2; ++ii) {
-          if constexpr (SWAP)
-            acc[asub * 2 + ii][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Wf[ks], Xf[ii][ks], acc[asub * 2 + ii][b], 0, 0, 0);
-          else
-            acc[asub * 2 + ii][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Xf[ii][ks], Wf[ks], acc[asub * 2 + ii][b], 0, 0, 0);
-        }
+        for (int ii = 0; ii < 2; ++ii)
+          acc[asub * 2 + ii][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Wf[ks], Xf[ii][ks], acc[asub * 2 + ii][b], 0, 0, 0);
     }
   };
 
-  // One phase.  s = phase index inside the 8-phase (two K-tile) loop body; P = s & 3, par = s >> 2.
-  // Even K-tile: b0 in Wx, b1 -> Wy, next b0 -> Wy.  Odd K-tile: b0 in Wy, b1 -> Wx, next b0 -> Wx.
-  auto phase = [&](auto sc) {
-    constexpr int s = decltype(sc)::value;
-    constexpr int P = s & 3, par = s >> 2;
-    // ---- read section
-    if constexpr (!(ABL & PP_ABL_NOREAD)) {
-      if constexpr (P == 0) read_a(par, 0);
-      if constexpr (P == 1) { if constexpr (par == 0) read_b(Wy, par, 1); else read_b(Wx, par, 1); }
-      if constexpr (P == 2) read_a(par, 1);
-      if constexpr (P == 3) { if constexpr (par == 0) read_b(Wy, par ^ 1, 0); else read_b(Wx, par ^ 1, 0); }
-    }
-    issue_psi(std::integral_constant<int, (s + 1 + DIST) & 7>{});
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WAITN) : "memory");
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_sched_barrier(0);
-    // ---- matrix section
-    if constexpr (!(ABL & PP_ABL_NOPRIO)) __builtin_amdgcn_s_setprio(1);
-    if constexpr (P == 0) { if constexpr (par == 0) mma_quadrant(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, Wx);
-                            else mma_quadrant(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, Wy); }
-    if constexpr (P == 1) { if constexpr (par == 0) mma_quadrant(std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{}, Wy);
-                            else mma_quadrant(std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{}, Wx); }
-    if constexpr (P == 2) { if constexpr (par == 0) mma_quadrant(std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{}, Wy);
-                            else mma_quadrant(std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{}, Wx); }
-    if constexpr (P == 3) { if constexpr (par == 0) mma_quadrant(std::integral_constant<int, 1>{}, std::integral_constant<int, 0>{}, Wx);
-                            else mma_quadrant(std::integral_constant<int, 1>{}, std::integral_constant<int, 0>{}, Wy); }
-    if constexpr (!(ABL & PP_ABL_NOPRIO)) __builtin_amdgcn_s_setprio(0);
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_sched_barrier(0);
-  };
-
-  // ---- SCHED 1 building blocks: fragment set / quadrant of phase s (P = s & 3, LDS parity = s >> 2)
+  // ---- building blocks: fragment set / quadrant of phase s (P = s & 3, LDS parity = s >> 2)
   auto read_set = [&](auto sc) {
     constexpr int s = decltype(sc)::value & 7;
     constexpr int P = s & 3, par = s >> 2;
-    if constexpr (!(ABL & PP_ABL_NOREAD)) {
-      if constexpr (P == 0) { read_a(par, 0); read_b(Wx, par, 0); }
-      if constexpr (P == 1) read_b(Wy, par, 1);
-      if constexpr (P == 2) read_a(par, 1);
-    }
+    if constexpr (P == 0) { read_a(par, 0); read_b(Wx, Wxp, par, 0); }
+    if constexpr (P == 1) read_b(Wy, Wyp, par, 1);
+    if constexpr (P == 2) read_a(par, 1);
   };
-  auto mma_set = [&](auto sc) {
+  auto mma_set = [&](auto sc, auto f8c) {
     constexpr int P = decltype(sc)::value & 3;
-    if constexpr (P == 0) mma_quadrant(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, Wx);
-    if constexpr (P == 1) mma_quadrant(std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{}, Wy);
-    if constexpr (P == 2) mma_quadrant(std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{}, Wy);
-    if constexpr (P == 3) mma_quadrant(std::integral_constant<int, 1>{}, std::integral_constant<int, 0>{}, Wx);
+    if constexpr (P == 0) mma_quadrant(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, f8c, Wx, Wxp);
+    if constexpr (P == 1) mma_quadrant(std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{}, f8c, Wy, Wyp);
+    if constexpr (P == 2) mma_quadrant(std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{}, f8c, Wy, Wyp);
+    if constexpr (P == 3) mma_quadrant(std::integral_constant<int, 1>{}, std::integral_constant<int, 0>{}, f8c, Wx, Wxp);
   };
-  auto interval = [&](auto sc, auto grpc, bool last_of_tile = false) {
+  auto interval = [&](auto sc, auto grpc, auto f8c, bool last_of_tile = false) {
     constexpr int s = decltype(sc)::value;
     constexpr int grp = decltype(grpc)::value;
     if constexpr (grp == 0) {  // matrix pipe first, then the NEXT phase's fragments
-      if constexpr (!(ABL & PP_ABL_NOPRIO)) __builtin_amdgcn_s_setprio(1);
-      mma_set(sc);
-      if constexpr (!(ABL & PP_ABL_NOPRIO)) __builtin_amdgcn_s_setprio(0);
+      __builtin_amdgcn_s_setprio(1);
+      mma_set(sc, f8c);
+      __builtin_amdgcn_s_setprio(0);
       __builtin_amdgcn_sched_barrier(0);
       // the next OUTPUT tile's first fragments are read after its accumulator init instead (run_tiles): keeping
       // 48 fragment VGPRs live across the epilogue + init costs more than one exposed LDS read per tile
       if (!(s == 7 && last_of_tile)) read_set(std::integral_constant<int, (s + 1) & 7>{});
-      issue_psi(std::integral_constant<int, (s + 3 + DIST) & 7>{});
+      issue_psi(std::integral_constant<int, (s + 3 + PP_F) & 7>{});
     } else {  // this phase's fragments first, then the matrix pipe as the other half releases it
       read_set(sc);
-      issue_psi(std::integral_constant<int, (s + 3 + DIST) & 7>{});
+      issue_psi(std::integral_constant<int, (s + 3 + PP_F) & 7>{});
       __builtin_amdgcn_sched_barrier(0);
-      mma_set(sc);
+      mma_set(sc, f8c);
+    }
+    if constexpr (X8) {
+      // pin this interval's accumulators here: the scaled-MFMA builtin is a pure function to hipcc's IR passes, which otherwise
+      // sink four intervals' worth of them across the barriers into one block (20 + 0 + 0 ... per interval instead of 4 each,
+      // 18 fragment tuples live at once, 400-600 bytes of scratch per lane)
+#if defined(__HIP_DEVICE_COMPILE__)
+      constexpr int P = s & 3, a0 = (P >= 2) ? 2 : 0, bq = (P == 1 || P == 2) ? 1 : 0;  // the quadrant of phase P (mma_set)
+      asm volatile("" : "+v"(acc[a0][bq]), "+v"(acc[a0 + 1][bq]));
+#endif
     }
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WAITN) : "memory");
     __builtin_amdgcn_sched_barrier(0);
@@ -541,218 +473,117 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmArgs a) {
     issue_stats(0, tm, tn);
   }
 
-  // ---- prologue.  SCHED 0: half-tiles psi = 0 .. DIST in flight, psi 0 (b0 of K-tile 0) and 1 (a0) landed.
-  //               SCHED 1: psi = 0 .. 2 + F in flight, psi 0 .. 2 landed.
-  constexpr int NPRO = SCHED == 0 ? DIST + 1 : DIST + 3;
+  // ---- prologue: half-tiles psi = 0 .. 2 + F in flight, psi 0 .. 2 landed
   issue_psi(std::integral_constant<int, 0>{});
   issue_psi(std::integral_constant<int, 1>{});
   issue_psi(std::integral_constant<int, 2>{});
-  if constexpr (NPRO > 3) issue_psi(std::integral_constant<int, 3>{});
-  if constexpr (NPRO > 4) issue_psi(std::integral_constant<int, 4>{});
-  if constexpr (NPRO > 5) issue_psi(std::integral_constant<int, 5>{});
-  if constexpr (NPRO > 6) issue_psi(std::integral_constant<int, 6>{});
+  issue_psi(std::integral_constant<int, 3>{});
+  issue_psi(std::integral_constant<int, 4>{});
+  issue_psi(std::integral_constant<int, 5>{});
+  issue_psi(std::integral_constant<int, 6>{});
   asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(WAITN) : "memory");  // lgkmcnt: the bias image writes
   __builtin_amdgcn_sched_barrier(0);
   __builtin_amdgcn_s_barrier();
   __builtin_amdgcn_sched_barrier(0);
-  constexpr bool STAGGER = !(ABL & PP_ABL_NOSTAGGER);
-  if constexpr (SCHED == 0) {
-    if constexpr (!(ABL & PP_ABL_NOREAD)) read_b(Wx, 0, 0);
-    __builtin_amdgcn_sched_barrier(0);
-    if constexpr (STAGGER) {
-      if (wr == 1) __builtin_amdgcn_s_barrier();  // the second M-half runs one barrier behind the first
-    }
-    __builtin_amdgcn_sched_barrier(0);
-  }
 
-  unsigned long long c_init = 0ull, c_main = 0ull, c_epi = 0ull;
   auto run_tiles = [&](auto grpc) {
   for (int it = 0;; ++it) {
     const int L = it * G + bslot;
     if (L >= ntiles) break;
-    unsigned long long tA = 0ull, tB = 0ull, tC = 0ull;
-    if constexpr (ABL & PP_ABL_CLK) tA = __builtin_amdgcn_s_memtime();
     int tile_m, tile_n;
     raster(L, tm_count, tn_count, a.GN, tile_m, tile_n);
     int next_m = 0, next_n = 0;  // RAW: the workgroup's next tile (issue_stats); PP_RESLN3: its residual tile is requested
     const bool has_next = L + G < ntiles;  // during this tile's epilogue
-    if constexpr (RAW || HILO) {
-      if (has_next) raster(L + G, tm_count, tn_count, a.GN, next_m, next_n);
-    }
+    if (has_next) raster(L + G, tm_count, tn_count, a.GN, next_m, next_n);
     (void)next_m; (void)next_n; (void)has_next;
     const int mw = (tile_m << 8) + wr * 128;  // first token row of this wave
     const int nw = (tile_n << 8) + wc * 64;   // first output column of this wave
 
-    // ---- accumulator init: bias (+ residual).  The bias image is read with inline-asm ds_reads: hipcc would
-    // put `s_waitcnt vmcnt(0)` in front of a compiler-visible LDS load here (LDS-DMA in flight) and drain the
+    // ---- accumulator init: zero (RAW) or bias + LayerNorm(residual).  The images are read with inline-asm ds_reads: hipcc
+    // would put `s_waitcnt vmcnt(0)` in front of a compiler-visible LDS load here (LDS-DMA in flight) and drain the
     // operand pipeline once per output tile.  Loads and their lgkmcnt wait are one statement (guide §5.7 form i).
-    if constexpr (SWAP) {
-      float4 bv[2][4];
+    {
       const uint32_t baddr = (uint32_t)(PP_LDS_BIAS + (nw + 4 * hi) * 4);
-      if constexpr (!RAW)  // (RAW: accumulators start from zero; bias' is applied in the epilogue from the per-tile image)
-      asm volatile(
-          "ds_read_b128 %0, %8\n\tds_read_b128 %1, %8 offset:32\n\tds_read_b128 %2, %8 offset:64\n\t"
-          "ds_read_b128 %3, %8 offset:96\n\tds_read_b128 %4, %8 offset:128\n\tds_read_b128 %5, %8 offset:160\n\t"
-          "ds_read_b128 %6, %8 offset:192\n\tds_read_b128 %7, %8 offset:224\n\ts_waitcnt lgkmcnt(0)"
-          : "=&v"(bv[0][0]), "=&v"(bv[0][1]), "=&v"(bv[0][2]), "=&v"(bv[0][3]), "=&v"(bv[1][0]), "=&v"(bv[1][1]),
-            "=&v"(bv[1][2]), "=&v"(bv[1][3])
-          : "v"(baddr)
-          : "memory");
       // scratch addresses of this lane: MFMA layout (row = lane & 31) and coalesced layout (row = lane >> 2)
       const uint32_t scr = (uint32_t)(LDS_SCR + wave * 2048);
       const uint32_t sf = (uint32_t)((l31 >> 2) & 3);
-      const uint32_t scr_m32 = scr + l31 * 64 + (((uint32_t)hi ^ sf) << 4);          // fp32 rounds: chunk 2 gg + hi -> ^ (gg * 32)
       const uint32_t scr_c = scr + (lane >> 2) * 64 + ((((uint32_t)lane & 3) ^ (((uint32_t)lane >> 4) & 3)) << 4);
-      if constexpr (IS_RES && COAL) {
+      if constexpr (IS_RES) {
         // residual tile by full-line loads (16 rows x 64 B per instruction), transposed into the C/D layout
         // (the raw lines are parked in the accumulator registers they will be transposed into)
-        float2 lnst[4];  // PP_RESLN: (mean, rstd) of this lane's four token rows
-        float2 lnp[4][3];  // virtual LayerNorm: the rows' vstats, loaded here and turned into (mean, rstd) only AFTER the
-                           // residual tile's loads are issued (in source order hipcc waits for these loads first and the
-                           // two memory latencies add up: +1.3 us per tile)
-        if constexpr (IS_RESLN) {
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            if constexpr (EMITS) {
-              const float2* pp = (const float2*)(a.lnstats + 6 * (size_t)(mw + i * 32 + l31));
-              lnp[i][0] = pp[0]; lnp[i][1] = pp[1]; lnp[i][2] = pp[2];
-            } else {
-              lnst[i] = *(const float2*)(a.lnstats + 2 * (size_t)(mw + i * 32 + l31));
-            }
-          }
-        }
-        auto finish_stats = [&]() {
-          if constexpr (EMITS) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) lnst[i] = ln_from_partials(lnp[i][0], lnp[i][1], lnp[i][2], a.ln_eps);
-          }
-        };
-        (void)lnp;
-        if constexpr (HILO) {
-          // the two fp16 planes of the raw stream by full-line loads (16 rows x 64 B per instruction), parked in the
-          // accumulator registers: [i][j] registers 0-3 / 4-7 = hi rows crow / crow + 16, 8-11 / 12-15 = lo
-          const uint32_t wbase = scr + l31 * 64 + hi * 8 + (sf << 4);
-          // (tiles after the workgroup's first: the lines were requested fragment pair by fragment pair during the PREVIOUS
-          //  tile's epilogue, each as soon as its accumulator registers had been stored — park_residual below — so the read
-          //  phase of this tile runs under the write phase of the last one instead of after it)
-          if (it == 0) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) park_residual(i, mw, nw);
-          }
-          finish_stats();
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {
-#pragma clang fp contract(off)
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-              u32x4 p[4];
-#pragma unroll
-              for (int q = 0; q < 4; ++q)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) p[q][e] = f2u(acc[i][j][4 * q + e]);
-              u32x2 oh[4], ol[4];
-              scr_f16_rev2(scr_c, p[0], p[1], p[2], p[3], wbase, wbase ^ 16u, wbase ^ 32u, wbase ^ 48u, oh, ol);
-#pragma unroll
-              for (int g = 0; g < 4; ++g) {
-                float4 bi, ga, be;
-                lds_read_bgb1(baddr + j * 128 + g * 32, bi, ga, be);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                  const uint32_t wh = oh[g][e >> 1], wl = ol[g][e >> 1];  // scalar copies before the bit casts (see f2u)
-                  const half2_t h2 = __builtin_bit_cast(half2_t, wh);
-                  const half2_t l2 = __builtin_bit_cast(half2_t, wl);
-                  const float r = (float)h2[e & 1] + (float)l2[e & 1];
-                  const float t = (r - lnst[i].x) * lnst[i].y;
-                  acc[i][j][4 * g + e] = __builtin_fmaf(t, ((const float*)&ga)[e], ((const float*)&be)[e]) + ((const float*)&bi)[e];
-                }
-              }
-            }
-          }
-        } else {
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-          for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int h = 0; h < 2; ++h)
-#pragma unroll
-              for (int x = 0; x < 2; ++x) {
-                if constexpr (ABL & PP_ABL_B34) { if (j == 1 && x == 1) continue; }
-                const float4 t = *(const float4*)(a.xres + (size_t)(mw + i * 32 + x * 16 + (lane >> 2)) * MV_HIDDEN + nw + j * 32 + h * 16 + 4 * (lane & 3));
-                acc[i][j][4 * (2 * h + x) + 0] = t.x; acc[i][j][4 * (2 * h + x) + 1] = t.y;
-                acc[i][j][4 * (2 * h + x) + 2] = t.z; acc[i][j][4 * (2 * h + x) + 3] = t.w;
-              }
-        finish_stats();
+        float2 lnst[4];    // (mean, rstd) of this lane's four token rows
+        float2 lnp[4][3];  // the rows' vstats, loaded here and turned into (mean, rstd) only AFTER the residual tile's loads
+                           // are issued (in source order hipcc waits for these loads first and the two memory latencies add
+                           // up: +1.3 us per tile)
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-          u32x4 d[8], o[8];
+          const float2* pp = (const float2*)(a.lnstats + 6 * (size_t)(mw + i * 32 + l31));
+          lnp[i][0] = pp[0]; lnp[i][1] = pp[1]; lnp[i][2] = pp[2];
+        }
+        const uint32_t wbase = scr + l31 * 64 + hi * 8 + (sf << 4);
+        // (tiles after the workgroup's first: the lines were requested fragment pair by fragment pair during the PREVIOUS
+        //  tile's epilogue, each as soon as its accumulator registers had been stored — park_residual below — so the read
+        //  phase of this tile runs under the write phase of the last one instead of after it)
+        if (it == 0) {
 #pragma unroll
-          for (int q = 0; q < 8; ++q)  // q = (j, h, x): registers 4 q .. 4 q + 3 of fragment pair i
+          for (int i = 0; i < 4; ++i) park_residual(i, mw, nw);
+        }
 #pragma unroll
-            for (int e = 0; e < 4; ++e) d[q][e] = f2u(acc[i][q >> 2][4 * (q & 3) + e]);
-          scr_f32x4(scr_c, scr_c + 1024, d, scr_m32, scr_m32 ^ 32u, o);
-          if constexpr (IS_RESLN) {
+        for (int i = 0; i < 4; ++i) lnst[i] = ln_from_partials(lnp[i][0], lnp[i][1], lnp[i][2], a.ln_eps);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
 #pragma clang fp contract(off)
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-              float4 bi[4], ga[4], be[4];
-              lds_read_bgb(baddr + j * 128, bi, ga, be);
+          for (int j = 0; j < 2; ++j) {
+            u32x4 p[4];
 #pragma unroll
-              for (int g = 0; g < 4; ++g)
+            for (int q = 0; q < 4; ++q)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                  const float t = (u2f(o[4 * j + g][e]) - lnst[i].x) * lnst[i].y;
-                  acc[i][j][4 * g + e] =
-                      __builtin_fmaf(t, ((const float*)&ga[g])[e], ((const float*)&be[g])[e]) + ((const float*)&bi[g])[e];
-                }
+              for (int e = 0; e < 4; ++e) p[q][e] = f2u(acc[i][j][4 * q + e]);
+            u32x2 oh[4], ol[4];
+            scr_f16_rev2(scr_c, p[0], p[1], p[2], p[3], wbase, wbase ^ 16u, wbase ^ 32u, wbase ^ 48u, oh, ol);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+              float4 bi, ga, be;
+              lds_read_bgb1(baddr + j * 128 + g * 32, bi, ga, be);
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                const uint32_t wh = oh[g][e >> 1], wl = ol[g][e >> 1];  // scalar copies before the bit casts (see f2u)
+                const half2_t h2 = __builtin_bit_cast(half2_t, wh);
+                const half2_t l2 = __builtin_bit_cast(half2_t, wl);
+                const float r = (float)h2[e & 1] + (float)l2[e & 1];
+                const float t = (r - lnst[i].x) * lnst[i].y;
+                acc[i][j][4 * g + e] = __builtin_fmaf(t, ((const float*)&ga)[e], ((const float*)&be)[e]) + ((const float*)&bi)[e];
+              }
             }
-          } else {
-#pragma unroll
-          for (int q = 0; q < 8; ++q)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) acc[i][q >> 2][4 * (q & 3) + e] = u2f(o[q][e]) + ((const float*)&bv[q >> 2][q & 3])[e];
           }
         }
-        }  // !HILO
       } else {
 #pragma unroll
-      for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < 2; ++j)
 #pragma unroll
-        for (int g = 0; g < 4; ++g)
+          for (int g = 0; g < 4; ++g)
 #pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            if constexpr (RAW) {
+            for (int i = 0; i < 4; ++i) {
               acc[i][j][4 * g + 0] = 0.f; acc[i][j][4 * g + 1] = 0.f; acc[i][j][4 * g + 2] = 0.f; acc[i][j][4 * g + 3] = 0.f;
-            } else if constexpr (IS_RES) {
-              const float4 xv = *(const float4*)(a.xres + (size_t)(mw + i * 32 + l31) * MV_HIDDEN + nw + j * 32 + 8 * g + 4 * hi);
-              acc[i][j][4 * g + 0] = xv.x + bv[j][g].x; acc[i][j][4 * g + 1] = xv.y + bv[j][g].y;
-              acc[i][j][4 * g + 2] = xv.z + bv[j][g].z; acc[i][j][4 * g + 3] = xv.w + bv[j][g].w;
-            } else {
-              acc[i][j][4 * g + 0] = bv[j][g].x; acc[i][j][4 * g + 1] = bv[j][g].y;
-              acc[i][j][4 * g + 2] = bv[j][g].z; acc[i][j][4 * g + 3] = bv[j][g].w;
             }
-          }
       }
-      (void)scr_m32; (void)scr_c;
-    } else {  // lane = output column
-      float b0, b1;
-      const uint32_t baddr = (uint32_t)(PP_LDS_BIAS + (nw + l31) * 4);
-      asm volatile("ds_read_b32 %0, %2\n\tds_read_b32 %1, %2 offset:128\n\ts_waitcnt lgkmcnt(0)"
-                   : "=&v"(b0), "=&v"(b1)
-                   : "v"(baddr)
-                   : "memory");
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          acc[i][0][r] = RAW ? 0.f : b0;
-          acc[i][1][r] = RAW ? 0.f : b1;
-        }
+      (void)baddr; (void)scr_c; (void)sf;
     }
 
-    if constexpr (ABL & PP_ABL_CLK) tB = __builtin_amdgcn_s_memtime();
-    if constexpr (SCHED == 1 && decltype(grpc)::value == 0) read_set(std::integral_constant<int, 0>{});
-    for (int kt = 0; kt < nk; kt += 2) {
+    if constexpr (decltype(grpc)::value == 0) read_set(std::integral_constant<int, 0>{});
+    auto two_ktiles = [&](auto f8c, int kt, bool last) {
+      interval(std::integral_constant<int, 0>{}, grpc, f8c);
+      interval(std::integral_constant<int, 1>{}, grpc, f8c);
+      interval(std::integral_constant<int, 2>{}, grpc, f8c);
+      interval(std::integral_constant<int, 3>{}, grpc, f8c);
+      interval(std::integral_constant<int, 4>{}, grpc, f8c);
+      interval(std::integral_constant<int, 5>{}, grpc, f8c);
+      interval(std::integral_constant<int, 6>{}, grpc, f8c);
+      interval(std::integral_constant<int, 7>{}, grpc, f8c, last);
+      (void)kt;
+    };
+    for (int kt = 0; kt < nk0; kt += 2) {
       if constexpr (RAW) {  // every wave has left the previous tile's epilogue (>= 8 barriers ago): its stats image is free
         if (kt == 2) {
           issue_stats(it + 1, next_m, next_n);
@@ -772,41 +603,19 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmArgs a) {
           }
         }
       }
-      if constexpr (SCHED == 0) {
-        phase(std::integral_constant<int, 0>{});
-        phase(std::integral_constant<int, 1>{});
-        phase(std::integral_constant<int, 2>{});
-        phase(std::integral_constant<int, 3>{});
-        phase(std::integral_constant<int, 4>{});
-        phase(std::integral_constant<int, 5>{});
-        phase(std::integral_constant<int, 6>{});
-        phase(std::integral_constant<int, 7>{});
-      } else {
-        interval(std::integral_constant<int, 0>{}, grpc);
-        interval(std::integral_constant<int, 1>{}, grpc);
-        interval(std::integral_constant<int, 2>{}, grpc);
-        interval(std::integral_constant<int, 3>{}, grpc);
-        interval(std::integral_constant<int, 4>{}, grpc);
-        interval(std::integral_constant<int, 5>{}, grpc);
-        interval(std::integral_constant<int, 6>{}, grpc);
-        interval(std::integral_constant<int, 7>{}, grpc, kt + 2 >= nk);
-      }
+      two_ktiles(std::false_type{}, kt, !X8 && kt + 2 >= nk0);
+    }
+    if constexpr (X8) {  // the correction sweep: the same intervals on the fp8 matrix path
+      for (int kt = nk0; kt < nk; kt += 2) two_ktiles(std::true_type{}, kt, kt + 2 >= nk);
     }
 
-    if constexpr (ABL & PP_ABL_CLK) tC = __builtin_amdgcn_s_memtime();
-    // ---- epilogue (store only)
-    if constexpr (ABL & PP_ABL_NOEPI) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) keep_live(acc[i][j]);
-    } else if constexpr (COAL) {
-      // ---- coalesced epilogue: every 32x32 fragment goes through the wave's [32][64 B] LDS image
+    // ---- epilogue (store only): every 32x32 fragment goes through the wave's [32][64 B] LDS image
+    {
       const uint32_t scr = (uint32_t)(LDS_SCR + wave * 2048);
       const uint32_t sf = (uint32_t)((l31 >> 2) & 3);
       const uint32_t scr_c = scr + (lane >> 2) * 64 + ((((uint32_t)lane & 3) ^ (((uint32_t)lane >> 4) & 3)) << 4);
       const int crow = lane >> 2, cchunk = lane & 3;  // coalesced layout: row (+16 for the second read), 16-B chunk
-      if constexpr (EMITS) {
+      if constexpr (IS_RES) {
         // vstats of the new raw rows: (sum, sum of squares) over this TILE's 256 columns.  Each wave reduces its 64 columns
         // (lane = token row, the two half-waves hold disjoint column sets), parks the 128 pairs in its own scratch, and after
         // a workgroup barrier the first column wave of each M-half adds the four shares in wave order (deterministic) and
@@ -856,39 +665,11 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmArgs a) {
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
       }
-      if constexpr ((EPI == PP_F32 || IS_RES) && !HILO) {
-        const uint32_t scr_m32 = scr + l31 * 64 + (((uint32_t)hi ^ sf) << 4);
-        float* obase = (IS_RES ? a.xres : a.outf) + (size_t)(mw + crow) * a.N + nw + 4 * cchunk;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          u32x4 d[8], o[8];
-#pragma unroll
-          for (int q = 0; q < 8; ++q)  // q = (j, h, gg): C/D registers 4 q .. 4 q + 3 of fragment pair i
-#pragma unroll
-            for (int e = 0; e < 4; ++e) d[q][e] = f2u(acc[i][q >> 2][4 * (q & 3) + e]);
-          scr_f32x4(scr_m32, scr_m32 ^ 32u, d, scr_c, scr_c + 1024, o);
-#pragma unroll
-          for (int q = 0; q < 8; ++q) {  // q = (j, h, x): rows 16 x + crow, columns 32 j + 16 h + 4 cchunk
-            float* op = obase + (size_t)(i * 32 + (q & 1) * 16) * a.N + (q >> 2) * 32 + ((q >> 1) & 1) * 16;
-            if constexpr (ABL & PP_ABL_B34) { if ((q >> 2) == 1 && (q & 1) == 1) continue; }
-            *(u32x4*)op = o[q];
-            if constexpr (EPI == PP_RESLN2) {
-              if (a.raw) {  // fp16 copy straight from the transposed fp32 image: 8 bytes per lane, 32-byte row pieces
-                half_t* hp = a.out16 + (size_t)(mw + crow + i * 32 + (q & 1) * 16) * a.N + nw + 4 * cchunk + (q >> 2) * 32 + ((q >> 1) & 1) * 16;
-                u32x2 hv;
-                hv[0] = pack_h2(u2f(o[q][0]), u2f(o[q][1]));
-                hv[1] = pack_h2(u2f(o[q][2]), u2f(o[q][3]));
-                *(u32x2*)hp = hv;
-              }
-            }
-          }
-        }
-      }
-      if constexpr (!(EPI == PP_F32 || IS_RES) || EMITS)
-      if (EPI != PP_RESLN2 || !a.raw) {
+      {
         // fp16 outputs: 8-B units (4 values) of the C/D layout -> chunk g, half hi of the row
-        // (PP_RESLN2: the fp16 copy of the raw stream, the A operand of the next RAW consumer)
+        // (PP_RESLN3: the hi plane of the raw stream, the A operand of the next RAW consumer)
         const uint32_t wbase = scr + l31 * 64 + hi * 8 + (sf << 4);
+        const uint32_t wbase8 = scr + l31 * 64 + hi * 4 + (sf << 4);  // fp8 planes (scr_f8x2)
         half_t* obase;    // pointer of (row crow, chunk cchunk) of fragment (i = 0, j = 0)
         size_t rstride;   // elements between image rows in the output
         size_t istride;   // elements between i blocks (32 C/D rows along the register axis or the lane axis)
@@ -896,10 +677,10 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmArgs a) {
         bool live = true;
         bool vtile = false;  // PP_QK: this tile belongs to the V block and is stored as V^T
         const uint32_t tbase = scr + hi * 256 + (((uint32_t)(l31 >> 3) ^ (uint32_t)hi) << 4) + (uint32_t)(l31 & 7) * 2;
-        if constexpr (EPI == PP_F16 || EPI == PP_GELU || EMITS) {
+        if constexpr (EPI == PP_GELU || IS_RES) {
           obase = a.out16 + (size_t)(mw + crow) * a.N + nw + 8 * cchunk;
           rstride = a.N; istride = (size_t)32 * a.N; jstride = 32;
-        } else if constexpr (EPI == PP_QK) {  // one head per wave; S % 64 == 0 so a 128-row block may span two batch rows
+        } else {  // PP_QK: one head per wave; S % 64 == 0 so a 128-row block may span two batch rows
           // columns [0,768) -> Q, [768,1536) -> K, [1536,2304) -> V^T (a merged launch); col0 = 768: K (and V) only
           const int colg = nw + a.col0;
           const int which = colg >= 2 * MV_HIDDEN ? 2 : (colg >= MV_HIDDEN ? 1 : 0);
@@ -912,10 +693,6 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmArgs a) {
             obase = (which ? a.k : a.q) + (size_t)head * a.S * MV_HEAD_DIM + (size_t)crow * MV_HEAD_DIM + 8 * cchunk;
             rstride = MV_HEAD_DIM; istride = 0; jstride = 32;  // the batch-row part is added per i below
           }
-        } else {  // PP_VT: image rows = head dims, image columns = tokens
-          const int head = nw >> 6;
-          obase = a.vt + ((size_t)head * MV_HEAD_DIM + crow) * a.S + 8 * cchunk;
-          rstride = a.S; istride = 0; jstride = (size_t)32 * a.S;
         }
         // RAW: bias' of this wave's columns (per-tile LDS image) and rstd of its token rows (from the vstats image, one row
         // per lane and i), applied as fma(rstd, acc, bias')
@@ -936,17 +713,17 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmArgs a) {
               : "memory");
           __builtin_amdgcn_sched_barrier(0);
         }
-        (void)rbv; (void)rrs;
+        (void)rbv; (void)rrs; (void)wbase8;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           const int mb = mw + i * 32;
           half_t* ob = obase + i * istride;
           const float rrs_i = RAW ? rrs[i] : 1.f;  // RAW: rstd of token row 32 i + l31
           (void)rrs_i;
-          if constexpr (EPI == PP_QK || EPI == PP_VT) {
+          if constexpr (EPI == PP_QK) {
             live = mb < a.Mreal;
             const int b = mb / a.S, s0 = mb - b * a.S;
-            if (EPI == PP_QK && !vtile) ob = obase + ((size_t)b * MV_HEADS * a.S + s0) * MV_HEAD_DIM;
+            if (!vtile) ob = obase + ((size_t)b * MV_HEADS * a.S + s0) * MV_HEAD_DIM;
             else ob = obase + (size_t)b * MV_HEADS * MV_HEAD_DIM * a.S + s0;
           }
           u32x2 d[2][4];
@@ -966,7 +743,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmArgs a) {
                 a01 = gelu_erf2(a01);
                 a23 = gelu_erf2(a23);
                 v0 = a01.x; v1 = a01.y; v2 = a23.x; v3 = a23.y;
-                if constexpr (X2) {  // split-operand mode: the lo plane below is taken from the activated values
+                if constexpr (X8) {  // the fp8 planes below are taken from the activated values
                   acc[i][j][4 * g + 0] = v0; acc[i][j][4 * g + 1] = v1; acc[i][j][4 * g + 2] = v2; acc[i][j][4 * g + 3] = v3;
                 }
               }
@@ -983,7 +760,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmArgs a) {
               *(u32x4*)(op + 16 * rstride) = o[2 * j + 1];
             }
           }
-          if constexpr (HILO || (X2 && EPI == PP_GELU)) {  // second plane: lo = fp16(r - hi), same addresses in the lo buffer
+          if constexpr (IS_RES) {  // second plane: lo = fp16(r - hi), same addresses in the lo buffer
 #pragma unroll
             for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -1000,83 +777,34 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmArgs a) {
               *(u32x4*)op = o[2 * j];
               *(u32x4*)(op + 16 * rstride) = o[2 * j + 1];
             }
-            if constexpr (HILO) {  // fragment pair i is out: request pair i of the NEXT tile's residual into its registers
-              if (has_next) park_residual(i, (next_m << 8) + wr * 128, (next_n << 8) + wc * 64);
-            }
+          }
+          if constexpr (X8 && (IS_RES || EPI == PP_GELU)) {
+            // MV_F16X8: the [lo8 | hi8] planes of this output (the A8 operand of the next GEMM's correction sweep): rows of
+            // 2 N bytes, lo8 of column n at byte n, hi8 at byte N + n; one 16-B store per lane, plane and 16-row half
+            uint32_t dl[8], dh[8];
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+              for (int g = 0; g < 4; ++g)
+                x8_planes4(acc[i][j][4 * g + 0], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3], dh[4 * j + g], dl[4 * j + g]);
+            scr_f8x2(wbase8, wbase8 ^ 16u, wbase8 ^ 32u, wbase8 ^ 48u, dl, dh, scr_c, o);
+            uint8_t* o8 = a.out8 + (size_t)(mb + crow) * (2 * a.N) + nw + 16 * cchunk;
+            *(u32x4*)o8 = o[0];
+            *(u32x4*)(o8 + (size_t)16 * (2 * a.N)) = o[1];
+            *(u32x4*)(o8 + a.N) = o[2];
+            *(u32x4*)(o8 + a.N + (size_t)16 * (2 * a.N)) = o[3];
+          }
+          if constexpr (IS_RES) {  // fragment pair i is out: request pair i of the NEXT tile's residual into its registers
+            if (has_next) park_residual(i, (next_m << 8) + wr * 128, (next_n << 8) + wc * 64);
           }
         }
       }
-    } else {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int mb = mw + i * 32;  // 32-row block: wave-uniform
-        if constexpr (EPI == PP_F32 || IS_RES) {
-          float* base = (IS_RES ? a.xres : a.outf) + (size_t)(mb + l31) * a.N + nw + 4 * hi;
-#pragma unroll
-          for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-              float4 v;
-              v.x = acc[i][j][4 * g + 0]; v.y = acc[i][j][4 * g + 1]; v.z = acc[i][j][4 * g + 2]; v.w = acc[i][j][4 * g + 3];
-              *(float4*)(base + j * 32 + 8 * g) = v;
-            }
-        } else if constexpr (EPI == PP_F16 || EPI == PP_GELU) {
-          half_t* rowptr = a.out16 + (size_t)(mb + l31) * a.N + nw;
-#pragma unroll
-          for (int j = 0; j < 2; ++j) {
-            if constexpr (EPI == PP_GELU) store_frag_f16(acc[i][j], rowptr + j * 32, hi, [](float x) { return gelu_erf(x); });
-            else store_frag_f16(acc[i][j], rowptr + j * 32, hi, [](float x) { return x; });
-          }
-        } else if constexpr (EPI == PP_QK) {  // N = 1536: columns [0,768) -> Q, [768,1536) -> K; 64 columns of a wave = one head
-          if (mb < a.Mreal) {
-            const int which = (nw + a.col0) >= MV_HIDDEN;
-            const int head = (nw + a.col0 - which * MV_HIDDEN) >> 6;
-            const int b = mb / a.S, s0 = mb - b * a.S;
-            half_t* rowptr = (which ? a.k : a.q) + ((size_t)(b * MV_HEADS + head) * a.S + s0 + l31) * MV_HEAD_DIM;
-#pragma unroll
-            for (int j = 0; j < 2; ++j) store_frag_f16(acc[i][j], rowptr + j * 32, hi, [](float x) { return x; });
-          }
-        } else {  // PP_VT: N = 768 (the V block); lane = head dim, registers = consecutive tokens
-          if (mb < a.Mreal) {
-            const int head = nw >> 6;
-            const int b = mb / a.S, s0 = mb - b * a.S;
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-              half_t* rowptr = a.vt + ((size_t)(b * MV_HEADS + head) * MV_HEAD_DIM + j * 32 + l31) * a.S + s0;
-              store_frag_f16(acc[i][j], rowptr, hi, [](float x) { return x; });
-            }
-          }
-        }
-      }
-    }
-    if constexpr (ABL & PP_ABL_CLK) {
-      c_init += tB - tA;
-      c_main += tC - tB;
-      c_epi += __builtin_amdgcn_s_memtime() - tC;
     }
   }
 
   };  // run_tiles
-  if constexpr (SCHED == 1 && STAGGER) {
-    if (wr == 0) run_tiles(std::integral_constant<int, 0>{});
-    else run_tiles(std::integral_constant<int, 1>{});
-  } else {
-    run_tiles(std::integral_constant<int, 1>{});
-  }
+  if (wr == 0) run_tiles(std::integral_constant<int, 0>{});
+  else run_tiles(std::integral_constant<int, 1>{});
 
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // no LDS-DMA may outlive the workgroup's LDS allocation
-  if constexpr (ABL & PP_ABL_CLK) {
-    if (a.clk && (tid & 63) == 0) {
-      unsigned long long* c = a.clk + (size_t)(blockIdx.x * 8 + wave) * 4;
-      c[0] = __builtin_amdgcn_s_memtime() - clk0;
-      c[1] = c_init;
-      c[2] = c_main;
-      c[3] = c_epi;
-    }
-  } else {
-    if (a.clk && tid == 0) a.clk[blockIdx.x] = __builtin_amdgcn_s_memtime() - clk0;
-  }
-  if constexpr (SCHED == 0 && STAGGER) {
-    if (wr == 0) __builtin_amdgcn_s_barrier();
-  }
 }

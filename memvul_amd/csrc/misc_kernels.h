@@ -59,7 +59,8 @@ __device__ __forceinline__ void ln_row_store(const float4 (&x)[3], const float* 
 // K1: x = LN(word[id] + pos[s] + type[0])   (HF BertEmbeddings; token-type ids are all zero in this
 // path, custom_PTM_embedder.py:199-202).  ids are [B][S_in] (0-padded), the engine row pitch is Sp.
 // RAWOUT (virtual LayerNorm, gemm_pp.h): x32 <- the un-normalised sum, x16 <- its fp16 copy, stats <- the row's vstats
-// (the exact two-pass mean and variance, expressed as one (sum, sum of squares) pair).
+// (the exact two-pass mean and variance, expressed as one (sum, sum of squares) pair); xlo: the stream as two fp16 planes
+// (gemm_pp PP_RESLN3), x8: + its fp8 planes (MV_F16X8).
 // `pitch` = ints between the rows of ids (>= S_in: a length-bucketed sweep reads only the first S_in columns of wider rows).
 template <bool RAWOUT>
 __global__ __launch_bounds__(256) void embed_ln_kernel(const int32_t* __restrict__ ids, int pitch, int S_in, int Sp, int n_tok,
@@ -67,7 +68,7 @@ __global__ __launch_bounds__(256) void embed_ln_kernel(const int32_t* __restrict
                                                        const float* __restrict__ pemb, const float* __restrict__ temb,
                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
                                                        float eps, float* __restrict__ x32, half_t* __restrict__ x16,
-                                                       float* __restrict__ stats, half_t* __restrict__ xlo) {
+                                                       float* __restrict__ stats, half_t* __restrict__ xlo, uint8_t* __restrict__ x8) {
   const int lane = threadIdx.x & 63;
   const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (t >= n_tok) return;
@@ -113,6 +114,12 @@ __global__ __launch_bounds__(256) void embed_ln_kernel(const int32_t* __restrict
         l[0] = (half_t)(x[i].x - (float)h[0]); l[1] = (half_t)(x[i].y - (float)h[1]);
         l[2] = (half_t)(x[i].z - (float)h[2]); l[3] = (half_t)(x[i].w - (float)h[3]);
         *(half4_t*)(xlo + (size_t)t * MV_HIDDEN + c) = l;
+        if (x8) {  // MV_F16X8: [lo8 | hi8] planes of the raw stream (the A8 operand of the first QKV GEMM, gemm_pp.h)
+          uint32_t h8, l8;
+          x8_planes4(x[i].x, x[i].y, x[i].z, x[i].w, h8, l8);
+          *(uint32_t*)(x8 + (size_t)t * (2 * MV_HIDDEN) + c) = l8;
+          *(uint32_t*)(x8 + (size_t)t * (2 * MV_HIDDEN) + MV_HIDDEN + c) = h8;
+        }
       } else {
         *(float4*)(x32 + (size_t)t * MV_HIDDEN + c) = x[i];
       }

@@ -26,7 +26,7 @@ from typing import Any, Dict, List, Optional
 
 import numpy as np
 
-from .binding import Engine, MV_F16, MV_F16X2
+from .binding import Engine, compute_dtype_of
 from .custom_metric import SiameseMeasureV1
 from .data import Instance, collate
 from .registry import Model, TextFieldEmbedder, TokenEmbedder, Vocabulary
@@ -167,10 +167,10 @@ class ModelMemory(Model):
         type_vocab = sd[PFX_BERT + "embeddings.token_type_embeddings.weight"].shape[0]
         opts = dict(max_tokens=128 * 512, max_batch=512, max_anchors=1024)
         opts.update(self._engine_options)
-        # compute dtype: MV_F16 (default, the benchmarked path) or MV_F16X2 = split-operand GEMMs, ~22-bit operands at about
-        # 1 / 2.5 of the rate (include/memvul_hip.h); engine_options["compute_dtype"] or $MEMVUL_COMPUTE = f16 | f16x2
-        cd = opts.pop("compute_dtype", os.environ.get("MEMVUL_COMPUTE", "f16"))
-        cd = {"f16": MV_F16, "f16x2": MV_F16X2}.get(cd, cd)
+        # compute dtype: MV_F16 (default, the benchmarked path) or MV_F16X8 ("precise": + one fp8 correction sweep per GEMM, the mode
+        # that holds 1e-3 on trained-like logits; include/memvul_hip.h); engine_options["compute_dtype"] or $MEMVUL_COMPUTE =
+        # f16 | f16x8 | precise.  An unknown name raises here (ValueError), not inside ctypes.
+        cd = compute_dtype_of(opts.pop("compute_dtype", os.environ.get("MEMVUL_COMPUTE", "f16")))
         if self._engine is not None:
             self._engine.close()
         self._engine = Engine(self._device_index, vocab_size=vocab_size, layers=layers, max_pos=max_pos, type_vocab=type_vocab,

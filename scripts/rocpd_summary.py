@@ -2,6 +2,8 @@
 
     python scripts/rocpd_summary.py stats <results.db>          # == --kernel-trace --stats summary
     python scripts/rocpd_summary.py pmc <results.db> [<results.db> ...]   # per-kernel mean counter values
+    python scripts/rocpd_summary.py json <lib stamp file> <results.db> [...]   # the GEMM classes' counter figures as
+                                                                              # profiles/pmc_current.json (bench.py load_pmc)
 """
 import sqlite3
 import sys
@@ -100,8 +102,66 @@ def pmc(dbs):
         print(line)
 
 
+# kernel symbol (+ duration class for the residual GEMM, which serves two shapes) -> bench.py kernel class
+CLASS_OF = (("gemm_pp_kernel<1, 1, 0>", None, "gemm_qkv"), ("gemm_pp_kernel<3, 1, 0>", None, "gemm_ffn1_gelu"),
+            ("gemm_pp_kernel<8, 0, 0>", "long", "gemm_ffn2"), ("gemm_pp_kernel<8, 0, 0>", "short", "gemm_attn_out"),
+            ("attention_v2_kernel<4, 1, 0>", None, "attention"))
+
+
+def pmc_json(stamp_file, dbs):
+    """Mean per-dispatch counters of the encoder's kernel classes at the default bench workload -> JSON with the stamp of the
+    library that was profiled: traffic_bytes = 2 x FETCH_SIZE + WRITE_SIZE (KiB -> bytes; the gfx950 FETCH correction of
+    MI355X_MICROARCH.md), mfma_busy_frac = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8), effective clock =
+    GRBM_GUI_ACTIVE / 8 / profiled duration."""
+    import json
+
+    rows = []
+    for db in dbs:
+        con = sqlite3.connect(db)
+        rows += list(con.execute("select kernel_name, grid_size_x, counter_name, value, duration from counters_collection"))
+    by_sym = defaultdict(list)
+    for name, gx, cname, val, d in rows:
+        by_sym[name].append(d)
+    out = {}
+    for sym, dclass, cls in CLASS_OF:
+        names = [n for n in by_sym if sym in n]
+        if not names:
+            continue
+        name = names[0]
+        ds = sorted(by_sym[name])
+        cut = None
+        if dclass:
+            lo, hi = ds[len(ds) // 10], ds[-1 - len(ds) // 10]
+            cut = (lo * hi) ** 0.5
+        vals, durs = defaultdict(list), []
+        for n, gx, cname, val, d in rows:
+            if n != name or (cut and ((d > cut) != (dclass == "long"))):
+                continue
+            vals[cname].append(val)
+            durs.append(d)
+        if not durs:
+            continue
+        mean = {k: sum(v) / len(v) for k, v in vals.items()}
+        us = sum(durs) / len(durs) / 1000.0
+        rec = {"profiled_avg_us": round(us, 2), "dispatches": len(durs) // max(1, len(vals))}
+        if "FETCH_SIZE" in mean and "WRITE_SIZE" in mean:
+            rec["traffic_bytes"] = int((2 * mean["FETCH_SIZE"] + mean["WRITE_SIZE"]) * 1024)
+            rec["fetch_bytes_corrected"] = int(2 * mean["FETCH_SIZE"] * 1024)
+            rec["write_bytes"] = int(mean["WRITE_SIZE"] * 1024)
+        if "GRBM_GUI_ACTIVE" in mean:
+            cyc = mean["GRBM_GUI_ACTIVE"] / 8
+            rec["effective_clock_ghz"] = round(cyc / us / 1000.0, 3)
+            if "SQ_VALU_MFMA_BUSY_CYCLES" in mean:
+                rec["mfma_busy_frac"] = round(mean["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024 * cyc), 4)
+        out[cls] = rec
+    print(json.dumps({"lib_stamp": open(stamp_file).read().strip(), "workload": "bench.py default (S=256, B=256, G=124, 12 layers, MV_F16), one batch in flight",
+                      "source": "rocprofv3 --kernel-trace --pmc, one counter group per pass (scripts/gpu_pmc.sh)", "classes": out}, indent=1))
+
+
 if __name__ == "__main__":
     if sys.argv[1] == "stats":
         stats(sys.argv[2])
+    elif sys.argv[1] == "json":
+        pmc_json(sys.argv[2], sys.argv[3:])
     else:
         pmc(sys.argv[2:])

@@ -32,13 +32,11 @@ def weights_for(dims_kw: dict, w_kw: dict):
     return _weights[key]
 
 
-def engine_for(dims_kw: dict, w_kw: dict, gemm_tile: int = 0, env: dict = None, compute_dtype: int = 1, **eng_kw) -> Engine:
-    """gemm_tile: 0 = the engine's own choice, 128 / 256 = one-tile-per-workgroup kernels, 512 = persistent
-    ping-pong kernel forced (MEMVUL_GEMM_TILE, read at mv_create).  env: further MEMVUL_* switches read at
-    mv_create (MEMVUL_CLS_PRUNE, MEMVUL_LN_FUSE, MEMVUL_ATTN), e.g. {"MEMVUL_CLS_PRUNE": "0"}."""
+def engine_for(dims_kw: dict, w_kw: dict, gemm_tile: int = 0, env: dict = None, compute_dtype=1, **eng_kw) -> Engine:
+    """gemm_tile: 0 = the engine's own choice by pass size, 128 = the small-pass kernels, 512 = the persistent kernels forced
+    (MEMVUL_GEMM_TILE, read at mv_create).  env: further MEMVUL_* switches read at mv_create (MEMVUL_CLS_PRUNE,
+    MEMVUL_STREAMS), e.g. {"MEMVUL_CLS_PRUNE": "0"}.  compute_dtype: 1 / "f16" = MV_F16, 6 / "precise" = MV_F16X8."""
     env = dict(env or {})
-    if os.environ.get("MEMVUL_FORCE_ATTN"):  # GPU-visit hang guard (scripts/gpu_round2.sh)
-        env["MEMVUL_ATTN"] = os.environ["MEMVUL_FORCE_ATTN"]
     if gemm_tile:
         env["MEMVUL_GEMM_TILE"] = str(gemm_tile)
     key = (tuple(sorted(dims_kw.items())), tuple(sorted(w_kw.items())), tuple(sorted(eng_kw.items())), tuple(sorted(env.items())), compute_dtype)
@@ -49,7 +47,7 @@ def engine_for(dims_kw: dict, w_kw: dict, gemm_tile: int = 0, env: dict = None, 
         dims, w = weights_for(dims_kw, w_kw)
         kw = dict(max_tokens=16384, max_batch=64, max_anchors=64)
         kw.update(eng_kw)
-        switches = ("MEMVUL_GEMM_TILE", "MEMVUL_CLS_PRUNE", "MEMVUL_LN_FUSE", "MEMVUL_LN_VIRTUAL", "MEMVUL_RES_HILO", "MEMVUL_ATTN", "MEMVUL_STREAMS")
+        switches = ("MEMVUL_GEMM_TILE", "MEMVUL_CLS_PRUNE", "MEMVUL_STREAMS")
         old = {k: os.environ.get(k) for k in switches}
         for k in switches:
             os.environ.pop(k, None)
@@ -62,6 +60,6 @@ def engine_for(dims_kw: dict, w_kw: dict, gemm_tile: int = 0, env: dict = None, 
                     os.environ.pop(k, None)
                 else:
                     os.environ[k] = v
-        e.load_state_dict(w, compute_dtype)  # 1 = MV_F16, 5 = MV_F16X2 (split operands)
+        e.load_state_dict(w, compute_dtype)
         _engines[key] = e
     return _engines[key]

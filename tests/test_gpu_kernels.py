@@ -17,18 +17,13 @@ def gu():
     return gpu_util
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 30])
+@pytest.mark.parametrize("variant", [0, 19])
 @pytest.mark.parametrize("shape", [(128, 128, 64), (256, 384, 768), (384, 256, 3072), (256, 256, 64), (512, 768, 128), (1024, 2304, 768)])
 def test_gemm_variants(gu, variant, shape):
-    """0: 128^2 tile LDS-DMA, 1: 128^2 register-staged, 2: 256^2 tile, 10+: LDS-ring variants (tile / BK /
-    stages, see mv_test_gemm in engine.hip; 19 = the 64^2-tile skinny-M path of the [CLS] tail), 30: persistent kernel.  All accumulate over K in the same
-    order, so they must agree bit-for-bit with each other (checked against variant 0) and with fp32 numpy to
-    rounding."""
+    """0: the 128^2-tile LDS-DMA kernel of small passes, 19: the 64^2-tile ring kernel of the [CLS] tail (mv_test_gemm).  Both
+    accumulate over K in the same order, so they must agree bit-for-bit with each other and with fp32 numpy to rounding.
+    (The ring-geometry sweep, the 256^2 one-tile kernel and the register-staged form of rounds 1-2 live in tools/legacy/.)"""
     M, N, K = shape
-    if variant >= 2 and variant != 19 and (M % 256 or N % 256):
-        pytest.skip("256^2 tile needs M, N % 256 == 0")
-    if variant == 30 and K % 128:
-        pytest.skip("the ping-pong kernel walks K two 64-wide tiles at a time")
     rng = np.random.default_rng(M + N + K)
     A = rng.standard_normal((M, K)).astype(np.float16)
     W = (rng.standard_normal((N, K)) * 0.05).astype(np.float16)
@@ -42,6 +37,55 @@ def test_gemm_variants(gu, variant, shape):
     if variant != 0:
         out0, _ = eng.test_gemm(A, W, bias, variant=0, iters=1)
         assert np.array_equal(out, out0), "tile variants must be bit-identical"
+
+
+def _gelu64(x):
+    from math import erf
+    return 0.5 * x * (1.0 + np.vectorize(erf)(x / np.sqrt(2.0)))
+
+
+@pytest.mark.parametrize("shape", [(256, 256, 256), (512, 768, 768), (256, 3072, 768), (768, 768, 3072), (16384, 768, 768)])
+def test_persistent_gemm_fp16_and_fp8_correction_sweep(gu, shape):
+    """gemm_pp_kernel<PP_GELU> on caller data (mv_test_gemm_pp), plain and as the MV_F16X8 build.  The reference is the
+    float64 product of the UNROUNDED operands; what is checked is the operand precision each build delivers:
+      * MV_F16: pre-activation error at the fp16-operand level (2^-12 per operand, ~sqrt(K) accumulation);
+      * MV_F16X8: the fp8 correction sweep (v_mfma_scale_f32_32x32x64_f8f6f4, A_lo8 W_hi8 + A_hi8 W_lo8 over a virtual K of
+        2 K) must remove most of it — this is also the test of the instruction's operand layout as the kernel uses it
+        (fragment chunks (2 ks + hi) of a 128-byte row, uniform E8M0 scales): a wrong byte order or scale shows up as NO
+        improvement or as garbage — and the [lo8 | hi8] planes of the output must decode to the output itself."""
+    from memvul_amd.binding import e4m3_decode
+    from oracle import precision_model as pm
+
+    M, N, K = shape
+    rng = np.random.default_rng(M * 7 + N * 3 + K)
+    A = (rng.standard_normal((M, K)) * (1.0 + 3.0 * (rng.random((1, K)) < 0.01))).astype(np.float32)  # a few outlier columns
+    W = (rng.standard_normal((N, K)) * 0.04).astype(np.float32)
+    bias = (rng.standard_normal(N) * 0.1).astype(np.float32)
+    eng = gu.engine_for(L2, WK)
+    pre = A.astype(np.float64) @ W.astype(np.float64).T + bias
+    ref = _gelu64(pre)
+    scale = float(np.sqrt((pre ** 2).mean()))
+    half_ulp16 = np.abs(ref) * 2.0 ** -11 + 2.0 ** -25  # the fp16 rounding of the stored output itself
+    out, _, ms = eng.test_gemm_pp(A, W, bias, x8=False)
+    e16 = np.abs(out.astype(np.float64) - ref) - half_ulp16
+    out_x, planes, ms8 = eng.test_gemm_pp(A, W, bias, x8=True)
+    # the stored output decoded from its planes: hi16 + lo8 / 2^(11 + s)  (s = MV_X8_ACT_SHIFT = 2)
+    lo8 = e4m3_decode(planes[:, :N]).astype(np.float64) / 2.0 ** 13
+    hi8 = e4m3_decode(planes[:, N:]).astype(np.float64) / 4.0
+    full = out_x.astype(np.float64) + lo8
+    ex = np.abs(full - ref)
+    # the same three-term product formed on the CPU (oracle/precision_model.py: fp16 / e4m3 planes, exact accumulation)
+    emul = _gelu64(pm._mm("f16x8", "f16x8", A.astype(np.float64), W.astype(np.float64)) + bias)
+    em = np.abs(full - emul)
+    lo8_res = np.abs(ref) * 2.0 ** -15 + 2.0 ** -22       # what the 4-bit lo8 plane leaves of the output's own rounding
+    gu.record("gemm_pp", M=M, N=N, K=K, err_f16=float(e16.max()), err_x8=float(ex.max()), x8_vs_cpu_emulation=float(em.max()),
+              emulation_vs_exact=float(np.abs(emul - ref).max()), rms_pre=scale, ms_f16=ms, ms_x8=ms8)
+    assert np.isfinite(full).all()
+    assert e16.max() < 1.5e-3 * scale, float(e16.max())                 # fp16 operands: 2^-12 each, ~5 sigma over M N outputs
+    assert (em <= lo8_res + 3e-5 * scale).all(), float(em.max())        # the kernel forms exactly the modelled product (fp32 sums)
+    assert (ex <= lo8_res + 2.5e-4 * scale).all(), float(ex.max())      # ... which is ~2^-15.5 operands
+    assert ex.max() < 0.5 * max(e16.max(), 1e-4 * scale)                # several times below the fp16 build on the same data
+    assert np.abs(hi8 - out_x.astype(np.float64)).max() <= np.abs(out_x.astype(np.float64)).max() * 2.0 ** -4 + 2.0 ** -11
 
 
 def _taps(gu, B, S, ragged):
@@ -66,16 +110,17 @@ def test_embeddings_layernorm(gu, B, S, ragged):
     assert np.abs(x16 - taps["embed"]).max() < 4e-3
 
 
-@pytest.mark.parametrize("attn", ["1", "0"])
-@pytest.mark.parametrize("gemm_tile", [0, 512])
+@pytest.mark.parametrize("gemm_tile,compute", [(0, "f16"), (512, "f16"), (0, "precise")])
 @pytest.mark.parametrize("B,S,ragged", [(2, 64, False), (3, 128, True), (2, 192, True), (2, 256, True), (1, 320, True), (2, 100, True),
                                         (2, 384, True), (2, 512, True), (1, 500, True)])
-def test_layer0_stages(gu, B, S, ragged, gemm_tile, attn):
+def test_layer0_stages(gu, B, S, ragged, gemm_tile, compute):
     """QKV projection, attention, FFN and both LayerNorms of encoder layer 0 against the oracle taps.
     Tolerances are fp16-operand level (inputs rounded to fp16, fp32 accumulation)."""
     dims, w, ids, lens, mask, taps, _ = _taps(gu, B, S, ragged)
-    # 512: every projection through the persistent ping-pong GEMM; attn 1: attention_v2.h for Sp <= 256 and (in chunks of 128 keys) Sp = 384 / 512, 0: attention.h
-    eng = gu.engine_for(L2, WK, gemm_tile=gemm_tile, env={"MEMVUL_ATTN": attn})
+    # gemm_tile 0: these passes are small -> the small-pass kernels; 512: the persistent kernels (virtual LayerNorm, two-plane
+    # stream) forced; "precise": MV_F16X8, always persistent.  Attention: attention_v2 for every padded length (64-key blocks
+    # up to 256, 128-key chunks at 384 / 512; 320 and 500 run padded to 384 / 512)
+    eng = gu.engine_for(L2, WK, gemm_tile=gemm_tile, compute_dtype=compute)
     eng.debug_encode(ids, lens, 1)
     q = eng.debug_read(2)[:, :, :S].astype(np.float32) * 8.0  # engine folds 1/sqrt(64) into W_q
     k = eng.debug_read(3)[:, :, :S].astype(np.float32)
@@ -92,7 +137,7 @@ def test_layer0_stages(gu, B, S, ragged, gemm_tile, attn):
         gelu=np.abs(h16 - taps["l0_gelu"])[m].max(),
         layer0=np.abs(x - taps["layer0"])[m].max(),
     )
-    gu.record("layer0", B=B, S=S, gemm_tile=gemm_tile, attn=attn, **{k_: float(v_) for k_, v_ in errs.items()})
+    gu.record("layer0", B=B, S=S, gemm_tile=gemm_tile, compute=compute, **{k_: float(v_) for k_, v_ in errs.items()})
     scale_q = float(np.abs(taps["l0_q"]).max())
     assert errs["q"] < 3e-3 * max(1.0, scale_q), errs
     assert errs["k"] < 3e-3 * max(1.0, float(np.abs(taps["l0_k"]).max())), errs
@@ -102,18 +147,19 @@ def test_layer0_stages(gu, B, S, ragged, gemm_tile, attn):
     assert errs["layer0"] < 1e-2, errs
 
 
-@pytest.mark.parametrize("attn", ["1", "0"])
-@pytest.mark.parametrize("B,S", [(48, 256), (70, 128), (40, 192), (26, 512), (30, 384)])
-def test_attention_persistent_item_loop(gu, B, S, attn):
+@pytest.mark.parametrize("compute", ["f16", "precise"])
+@pytest.mark.parametrize("B,S", [(48, 256), (70, 128), (40, 192), (26, 512), (30, 384), (21, 320)])
+def test_attention_persistent_item_loop(gu, B, S, compute):
     """attention_v2 walks (batch row, head[, query block]) units with a 2-deep LDS ring: more units than resident
     workgroups, uneven tails, ragged lengths, one to four key chunks per unit; checked against the oracle's layer-0
-    context (attn 0: the same inputs through attention.h, whose error is the yardstick: peaked attention, fp16 P and V)."""
+    context ("precise": the instantiations that also write the fp8 planes of the context)."""
     dims, w, ids, lens, mask, taps, _ = _taps(gu, B, S, True)
-    eng = gu.engine_for(L2, WK, env={"MEMVUL_ATTN": attn}, max_tokens=B * S, max_batch=B)
+    Sp = (S + 63) // 64 * 64 if S <= 256 else (S + 127) // 128 * 128
+    eng = gu.engine_for(L2, WK, compute_dtype=compute, max_tokens=B * Sp, max_batch=B)
     eng.debug_encode(ids, lens, 1)
     ctx = eng.debug_read(5)[:, :S].astype(np.float32)
     err = float(np.abs(ctx - taps["l0_ctx"])[mask].max())
-    gu.record("attention_items", B=B, S=S, attn=attn, max_err=err)
+    gu.record("attention_items", B=B, S=S, compute=compute, max_err=err)
     assert err < 1.2e-2
 
 

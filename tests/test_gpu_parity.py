@@ -13,10 +13,11 @@ pytestmark = pytest.mark.gpu
 LOGIT_TOL = 1e-3  # north_star: logits within 1e-3 of the CPU reference
 # Trained-like regime (|logit| ~ 3 through a matcher of norm ~ 17): what fp16 MFMA operands deliver, MEASURED — 3.3e-3 ..
 # 5.7e-3 on the MI355X (profiles/r02_a_trained_like.txt), 2.5e-3 .. 3.2e-3 in the float64 rounding model
-# (tests/test_precision_model.py), i.e. the 1e-3 budget is NOT met here; DESIGN.md §2 prices what would meet it
-# (exact [CLS] rows: ~1e-3; + split weights = 2x the MFMA work: 3e-4).  The probabilities — what thresholds, decisions
-# and every metric of the path consume — stay within 1e-4 because softmax_2 is flat at |logit| ~ 3.
-TRAINED_LIKE_LOGIT_BOUND = 8e-3  # MV_F16; MV_F16X2 holds LOGIT_TOL: test_split_operand_mode_holds_1e3_in_the_trained_like_regime
+# (tests/test_precision_model.py), i.e. the 1e-3 budget is NOT met by MV_F16 here.  The compute dtype that meets it is
+# MV_F16X8 ("precise": + one fp8 correction sweep per GEMM): test_precise_mode_holds_1e3_in_the_trained_like_regime
+# asserts LOGIT_TOL for it.  The probabilities — what thresholds, decisions and every metric of the path consume — stay
+# within 1e-4 in either mode because softmax_2 is flat at |logit| ~ 3.
+TRAINED_LIKE_LOGIT_BOUND = 8e-3  # MV_F16 only (measured bound, not the target)
 TRAINED_LIKE_P_TOL = 2e-4
 
 
@@ -85,18 +86,20 @@ def test_trained_like_logits(gu, golden_dir, name, gemm_tile):
     eng.anchor_reset()
 
 
-@pytest.mark.parametrize("name", ["l12_trained_s256", "l12_trained_ragged", "l12_base_ragged"])
-def test_split_operand_mode_holds_1e3_in_the_trained_like_regime(gu, golden_dir, name):
-    """MV_F16X2 (compute dtype): every GEMM of the encoder runs three MFMA sweeps over hi / lo fp16 planes of BOTH operands
-    (A_hi W_hi + A_lo W_hi + A_hi W_lo: ~22-bit operands; Q / K / V and P stay fp16) — the engine change that meets the
-    1e-3 logit tolerance where plain fp16 operands measure 3 - 6e-3 (test_trained_like_logits), at about 1 / 2.5 of the
-    issue-report rate.  oracle/precision_model.py predicts 4e-4 for this configuration."""
+@pytest.mark.parametrize("name", ["l12_trained_s256", "l12_trained_ragged", "l12_base_ragged", "l12_base_s256"])
+def test_precise_mode_holds_1e3_in_the_trained_like_regime(gu, golden_dir, name):
+    """MV_F16X8 (compute dtype "precise"): every GEMM of the encoder adds ONE correction sweep on the fp8 matrix path —
+    A_lo8 W_hi8 + A_hi8 W_lo8, the first-order terms of the split-operand product in OCP e4m3 — to its fp16 sweep
+    (gemm_pp.h X8; Q / K / V and P stay fp16): the engine change that meets the 1e-3 logit tolerance where plain fp16
+    operands measure 3 - 6e-3 (test_trained_like_logits).  oracle/precision_model.py predicts 3.4e-4 for this configuration
+    (tests/test_precision_model.py::test_fp8_correction_sweeps_hold_the_budget); the bench line's `precise` object carries its
+    rate.  The mode always runs the persistent kernels (both GEMM paths of the other tests collapse into one here)."""
     import make_golden
-    from memvul_amd.binding import MV_F16X2
+    from memvul_amd.binding import MV_F16X8
 
     g = np.load(os.path.join(golden_dir, f"{name}.npz"))
     dk, wk, B, S, ragged, G, SA = make_golden.CASES[name]
-    eng = gu.engine_for(dk, wk, compute_dtype=MV_F16X2, max_tokens=16384, max_batch=64, max_anchors=64)
+    eng = gu.engine_for(dk, wk, compute_dtype=MV_F16X8, max_tokens=16384, max_batch=64, max_anchors=64)
     eng.anchor_reset()
     LA = int(g["anchor_lens"].max())
     eng.anchor_append(g["anchor_ids"][:, :LA], g["anchor_lens"])
@@ -105,9 +108,36 @@ def test_split_operand_mode_holds_1e3_in_the_trained_like_regime(gu, golden_dir,
     errs = dict(v=float(np.abs(v - g["v"]).max()), u=float(np.abs(out["embed"] - g["u"]).max()),
                 logits=float(np.abs(out["logits"] - g["logits"]).max()), p=float(np.abs(out["probs"] - g["p"]).max()),
                 logit_scale=float(np.abs(g["logits"]).max()))
-    gu.record("split_operands", case=name, **errs)
+    gu.record("precise_mode", case=name, **errs)
     assert errs["logits"] <= LOGIT_TOL, errs
     assert errs["p"] <= 1e-4, errs
+    eng.anchor_reset()
+
+
+@pytest.mark.parametrize("compute", ["f16", "precise"])
+def test_ref12_logits_against_the_reference_run(gu, compute):
+    """tests/golden/ref12: the REFERENCE'S OWN CODE executed on a 12-layer trained-like model (oracle/ref_harness/, a forward
+    hook on ModelMemory._projector for the logits, model_memory.py:141): 19 issue reports of up to 256 tokens against 6
+    anchors of up to 512, max |logit| 2.5.  MV_F16 is reported against its measured bound; the precise mode must hold the
+    contract's 1e-3 on the LOGITS."""
+    import test_reference_pin as trp
+
+    ref = trp.get_ref("ref12")
+    aids, amask = trp._pad(ref["reader"]["golden"])
+    ids, mask = trp._pad(ref["reader"]["test"])
+    dk = dict(layers=ref["meta"]["layers"], vocab_size=ref["meta"]["vocab_size"])
+    wk = dict(ref["meta"]["weight_kwargs"])
+    eng = gu.engine_for(dk, wk, compute_dtype=compute, max_tokens=32 * 512, max_batch=32, max_anchors=16)
+    eng.anchor_reset()
+    eng.anchor_append(aids.astype(np.int32), amask.sum(1).astype(np.int32))
+    v = eng.anchor_get()
+    out = eng.forward(ids.astype(np.int32), mask.sum(1).astype(np.int32))
+    errs = dict(v=float(np.abs(v - ref["anchors"]).max()), logits=float(np.abs(out["logits"] - ref["logits"]).max()),
+                p=float(np.abs(out["probs"] - ref["probs"]).max()), logit_scale=float(np.abs(ref["logits"]).max()))
+    gu.record("ref12", compute=compute, **errs)
+    assert errs["logit_scale"] > 2.0
+    assert errs["logits"] <= (LOGIT_TOL if compute == "precise" else TRAINED_LIKE_LOGIT_BOUND), errs
+    assert errs["p"] <= TRAINED_LIKE_P_TOL, errs
     eng.anchor_reset()
 
 
@@ -157,7 +187,7 @@ def test_full_batch_properties(gu):
     assert np.array_equal(out2["embed"], out["embed"][perm])
     assert np.array_equal(out2["logits"], out["logits"][perm])
     # resident-corpus path == host path (bit-exact), in two batches of 128
-    # (batches of 128 rows run the 128^2-tile GEMM, the batch of 256 the 256^2 one: bit-identical by design)
+    # (a row's result does not depend on the batch it travels in)
     eng.corpus_upload(ids, lens)
     eng.corpus_run(0, B, 128, keep_probs=True)
     best, idx, ps = eng.corpus_results(0, B, with_probs=True)
@@ -230,45 +260,31 @@ def test_last_layer_pruning_matches_full_forward(gu, B, S, ragged, gemm_tile):
     d = float(np.abs(u_full - u_cls).max())
     gu.record("cls_prune", B=B, S=S, gemm_tile=gemm_tile, full_vs_pruned=d, pruned_vs_oracle=float(np.abs(u_cls - u_ref).max()),
               full_vs_oracle=float(np.abs(u_full - u_ref).max()))
-    # one fp16 ulp of a context value (different summation order) reaches u at the 5e-5 level; on the persistent-GEMM
+    # one fp16 ulp of a context value (different summation order) reaches u at the 5e-5 level; on the persistent
     # path the full forward's last layer also runs with the virtual LayerNorm while the [CLS] tail uses the explicit one
     # (different fp16 roundings of the same mathematics: the 2e-4 level, like either of them against the oracle)
     assert d < 6e-4
     assert np.abs(u_cls - u_ref).max() < 2e-3
 
 
-@pytest.mark.parametrize("prune", ["0", "1"])
-def test_layernorm_folded_into_residual_read_is_bit_identical(gu, prune):
-    """MEMVUL_LN_FUSE without the virtual LayerNorm (persistent-GEMM path): the LayerNorm kernels write fp16 operand +
-    row statistics only and the next residual GEMM normalises the raw stream while initialising its accumulators,
-    with the same IEEE operations -> the embeddings must not change by a single bit."""
-    dk, wk = dict(layers=3, vocab_size=2048), dict(qk_scale=2.0)
-    dims, w = gu.weights_for(dk, wk)
-    ids, lens = synth.make_ids(6, 128, dims.vocab_size, ragged=True, min_len=9)
-    u_f = gu.engine_for(dk, wk, gemm_tile=512, env={"MEMVUL_CLS_PRUNE": prune, "MEMVUL_LN_VIRTUAL": "0"}).encode(ids, lens)
-    u_n = gu.engine_for(dk, wk, gemm_tile=512, env={"MEMVUL_CLS_PRUNE": prune, "MEMVUL_LN_FUSE": "0"}).encode(ids, lens)
-    assert np.array_equal(u_f, u_n)
-
-
-@pytest.mark.parametrize("hilo", ["1", "0"])
 @pytest.mark.parametrize("outliers", [False, True])
 @pytest.mark.parametrize("prune", ["0", "1"])
 @pytest.mark.parametrize("B,S", [(6, 128), (3, 256), (5, 200)])
-def test_virtual_layernorm_matches_explicit_layernorm(gu, B, S, prune, outliers, hilo):
-    """MEMVUL_LN_VIRTUAL (default on the persistent-GEMM path): no LayerNorm kernel between the GEMMs — the consumer
-    GEMMs read the raw stream in fp16 with gamma / beta / the row mean folded into their weights and scale rows by
-    rstd in the epilogue (W LN(r) + b = rstd (W'' r) + b'), the residual GEMMs emit the fp16 copy and the partial row
-    sums.  Same mathematics, different roundings: agreement with the explicit-LayerNorm engine and with the oracle at
-    the fp16-operand level, also with trained-checkpoint-like outlier dimensions in every LayerNorm."""
+def test_virtual_layernorm_matches_explicit_layernorm(gu, B, S, prune, outliers):
+    """The persistent path has no LayerNorm kernel between the GEMMs — the consumer GEMMs read the raw stream (two fp16
+    planes) with gamma / beta / the row mean folded into their weights and scale rows by rstd in the epilogue
+    (W LN(r) + b = rstd (W'' r) + b'), the residual GEMMs emit the rows' partial sums — while the small-pass path
+    (MEMVUL_GEMM_TILE=128) runs explicit LayerNorm kernels on an fp32 stream.  Same mathematics, different roundings:
+    agreement of the two engines and of each with the oracle at the fp16-operand level, also with
+    trained-checkpoint-like outlier dimensions in every LayerNorm."""
     dk, wk = dict(layers=4, vocab_size=2048), dict(qk_scale=2.0, ln_outliers=outliers)
     dims, w = gu.weights_for(dk, wk)
     ids, lens = synth.make_ids(B, S, dims.vocab_size, ragged=True, min_len=9)
-    # hilo 1 (default): the raw stream lives as two fp16 planes hi + lo (PP_RESLN3); 0: fp32 + fp16 copy (PP_RESLN2)
-    u_v = gu.engine_for(dk, wk, gemm_tile=512, env={"MEMVUL_CLS_PRUNE": prune, "MEMVUL_RES_HILO": hilo}).encode(ids, lens)
-    u_e = gu.engine_for(dk, wk, gemm_tile=512, env={"MEMVUL_CLS_PRUNE": prune, "MEMVUL_LN_VIRTUAL": "0"}).encode(ids, lens)
+    u_v = gu.engine_for(dk, wk, gemm_tile=512, env={"MEMVUL_CLS_PRUNE": prune}).encode(ids, lens)
+    u_e = gu.engine_for(dk, wk, gemm_tile=128, env={"MEMVUL_CLS_PRUNE": prune}).encode(ids, lens)
     u_ref = orc.instance_forward(w, ids.astype(np.int64), synth.mask_from_lens(lens, S))
     ev, ee = float(np.abs(u_v - u_ref).max()), float(np.abs(u_e - u_ref).max())
-    gu.record("virtual_ln", B=B, S=S, prune=prune, outliers=outliers, hilo=hilo, virtual_vs_oracle=ev, explicit_vs_oracle=ee,
+    gu.record("virtual_ln", B=B, S=S, prune=prune, outliers=outliers, virtual_vs_oracle=ev, explicit_vs_oracle=ee,
               virtual_vs_explicit=float(np.abs(u_v - u_e).max()), u_scale=float(np.abs(u_ref).max()))
     assert ev < 2e-3 and ev < 3 * ee + 2e-4
 

@@ -231,10 +231,10 @@ def test_product_drivers_reproduce_the_reference_run_cpu(which, tmp_path, monkey
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("sweep,compute", [(False, "f16"), ("arrays", "f16"), ("arrays", "f16x2")])
+@pytest.mark.parametrize("sweep,compute", [(False, "f16"), ("arrays", "f16"), ("arrays", "precise")])
 def test_hip_path_reproduces_the_reference_run(ref, tmp_path, monkeypatch, sweep, compute):
     """The same files through the HIP engine (C ABI): every anchor-match score within 1e-3 of the reference run (MV_F16,
-    the benchmarked path; measured 7.1e-4), within 2.5e-4 with split operands (MV_F16X2; measured 1.3e-4)."""
+    the benchmarked path; measured 7.1e-4), within 2.5e-4 in the precise mode (MV_F16X8: + fp8 correction sweeps)."""
     import gpu_util
 
     root, arch = _stage(tmp_path, ref, monkeypatch)

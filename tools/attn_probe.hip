@@ -7,9 +7,9 @@
 #include <cstdio>
 #include <vector>
 
-#include "../memvul_amd/csrc/gemm.h"
-#include "../memvul_amd/csrc/gemm_pp.h"
-#include "../memvul_amd/csrc/attention_v2.h"
+#include "legacy/gemm.h"
+#include "legacy/gemm_pp.h"
+#include "legacy/attention_v2.h"
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "HIP error %s: %s\n", #x, hipGetErrorString(e_)); return 2; } } while (0)
 

@@ -12,8 +12,8 @@
 #include <type_traits>
 #include <vector>
 
-#include "../memvul_amd/csrc/gemm.h"
-#include "../memvul_amd/csrc/gemm_pp.h"
+#include "legacy/gemm.h"
+#include "legacy/gemm_pp.h"
 
 #define CK(x)                                                                                  \
   do {                                                                                         \

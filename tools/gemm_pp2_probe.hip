@@ -16,8 +16,8 @@
 #include <cstring>
 #include <vector>
 
-#include "../memvul_amd/csrc/gemm.h"
-#include "../memvul_amd/csrc/gemm_pp.h"
+#include "legacy/gemm.h"
+#include "legacy/gemm_pp.h"
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "HIP error %s: %s\n", #x, hipGetErrorString(e_)); exit(2); } } while (0)
 

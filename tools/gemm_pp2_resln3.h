@@ -28,7 +28,7 @@
 // tools/gemm_pp2_probe.hip) and the other workgroup's accumulator init / epilogue go through the LDS as well (the transposition
 // scratch), so the two compete for the same unit instead of using different ones.  Removed from the library again.
 #pragma once
-#include "../memvul_amd/csrc/gemm_pp.h"
+#include "legacy/gemm_pp.h"
 
 #define PP2_STAGE 24576
 #define PP2_NSTG 3

@@ -26,16 +26,17 @@
 //     with 64 score registers per lane and two 4-wave workgroups per CU (engine.hip: attention_v2_kernel<2, S / 128>).
 #pragma once
 #include "attention.h"
-#include "gemm_pp.h"  // glds16, pack_h2, x8_planes4
+#include "gemm.h"  // glds16
 
 #define ATT2_BUF_BYTES(NKB) ((NKB) * 16384)
 #define ATT2_LDS_BYTES(NKB) (2 * ATT2_BUF_BYTES(NKB))
 
-// X8 1 (MV_F16X8, gemm_pp.h): the context is also written as fp8 planes [lo8 (768) | hi8 (768)] per token row to
-// AttnArgs::ctx8 — e4m3 of (O - fp16(O)) 2^(11 + s) and of O 2^s, the A8 operand of the output projection's correction sweep
+// ABL (tools/attn_probe.hip only; wrong results), bit mask: 8 = no Q loads, 16 = no O stores, 32 = no K / V^T LDS-DMA,
+// 1 = v_exp_f32 replaced by a move, 2 = no MFMA in QK^T / PV,
+// 4 = K / V^T fragments not read from LDS (the DMA into LDS still runs)
+// LO 1 (split-operand mode, MV_F16X2): the context is also written as a second plane fp16(O - fp16(O)) to AttnArgs::ctx_lo
 // (16 more registers across the unit boundary, a second pass through the O image); a separate instantiation.
-// (The timing ablations of rounds 1-2 — no Q loads / O stores / DMA / exp / MFMA / fragment reads — are tools/legacy/.)
-template <int NKB, int NCH = 1, int X8 = 0>  // chunk = 64 NKB keys = 2 NKB waves x 32 queries; padded length S = 64 NKB NCH
+template <int NKB, int NCH = 1, int ABL = 0, int LO = 0>  // chunk = 64 NKB keys = 2 NKB waves x 32 queries; padded length S = 64 NKB NCH
 __global__ __launch_bounds__(NKB * 128) __attribute__((amdgpu_waves_per_eu(2, 2))) void attention_v2_kernel(AttnArgs a, int nunits) {
   constexpr int S = NKB * 64;        // keys per chunk = queries per unit
   constexpr int ST = S * NCH;        // padded sequence length (row pitch of V^T, rows per head of Q / K)
@@ -79,6 +80,7 @@ __global__ __launch_bounds__(NKB * 128) __attribute__((amdgpu_waves_per_eu(2, 2)
     const char* kg = (const char*)(a.k + ((size_t)bh * ST + (size_t)j * S) * MV_HEAD_DIM);
     const char* vg = (const char*)(a.vt + (size_t)bh * MV_HEAD_DIM * ST + (size_t)j * S);
     char* kb = smem + pb * BUF;
+    if (ABL & 32) return;
 #pragma unroll
     for (int x = 0; x < 4; ++x) {
       const int p = 4 * wave + x;
@@ -93,6 +95,7 @@ __global__ __launch_bounds__(NKB * 128) __attribute__((amdgpu_waves_per_eu(2, 2)
   auto load_q = [&](int u, half8_t (&qf)[4]) {  // B operand of S^T = K Q^T: lane holds Q[qb S + 32 wave + ql][16 kk + 8 hi ..+7]
     const int bh = unit_bh(u), qb = unit_qb(u);
     const half_t* gq = a.q + ((size_t)bh * ST + qb * S + 32 * wave + ql) * MV_HEAD_DIM + hi * 8;
+    if (ABL & 8) gq = a.q + (size_t)(32 * wave + ql) * MV_HEAD_DIM + hi * 8;  // the same (cached) 32 KB every time
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) qf[kk] = *(const half8_t*)(gq + kk * 16);
   };
@@ -117,7 +120,7 @@ __global__ __launch_bounds__(NKB * 128) __attribute__((amdgpu_waves_per_eu(2, 2)
   int len_n = a.lens[unit_bh(first) / MV_HEADS];  // prefetched like Q: a VGPR-destination load must never be waited for mid-unit
 
   uint32_t opk[2][4][2];  // normalised O^T of the previous unit, fp16 pairs: [dt][rg] = dims 32 dt + 8 rg + 4 hi ..+3
-  uint32_t op8[X8 ? 2 : 1][4][2];  // X8: [dt][rg][0] = lo8, [1] = hi8 of the same four dims, one byte each
+  uint32_t opl[LO ? 2 : 1][4][2];  // LO: the lo plane, fp16(O - fp16(O)), same packing
   auto flush_plane = [&](int u, char* kb, const uint32_t (&pk)[2][4][2], half_t* base) {
     // ---- O(u) -> LDS image (this wave's 32 rows) -> whole-row global stores
 #pragma unroll
@@ -134,42 +137,23 @@ __global__ __launch_bounds__(NKB * 128) __attribute__((amdgpu_waves_per_eu(2, 2)
     u32x4 v[4];
 #pragma unroll
     for (int it = 0; it < 4; ++it) v[it] = *(const u32x4*)(kb + o_rd + it * 1024);
+    if (ABL & 16) dst = base + (size_t)(32 * wave + (lane >> 3)) * MV_HIDDEN + 8 * (lane & 7);  // the same lines every time
 #pragma unroll
     for (int it = 0; it < 4; ++it) *(u32x4*)(dst + (size_t)(8 * it) * MV_HIDDEN) = v[it];
   };
-  // X8: the fp8 planes through the same image: row q = [lo8 of dims 0..63 | hi8 of dims 0..63], i.e. 16-B slot
-  // 2 dt + (rg >> 1) (+ 4 for hi8) at byte 8 (rg & 1) + 4 hi; read back as whole rows, stored as two 64-B segments per row
-  auto flush_x8 = [&](int u, char* kb) {
-    const uint32_t o_wr8 = (uint32_t)((32 * wave + ql) * 128 + 4 * hi);
-#pragma unroll
-    for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-      for (int rg = 0; rg < 4; ++rg)
-#pragma unroll
-        for (int pl = 0; pl < 2; ++pl)
-          *(uint32_t*)(kb + (o_wr8 ^ (uint32_t)(((4 * pl + 2 * dt + (rg >> 1)) ^ (ql & 7)) << 4)) + 8 * (rg & 1)) = op8[dt][rg][pl];
-    const int bh = unit_bh(u), qb = unit_qb(u);
-    const int b = bh / MV_HEADS, h = bh - b * MV_HEADS;
-    const int slot = lane & 7;
-    uint8_t* dst = a.ctx8 + ((size_t)b * ST + qb * S + 32 * wave + (lane >> 3)) * (2 * MV_HIDDEN) + (slot >> 2) * MV_HIDDEN +
-                   h * MV_HEAD_DIM + 16 * (slot & 3);
-    u32x4 v[4];
-#pragma unroll
-    for (int it = 0; it < 4; ++it) v[it] = *(const u32x4*)(kb + o_rd + it * 1024);
-#pragma unroll
-    for (int it = 0; it < 4; ++it) *(u32x4*)(dst + (size_t)(8 * it) * (2 * MV_HIDDEN)) = v[it];
-  };
   auto flush_o = [&](int u, char* kb) {
     flush_plane(u, kb, opk, a.ctx);
-    if constexpr (X8) {
-      // the image rows are wave-private and LDS executes a wave's instructions in order: the second pass's writes may
+    if constexpr (LO) {
+      // the image rows are wave-private and LDS executes a wave's instructions in order: the second plane's writes may
       // follow the first plane's reads directly (hipcc waits for the read results before the global stores use them)
-      flush_x8(u, kb);
+      flush_plane(u, kb, opl, a.ctx_lo);
     }
   };
 
   int pb = 0, prev = -1, len = 0;
   floatx16 o[2];
+  const unsigned long long clk0 = a.clk ? __builtin_amdgcn_s_memtime() : 0ull;
+  unsigned long long clk_wait = 0ull, clk_vm = 0ull;
   float m_run = 0.f, l_run = 0.f;  // NCH > 1: running row maximum / this lane's share of the running row sum
   for (int unit = first; unit < nunits; unit += stride) {
     const int nxt = unit + stride;
@@ -178,11 +162,14 @@ __global__ __launch_bounds__(NKB * 128) __attribute__((amdgpu_waves_per_eu(2, 2)
       char* kb = smem + pb * BUF;
       // ---- hand-over: this chunk's K / V^T (and, for j = 0, Q) have landed for every wave, and every wave has left
       // the other ring half (its last reads were the previous chunk's PV)
+      const unsigned long long tw0 = a.clk ? __builtin_amdgcn_s_memtime() : 0ull;
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __builtin_amdgcn_sched_barrier(0);
+      if (a.clk) clk_vm += __builtin_amdgcn_s_memtime() - tw0;
       __builtin_amdgcn_s_barrier();
       __builtin_amdgcn_sched_barrier(0);
       asm volatile("" ::: "memory");
+      if (a.clk) clk_wait += __builtin_amdgcn_s_memtime() - tw0;
       if (j == 0) {
         // the prefetched registers are consumed HERE (hipcc would otherwise put its own `s_waitcnt vmcnt(0)` in front
         // of their first use, i.e. after the next chunk's DMA has been issued, and drain it)
@@ -215,13 +202,19 @@ __global__ __launch_bounds__(NKB * 128) __attribute__((amdgpu_waves_per_eu(2, 2)
           __builtin_amdgcn_sched_barrier(0);
           if (t + 1 < NT) {
 #pragma unroll
-            for (int kk = 0; kk < 4; ++kk) kf[(t + 1) & 1][kk] = *(const half8_t*)(kb + (t + 1) * 4096 + koff[kk]);
+            for (int kk = 0; kk < 4; ++kk) {
+              if (ABL & 4) kf[(t + 1) & 1][kk] = qf[(kk + t) & 3];
+              else kf[(t + 1) & 1][kk] = *(const half8_t*)(kb + (t + 1) * 4096 + koff[kk]);
+            }
           }
           __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
           for (int r = 0; r < 16; ++r) st[t][r] = 0.f;
 #pragma unroll
-          for (int kk = 0; kk < 4; ++kk) st[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[t & 1][kk], qf[kk], st[t], 0, 0, 0);
+          for (int kk = 0; kk < 4; ++kk) {
+            if (ABL & 2) st[t][kk] += (float)kf[t & 1][kk][0] * (float)qf[kk][0];
+            else st[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[t & 1][kk], qf[kk], st[t], 0, 0, 0);
+          }
         }
         __builtin_amdgcn_sched_barrier(0);
       }
@@ -260,7 +253,7 @@ __global__ __launch_bounds__(NKB * 128) __attribute__((amdgpu_waves_per_eu(2, 2)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const float e = __builtin_fmaf(st[t][r], LOG2E, nm);
-          const float p = __builtin_amdgcn_exp2f(e);
+          const float p = (ABL & 1) ? e : __builtin_amdgcn_exp2f(e);
           ps4[r & 3] += p;
           pf[t][r >> 3][r & 7] = (half_t)p;
         }
@@ -292,7 +285,8 @@ __global__ __launch_bounds__(NKB * 128) __attribute__((amdgpu_waves_per_eu(2, 2)
           for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
             for (int u = 0; u < 2; ++u)
-              dstf[2 * dt + u] = *(const half8_t*)(kb + VOFF + (t >> 1) * 8192 + dt * 4096 + voff[2 * (t & 1) + u]);
+              if (ABL & 4) dstf[2 * dt + u] = pf[(t + dt) % NT][u];
+              else dstf[2 * dt + u] = *(const half8_t*)(kb + VOFF + (t >> 1) * 8192 + dt * 4096 + voff[2 * (t & 1) + u]);
         };
         read_v(0, vf[0]);
 #pragma unroll
@@ -304,7 +298,8 @@ __global__ __launch_bounds__(NKB * 128) __attribute__((amdgpu_waves_per_eu(2, 2)
           for (int u = 0; u < 2; ++u)
 #pragma unroll
             for (int dt = 0; dt < 2; ++dt)
-              o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[t & 1][2 * dt + u], pf[t][u], o[dt], 0, 0, 0);
+              if (ABL & 2) o[dt][u] += (float)vf[t & 1][2 * dt + u][0] * (float)pf[t][u][0];
+              else o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[t & 1][2 * dt + u], pf[t][u], o[dt], 0, 0, 0);
         }
         __builtin_amdgcn_sched_barrier(0);
       }
@@ -318,7 +313,10 @@ __global__ __launch_bounds__(NKB * 128) __attribute__((amdgpu_waves_per_eu(2, 2)
             const float x0 = o[dt][4 * rg + 0] * inv, x1 = o[dt][4 * rg + 1] * inv, x2 = o[dt][4 * rg + 2] * inv, x3 = o[dt][4 * rg + 3] * inv;
             opk[dt][rg][0] = pack_h2(x0, x1);
             opk[dt][rg][1] = pack_h2(x2, x3);
-            if constexpr (X8) x8_planes4(x0, x1, x2, x3, op8[dt][rg][1], op8[dt][rg][0]);
+            if constexpr (LO) {
+              opl[dt][rg][0] = pack_h2(x0 - (float)(half_t)x0, x1 - (float)(half_t)x1);
+              opl[dt][rg][1] = pack_h2(x2 - (float)(half_t)x2, x3 - (float)(half_t)x3);
+            }
           }
         prev = unit;
       }
@@ -327,4 +325,10 @@ __global__ __launch_bounds__(NKB * 128) __attribute__((amdgpu_waves_per_eu(2, 2)
   // ---- last unit's O: the K half of the slot no DMA was issued into (nothing reads it any more)
   flush_o(prev, smem + pb * BUF);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // no LDS-DMA may outlive the workgroup's LDS allocation
+  if (a.clk && lane == 0) {
+    unsigned long long* c = a.clk + (size_t)(blockIdx.x * 8 + wave) * 3;
+    c[0] = __builtin_amdgcn_s_memtime() - clk0;
+    c[1] = clk_wait;
+    c[2] = clk_vm;
+  }
 }

@@ -17,27 +17,6 @@ typedef float floatx16 __attribute__((ext_vector_type(16)));
 #define MV_PROJ 512
 #define MV_WAVE 64
 
-// ---- MV_F16X8 planes: OCP e4m3 of x 2^MV_X8_ACT_SHIFT (hi8) and of (x - fp16(x)) 2^(11 + MV_X8_ACT_SHIFT) (lo8).
-// v_cvt_pk_fp8_f32 does not saturate (overflow -> NaN): clamp to the format's +-448 first (what hip_fp8.h does too).
-// Activations use ONE static shift: |x| up to 112 keeps its hi8 / lo8 exact-range; larger values only lose the
-// correction term of that element (graceful: fp16-level accuracy there).
-#define MV_X8_ACT_SHIFT 2
-__device__ __forceinline__ uint32_t pack_fp8x4(float a, float b, float c, float d) {
-  a = __builtin_amdgcn_fmed3f(a, -448.f, 448.f); b = __builtin_amdgcn_fmed3f(b, -448.f, 448.f);
-  c = __builtin_amdgcn_fmed3f(c, -448.f, 448.f); d = __builtin_amdgcn_fmed3f(d, -448.f, 448.f);
-  int v = 0;
-  v = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, v, false);
-  v = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, v, true);
-  return (uint32_t)v;
-}
-// four consecutive values -> (hi8 dword, lo8 dword)
-__device__ __forceinline__ void x8_planes4(float v0, float v1, float v2, float v3, uint32_t& hi8, uint32_t& lo8) {
-  constexpr float SH = (float)(1 << MV_X8_ACT_SHIFT), SL = (float)(2048 << MV_X8_ACT_SHIFT);
-  hi8 = pack_fp8x4(v0 * SH, v1 * SH, v2 * SH, v3 * SH);
-  lo8 = pack_fp8x4((v0 - (float)(half_t)v0) * SL, (v1 - (float)(half_t)v1) * SL, (v2 - (float)(half_t)v2) * SL,
-                   (v3 - (float)(half_t)v3) * SL);
-}
-
 // Sum / max over the 64 lanes of a wave (all lanes receive the result).
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

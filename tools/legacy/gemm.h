@@ -18,10 +18,14 @@
 //     128^2 and 256^2 kernels produce bit-identical results.
 //
 // gemm128: 256 threads = 4 waves as 2(M) x 2(N), 64x64 per wave, 2 x 32 KB LDS => two workgroups per CU;
-//          one barrier per K-step ("step-3" structure of the guide).  The mid-size path (passes too small to fill the
-//          chip with 256^2 tiles); the bench-scale path is gemm_pp.h, the skinny-M path ([CLS] tail) gemm_ring below.
-//          (The round-1/2 library also carried a 256^2 one-tile-per-workgroup kernel, a register-staged 128^2 form and a
-//          sweep of ring geometries: tools/legacy/, A/B records in profiles/r01_d_gemm_ablation.txt.)
+//          one barrier per K-step ("step-3" structure of the guide).  Used for small M.
+// gemm256: 512 threads = 8 waves as 2(M) x 4(N), 128x64 per wave (128 accumulator VGPRs), 2 x 64 KB LDS
+//          => one workgroup per CU; one barrier per K-step, operand fragments register-double-buffered across
+//          the 16-wide sub-steps and across the barrier (the last sub-step's MFMAs run after the barrier and
+//          cover the first fragment reads of the next tile); the LDS-DMA for tile t+2 is issued right after the
+//          barrier that retires tile t, so every load has a full K-step (~2k cycles) in flight and the
+//          `s_waitcnt vmcnt(0)` at the next barrier is not a stall.  Halves both the LDS and the L2 bytes per
+//          FLOP of gemm128.
 #pragma once
 #include "common.h"
 
@@ -36,7 +40,7 @@ struct GemmArgs {
   int N, K;
   int GN;             // raster group width in tiles (divides N / tile)
   float* outf;        // EPI_F32: [M][N]
-  half_t* out16;      // EPI_GELU: [M][N]; PP_RESLN3: the hi plane of the raw stream (the next consumer's fp16 operand)
+  half_t* out16;      // EPI_GELU: [M][N]; PP_RESLN2 / 3: the fp16 operand copy (hi plane) of the raw stream
   half_t* out16b;     // PP_RESLN3: the lo plane, fp16(r - hi)
   float* xres;        // EPI_RES: [M][N] residual stream, updated in place
   half_t* q;          // EPI_QKV: [B][12][S][64]  (W_q, b_q pre-scaled by 1/8)
@@ -44,17 +48,21 @@ struct GemmArgs {
   half_t* vt;         //          [B][12][64][S]
   int S;              // padded sequence length (multiple of 64)
   int col0;           // EPI_QKV / PP_QK: packed-QKV column of this launch's first output column (0, or 768 = K,V only)
-  const float* lnstats;  // gemm_pp: the rows' "vstats" [M][3][2] of the LayerNorm in front of this GEMM (common.h ln_from_partials);
-                         // lng / lnb: that LayerNorm's gamma, beta [768] (PP_RESLN3)
+  const float* lnstats;  // PP_RESLN: [M][2] (mean, rstd) of the residual rows; PP_RESLN2 / 3 and RAW consumers: the rows' "vstats"
+                         // [M][3][2] (misc_kernels.h ln_from_partials); lng / lnb: that LayerNorm's gamma, beta [768]
   const float* lng;
   const float* lnb;
-  float* lnpart;         // PP_RESLN3 (N = 768): vstats of the NEW raw rows, [M][3][2] = (sum, sum of squares) per row and 256-column tile
+  int stagger;           // gemm_pp: workgroup w starts (hash(w) % (stagger + 1)) x ~8k cycles late (breaks the lockstep of the memory bursts)
+  int raw;               // RAW consumer (gemm_pp.h): A is the raw fp16 stream, W / bias are the folded ones, lnstats = row statistics
+  float* lnpart;         // PP_RESLN2 / 3 (N = 768): vstats of the NEW raw rows, [M][3][2] = (sum, sum of squares) per row and 256-column tile
   float ln_eps;          // LayerNorm epsilon of the vstats consumers
-  // MV_F16X8 (gemm_pp.h X8): the fp8 (OCP e4m3) correction sweep  2^-s (A_lo8 W_hi8 + A_hi8 W_lo8)  over a virtual K of 2 K
-  const uint8_t* A8;     // [Mpad][2 K]: row = [lo8 (K bytes) | hi8 (K bytes)] of the A operand, pre-scaled by 2^(11 + sa) / 2^sa
-  const uint8_t* W8;     // [N][2 K]:    row = [hi8 | lo8] of W, pre-scaled by 2^sw / 2^(11 + sw)
-  uint8_t* out8;         // PP_GELU / PP_RESLN3: [M][2 N] = [lo8 | hi8] planes of this GEMM's output (the next GEMM's A8)
-  int x8_scale;          // E8M0 byte of 2^-(11 + sa + sw), replicated in the four bytes (the other scale operand is 1.0)
+  unsigned long long* clk;  // optional (development probe): per-workgroup s_memtime span of the persistent kernel
+  // split-operand ("precise") mode of gemm_pp (nseg == 3): the K sweep runs three times over the same accumulators,
+  //   A_hi W_hi + A_lo W_hi + A_hi W_lo   with  A = A_hi + A_lo,  W = W_hi + W_lo  (fp16 planes; the lo x lo term is 2^-22),
+  // i.e. ~22-bit operands on the fp16 matrix cores at 3x the MFMA work.  A2 / W2 = the lo planes (same layouts as A / W).
+  const half_t* A2;
+  const half_t* W2;
+  int nseg;              // 0 / 1: plain; 3: split operands
 };
 
 // logical tile index -> (tile_m, tile_n) under the grouped raster
@@ -146,7 +154,7 @@ __device__ __forceinline__ void glds16(const half_t* src, char* lds_wave_base) {
 #define G128_TILE_BYTES (128 * 64 * 2)        // 16 KiB per operand tile
 #define G128_LDS_BYTES (4 * G128_TILE_BYTES)  // 2 buffers x (A + W)
 
-template <int EPI>
+template <int EPI, bool GLDS>
 __global__ __launch_bounds__(256, 2) void gemm128_kernel(GemmArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
@@ -211,16 +219,49 @@ __global__ __launch_bounds__(256, 2) void gemm128_kernel(GemmArgs a) {
   };
 
   const int nk = K / 64;
-  stage_glds(0, 0);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  int cur = 0;
-  for (int kt = 0; kt < nk; ++kt) {
-    if (kt + 1 < nk) stage_glds(cur ^ 1, kt + 1);
-    compute(cur);
+  if constexpr (GLDS) {
+    stage_glds(0, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    cur ^= 1;
+    int cur = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+      if (kt + 1 < nk) stage_glds(cur ^ 1, kt + 1);
+      compute(cur);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      cur ^= 1;
+    }
+  } else {
+    // register staging: global -> VGPR -> ds_write_b128 (same LDS image as the LDS-DMA path)
+    half8_t ra[4], rw[4];
+    auto gload = [&](int kt) {
+      const int koff = kt * 64;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        ra[i] = *(const half8_t*)(srcA[i] + koff);
+        rw[i] = *(const half8_t*)(srcW[i] + koff);
+      }
+    };
+    auto lwrite = [&](int buf) {
+      char* baseA = smem + buf * (2 * G128_TILE_BYTES) + wave * 4096 + lane * 16;
+      char* baseW = baseA + G128_TILE_BYTES;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        *(half8_t*)(baseA + i * 1024) = ra[i];
+        *(half8_t*)(baseW + i * 1024) = rw[i];
+      }
+    };
+    gload(0);
+    lwrite(0);
+    __syncthreads();
+    int cur = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+      if (kt + 1 < nk) gload(kt + 1);
+      compute(cur);
+      if (kt + 1 < nk) lwrite(cur ^ 1);
+      __syncthreads();
+      cur ^= 1;
+    }
   }
 
 #pragma unroll
@@ -228,6 +269,102 @@ __global__ __launch_bounds__(256, 2) void gemm128_kernel(GemmArgs a) {
 #pragma unroll
     for (int j = 0; j < 2; ++j)
       epilogue_frag<EPI>(a, acc[i][j], m0 + wm * 64 + i * 32, n0 + wn * 64 + j * 32, lane);
+}
+
+// =================================================================================================
+#define G256_TILE_BYTES (256 * 64 * 2)        // 32 KiB per operand tile
+#define G256_LDS_BYTES (4 * G256_TILE_BYTES)  // 2 buffers x (A + W) = 128 KiB
+
+template <int EPI>
+__global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int hi = lane >> 5;
+  int tile_m, tile_n;
+  raster(xcd_remap(blockIdx.x, gridDim.x), a.M >> 8, a.N >> 8, a.GN, tile_m, tile_n);
+  const int m0 = tile_m << 8, n0 = tile_n << 8;
+  const int wm = wave >> 2, wn = wave & 3;
+  const int K = a.K;
+
+  // staging: wave w fills slabs w*4 .. w*4+3 (8 rows each) of the 256-row A and W tiles
+  const half_t* srcA[4];
+  const half_t* srcW[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = (wave * 4 + i) * 8 + (lane >> 3);
+    const int sc = (lane & 7) ^ ((row >> 1) & 7);
+    srcA[i] = a.A + (size_t)(m0 + row) * K + sc * 8;
+    srcW[i] = a.W + (size_t)(n0 + row) * K + sc * 8;
+  }
+  auto stage = [&](int buf, int kt) {
+    char* baseA = smem + buf * (2 * G256_TILE_BYTES) + wave * 4096;
+    char* baseW = baseA + G256_TILE_BYTES;
+    const int koff = kt * 64;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      glds16(srcA[i] + koff, baseA + i * 1024);
+      glds16(srcW[i] + koff, baseW + i * 1024);
+    }
+  };
+
+  const int swz = (lane >> 1) & 7;
+  const int arow = (wm * 128 + (lane & 31)) * 128;
+  const int brow = (wn * 64 + (lane & 31)) * 128;
+
+  floatx16 acc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) init_frag<EPI>(a, acc[i][j], m0 + wm * 128 + i * 32, n0 + wn * 64 + j * 32, lane);
+
+  auto load_frags = [&](int buf, int kk, half8_t (&fa)[4], half8_t (&fb)[2]) {
+    const char* baseA = smem + buf * (2 * G256_TILE_BYTES);
+    const char* baseW = baseA + G256_TILE_BYTES;
+    const int coff = ((kk * 2 + hi) ^ swz) << 4;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) fb[j] = *(const half8_t*)(baseW + brow + j * 32 * 128 + coff);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) fa[i] = *(const half8_t*)(baseA + arow + i * 32 * 128 + coff);
+  };
+  auto mma = [&](const half8_t (&fa)[4], const half8_t (&fb)[2]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+  };
+
+  const int nk = K / 64;
+  half8_t fa0[4], fb0[2], fa1[4], fb1[2];
+  stage(0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (nk > 1) stage(1, 1);
+  load_frags(0, 0, fa0, fb0);
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+    load_frags(cur, 1, fa1, fb1);
+    mma(fa0, fb0);
+    load_frags(cur, 2, fa0, fb0);
+    mma(fa1, fb1);
+    load_frags(cur, 3, fa1, fb1);
+    mma(fa0, fb0);
+    // tile kt+1 (issued one K-step ago) has landed for this wave; all waves are done READING buffer `cur`
+    // once they pass the barrier (their fragment reads are complete: __syncthreads waits lgkmcnt(0)).
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (kt + 1 < nk) load_frags(cur ^ 1, 0, fa0, fb0);
+    if (kt + 2 < nk) stage(cur, kt + 2);
+    mma(fa1, fb1);
+  }
+
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+      epilogue_frag<EPI>(a, acc[i][j], m0 + wm * 128 + i * 32, n0 + wn * 64 + j * 32, lane);
 }
 
 // =================================================================================================
@@ -255,7 +392,9 @@ __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-template <int EPI, int FR_M, int FR_N, int WAVES_M, int WAVES_N, int BK, int STAGES, int MIN_WAVES_PER_SIMD>
+// ABL (timing ablations, wrong results by construction; cdna_hip_programming.md §5.4 rule 8/17):
+//   0 = real kernel, 1 = no LDS-DMA inside the loop, 2 = no MFMA (fragments kept live), 3 = no fragment reads.
+template <int EPI, int FR_M, int FR_N, int WAVES_M, int WAVES_N, int BK, int STAGES, int MIN_WAVES_PER_SIMD, int ABL = 0>
 __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, MIN_WAVES_PER_SIMD) void gemm_ring_kernel(GemmArgs a) {
   using Gm = RingGeom<BK>;
   constexpr int NW = WAVES_M * WAVES_N;
@@ -300,21 +439,42 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, MIN_WAVES_PER_SIMD) void ge
   const int swzl = Gm::swz(lane & 31);
   const int arow = ((wm * FR_M) * 32 + (lane & 31)) * Gm::ROW_BYTES;
   const int brow = (BM + (wn * FR_N) * 32 + (lane & 31)) * Gm::ROW_BYTES;
+  half8_t fa_c[FR_M], fb_c[FR_N];  // ABL 3: constant fragments
+  if constexpr (ABL == 3) {
+#pragma unroll
+    for (int i = 0; i < FR_M; ++i) fa_c[i] = *(const half8_t*)(a.A + (size_t)(m0 + i * 32 + (lane & 31)) * K + hi * 8);
+#pragma unroll
+    for (int j = 0; j < FR_N; ++j) fb_c[j] = *(const half8_t*)(a.W + (size_t)(n0 + j * 32 + (lane & 31)) * K + hi * 8);
+  }
   auto compute = [&](int slot) {
     const char* base = smem + slot * STAGE_BYTES;
 #pragma unroll
     for (int kk = 0; kk < KK; ++kk) {
       const int coff = ((kk * 2 + hi) ^ swzl) << 4;
       half8_t fa[FR_M], fb[FR_N];
+      if constexpr (ABL == 3) {
 #pragma unroll
-      for (int j = 0; j < FR_N; ++j) fb[j] = *(const half8_t*)(base + brow + j * 32 * Gm::ROW_BYTES + coff);
+        for (int j = 0; j < FR_N; ++j) fb[j] = fb_c[j];
 #pragma unroll
-      for (int i = 0; i < FR_M; ++i) fa[i] = *(const half8_t*)(base + arow + i * 32 * Gm::ROW_BYTES + coff);
+        for (int i = 0; i < FR_M; ++i) fa[i] = fa_c[i];
+      } else {
 #pragma unroll
-      for (int i = 0; i < FR_M; ++i)
+        for (int j = 0; j < FR_N; ++j) fb[j] = *(const half8_t*)(base + brow + j * 32 * Gm::ROW_BYTES + coff);
 #pragma unroll
-        for (int j = 0; j < FR_N; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+        for (int i = 0; i < FR_M; ++i) fa[i] = *(const half8_t*)(base + arow + i * 32 * Gm::ROW_BYTES + coff);
+      }
+      if constexpr (ABL == 2) {
+#pragma unroll
+        for (int j = 0; j < FR_N; ++j) asm volatile("" ::"v"(fb[j]));
+#pragma unroll
+        for (int i = 0; i < FR_M; ++i) asm volatile("" ::"v"(fa[i]));
+      } else {
+#pragma unroll
+        for (int i = 0; i < FR_M; ++i)
+#pragma unroll
+          for (int j = 0; j < FR_N; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+      }
     }
   };
 
@@ -332,7 +492,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, MIN_WAVES_PER_SIMD) void ge
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wave's reads of the slot about to be refilled are done
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-    if (kt + STAGES - 1 < nk) stage(fill, kt + STAGES - 1);
+    if (ABL != 1 && kt + STAGES - 1 < nk) stage(fill, kt + STAGES - 1);
     compute(slot);
     asm volatile("" ::: "memory");
     slot = (slot + 1 == STAGES) ? 0 : slot + 1;
