@@ -90,7 +90,7 @@ def main():
     ap.add_argument("--anchors", type=int, default=124)
     ap.add_argument("--anchor-len", type=int, default=512)
     ap.add_argument("--layers", type=int, default=12)
-    ap.add_argument("--cpu-sample", type=int, default=96, help="IRs timed on the CPU baseline (0 disables)")
+    ap.add_argument("--cpu-sample", type=int, default=256, help="IRs timed on the CPU baseline (bounded at ~40 s; 0 disables)")
     ap.add_argument("--no-profile", action="store_true", help="skip the per-kernel HIP-event passes (no `roofline` / `kernels`)")
     ap.add_argument("--ragged", action="store_true", help="also time a ragged corpus (lengths uniform in [16, seq_len]) swept "
                     "padded to seq_len and length-bucketed (each batch at its longest member); adds a `ragged` object")
@@ -539,7 +539,7 @@ def precise_leg(args, dims, weights, aids, alens, ids, lens, with_cpu=True):
                            "frac": round(ach / MFMA_PEAK_TFLOPS, 4), "avg_launch_us": round(us, 2), "traffic": None,
                            "note": "algorithmic FLOPs of the GEMM / its launch time (the fp8 correction sweep is not counted as work)"}
         res["kernels_avg_us"] = {k: round(v[0] / v[1] * 1e3, 2) for k, v in bd.items() if v[1]}
-        fpi_exec = executed_flops_per_ir(S, G, dims.layers, cls_prune=False)
+        fpi_exec = executed_flops_per_ir(S, G, dims.layers, cls_prune=os.environ.get("MEMVUL_CLS_PRUNE", "1") != "0")
         res["e2e_mfma_frac"] = round(res["value"] * fpi_exec / 1e12 / MFMA_PEAK_TFLOPS, 4)
     eng.close()
     if with_cpu:

@@ -28,10 +28,11 @@ struct AttnArgs {
 // keys per instruction); the 8 lanes of a row combine their partial sums with three xor-shuffles.
 // Numerics mirror attention_kernel: fp16 q, k, v and fp16-rounded P, fp32 scores / statistics / accumulation,
 // additive -10000 on padded keys.
-// q: [Bpad][768] fp32 (the Q projection of the gathered [CLS] rows, 1/8 already folded into W_q), ctx: [Bpad][768] fp16.
+// q: [Bpad][768] fp32 (the Q projection of the gathered [CLS] rows, 1/8 already folded into W_q), ctx: [Bpad][768] fp16
+// (or ctx32: the same rows in fp32).
 __global__ __launch_bounds__(256) void attention_cls_kernel(const float* __restrict__ q, const half_t* __restrict__ k,
                                                             const half_t* __restrict__ vt, const int32_t* __restrict__ lens,
-                                                            half_t* __restrict__ ctx, int S, int nbh) {
+                                                            half_t* __restrict__ ctx, int S, int nbh, float* __restrict__ ctx32 = nullptr) {
   __shared__ float ps[4][512];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int bh = blockIdx.x * 4 + wave;
@@ -97,5 +98,6 @@ __global__ __launch_bounds__(256) void attention_cls_kernel(const float* __restr
     t += __shfl_xor(t, 4, 64);
     out = (c == db) ? t : out;  // lane (sub, c) keeps dim 8 c + sub
   }
-  ctx[(size_t)b * MV_HIDDEN + h * MV_HEAD_DIM + 8 * c + sub] = (half_t)(out * inv);
+  if (ctx32) ctx32[(size_t)b * MV_HIDDEN + h * MV_HEAD_DIM + 8 * c + sub] = out * inv;  // the fp32 [CLS] tail of MV_F16X8
+  else ctx[(size_t)b * MV_HIDDEN + h * MV_HEAD_DIM + 8 * c + sub] = (half_t)(out * inv);
 }

@@ -51,6 +51,8 @@ struct LayerW {
   // E8M0 scale word of each GEMM's correction sweep (2^-(11 + MV_X8_ACT_SHIFT + the matrix' own shift))
   uint8_t *wqkv_f8 = nullptr, *wo8 = nullptr, *w1_f8 = nullptr, *w28 = nullptr;
   int sc_qkv = 0, sc_o = 0, sc_1 = 0, sc_2 = 0;
+  // MV_F16X8, last layer only: fp32 transposed ([k][n]) weights of the [CLS] tail (misc_kernels.h dense768_kernel)
+  float *wqT32 = nullptr, *woT32 = nullptr, *w1T32 = nullptr, *w2T32 = nullptr;
   float *ln1g = nullptr, *ln1b = nullptr, *ln2g = nullptr, *ln2b = nullptr;
 };
 
@@ -127,6 +129,7 @@ struct Work {
   int32_t* part_i = nullptr;
   float* u_in = nullptr;                        // host-provided embeddings for mv_match / mv_topk
   float *c32 = nullptr, *cq = nullptr;          // [CLS]-row buffers of the pruned last layer
+  float* ch32 = nullptr;                        // MV_F16X8: the fp32 [CLS] tail's FFN intermediate [Bp][3072]
   half_t *c16 = nullptr, *cctx = nullptr, *ch16 = nullptr;
   float *lnstats = nullptr, *lnpart = nullptr;  // the two vstats buffers [T][3][2] of the virtual LayerNorm (layer input / mid-layer;
                                                 // each residual GEMM reads one, writes the other)
@@ -411,8 +414,7 @@ int encode_dev(mv_handle* h, const int32_t* d_ids, const int32_t* d_lens, int B,
   h->dbg_Sp = Sp;
   const bool big = pp_selected(h, Mpad);  // persistent GEMMs, raw two-plane stream (x16 = hi, xlo = lo), virtual LayerNorm
   const bool x8 = h->precise;             // MV_F16X8: + fp8 correction sweeps (forces the persistent path, pp_selected)
-  // MV_F16X8: every layer goes through the persistent kernels (the [CLS] tail's skinny GEMMs are plain fp16)
-  const bool prune = !full && h->cls_prune && !x8 && u_out && n_layers == c.layers && n_layers > 0;
+  const bool prune = !full && h->cls_prune && u_out && n_layers == c.layers && n_layers > 0;
   const unsigned ln_grid = (unsigned)((M + 3) / 4);
   {
     ProfScope ps(h, KC_EMBED_LN);
@@ -457,8 +459,11 @@ int encode_dev(mv_handle* h, const int32_t* d_ids, const int32_t* d_lens, int B,
       const int Bp = (int)round_up(B, 128);
       g.A = h->w->x16; g.W = wqkv + (size_t)MV_HIDDEN * MV_HIDDEN; g.bias = bqkv + MV_HIDDEN; g.N = 2 * MV_HIDDEN; g.K = MV_HIDDEN;
       g.col0 = MV_HIDDEN;
-      if (big) { g.lnstats = st_in; if (int rc = launch_pp<PP_QK>(h, KC_GEMM_KV_LAST, g)) return rc; }
-      else if (int rc = launch_small<EPI_QKV>(h, KC_GEMM_KV_LAST, g)) return rc;
+      if (big) {
+        g.lnstats = st_in;
+        if (x8) { g.A8 = h->w->x8; g.W8 = w.wqkv_f8 + (size_t)MV_HIDDEN * 2 * MV_HIDDEN; g.x8_scale = w.sc_qkv; }
+        if (int rc = launch_pp<PP_QK>(h, KC_GEMM_KV_LAST, g)) return rc;
+      } else if (int rc = launch_small<EPI_QKV>(h, KC_GEMM_KV_LAST, g)) return rc;
       ProfScope tail(h, KC_CLS_TAIL);
       const uint32_t keep_mask = h->prof_mask;
       h->prof_mask = 0;  // the tail is one profiled span; its inner launches carry no events of their own
@@ -467,6 +472,30 @@ int encode_dev(mv_handle* h, const int32_t* d_ids, const int32_t* d_lens, int B,
                            big ? st_in : (const float*)nullptr, pend_g, pend_b, h->w->c32, h->w->c16, big ? 1 : 0,
                            big ? h->w->xlo : (const half_t*)nullptr, big ? 1 : 0, c.ln_eps);
         if (int rc = launch_check(h, "cls_gather")) return rc;
+        if (x8) {
+          // MV_F16X8: the B [CLS] rows in full fp32 on the fp32-input matrix cores (their operand rounding would reach the
+          // pooler un-attenuated): Q projection, single-query attention (fp16 K / V^T of the main path, fp32 context), output
+          // projection + residual, LayerNorm, FFN, LayerNorm — the fp16 skinny GEMMs below are MV_F16's tail
+          const unsigned gx = (unsigned)((B + 31) / 32);
+          hipLaunchKernelGGL((dense768_kernel<2, MV_HIDDEN>), dim3(gx, MV_HIDDEN / 32), dim3(512), 0, h->w->stream, (const float*)h->w->c32,
+                             (size_t)MV_HIDDEN, B, (const float*)w.wqT32, (const float*)w.bqkv, MV_HIDDEN, h->w->cq, (const float*)nullptr);
+          if (int rc = launch_check(h, "cls q")) return rc;
+          hipLaunchKernelGGL(attention_cls_kernel, dim3((B * MV_HEADS + 3) / 4), dim3(256), 0, h->w->stream, h->w->cq, h->w->k, h->w->vt,
+                             d_lens, h->w->cctx, Sp, B * MV_HEADS, h->w->pooled);
+          if (int rc = launch_check(h, "attention_cls")) return rc;
+          hipLaunchKernelGGL((dense768_kernel<4, MV_HIDDEN>), dim3(gx, MV_HIDDEN / 32), dim3(512), 0, h->w->stream, (const float*)h->w->pooled,
+                             (size_t)MV_HIDDEN, B, (const float*)w.woT32, (const float*)w.bo, MV_HIDDEN, h->w->c32, (const float*)h->w->c32);
+          if (int rc = launch_check(h, "cls out")) return rc;
+          if (int rc = run_ln(h->w->c32, h->w->c16, B, w.ln1g, w.ln1b)) return rc;
+          hipLaunchKernelGGL((dense768_kernel<3, MV_HIDDEN>), dim3(gx, MV_INTER / 32), dim3(512), 0, h->w->stream, (const float*)h->w->c32,
+                             (size_t)MV_HIDDEN, B, (const float*)w.w1T32, (const float*)w.b1, MV_INTER, h->w->ch32, (const float*)nullptr);
+          if (int rc = launch_check(h, "cls ffn1")) return rc;
+          hipLaunchKernelGGL((dense768_kernel<4, MV_INTER>), dim3(gx, MV_HIDDEN / 32), dim3(512), 0, h->w->stream, (const float*)h->w->ch32,
+                             (size_t)MV_INTER, B, (const float*)w.w2T32, (const float*)w.b2, MV_HIDDEN, h->w->c32, (const float*)h->w->c32);
+          if (int rc = launch_check(h, "cls ffn2")) return rc;
+          if (int rc = run_ln(h->w->c32, h->w->c16, B, w.ln2g, w.ln2b)) return rc;
+          return pool_head(h, h->w->c32, MV_HIDDEN, B, u_out);
+        }
         GemmArgs t{};
         t.M = Bp; t.Mreal = B; t.S = 64;
         t.A = h->w->c16; t.W = w.wqkv; t.bias = w.bqkv; t.N = MV_HIDDEN; t.K = MV_HIDDEN; t.outf = h->w->cq;
@@ -980,6 +1009,21 @@ int mv_finalize_weights(mv_handle* h, int compute_dtype) {
     NEED(q + "output.LayerNorm.bias", H);
     if ((rc = upload_f32(h, &w.ln2b, t->data.data(), H))) return rc;
   }
+  if (precise && c.layers > 0) {  // fp32 [CLS] tail of the last layer: weights transposed to [k][n]
+    const std::string q = P + "encoder.layer." + std::to_string(c.layers - 1) + ".";
+    LayerW& w = h->L[c.layers - 1];
+    auto up_T = [&](const std::string& key, int64_t N, int64_t K, float scale, float** dst) -> int {
+      const HostTensor* tt = nullptr;
+      if (int r = need(h, key, {N, K}, &tt)) return r;
+      std::vector<float> tr((size_t)(N * K));
+      for (int64_t n = 0; n < N; ++n) for (int64_t k = 0; k < K; ++k) tr[(size_t)(k * N + n)] = tt->data[(size_t)(n * K + k)] * scale;
+      return upload_f32(h, dst, tr.data(), N * K);
+    };
+    if ((rc = up_T(q + "attention.self.query.weight", H, H, 0.125f, &w.wqT32))) return rc;  // 1/sqrt(64) folded like the packed QKV
+    if ((rc = up_T(q + "attention.output.dense.weight", H, H, 1.0f, &w.woT32))) return rc;
+    if ((rc = up_T(q + "intermediate.dense.weight", I, H, 1.0f, &w.w1T32))) return rc;
+    if ((rc = up_T(q + "output.dense.weight", H, I, 1.0f, &w.w2T32))) return rc;
+  }
   // pooler / header: transposed to [k][n] (fp32)
   NEED("_bert_pooler.pooler.dense.weight", H, H);
   {
@@ -1008,6 +1052,7 @@ int mv_finalize_weights(mv_handle* h, int compute_dtype) {
       rc = dev_alloc(h, &h->work[wi].x8, h->cap_tokens * 2 * MV_HIDDEN);
       if (rc == MV_OK) rc = dev_alloc(h, &h->work[wi].ctx8, h->cap_tokens * 2 * MV_HIDDEN);
       if (rc == MV_OK) rc = dev_alloc(h, &h->work[wi].h8, h->cap_tokens * 2 * MV_INTER);
+      if (rc == MV_OK) rc = dev_alloc(h, &h->work[wi].ch32, (int64_t)round_up(h->cfg.max_batch, 256) * MV_INTER);
       if (rc == MV_OK && hipStreamSynchronize(h->w->stream) != hipSuccess) rc = MV_ERR_HIP;
       h->w = keep;
       if (rc != MV_OK) return rc;

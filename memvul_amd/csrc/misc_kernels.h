@@ -224,11 +224,16 @@ __global__ __launch_bounds__(256) void cls_gather_kernel(const float* __restrict
 // stored transposed ([k][n]): a B-operand load is two 128-byte row pieces; grid = B / 32 x N / 32 (192 + 128
 // workgroups at B = 256).
 typedef float floatx16_t __attribute__((ext_vector_type(16)));
-template <int ACT>  // 0: tanh (BertPooler), 1: ReLU (header FeedForward)
+// ACT 0: tanh (BertPooler), 1: ReLU (header FeedForward).  The [CLS] tail of the pruned last layer in the precise compute
+// dtype (MV_F16X8) runs on the same kernel in full fp32 — its rows feed the pooler directly, so their operand rounding is not
+// attenuated by later layers: 2: identity (Q projection), 3: exact-erf GELU (FFN-1), 4: + residual `res` (output projection,
+// FFN-2; `res` may alias `out`: every element is read and written by the same thread).  KT = the contraction length.
+template <int ACT, int KT = MV_HIDDEN>
 __global__ __launch_bounds__(512) void dense768_kernel(const float* __restrict__ x, size_t row_stride, int B,
                                                        const float* __restrict__ WT, const float* __restrict__ bias, int N,
-                                                       float* __restrict__ out) {
-  constexpr int NW = 8, KW = MV_HIDDEN / NW;  // waves, k per wave
+                                                       float* out, const float* res = nullptr) {
+  constexpr int NW = 8, KW = KT / NW;  // waves, k per wave
+  static_assert(KW % 96 == 0, "a wave walks its K share in chunks of 96");
   __shared__ float part[NW][16][64];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -240,16 +245,19 @@ __global__ __launch_bounds__(512) void dense768_kernel(const float* __restrict__
   floatx16_t acc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll 1
+  for (int kc = 0; kc < KW; kc += 96) {
 #pragma unroll
-  for (int k0 = 0; k0 < KW; k0 += 8) {
-    const float4 a0 = *(const float4*)(xr + k0), a1 = *(const float4*)(xr + k0 + 4);
-    // lanes 0-31 carry k0 + 2 j, lanes 32-63 k0 + 2 j + 1
-    const float s0 = h ? a0.y : a0.x, s1 = h ? a0.w : a0.z, s2 = h ? a1.y : a1.x, s3 = h ? a1.w : a1.z;
-    const float w0 = wc[(size_t)(k0 + 0) * N], w1 = wc[(size_t)(k0 + 2) * N], w2 = wc[(size_t)(k0 + 4) * N], w3 = wc[(size_t)(k0 + 6) * N];
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(s0, w0, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(s1, w1, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(s2, w2, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(s3, w3, acc, 0, 0, 0);
+    for (int k0 = kc; k0 < kc + 96; k0 += 8) {
+      const float4 a0 = *(const float4*)(xr + k0), a1 = *(const float4*)(xr + k0 + 4);
+      // lanes 0-31 carry k0 + 2 j, lanes 32-63 k0 + 2 j + 1
+      const float s0 = h ? a0.y : a0.x, s1 = h ? a0.w : a0.z, s2 = h ? a1.y : a1.x, s3 = h ? a1.w : a1.z;
+      const float w0 = wc[(size_t)(k0 + 0) * N], w1 = wc[(size_t)(k0 + 2) * N], w2 = wc[(size_t)(k0 + 4) * N], w3 = wc[(size_t)(k0 + 6) * N];
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(s0, w0, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(s1, w1, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(s2, w2, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(s3, w3, acc, 0, 0, 0);
+    }
   }
 #pragma unroll
   for (int r = 0; r < 16; ++r) part[wave][r][lane] = acc[r];
@@ -261,7 +269,14 @@ __global__ __launch_bounds__(512) void dense768_kernel(const float* __restrict__
 #pragma unroll
     for (int q = 1; q < NW; ++q) v += part[q][r][ln];
     const int orow = b0 + (r & 3) + 8 * (r >> 2) + 4 * (ln >> 5), ocol = n0 + (ln & 31);
-    if (orow < B) out[(size_t)orow * N + ocol] = ACT == 0 ? tanhf(v + bias[ocol]) : fmaxf(v + bias[ocol], 0.f);
+    if (orow < B) {
+      v += bias[ocol];
+      if constexpr (ACT == 0) v = tanhf(v);
+      else if constexpr (ACT == 1) v = fmaxf(v, 0.f);
+      else if constexpr (ACT == 3) v = gelu_erf(v);
+      else if constexpr (ACT == 4) v += res[(size_t)orow * N + ocol];
+      out[(size_t)orow * N + ocol] = v;
+    }
   }
 }
 

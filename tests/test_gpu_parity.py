@@ -137,7 +137,8 @@ def test_ref12_logits_against_the_reference_run(gu, compute):
     gu.record("ref12", compute=compute, **errs)
     assert errs["logit_scale"] > 2.0
     assert errs["logits"] <= (LOGIT_TOL if compute == "precise" else TRAINED_LIKE_LOGIT_BOUND), errs
-    assert errs["p"] <= TRAINED_LIKE_P_TOL, errs
+    # (this fixture's logit pairs are less saturated than the goldens': MV_F16 measures 6.8e-4 on P, the precise mode 6.5e-5)
+    assert errs["p"] <= (TRAINED_LIKE_P_TOL if compute == "precise" else LOGIT_TOL), errs
     eng.anchor_reset()
 
 
@@ -244,9 +245,9 @@ def test_engine_coexists_with_torch_hip_runtime():
     assert outs[0] == outs[1]  # same numbers with and without the process group
 
 
-@pytest.mark.parametrize("gemm_tile", [0, 512])
+@pytest.mark.parametrize("gemm_tile,compute", [(0, "f16"), (512, "f16"), (0, "precise")])
 @pytest.mark.parametrize("B,S,ragged", [(5, 64, False), (3, 200, True), (2, 320, True)])
-def test_last_layer_pruning_matches_full_forward(gu, B, S, ragged, gemm_tile):
+def test_last_layer_pruning_matches_full_forward(gu, B, S, ragged, gemm_tile, compute):
     """MEMVUL_CLS_PRUNE: after the last layer's K / V projection only the [CLS] rows are processed (the pooler
     reads hidden[:, 0], model_memory.py:99).  Same embedding as the all-token forward up to the different
     summation order of the single-query attention (fp32 rounding, then fp16 rounding of the context), and the same
@@ -254,11 +255,12 @@ def test_last_layer_pruning_matches_full_forward(gu, B, S, ragged, gemm_tile):
     dk, wk = dict(layers=2, vocab_size=2048), dict(qk_scale=3.0)
     dims, w = gu.weights_for(dk, wk)
     ids, lens = synth.make_ids(B, S, dims.vocab_size, ragged=ragged, min_len=7)
-    u_full = gu.engine_for(dk, wk, gemm_tile=gemm_tile, env={"MEMVUL_CLS_PRUNE": "0"}).encode(ids, lens)
-    u_cls = gu.engine_for(dk, wk, gemm_tile=gemm_tile).encode(ids, lens)
+    # ("precise": the pruned tail of MV_F16X8 runs in full fp32 on the fp32-input matrix cores, misc_kernels.h dense768_kernel)
+    u_full = gu.engine_for(dk, wk, gemm_tile=gemm_tile, compute_dtype=compute, env={"MEMVUL_CLS_PRUNE": "0"}).encode(ids, lens)
+    u_cls = gu.engine_for(dk, wk, gemm_tile=gemm_tile, compute_dtype=compute).encode(ids, lens)
     u_ref = orc.instance_forward(w, ids.astype(np.int64), synth.mask_from_lens(lens, S))
     d = float(np.abs(u_full - u_cls).max())
-    gu.record("cls_prune", B=B, S=S, gemm_tile=gemm_tile, full_vs_pruned=d, pruned_vs_oracle=float(np.abs(u_cls - u_ref).max()),
+    gu.record("cls_prune", B=B, S=S, gemm_tile=gemm_tile, compute=compute, full_vs_pruned=d, pruned_vs_oracle=float(np.abs(u_cls - u_ref).max()),
               full_vs_oracle=float(np.abs(u_full - u_ref).max()))
     # one fp16 ulp of a context value (different summation order) reaches u at the 5e-5 level; on the persistent
     # path the full forward's last layer also runs with the virtual LayerNorm while the [CLS] tail uses the explicit one
