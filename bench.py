@@ -31,8 +31,15 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 from memvul_amd import synth  # noqa: E402
-from memvul_amd.binding import Engine  # noqa: E402
 from memvul_amd import distributed as mvdist  # noqa: E402
+
+if os.environ.get("MEMVUL_BENCH_STUB_ENGINE"):
+    # CPU regression test of this file's N > 1 control flow and JSON contract (tests/test_distributed_cpu.py): a numpy stand-in
+    # with the Engine surface, NO GPU, NO measurement — the line says so in `data` and `config.note`
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from bench_stub_engine import Engine  # noqa: E402
+else:
+    from memvul_amd.binding import Engine  # noqa: E402
 
 MFMA_PEAK_TFLOPS = 2500.0  # MI355X dense fp16/bf16 MFMA peak (MI355X_MICROARCH.md)
 H, I, P = 768, 3072, 512
@@ -113,14 +120,10 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     multi = world > 1
     # development check of the N > 1 control flow on a ONE-GPU box (not a measurement): every rank shares device 0 and the
-    # exchange runs over gloo instead of RCCL; the JSON line says so in `config.note`
-    smoke_mode = os.environ.get("MEMVUL_BENCH_ONE_GPU_SMOKE", "")  # "1": gloo, "tcp": the socket-hub fallback transport
-    one_gpu_smoke = multi and smoke_mode in ("1", "tcp")
+    # exchange runs over the rendezvous hub instead of RCCL (one GPU cannot host two RCCL ranks); the JSON line says so
+    one_gpu_smoke = multi and os.environ.get("MEMVUL_BENCH_ONE_GPU_SMOKE", "") != ""
+    stub = bool(os.environ.get("MEMVUL_BENCH_STUB_ENGINE"))
     if one_gpu_smoke:
-        if smoke_mode == "tcp":
-            mvdist.init_tcp(rank, world)
-        else:
-            mvdist.init_process_group("gloo")  # torch.distributed only in this development mode
         local_rank = 0
 
     B, S, G, K, W = args.batch, args.seq_len, args.anchors, args.steps, args.warmup
@@ -130,16 +133,11 @@ def main():
                  max_batch=max(B, 256), max_anchors=max(G, 1024))
     eng.load_state_dict(weights, args.compute)
     eng.set_streams(args.streams)
-    transport = "none (one rank)" if not multi else ("tcp hub (one-GPU smoke)" if smoke_mode == "tcp" else "gloo (one-GPU smoke)") if one_gpu_smoke else "rccl (bound in libmemvul_hip.so, engine stream)"
-    if multi and not one_gpu_smoke:
-        # the N > 1 transport: RCCL bound inside libmemvul_hip.so (mv_comm_*), collective on the engine's stream; this
-        # process never imports torch, so there is no second HIP runtime and no load-order rule
-        try:
-            mvdist.init_rccl(eng, rank, world)
-        except Exception as e:  # e.g. librccl not loadable / IPC mode: the same on every rank of the node
-            sys.stderr.write(f"[bench rank {rank}] RCCL init failed ({e}); statistics exchange falls back to the TCP hub\n")
-            mvdist.init_tcp(rank, world)
-            transport = "tcp-fallback (RCCL init failed: %s)" % str(e)[:120]
+    transport = "none (one rank)"
+    if multi:
+        # the N > 1 transport: the ranks agree over a rendezvous hub whether RCCL bound inside libmemvul_hip.so (mv_comm_*,
+        # collective on the engine's stream, no torch in the process) carries the statistics or the hub itself does
+        transport = mvdist.init_transport(eng, rank, world, prefer="tcp" if (one_gpu_smoke or stub) else "rccl")
 
     # anchor memory: G synthetic CWE descriptions of up to 512 tokens, built once per process (untimed;
     # predict_memory.py:81-83 forwards them in chunks of 128)
@@ -220,8 +218,7 @@ def main():
     sustained = sustained_leg(eng, step, B, args.sustain_s) if (not multi and args.sustain_s > 0) else None
 
     if rank != 0:
-        if multi and not one_gpu_smoke:
-            mvdist.shutdown_rccl()
+        mvdist.shutdown()
         return
     from memvul_amd.custom_metric import threshold_confusion_table
 
@@ -251,7 +248,10 @@ def main():
         "stats_table_sum": int(table.sum()),
     }
     if one_gpu_smoke:
-        out["config"]["note"] = "MEMVUL_BENCH_ONE_GPU_SMOKE: all ranks share ONE GPU, exchange over %s: control-flow check, not a measurement" % ("the TCP hub" if smoke_mode == "tcp" else "gloo")
+        out["config"]["note"] = "MEMVUL_BENCH_ONE_GPU_SMOKE: all ranks share ONE GPU, exchange over the rendezvous hub: control-flow check, not a measurement"
+    if stub:
+        out["data"] = "stub"
+        out["config"]["note"] = "MEMVUL_BENCH_STUB_ENGINE: numpy stand-in engine, NO GPU — a test of this file's control flow and JSON contract, not a measurement"
     if prof:
         kernels = {}
         for name, (ms, n) in breakdown.items():
@@ -288,8 +288,7 @@ def main():
         eng.close()
         out["precise"] = precise_leg(args, dims, weights, aids, alens, ids, lens, with_cpu=args.cpu_sample > 0)
     print(json.dumps(out), flush=True)
-    if multi and not one_gpu_smoke:
-        mvdist.shutdown_rccl()
+    mvdist.shutdown()
 
 
 def sustained_leg(eng, step, B, seconds):

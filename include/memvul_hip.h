@@ -152,12 +152,16 @@ int mv_corpus_results(mv_handle* h, int64_t first, int64_t count, float* best, i
  * One process per GPU, contiguous corpus shards, no data-path collective; the ONE exchange is an all-gather of the
  * per-rank (score, label) statistics.  RCCL (librccl.so, opened at run time) is bound directly: the collective runs
  * on the engine's own stream and the process needs neither torch nor a launcher-specific runtime.
- * mv_comm_init: ncclCommInitRank with a unique id that rank 0 writes to `id_path` (a file every rank of the node can
- * reach; ranks != 0 wait for it).  mv_comm_allgather: `bytes_per_rank` bytes of host memory per rank ->
- * world * bytes_per_rank bytes on every rank, in rank order (staged through device buffers the library owns).
- * world == 1 needs no init: the gather is then a copy (world == 1 WITH an id_path builds a real one-rank communicator:
- * the single-GPU test of this path). */
-int mv_comm_init(mv_handle* h, int rank, int world, const char* id_path);
+ * mv_comm_prepare: opens librccl.so and resolves its entry points (so that every rank can report "RCCL usable here" BEFORE
+ * any rank enters the collective ncclCommInitRank).  mv_comm_unique_id: rank 0 draws the 128-byte ncclUniqueId (returns the
+ * byte count).  mv_comm_init: ncclCommInitRank with those bytes — how they reach the other ranks is the host's business
+ * (memvul_amd/distributed.py broadcasts them over its rendezvous socket; nothing is written to a shared temp directory and
+ * nothing assumes one node).  mv_comm_allgather: `bytes_per_rank` bytes of host memory per rank -> world * bytes_per_rank
+ * bytes on every rank, in rank order (staged through device buffers the library owns).  world == 1 needs no init: the
+ * gather is then a copy (world == 1 WITH an id builds a real one-rank communicator: the single-GPU test of this path). */
+int mv_comm_prepare(mv_handle* h);
+int mv_comm_unique_id(mv_handle* h, void* id_out, int capacity);
+int mv_comm_init(mv_handle* h, int rank, int world, const void* id, int id_bytes);
 int mv_comm_allgather(mv_handle* h, const void* send, void* recv, int64_t bytes_per_rank);
 int mv_comm_destroy(mv_handle* h);
 

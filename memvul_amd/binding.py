@@ -38,7 +38,8 @@ ABI_SYMBOLS = [
     "mv_anchor_reset", "mv_anchor_append", "mv_anchor_count", "mv_anchor_get", "mv_anchor_set",
     "mv_forward", "mv_encode", "mv_match", "mv_topk", "mv_corpus_upload", "mv_corpus_run", "mv_corpus_run_len",
     "mv_corpus_results", "mv_set_streams", "mv_profile_enable", "mv_profile_select", "mv_profile_read", "mv_kernel_class_name",
-    "mv_debug_encode", "mv_debug_read", "mv_test_gemm", "mv_test_gemm_pp", "mv_test_e4m3", "mv_comm_init", "mv_comm_allgather", "mv_comm_destroy",
+    "mv_debug_encode", "mv_debug_read", "mv_test_gemm", "mv_test_gemm_pp", "mv_test_e4m3", "mv_comm_prepare", "mv_comm_unique_id", "mv_comm_init", "mv_comm_allgather",
+    "mv_comm_destroy",
 ]
 
 
@@ -102,7 +103,9 @@ def load_library(path: Optional[str] = None):
         "mv_test_gemm": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, C.c_int, P(C.c_float)]),
         "mv_test_gemm_pp": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, C.c_int, P(C.c_float)]),
         "mv_test_e4m3": (C.c_int, [vp, vp, C.c_int64]),
-        "mv_comm_init": (C.c_int, [vp, C.c_int, C.c_int, C.c_char_p]),
+        "mv_comm_prepare": (C.c_int, [vp]),
+        "mv_comm_unique_id": (C.c_int, [vp, vp, C.c_int]),
+        "mv_comm_init": (C.c_int, [vp, C.c_int, C.c_int, vp, C.c_int]),
         "mv_comm_allgather": (C.c_int, [vp, vp, vp, C.c_int64]),
         "mv_comm_destroy": (C.c_int, [vp]),
     }
@@ -276,9 +279,24 @@ class Engine:
         return best, idx, ps
 
     # -- multi-GPU exchange (RCCL bound inside the library; no torch in the process)
-    def comm_init(self, rank: int, world: int, id_path: Optional[str] = None):
-        self._check(self._lib.mv_comm_init(self._h, int(rank), int(world), (id_path or "").encode()), "mv_comm_init")
-        self.comm_rank, self.comm_world = int(rank), int(world)
+    def comm_prepare(self):
+        """dlopen librccl.so and resolve its entry points (raises if RCCL is not usable in this process)."""
+        self._check(self._lib.mv_comm_prepare(self._h), "mv_comm_prepare")
+
+    def comm_unique_id(self) -> bytes:
+        """Rank 0: the 128-byte ncclUniqueId every rank passes to comm_init."""
+        buf = C.create_string_buffer(128)
+        n = self._lib.mv_comm_unique_id(self._h, buf, 128)
+        if n <= 0:
+            self._check(n, "mv_comm_unique_id")
+        return buf.raw[:n]
+
+    def comm_init(self, rank: int, world: int, unique_id: Optional[bytes] = None):
+        if unique_id is None:
+            self._check(self._lib.mv_comm_init(self._h, int(rank), int(world), None, 0), "mv_comm_init")
+        else:
+            self._check(self._lib.mv_comm_init(self._h, int(rank), int(world), C.c_char_p(bytes(unique_id)), len(unique_id)), "mv_comm_init")
+        self.comm_world = int(world)
 
     def comm_allgather(self, block: np.ndarray) -> np.ndarray:
         """Every rank contributes a same-shape array; returns ``[world, *block.shape]`` in rank order."""

@@ -27,16 +27,19 @@ STAMP_PATH = LIB_PATH + ".stamp"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", "-shared", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function", "-Wno-unused-value"]
 
 
-def build_fingerprint(extra_flags=()) -> str:
-    """What the binary depends on: compiler identity, flags, and the CONTENT of every source / header (not mtimes —
-    a checkout or a copy to another box rewrites those)."""
+def _compiler_id():
+    try:
+        return subprocess.run([hipcc_path(), "--version"], capture_output=True, check=True).stdout
+    except Exception:  # no compiler here (a GPU box without the ROCm dev tools)
+        return None
+
+
+def source_fingerprint(extra_flags=()) -> str:
+    """sha256 of the flags and the CONTENT of every source / header (not mtimes — a checkout or a copy to another box
+    rewrites those)."""
     import hashlib
 
     h = hashlib.sha256()
-    try:
-        h.update(subprocess.run([hipcc_path(), "--version"], capture_output=True, check=True).stdout)
-    except Exception as e:  # no compiler here (GPU box without ROCm dev tools): fingerprint of the sources alone
-        h.update(repr(type(e)).encode())
     h.update(" ".join([ARCH, *FLAGS, *extra_flags]).encode())
     deps = [os.path.join(CSRC, s) for s in SOURCES] + [h_ if os.path.isabs(h_) else os.path.join(CSRC, h_) for h_ in HEADERS]
     for d in deps:
@@ -46,11 +49,27 @@ def build_fingerprint(extra_flags=()) -> str:
     return h.hexdigest()
 
 
+def build_fingerprint(extra_flags=()) -> str:
+    """What the binary depends on, as the two lines of the stamp file: `src <sha256 of flags + sources>` and
+    `cc <sha256 of the compiler's --version>`.  bench.py keys its counter figures on the whole stamp."""
+    import hashlib
+
+    cc = _compiler_id()
+    return "src %s\ncc %s" % (source_fingerprint(extra_flags), hashlib.sha256(cc).hexdigest() if cc is not None else "unknown")
+
+
 def is_stale(extra_flags=()) -> bool:
+    """True when the library must be rebuilt: no binary / stamp, other sources or flags, or — where a compiler exists to
+    compare with — another compiler.  On a box WITHOUT hipcc only the source line is compared (the binary that travelled with
+    the tree is then the one to use; ADVICE r2: the old single-hash stamp could never match there)."""
     if not os.path.exists(LIB_PATH) or not os.path.exists(STAMP_PATH):
         return True
     with open(STAMP_PATH) as f:
-        return f.read().strip() != build_fingerprint(extra_flags)
+        have = dict(line.split(" ", 1) for line in f.read().strip().splitlines() if " " in line)
+    want = dict(line.split(" ", 1) for line in build_fingerprint(extra_flags).splitlines())
+    if have.get("src") != want["src"]:
+        return True
+    return want["cc"] != "unknown" and have.get("cc") != want["cc"]
 
 
 def build(force: bool = False, verbose: bool = True, extra_flags=()) -> str:

@@ -198,7 +198,6 @@ struct mv_handle {
   void* rccl_lib = nullptr;
   ncclComm_t comm = nullptr;
   int comm_rank = 0, comm_world = 1;
-  std::string comm_id_path;
   decltype(&ncclGetUniqueId) p_ncclGetUniqueId = nullptr;
   decltype(&ncclCommInitRank) p_ncclCommInitRank = nullptr;
   decltype(&ncclAllGather) p_ncclAllGather = nullptr;
@@ -1273,56 +1272,53 @@ int mv_corpus_results(mv_handle* h, int64_t first, int64_t count, float* best, i
 }
 
 // ---- multi-GPU exchange: RCCL bound directly ---------------------------------------------------
-int mv_comm_init(mv_handle* h, int rank, int world, const char* id_path) {
+// librccl.so is opened at run time (never linked).  The unique id is drawn by rank 0 (mv_comm_unique_id) and handed to every
+// rank's mv_comm_init as BYTES: how they travel is the host's business (memvul_amd/distributed.py broadcasts them over its
+// rendezvous socket — no id file in a shared temp directory, no single-node assumption).
+int mv_comm_prepare(mv_handle* h) {
+  if (!h) return MV_ERR_INVALID;
+  if (h->rccl_lib) return MV_OK;
+  for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+    h->rccl_lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+    if (h->rccl_lib) break;
+  }
+  if (!h->rccl_lib) return fail(h, MV_ERR_HIP, std::string("mv_comm_prepare: cannot open librccl.so: ") + dlerror());
+#define RCCL_SYM(name)                                                                   \
+  h->p_##name = (decltype(&name))dlsym(h->rccl_lib, #name);                            \
+  if (!h->p_##name) { dlclose(h->rccl_lib); h->rccl_lib = nullptr; return fail(h, MV_ERR_HIP, "mv_comm_prepare: librccl.so lacks " #name); }
+  RCCL_SYM(ncclGetUniqueId);
+  RCCL_SYM(ncclCommInitRank);
+  RCCL_SYM(ncclAllGather);
+  RCCL_SYM(ncclCommDestroy);
+  RCCL_SYM(ncclGetErrorString);
+#undef RCCL_SYM
+  return MV_OK;
+}
+
+int mv_comm_unique_id(mv_handle* h, void* id_out, int capacity) {
+  if (!h || !id_out) return MV_ERR_INVALID;
+  if (capacity < (int)sizeof(ncclUniqueId)) return fail(h, MV_ERR_INVALID, "mv_comm_unique_id: buffer smaller than ncclUniqueId (128 bytes)");
+  if (int rc = mv_comm_prepare(h)) return rc;
+  HIPCHK(h, hipSetDevice(h->device));
+  ncclUniqueId id;
+  ncclResult_t r = h->p_ncclGetUniqueId(&id);
+  if (r != ncclSuccess) return fail(h, MV_ERR_HIP, std::string("ncclGetUniqueId: ") + h->p_ncclGetErrorString(r));
+  std::memcpy(id_out, &id, sizeof(id));
+  return (int)sizeof(id);
+}
+
+int mv_comm_init(mv_handle* h, int rank, int world, const void* id, int id_bytes) {
   if (!h || world < 1 || rank < 0 || rank >= world) return fail(h, MV_ERR_INVALID, "mv_comm_init: bad rank / world");
   if (h->comm) return fail(h, MV_ERR_STATE, "mv_comm_init: communicator already initialised");
   h->comm_rank = rank;
   h->comm_world = world;
-  if (world == 1 && (!id_path || !*id_path)) return MV_OK;  // no transport needed (with an id_path: a real 1-rank communicator, the GPU-box test)
-  if (!id_path || !*id_path) return fail(h, MV_ERR_INVALID, "mv_comm_init: id_path required for world > 1");
+  if (world == 1 && !id) return MV_OK;  // no transport needed (with an id: a real 1-rank communicator, the GPU-box test)
+  if (!id || id_bytes != (int)sizeof(ncclUniqueId)) return fail(h, MV_ERR_INVALID, "mv_comm_init: the 128-byte unique id of rank 0 (mv_comm_unique_id) is required");
+  if (int rc = mv_comm_prepare(h)) return rc;
   HIPCHK(h, hipSetDevice(h->device));
-  if (!h->rccl_lib) {
-    for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
-      h->rccl_lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
-      if (h->rccl_lib) break;
-    }
-    if (!h->rccl_lib) return fail(h, MV_ERR_HIP, std::string("mv_comm_init: cannot open librccl.so: ") + dlerror());
-#define RCCL_SYM(name)                                                                   \
-    h->p_##name = (decltype(&name))dlsym(h->rccl_lib, #name);                            \
-    if (!h->p_##name) return fail(h, MV_ERR_HIP, "mv_comm_init: librccl.so lacks " #name)
-    RCCL_SYM(ncclGetUniqueId);
-    RCCL_SYM(ncclCommInitRank);
-    RCCL_SYM(ncclAllGather);
-    RCCL_SYM(ncclCommDestroy);
-    RCCL_SYM(ncclGetErrorString);
-#undef RCCL_SYM
-  }
-  ncclUniqueId id;
-  const std::string path = id_path;
-  if (rank == 0) {
-    ncclResult_t r = h->p_ncclGetUniqueId(&id);
-    if (r != ncclSuccess) return fail(h, MV_ERR_HIP, std::string("ncclGetUniqueId: ") + h->p_ncclGetErrorString(r));
-    const std::string tmp = path + ".tmp";
-    FILE* f = fopen(tmp.c_str(), "wb");
-    if (!f || fwrite(&id, sizeof(id), 1, f) != 1) { if (f) fclose(f); return fail(h, MV_ERR_INVALID, "mv_comm_init: cannot write " + tmp); }
-    fclose(f);
-    if (rename(tmp.c_str(), path.c_str()) != 0) return fail(h, MV_ERR_INVALID, "mv_comm_init: cannot publish " + path);
-    h->comm_id_path = path;
-  } else {
-    const auto t0 = std::chrono::steady_clock::now();
-    for (;;) {
-      FILE* f = fopen(path.c_str(), "rb");
-      if (f) {
-        const size_t n = fread(&id, sizeof(id), 1, f);
-        fclose(f);
-        if (n == 1) break;
-      }
-      if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(180))
-        return fail(h, MV_ERR_STATE, "mv_comm_init: rank 0 did not publish the RCCL unique id at " + path + " within 180 s");
-      usleep(20000);
-    }
-  }
-  ncclResult_t r = h->p_ncclCommInitRank(&h->comm, world, id, rank);
+  ncclUniqueId uid;
+  std::memcpy(&uid, id, sizeof(uid));
+  ncclResult_t r = h->p_ncclCommInitRank(&h->comm, world, uid, rank);
   if (r != ncclSuccess) { h->comm = nullptr; return fail(h, MV_ERR_HIP, std::string("ncclCommInitRank: ") + h->p_ncclGetErrorString(r)); }
   return MV_OK;
 }
@@ -1360,7 +1356,6 @@ int mv_comm_destroy(mv_handle* h) {
   if (h->comm) { h->p_ncclCommDestroy(h->comm); h->comm = nullptr; }
   if (h->comm_send) { hipFree(h->comm_send); h->comm_send = nullptr; h->comm_send_cap = 0; }
   if (h->comm_recv) { hipFree(h->comm_recv); h->comm_recv = nullptr; h->comm_recv_cap = 0; }
-  if (!h->comm_id_path.empty()) { unlink(h->comm_id_path.c_str()); h->comm_id_path.clear(); }
   h->comm_world = 1; h->comm_rank = 0;
   return MV_OK;
 }

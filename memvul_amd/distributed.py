@@ -4,28 +4,35 @@ The reference's inference is single-process (predict_memory.py:103); each issue 
 independently against a read-only anchor bank (model_memory.py:133-147) and the only cross-IR state is
 the metric accumulator (custom_metric.py:61,72).  So: one process per GPU, contiguous corpus shards (the
 reference's positives-first order is preserved inside the concatenation, reader_memory.py:150-152), no
-data-path collective, and ONE all-gather (RCCL over xGMI when the backend is "nccl") of the per-rank
-``(score fp32, label u8)`` sufficient statistics at the end, after which every rank can run
-``find_best_thres`` / ROC-AUC / AP on the concatenation (bit-identical to a single-GPU run).
+data-path collective, and ONE all-gather of the per-rank ``(score fp32, label u8)`` sufficient statistics at the
+end, after which every rank can run ``find_best_thres`` / ROC-AUC / AP on the concatenation (bit-identical to a
+single-GPU run).
 
-Two transports behind the same four functions (all_gather_rows / all_gather_stats / barrier / all_reduce_max):
+Transport (``init_transport``), torch-free:
 
-* RCCL bound directly inside libmemvul_hip.so (``init_rccl(engine)`` -> mv_comm_init / mv_comm_allgather): the GPU path.
-  The collective runs on the engine's stream, the unique id travels through a file every rank of the node can reach,
-  and the process never imports torch — so there is no second HIP runtime in the process and no load-order rule.
-* torch.distributed (``init_process_group``): the gloo harness of the CPU tests (world size 2 here), imported lazily.
+1. every rank joins a small rendezvous hub on ``MASTER_ADDR : MASTER_PORT + 1`` (rank 0 listens; the handshake carries the
+   rank and a run token, both checked);
+2. over it the ranks AGREE on the data transport: each reports whether RCCL is usable in its process
+   (``mv_comm_prepare``), rank 0 draws the ncclUniqueId (``mv_comm_unique_id``) and broadcasts it, every rank calls
+   ``mv_comm_init`` and reports the outcome — only when ALL ranks succeeded does the run use RCCL bound inside
+   libmemvul_hip.so (collective on the engine's stream, over xGMI); otherwise ALL ranks use the hub itself as the
+   transport.  No rank decides alone, there is no id file in a shared temp directory and no single-node assumption.
+   (A rank that dies INSIDE the collective ncclCommInitRank still strands the others until RCCL's own timeout.)
+3. ``shutdown()`` tears the transport down; a later ``init_transport`` starts from scratch.
 
-A third, ``init_tcp``, is the fallback of the RCCL one: a rank-0 socket hub that serves the same ``comm_allgather`` call with
-the launcher's MASTER_ADDR / MASTER_PORT, so that a node whose RCCL cannot be initialised (library missing, IPC mode) still
-gets its whole-job measurement — the data path has no collective, only the 8 B per issue report of statistics cross ranks.
-bench.py says which transport carried a run.
+The data path has no collective, only 8 B per issue report of statistics cross ranks, so a run on the hub is still a
+whole-job measurement; bench.py reports which transport carried it.  ``torch.distributed`` appears only as the gloo
+harness of the CPU tests (``init_process_group("gloo")``).
 """
 from __future__ import annotations
 
+import hashlib
 import os
 from typing import Optional, Tuple
 
 import numpy as np
+
+RENDEZVOUS_TIMEOUT_S = 180.0
 
 
 def shard_range(n: int, rank: int, world: int) -> Tuple[int, int]:
@@ -40,34 +47,18 @@ def env_world() -> Tuple[int, int, int]:
     return int(os.environ.get("RANK", 0)), int(os.environ.get("LOCAL_RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
 
 
-_rccl_engine = None  # the Engine whose communicator carries the exchange (init_rccl)
+def run_token() -> bytes:
+    """16 bytes every rank of one launch derives identically (launcher address, port and run id, or $MEMVUL_RUN_TOKEN):
+    keeps a stray connection or a rank of ANOTHER job out of the hub.  Not a secret."""
+    tag = os.environ.get("MEMVUL_RUN_TOKEN") or "|".join(os.environ.get(k, "") for k in ("MASTER_ADDR", "MASTER_PORT", "TORCHELASTIC_RUN_ID"))
+    return hashlib.sha256(tag.encode()).digest()[:16]
 
 
-def rccl_id_path() -> str:
-    """A path every rank of this node derives identically: launcher port + the launcher's pid (all ranks are children of
-    one torchrun / mpirun process); rank 0 publishes the RCCL unique id there and removes it when the communicator goes."""
-    import tempfile
+class _Hub:
+    """Rank-0 socket hub: ``comm_allgather`` (every rank sends its block to rank 0, rank 0 returns the rank-ordered stack) and
+    ``bcast`` (rank 0 -> all).  Same call surface as the Engine's RCCL methods (comm_world / comm_allgather / comm_destroy)."""
 
-    tag = os.environ.get("MEMVUL_RCCL_ID_TAG") or f"{os.environ.get('MASTER_PORT', '0')}_{os.environ.get('TORCHELASTIC_RUN_ID', 'x')}_{os.getppid()}"
-    return os.path.join(tempfile.gettempdir(), f"memvul_rccl_{tag}.id")
-
-
-def init_rccl(engine, rank: Optional[int] = None, world: Optional[int] = None, id_path: Optional[str] = None):
-    """Make `engine`'s RCCL communicator the transport of this module (GPU runs).  world == 1: a no-op transport."""
-    global _rccl_engine
-    r, _, w = env_world()
-    rank = r if rank is None else rank
-    world = w if world is None else world
-    engine.comm_init(rank, world, id_path or (rccl_id_path() if world > 1 else None))
-    _rccl_engine = engine
-    return engine
-
-
-class _TcpComm:
-    """``comm_allgather`` over sockets: every rank sends its block to rank 0, rank 0 returns the rank-ordered stack.  Same call
-    surface as the Engine's RCCL methods (comm_world / comm_allgather / comm_destroy), torch-free."""
-
-    def __init__(self, rank: int, world: int, addr: str, port: int, timeout_s: float = 120.0):
+    def __init__(self, rank: int, world: int, addr: str, port: int, timeout_s: float = RENDEZVOUS_TIMEOUT_S):
         import socket
         import time
 
@@ -76,17 +67,33 @@ class _TcpComm:
         self.sock = None
         if world <= 1:
             return
+        token = run_token()
         if rank == 0:
             srv = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
             srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
             srv.bind((addr, port))
-            srv.listen(world)
-            srv.settimeout(timeout_s)
+            srv.listen(world + 8)
+            deadline = time.time() + timeout_s
             by_rank = {}
             while len(by_rank) < world - 1:
-                c, _ = srv.accept()
+                srv.settimeout(max(0.1, deadline - time.time()))
+                try:
+                    c, _ = srv.accept()
+                except socket.timeout:
+                    srv.close()
+                    raise RuntimeError(f"rendezvous: only {len(by_rank) + 1} of {world} ranks reached {addr}:{port} within {timeout_s:.0f} s")
+                try:
+                    c.settimeout(10.0)
+                    hello = self._recvn(c, 20)
+                    r = int.from_bytes(hello[:4], "little")
+                    if hello[4:] != token or not (0 < r < world) or r in by_rank:
+                        raise ConnectionError("bad handshake")
+                except (OSError, ConnectionError):
+                    c.close()  # not one of this run's ranks: drop it and keep listening
+                    continue
+                c.settimeout(None)
                 c.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
-                by_rank[int.from_bytes(self._recvn(c, 4), "little")] = c
+                by_rank[r] = c
             srv.close()
             self.peers = [by_rank[r] for r in range(1, world)]
         else:
@@ -97,11 +104,11 @@ class _TcpComm:
                     break
                 except OSError:
                     if time.time() - t0 > timeout_s:
-                        raise
+                        raise RuntimeError(f"rendezvous: rank 0 not reachable at {addr}:{port} within {timeout_s:.0f} s")
                     time.sleep(0.05)
             c.settimeout(None)
             c.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
-            c.sendall(int(rank).to_bytes(4, "little"))
+            c.sendall(int(rank).to_bytes(4, "little") + token)
             self.sock = c
 
     @staticmethod
@@ -110,7 +117,7 @@ class _TcpComm:
         while len(buf) < n:
             part = c.recv(min(1 << 20, n - len(buf)))
             if not part:
-                raise ConnectionError("peer closed the statistics socket")
+                raise ConnectionError("peer closed the rendezvous socket")
             buf += part
         return bytes(buf)
 
@@ -129,6 +136,17 @@ class _TcpComm:
             whole = self._recvn(self.sock, nb * self.comm_world)
         return np.frombuffer(whole, arr.dtype).reshape((self.comm_world,) + arr.shape).copy()
 
+    def bcast(self, payload: Optional[bytes], nbytes: int) -> bytes:
+        """rank 0's `payload` (exactly nbytes) to every rank."""
+        if self.comm_world <= 1:
+            return payload
+        if self.rank == 0:
+            assert payload is not None and len(payload) == nbytes
+            for c in self.peers:
+                c.sendall(payload)
+            return payload
+        return self._recvn(self.sock, nbytes)
+
     def comm_destroy(self):
         for c in self.peers + ([self.sock] if self.sock is not None else []):
             try:
@@ -138,108 +156,159 @@ class _TcpComm:
         self.peers, self.sock = [], None
 
 
-def init_tcp(rank: Optional[int] = None, world: Optional[int] = None, addr: Optional[str] = None, port: Optional[int] = None):
-    """Fallback transport (see the module docstring): rank 0 listens on MASTER_ADDR : MASTER_PORT + 1."""
-    global _rccl_engine
+_comm = None        # the transport of all_gather_rows / barrier / all_reduce_max: an Engine (RCCL) or a _Hub
+_comm_note = "none"
+
+
+def init_transport(engine=None, rank: Optional[int] = None, world: Optional[int] = None, prefer: str = "rccl",
+                   addr: Optional[str] = None, port: Optional[int] = None) -> str:
+    """Set up the statistics exchange for this process (see the module docstring) and return a description of the transport
+    that ALL ranks agreed on: "rccl ..." or "tcp hub ...".  prefer="tcp" skips RCCL.  world == 1: a no-op transport."""
+    global _comm, _comm_note
+    shutdown()
     r, _, w = env_world()
     rank = r if rank is None else rank
     world = w if world is None else world
+    if world <= 1:
+        if engine is not None:
+            engine.comm_init(rank, 1)
+            _comm = engine
+        else:
+            _comm = _Hub(0, 1, "", 0)
+        _comm_note = "none (one rank)"
+        return _comm_note
     addr = addr or os.environ.get("MASTER_ADDR", "127.0.0.1")
     port = port if port is not None else int(os.environ.get("MASTER_PORT", "29500")) + 1
-    _rccl_engine = _TcpComm(rank, world, addr, port)
-    return _rccl_engine
+    hub = _Hub(rank, world, addr, port)
+    why = "requested" if prefer != "rccl" else ""
+    if prefer == "rccl" and engine is None:
+        why = "no engine given"
+    if prefer == "rccl" and engine is not None:
+        # step 1: is RCCL usable in EVERY process?  (nobody enters the collective init unless all say yes)
+        try:
+            engine.comm_prepare()
+            mine, err = 1, ""
+        except RuntimeError as e:
+            mine, err = 0, str(e)
+        if int(hub.comm_allgather(np.array([mine], np.uint8)).min()) == 0:
+            why = "RCCL not usable on every rank" + (f" (here: {err[:100]})" if err else "")
+        else:
+            # step 2: rank 0 draws the unique id and broadcasts [ok byte | 128 id bytes]
+            msg = None
+            if rank == 0:
+                try:
+                    msg = b"\x01" + engine.comm_unique_id().ljust(128, b"\0")
+                except RuntimeError as e:
+                    msg, err = b"\x00" + b"\0" * 128, str(e)
+            msg = hub.bcast(msg, 129)
+            if msg[0] != 1:
+                why = "rank 0 could not draw a unique id" + (f" ({err[:100]})" if err else "")
+            else:
+                # step 3: the collective init; every rank reports its outcome, all must succeed
+                try:
+                    engine.comm_init(rank, world, msg[1:129])
+                    ok, err = 1, ""
+                except RuntimeError as e:
+                    ok, err = 0, str(e)
+                if int(hub.comm_allgather(np.array([ok], np.uint8)).min()) == 1:
+                    hub.comm_destroy()
+                    _comm = engine
+                    _comm_note = "rccl (bound in libmemvul_hip.so, engine stream; unique id over the rendezvous socket)"
+                    return _comm_note
+                if ok:
+                    engine.comm_destroy()
+                why = "ncclCommInitRank failed on a rank" + (f" (here: {err[:100]})" if err else "")
+    _comm = hub
+    _comm_note = f"tcp hub on {addr}:{port} ({why or 'fallback'})"
+    return _comm_note
 
 
-def shutdown_rccl():
-    global _rccl_engine
-    if _rccl_engine is not None:
-        _rccl_engine.comm_destroy()
-        _rccl_engine = None
+def transport_note() -> str:
+    return _comm_note
 
 
-def _rccl_world() -> int:
-    return getattr(_rccl_engine, "comm_world", 1) if _rccl_engine is not None else 0
+def shutdown():
+    """Tear the transport down (idempotent).  Every driver calls it in a ``finally``: a second sharded call in the same
+    process then starts from scratch instead of inheriting a stale communicator."""
+    global _comm, _comm_note
+    if _comm is not None:
+        try:
+            _comm.comm_destroy()
+        finally:
+            _comm, _comm_note = None, "none"
 
 
-def _rccl_all_gather_rows(rows: np.ndarray) -> np.ndarray:
-    world = _rccl_world()
-    counts = _rccl_engine.comm_allgather(np.array([rows.shape[0]], np.int64)).reshape(world)
+def _world() -> int:
+    return getattr(_comm, "comm_world", 1) if _comm is not None else 0
+
+
+def _comm_all_gather_rows(rows: np.ndarray) -> np.ndarray:
+    world = _world()
+    counts = _comm.comm_allgather(np.array([rows.shape[0]], np.int64)).reshape(world)
     n_max = max(int(counts.max()), 1)
     block = np.zeros((n_max, rows.shape[1]), np.float32)
     block[: rows.shape[0]] = rows
-    out = _rccl_engine.comm_allgather(block)  # [world, n_max, k]
+    out = _comm.comm_allgather(block)  # [world, n_max, k]
     return np.concatenate([out[r, : int(counts[r])] for r in range(world)])
 
 
-def init_process_group(backend: Optional[str] = None):
-    """Initialise torch.distributed from the torchrun environment (RANK/WORLD_SIZE/MASTER_*)."""
+def init_process_group(backend: str = "gloo"):
+    """torch.distributed from the torchrun environment — the gloo harness of the CPU tests only (GPU runs use
+    init_transport and never import torch)."""
     import torch.distributed as dist
 
+    if backend != "gloo":
+        raise ValueError("torch.distributed is the CPU test harness here (backend 'gloo'); GPU runs use init_transport")
     if dist.is_initialized():
         return dist
-    rank, local_rank, world = env_world()
-    if backend is None:
-        import torch
-
-        backend = "nccl" if torch.cuda.is_available() else "gloo"
+    rank, _, world = env_world()
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29531")
-    if backend == "nccl":
-        import torch
-
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend, rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-    else:
-        dist.init_process_group(backend, rank=rank, world_size=world)
+    dist.init_process_group(backend, rank=rank, world_size=world)
     return dist
 
 
-def all_gather_rows(rows: np.ndarray, device=None) -> np.ndarray:
+def all_gather_rows(rows: np.ndarray) -> np.ndarray:
     """All-gather per-rank fp32 row blocks ``[n_r, k]`` (n_r may differ per rank); returns the rank-ordered concatenation
     ``[sum n_r, k]``.  One collective on a zero-padded ``[n_max, k]`` block per rank plus a tiny count gather."""
     rows = np.ascontiguousarray(rows, np.float32)
-    if _rccl_engine is not None:
-        if rows.ndim != 2:
-            raise ValueError("all_gather_rows expects [n, k]")
-        return _rccl_all_gather_rows(rows) if _rccl_world() > 1 else rows.copy()
+    if rows.ndim != 2:
+        raise ValueError("all_gather_rows expects [n, k]")
+    if _comm is not None:
+        return _comm_all_gather_rows(rows) if _world() > 1 else rows.copy()
     import torch
     import torch.distributed as dist
 
-    if rows.ndim != 2:
-        raise ValueError("all_gather_rows expects [n, k]")
     if not dist.is_initialized() or dist.get_world_size() == 1:
         return rows.copy()
     world = dist.get_world_size()
-    if device is None:
-        device = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
     k = rows.shape[1]
-    n = torch.tensor([rows.shape[0]], dtype=torch.int64, device=device)
+    n = torch.tensor([rows.shape[0]], dtype=torch.int64)
     counts = [torch.zeros_like(n) for _ in range(world)]
     dist.all_gather(counts, n)
     counts = [int(c.item()) for c in counts]
     n_max = max(max(counts), 1)
     block = torch.zeros((n_max, k), dtype=torch.float32)
     block[: rows.shape[0]] = torch.from_numpy(rows)
-    block = block.to(device)
-    out = torch.empty((world * n_max, k), dtype=torch.float32, device=device)  # rank-major concatenation
+    out = torch.empty((world * n_max, k), dtype=torch.float32)  # rank-major concatenation
     dist.all_gather_into_tensor(out, block)
-    out = out.cpu().numpy().reshape(world, n_max, k)
+    out = out.numpy().reshape(world, n_max, k)
     return np.concatenate([out[r, : counts[r]] for r in range(world)])
 
 
-def all_gather_stats(scores: np.ndarray, labels: np.ndarray, device=None) -> Tuple[np.ndarray, np.ndarray]:
+def all_gather_stats(scores: np.ndarray, labels: np.ndarray) -> Tuple[np.ndarray, np.ndarray]:
     """All-gather the per-rank ``(score, label)`` arrays; returns the rank-ordered concatenation, trimmed
     to the true per-rank counts (labels ride along as 0.0/1.0 in the same block: one collective)."""
     scores = np.ascontiguousarray(scores, np.float32)
     labels = np.ascontiguousarray(labels, np.uint8)
-    out = all_gather_rows(np.stack([scores, labels.astype(np.float32)], 1) if len(scores) else np.zeros((0, 2), np.float32), device)
+    out = all_gather_rows(np.stack([scores, labels.astype(np.float32)], 1) if len(scores) else np.zeros((0, 2), np.float32))
     return out[:, 0].copy(), out[:, 1].astype(np.uint8)
 
 
 def barrier():
-    if _rccl_engine is not None:
-        if _rccl_world() > 1:
-            _rccl_engine.comm_allgather(np.zeros(1, np.int32))  # returns when every rank has contributed
+    if _comm is not None:
+        if _world() > 1:
+            _comm.comm_allgather(np.zeros(1, np.int32))  # returns when every rank has contributed
         return
     import torch.distributed as dist
 
@@ -248,14 +317,13 @@ def barrier():
 
 
 def all_reduce_max(x: float) -> float:
-    if _rccl_engine is not None:
-        return float(_rccl_engine.comm_allgather(np.array([x], np.float64)).max()) if _rccl_world() > 1 else x
+    if _comm is not None:
+        return float(_comm.comm_allgather(np.array([x], np.float64)).max()) if _world() > 1 else x
     import torch
     import torch.distributed as dist
 
     if not dist.is_initialized() or dist.get_world_size() == 1:
         return x
-    dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
-    t = torch.tensor([x], dtype=torch.float64, device=dev)
+    t = torch.tensor([x], dtype=torch.float64)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())

@@ -190,9 +190,12 @@ def test_siamese_sharded(archive_file, input_file, input_golden_file, test_confi
     from . import distributed as mvdist
 
     rank, local_rank, world = mvdist.env_world()
-    use_torch = world > 1 and backend in ("gloo", "nccl")  # gloo: the CPU test harness; "nccl": torch.distributed's RCCL route
+    if backend not in (None, "rccl", "tcp", "gloo"):
+        raise ValueError(f"backend {backend!r}: expected None / 'rccl' (RCCL bound in the library, agreed over the rendezvous hub), 'tcp' "
+                         "(the hub itself) or 'gloo' (torch.distributed, the CPU test harness)")
+    use_torch = world > 1 and backend == "gloo"
     if use_torch:
-        mvdist.init_process_group(backend)
+        mvdist.init_process_group("gloo")
     # the reference takes the model's device from the config (predict_memory.py:210, test_config_memory.json "cuda:0");
     # here every rank must land on ITS GPU whatever the config says
     overrides = json.loads(test_config) if isinstance(test_config, str) and test_config else copy.deepcopy(test_config or {})
@@ -201,18 +204,21 @@ def test_siamese_sharded(archive_file, input_file, input_golden_file, test_confi
                            engine_options=engine_options)
     model = archive.model
     model.eval()
-    if world > 1 and not use_torch:
-        # the default on GPUs: RCCL bound inside libmemvul_hip.so, collective on the engine's stream, no torch.distributed
-        # (backend="tcp", or an RCCL that cannot be initialised on this node: the torch-free socket hub, distributed.init_tcp)
-        if backend == "tcp":
-            mvdist.init_tcp(rank, world)
-        else:
-            try:
-                mvdist.init_rccl(model.engine, rank, world)
-            except RuntimeError as e:
-                import sys
-                sys.stderr.write(f"[test_siamese_sharded rank {rank}] RCCL init failed ({e}); falling back to the TCP hub\n")
-                mvdist.init_tcp(rank, world)
+    try:
+        if world > 1 and not use_torch:
+            # the default on GPUs: RCCL bound inside libmemvul_hip.so, collective on the engine's stream, no torch.distributed; the
+            # ranks agree over the rendezvous hub whether RCCL carries the run or the hub does (distributed.init_transport)
+            note = mvdist.init_transport(None if backend == "tcp" else model.engine, rank, world, prefer="tcp" if backend == "tcp" else "rccl")
+            logger.info("statistics transport: %s", note)
+        return _sharded_body(archive, model, input_file, input_golden_file, output_file, predictions_output_file, batch_size, rank, world)
+    finally:
+        if not use_torch:
+            mvdist.shutdown()  # a later sharded call in this process starts from scratch (no stale communicator / sockets)
+
+
+def _sharded_body(archive, model, input_file, input_golden_file, output_file, predictions_output_file, batch_size, rank, world):
+    from . import distributed as mvdist
+
     golden_samples = list(archive.validation_dataset_reader.read(input_golden_file))
     model._golden_instances_embeddings = None
     model._golden_instances_labels = None

@@ -3,6 +3,7 @@ golden anchors + a test file of N issue reports of realistic length -> test_siam
 by one.  Usage (GPU box): python scripts/e2e_dropin_probe.py [N] [record_workers]"""
 import json
 import os
+os.environ.setdefault("MEMVUL_ALLOW_HASH_TOKENIZER", "1")  # synthetic corpus: the hashing stand-in tokenizer is what this probe times
 import sys
 import time
 

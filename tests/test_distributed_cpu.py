@@ -46,9 +46,12 @@ def test_all_gather_stats_world2_gloo(tmp_path, n):
         assert res["f1"] == m["f1"] and res["thres"] == float(m["thres"]) and res["auc"] == float(m["auc"])
 
 
-def test_sharded_driver_world2_gloo_equals_single_process(tmp_path, monkeypatch):
+@pytest.mark.parametrize("backend", ["gloo", "tcp"])
+def test_sharded_driver_world2_equals_single_process(tmp_path, monkeypatch, backend):
     """test_siamese_sharded on two ranks (contiguous shards, one all-gather of per-IR rows) == the single-process array
-    driver: the same metrics on every rank, and the assembled predictions file holds the same records in the same order."""
+    driver: the same metrics on every rank, and the assembled predictions file holds the same records in the same order.
+    backend "gloo": torch.distributed (the CPU harness); "tcp": the torch-free rendezvous hub as the transport — the path a
+    GPU run takes when the ranks agree that RCCL is not usable (distributed.init_transport)."""
     import plumbing_util as pu
     from memvul_amd import model_memory, predict_memory
 
@@ -56,9 +59,9 @@ def test_sharded_driver_world2_gloo_equals_single_process(tmp_path, monkeypatch)
     root, arch, golden, test_path, w, dims = fx
     out = str(tmp_path / "metrics.json")
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
-    port = 29820 + (os.getpid() % 150)
+    port = 29820 + (os.getpid() % 150) + (3 if backend == "tcp" else 0)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.join(ROOT, "tests", "dist_driver_worker.py"), root, arch, golden, test_path, out]
+           "--master-port", str(port), os.path.join(ROOT, "tests", "dist_driver_worker.py"), root, arch, golden, test_path, out, backend]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=420)
     assert r.returncode == 0, r.stderr[-3000:]
     m0, m1 = json.load(open(out + ".rank0")), json.load(open(out + ".rank1"))
@@ -84,8 +87,9 @@ def test_sharded_driver_world2_gloo_equals_single_process(tmp_path, monkeypatch)
 
 
 def test_tcp_fallback_transport_world3(tmp_path):
-    """The socket-hub fallback of the RCCL transport (distributed.init_tcp; bench.py uses it when mv_comm_init fails): three
-    torch-free processes, ragged row blocks — every rank gets the rank-ordered concatenation, the maximum and the statistics."""
+    """The rendezvous hub as the transport (distributed.init_transport(prefer="tcp"); what every rank falls back to TOGETHER when
+    RCCL is not usable on all of them): three torch-free processes, ragged row blocks — every rank gets the rank-ordered
+    concatenation, the maximum and the statistics."""
     world, port, out = 3, 30100 + (os.getpid() % 500), str(tmp_path / "tcp")
     procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "tcp_worker.py"), str(r), str(world), str(port), out],
                               stderr=subprocess.PIPE, text=True) for r in range(world)]
@@ -98,3 +102,73 @@ def test_tcp_fallback_transport_world3(tmp_path):
         assert np.array_equal(np.array(res["rows"], np.float32), want_rows)
         assert res["max"] == world - 0.5
         assert res["scores"] == [0.0, 0.5, 0.25, 0.5, 0.5, 0.5] and res["labels"] == [0, 1, 1, 1, 0, 1]
+
+
+def test_hub_rejects_strangers_and_bad_ranks():
+    """the hub used to accept any connection and to index by whatever rank it was told.  The handshake now carries
+    the rank and a run token: a stray connection, a wrong token and an out-of-range rank are dropped while the hub keeps
+    waiting for the real rank."""
+    import socket
+    import threading
+
+    port = 30700 + (os.getpid() % 300)
+    box = {}
+    os.environ["MEMVUL_RUN_TOKEN"] = "hub-test"
+    try:
+        t = threading.Thread(target=lambda: box.setdefault("hub", mvdist._Hub(0, 2, "127.0.0.1", port, timeout_s=30.0)))
+        t.start()
+        tok = mvdist.run_token()
+
+        def knock(payload):
+            for _ in range(200):
+                try:
+                    c = socket.create_connection(("127.0.0.1", port), timeout=2.0)
+                    break
+                except OSError:
+                    import time
+                    time.sleep(0.02)
+            c.sendall(payload)
+            return c
+
+        knock(b"GET / HTTP/1.0\r\n\r\n______")                     # a stranger
+        knock((1).to_bytes(4, "little") + b"x" * 16)                   # right rank, wrong token
+        knock((7).to_bytes(4, "little") + tok)                         # token ok, rank out of range
+        good = mvdist._Hub(1, 2, "127.0.0.1", port, timeout_s=30.0)   # the real rank 1
+        t.join(timeout=30)
+        assert "hub" in box and len(box["hub"].peers) == 1
+        out = {}
+        t2 = threading.Thread(target=lambda: out.setdefault("r0", box["hub"].comm_allgather(np.array([5], np.int32))))
+        t2.start()
+        r1 = good.comm_allgather(np.array([9], np.int32))
+        t2.join(timeout=10)
+        assert r1.ravel().tolist() == [5, 9] and out["r0"].ravel().tolist() == [5, 9]
+        good.comm_destroy(); box["hub"].comm_destroy()
+    finally:
+        os.environ.pop("MEMVUL_RUN_TOKEN", None)
+
+
+def test_bench_two_ranks_control_flow_and_json_contract(tmp_path):
+    """the REAL bench.py under `torch.distributed.run --nproc-per-node 2` with a numpy stand-in engine
+    (MEMVUL_BENCH_STUB_ENGINE; no GPU, not a measurement): rendezvous, agreed transport, barrier + max-over-ranks timing, the
+    corpus-shard leg with its ONE all-gather, and the N > 1 fields of the one JSON line rank 0 prints."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1", MEMVUL_BENCH_STUB_ENGINE="1")
+    port = 30400 + (os.getpid() % 200)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2", "--batch", "32",
+           "--seq-len", "64", "--anchors", "8", "--anchor-len", "64", "--layers", "1", "--shard-irs", "700"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]              # ONE line, from rank 0
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config"):
+        assert k in d, k
+    assert d["n_gpus"] == 2 and d["steps"] == 6 and d["warmup"] == 2 and d["scaling"] == "weak" and d["higher_is_better"] is True
+    assert d["value"] == pytest.approx(2 * 6 * 32 / (d["ms_per_step"] * 6e-3), rel=1e-3)   # whole-job aggregate over both ranks
+    assert d["data"] == "stub" and "NO GPU" in d["config"]["note"]
+    assert d["config"]["stats_transport"].startswith("tcp hub") and d["config"]["global_batch"] == 64
+    assert d["stats_table_sum"] == 2 * 8 * 32 * 40       # both ranks' (score, label) rows reached rank 0: 40 thresholds x rows
+    sh = d["corpus_shard"]
+    assert sh["irs_per_rank"] == 700 and sh["irs_total"] == 1400 and sh["allgather_bytes_per_rank"] == 5600
+    assert 0 < sh["scaling_vs_sum_of_ranks"] <= 1.0 + 1e-6 and sh["fixed_overhead_frac"] < 0.5
+    assert "cpu_baseline" not in d and "precise" not in d  # rank-0, N = 1 only
