@@ -18,24 +18,26 @@ typedef float floatx16 __attribute__((ext_vector_type(16)));
 #define MV_WAVE 64
 
 // ---- MV_F16X8 planes: OCP e4m3 of x 2^MV_X8_ACT_SHIFT (hi8) and of (x - fp16(x)) 2^(11 + MV_X8_ACT_SHIFT) (lo8).
-// v_cvt_pk_fp8_f32 does not saturate (overflow -> NaN): clamp to the format's +-448 first (what hip_fp8.h does too).
-// Activations use ONE static shift: |x| up to 112 keeps its hi8 / lo8 exact-range; larger values only lose the
-// correction term of that element (graceful: fp16-level accuracy there).
+// v_cvt_scalef32_pk_fp8_f32 converts src / scale (the power of two rides in the instruction: no multiply) but, like
+// v_cvt_pk_fp8_f32, does NOT saturate — overflow gives NaN (tools/cvt_fp8_probe.hip on the MI355X; hip_fp8.h clamps too) —
+// so each value is clamped to the format's +-448 / 2^shift first.  Activations use ONE static shift: |x| up to 112 keeps
+// its hi8 / lo8 in range; larger values only lose the correction term of that element (graceful: fp16-level accuracy there).
 #define MV_X8_ACT_SHIFT 2
-__device__ __forceinline__ uint32_t pack_fp8x4(float a, float b, float c, float d) {
-  a = __builtin_amdgcn_fmed3f(a, -448.f, 448.f); b = __builtin_amdgcn_fmed3f(b, -448.f, 448.f);
-  c = __builtin_amdgcn_fmed3f(c, -448.f, 448.f); d = __builtin_amdgcn_fmed3f(d, -448.f, 448.f);
-  int v = 0;
-  v = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, v, false);
-  v = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, v, true);
-  return (uint32_t)v;
+typedef short shortx2_t __attribute__((ext_vector_type(2)));
+// four values -> one dword of e4m3(v / scale), each value clamped to +-bound (= 448 scale) first
+__device__ __forceinline__ uint32_t pack_fp8x4_scaled(float a, float b, float c, float d, float scale, float bound) {
+  a = __builtin_amdgcn_fmed3f(a, -bound, bound); b = __builtin_amdgcn_fmed3f(b, -bound, bound);
+  c = __builtin_amdgcn_fmed3f(c, -bound, bound); d = __builtin_amdgcn_fmed3f(d, -bound, bound);
+  shortx2_t v = {0, 0};
+  v = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(v, a, b, scale, false);
+  v = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(v, c, d, scale, true);
+  return __builtin_bit_cast(uint32_t, v);
 }
 // four consecutive values -> (hi8 dword, lo8 dword)
 __device__ __forceinline__ void x8_planes4(float v0, float v1, float v2, float v3, uint32_t& hi8, uint32_t& lo8) {
-  constexpr float SH = (float)(1 << MV_X8_ACT_SHIFT), SL = (float)(2048 << MV_X8_ACT_SHIFT);
-  hi8 = pack_fp8x4(v0 * SH, v1 * SH, v2 * SH, v3 * SH);
-  lo8 = pack_fp8x4((v0 - (float)(half_t)v0) * SL, (v1 - (float)(half_t)v1) * SL, (v2 - (float)(half_t)v2) * SL,
-                   (v3 - (float)(half_t)v3) * SL);
+  constexpr float SH = 1.0f / (float)(1 << MV_X8_ACT_SHIFT), SL = 1.0f / (float)(2048 << MV_X8_ACT_SHIFT);
+  hi8 = pack_fp8x4_scaled(v0, v1, v2, v3, SH, 448.f * SH);
+  lo8 = pack_fp8x4_scaled(v0 - (float)(half_t)v0, v1 - (float)(half_t)v1, v2 - (float)(half_t)v2, v3 - (float)(half_t)v3, SL, 448.f * SL);
 }
 
 // Sum / max over the 64 lanes of a wave (all lanes receive the result).
