@@ -28,36 +28,30 @@
 //     iteration the 256 concurrent tiles are consecutive in it and each XCD takes a contiguous run of 32 (the
 //     group's W panels stay in that XCD's L2 while it sweeps the A row panels).
 //
-// Three kernel kinds (the encoder layer's four GEMMs; everything else the round-1/2 builds carried — fp32-stream
-// epilogues, the two-barrier schedule, timing ablations — lives in tools/legacy/ with its A/B records in profiles/):
+// Three kernel kinds (the encoder layer's four GEMMs; what rounds 1-2 also carried — fp32-stream epilogues, the two-barrier
+// schedule, timing ablations — lives in tools/legacy/ with its A/B records in profiles/):
 //   PP_QK   (RAW)  Q, K (head-major) and V^T in ONE launch: the V tiles go through the wave's LDS image transposed.
 //   PP_GELU (RAW)  FFN-1 + exact-erf GELU.
 //   PP_RESLN3      attention-output projection / FFN-2: + bias + LayerNorm(residual), in place on the raw stream.
 // "Virtual LayerNorm": no LayerNorm kernel between the GEMMs.  By linearity
 //   W LN(r) + b = rstd * (W'' r) + b',  W''[n][k] = W[n][k] gamma[k] - mean_k(W[n][.] gamma[.]),  b' = b + W beta
 // (the row mean of r drops out against the row-centred weights), so a RAW consumer takes the raw stream rounded to fp16 as
-// its A operand, the folded weights W'' (prepared once on the host), starts its accumulators from zero and applies
-// fma(rstd_row, acc, b'_col) in the epilogue; the 256 rows' statistics of the workgroup's next tile arrive by six LDS-DMA
-// pieces (and its 256 bias' values by a seventh) into 2 x 6 KiB (2 x 1 KiB) images.  The producer (PP_RESLN3) normalises
-// the residual tile it loads anyway (fma((x - mean) rstd, gamma, beta) + bias while initialising the accumulators) and
-// writes the new raw stream as TWO fp16 planes  hi = fp16(r)  (exactly the operand the RAW consumers read),
-// lo = fp16(r - hi)  (r ~= hi + lo to 2^-22 relative) plus the rows' "vstats": per row and 256-column tile the
-// (sum, sum of squares), the four column waves' shares added in wave order through LDS; every consumer turns the three
-// pairs of a row into (mean, rstd) itself (common.h ln_from_partials).
+// its A operand and the folded weights W'' (prepared once on the host), starts its accumulators from zero and applies
+// fma(rstd_row, acc, b'_col) in the epilogue; its next tile's row statistics and bias' arrive by seven LDS-DMA pieces.  The
+// producer (PP_RESLN3) normalises the residual tile it loads anyway while initialising the accumulators and writes the new raw
+// stream as TWO fp16 planes  hi = fp16(r)  (the operand of the RAW consumers),  lo = fp16(r - hi)  (r ~= hi + lo to 2^-22)
+// plus the rows' "vstats": per row and 256-column tile the (sum, sum of squares); every consumer turns the three pairs of a
+// row into (mean, rstd) itself (common.h ln_from_partials).
 //
 // X8 = 1 (compute dtype MV_F16X8, "precise"): every GEMM adds a SECOND sweep on the fp8 matrix path into the same fp32
-// accumulators,
-//   A W  ~=  A_hi W_hi  +  2^-s ( A_lo8 W_hi8 + A_hi8 W_lo8 ),     A_hi = fp16(A), A_lo8 = e4m3((A - A_hi) 2^(11 + sa)),
-//   A_hi8 = e4m3(A_hi 2^sa), W likewise with its own shift sw, s = 11 + sa + sw,
-// i.e. the two first-order correction terms of the split-operand product, which only need ~4 significant bits, run as ONE
-// v_mfma_scale_f32_32x32x64_f8f6f4 sweep (OCP e4m3, uniform E8M0 scales = the exact power of two 2^-s) over a virtual K of
-// 2 K elements: the fp8 operands are stored as rows [lo8 (K bytes) | hi8 (K bytes)] for A and [hi8 | lo8] for W, so row
-// pitch (2 K bytes), K-tile width (128 bytes) and K-tile count (K / 64) equal the fp16 sweep's and the staging code is
-// shared; an fp8 K-tile covers 128 products per row pair in the matrix-pipe time the fp16 tile needs for 64.  Cost: 2x
-// the main loop (a three-sweep fp16 split is 3x); error: operand rounding 2^-12 -> ~2^-15.5 (oracle/precision_model.py
-// "f16x8": 3.4e-4 on the trained-like logits against 2.5e-3 for MV_F16 — the same as the full 22-bit split, because
-// Q, K, V and P stay fp16).  The producing epilogues (PP_GELU, PP_RESLN3; embedding and attention kernels) write the
-// [lo8 | hi8] planes of their outputs next to the fp16 ones.
+// accumulators:  A W ~= A_hi W_hi + 2^-s (A_lo8 W_hi8 + A_hi8 W_lo8),  A_hi = fp16(A), A_lo8 = e4m3((A - A_hi) 2^(11 + sa)),
+// A_hi8 = e4m3(A_hi 2^sa), W likewise with its own shift sw, s = 11 + sa + sw — the first-order correction terms of the
+// split-operand product, which only need ~4 significant bits, as ONE v_mfma_scale_f32_32x32x64_f8f6f4 sweep (OCP e4m3, uniform
+// E8M0 scales = the exact power of two 2^-s) over a virtual K of 2 K: the fp8 operands are rows [lo8 (K bytes) | hi8 (K bytes)]
+// for A and [hi8 | lo8] for W, so row pitch (2 K bytes), K-tile width (128 bytes) and K-tile count (K / 64) equal the fp16
+// sweep's and the staging code is shared; an fp8 K-tile covers 128 products per row pair in the matrix-pipe time the fp16
+// tile needs for 64.  Cost: 2x the main loop (a three-sweep fp16 split: 3x); error: operand rounding 2^-12 -> ~2^-15.5
+// (oracle/precision_model.py "f16x8").  The producers (PP_GELU, PP_RESLN3; embedding, attention) write the [lo8 | hi8] planes.
 #pragma once
 #include "common.h"
 #include <type_traits>
@@ -101,9 +95,8 @@ typedef int intx8 __attribute__((ext_vector_type(8)));
 // 3.6 us per 256^2 tile).  Through the image each store covers 16 rows x 64 contiguous bytes.  Inline asm keeps
 // these LDS accesses out of hipcc's LDS-DMA alias bookkeeping (it would put `s_waitcnt vmcnt(0)` before them and
 // wait for the epilogue's own stores); LDS executes a wave's instructions in order, so the read-after-write
-// needs no wait, only the read results do (same statement, guide §5.7 form i).
-// Two fp16 fragments (j = 0, 1) per statement: LDS executes a wave's instructions in order, so the second
-// fragment's writes may follow the first one's reads into the same image without a wait in between.
+// needs no wait, only the read results do (same statement, guide §5.7 form i).  Two fp16 fragments (j = 0, 1) per statement:
+// the second fragment's writes may follow the first one's reads into the same image without a wait in between.
 __device__ __forceinline__ void scr_f16x2(uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3, const u32x2 (&da)[4],
                                           const u32x2 (&db)[4], uint32_t r, u32x4 (&o)[4]) {
 #if defined(__HIP_DEVICE_COMPILE__)
