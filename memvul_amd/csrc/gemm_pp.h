@@ -74,9 +74,7 @@ constexpr int PP_F = 4;  // half-tiles kept in flight across each barrier
 #define PP_LDS_BYTES_RAW (PP_LDS_RSTD + 2048)      // 163,840 = all of the CU's LDS
 
 __device__ __forceinline__ uint32_t pack_h2(float a, float b) {
-  half2_t h;
-  h[0] = (half_t)a;
-  h[1] = (half_t)b;
+  const half2_t h = {(half_t)a, (half_t)b};
   return __builtin_bit_cast(uint32_t, h);
 }
 
@@ -488,7 +486,6 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmArgs a) {
     int next_m = 0, next_n = 0;  // RAW: the workgroup's next tile (issue_stats); PP_RESLN3: its residual tile is requested
     const bool has_next = L + G < ntiles;  // during this tile's epilogue
     if (has_next) raster(L + G, tm_count, tn_count, a.GN, next_m, next_n);
-    (void)next_m; (void)next_n; (void)has_next;
     const int mw = (tile_m << 8) + wr * 128;  // first token row of this wave
     const int nw = (tile_n << 8) + wc * 64;   // first output column of this wave
 
@@ -561,11 +558,10 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmArgs a) {
               acc[i][j][4 * g + 0] = 0.f; acc[i][j][4 * g + 1] = 0.f; acc[i][j][4 * g + 2] = 0.f; acc[i][j][4 * g + 3] = 0.f;
             }
       }
-      (void)baddr; (void)scr_c; (void)sf;
     }
 
     if constexpr (decltype(grpc)::value == 0) read_set(std::integral_constant<int, 0>{});
-    auto two_ktiles = [&](auto f8c, int kt, bool last) {
+    auto two_ktiles = [&](auto f8c, bool last) {
       interval(std::integral_constant<int, 0>{}, grpc, f8c);
       interval(std::integral_constant<int, 1>{}, grpc, f8c);
       interval(std::integral_constant<int, 2>{}, grpc, f8c);
@@ -574,7 +570,6 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmArgs a) {
       interval(std::integral_constant<int, 5>{}, grpc, f8c);
       interval(std::integral_constant<int, 6>{}, grpc, f8c);
       interval(std::integral_constant<int, 7>{}, grpc, f8c, last);
-      (void)kt;
     };
     for (int kt = 0; kt < nk0; kt += 2) {
       if constexpr (RAW) {  // every wave has left the previous tile's epilogue (>= 8 barriers ago): its stats image is free
@@ -596,10 +591,10 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmArgs a) {
           }
         }
       }
-      two_ktiles(std::false_type{}, kt, !X8 && kt + 2 >= nk0);
+      two_ktiles(std::false_type{}, !X8 && kt + 2 >= nk0);
     }
     if constexpr (X8) {  // the correction sweep: the same intervals on the fp8 matrix path
-      for (int kt = nk0; kt < nk; kt += 2) two_ktiles(std::true_type{}, kt, kt + 2 >= nk);
+      for (int kt = nk0; kt < nk; kt += 2) two_ktiles(std::true_type{}, kt + 2 >= nk);
     }
 
     // ---- epilogue (store only): every 32x32 fragment goes through the wave's [32][64 B] LDS image
@@ -706,7 +701,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmArgs a) {
               : "memory");
           __builtin_amdgcn_sched_barrier(0);
         }
-        (void)rbv; (void)rrs; (void)wbase8;
+        (void)wbase8;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           const int mb = mw + i * 32;
