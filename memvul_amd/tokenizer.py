@@ -120,6 +120,14 @@ class PretrainedTransformerTokenizer(Tokenizer):
     def _hash_encode_many(self, texts: List[str]) -> List[List[int]]:
         return [self._hash_encode(t) for t in texts]
 
+    def batch_tokenize(self, texts: List[str]) -> List[List[Token]]:
+        """``[tokenize(t) for t in texts]`` with ONE call into the tokenizer backend (same tokens, same ids)."""
+        ids, lens = self.batch_ids(texts)
+        rows = [ids[i, :lens[i]].tolist() for i in range(len(texts))]
+        if self._hf is not None:
+            return [[Token(t, i, 0) for t, i in zip(self._hf.convert_ids_to_tokens(r), r)] for r in rows]
+        return [[Token(str(i), i, 0) for i in r] for r in rows]
+
     def tokenize(self, text: str) -> List[Token]:
         if self._hf is not None:
             enc = self._hf(text, add_special_tokens=self._add_special, truncation=self._max_length is not None,
