@@ -60,7 +60,9 @@ typedef struct mv_config {
   int32_t intermediate; /* 3072 (must be 3072) */
   int32_t max_pos;      /* 512 */
   int32_t type_vocab;   /* 2 */
-  int32_t proj_dim;     /* 512  (must be 512; FeedForward(768,1,[512],ReLU), model_memory.py:70) */
+  int32_t proj_dim;     /* 512: the header output (FeedForward(768,1,[512],ReLU), model_memory.py:70; use_header = true, every reference
+                         * config) — or 768: use_header = false (l.69-73): no `_projector_single`, the embedding is the pooler output
+                         * and `_projector.weight` is [2, 3 * 768] */
   float ln_eps;         /* 1e-12 */
   int32_t max_tokens;   /* capacity of one forward in padded tokens, B * Sp (Sp = S rounded up to 64, above 256 to 128) */
   int32_t max_batch;    /* capacity of one forward in issue reports */

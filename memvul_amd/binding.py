@@ -130,9 +130,12 @@ class Engine:
 
     def __init__(self, device: int = 0, *, vocab_size: int = 30522, layers: int = 12, max_pos: int = 512,
                  type_vocab: int = 2, ln_eps: float = 1e-12, max_tokens: int = 65536, max_batch: int = 512,
-                 max_anchors: int = 1024, same_idx: int = 0):
+                 max_anchors: int = 1024, same_idx: int = 0, proj_dim: int = 512):
+        """proj_dim: width of the embedding the matcher runs on — 512 (the header output: use_header=True, every reference
+        config) or 768 (use_header=False: the pooler output, no ``_projector_single`` in the state dict)."""
         self._lib = load_library()
-        self.cfg = MvConfig(vocab_size, 768, layers, 12, 3072, max_pos, type_vocab, 512, ln_eps, max_tokens,
+        self.P = int(proj_dim)
+        self.cfg = MvConfig(vocab_size, 768, layers, 12, 3072, max_pos, type_vocab, self.P, ln_eps, max_tokens,
                             max_batch, max_anchors, same_idx)
         h = C.c_void_p()
         rc = self._lib.mv_create(device, C.byref(self.cfg), C.byref(h))
@@ -197,12 +200,17 @@ class Engine:
         return int(self._lib.mv_anchor_count(self._h))
 
     def anchor_get(self) -> np.ndarray:
-        out = np.empty((self.n_anchors, 512), np.float32)
+        out = np.empty((self.n_anchors, self.P), np.float32)
         self._check(self._lib.mv_anchor_get(self._h, _ptr(out)), "mv_anchor_get")
         return out
 
+    def _check_width(self, a: np.ndarray, what: str):
+        if a.ndim != 2 or a.shape[1] != self.P:
+            raise ValueError(f"{what}: expected [n, {self.P}] embeddings (mv_config.proj_dim), got {a.shape}")
+
     def anchor_set(self, v: np.ndarray):
         v = _as(v, np.float32)
+        self._check_width(v, "anchor_set")
         self._check(self._lib.mv_anchor_set(self._h, _ptr(v), v.shape[0]), "mv_anchor_set")
 
     # -- hot loop
@@ -214,19 +222,20 @@ class Engine:
         probs = np.empty((B, G, 2), np.float32) if want_probs else None
         best = np.empty((B, 2), np.float32)
         idx = np.empty((B,), np.int32)
-        embed = np.empty((B, 512), np.float32) if want_embed else None
+        embed = np.empty((B, self.P), np.float32) if want_embed else None
         self._check(self._lib.mv_forward(self._h, _ptr(ids), _ptr(lens), B, S, _ptr(logits), _ptr(probs), _ptr(best),
                                          _ptr(idx), _ptr(embed)), "mv_forward")
         return {"logits": logits, "probs": probs, "best": best, "best_idx": idx, "embed": embed}
 
     def encode(self, ids: np.ndarray, lens: np.ndarray) -> np.ndarray:
         ids, lens = _as(ids, np.int32), _as(lens, np.int32)
-        out = np.empty((ids.shape[0], 512), np.float32)
+        out = np.empty((ids.shape[0], self.P), np.float32)
         self._check(self._lib.mv_encode(self._h, _ptr(ids), _ptr(lens), ids.shape[0], ids.shape[1], _ptr(out)), "mv_encode")
         return out
 
     def match(self, u: np.ndarray):
         u = _as(u, np.float32)
+        self._check_width(u, "match")
         B, G = u.shape[0], self.n_anchors
         logits = np.empty((B, G, 2), np.float32)
         probs = np.empty((B, G, 2), np.float32)
@@ -237,6 +246,7 @@ class Engine:
 
     def topk(self, u: np.ndarray, k: int):
         u = _as(u, np.float32)
+        self._check_width(u, "topk")
         p = np.empty((u.shape[0], k), np.float32)
         i = np.empty((u.shape[0], k), np.int32)
         self._check(self._lib.mv_topk(self._h, _ptr(u), u.shape[0], k, _ptr(p), _ptr(i)), "mv_topk")
@@ -347,7 +357,7 @@ class Engine:
         shapes = {
             0: ((B, Sp, 768), np.float32), 1: ((B, Sp, 768), np.float16), 2: ((B, 12, Sp, 64), np.float16),
             3: ((B, 12, Sp, 64), np.float16), 4: ((B, 12, 64, Sp), np.float16), 5: ((B, Sp, 768), np.float16),
-            6: ((B, Sp, 3072), np.float16), 7: ((B, 512), np.float32),
+            6: ((B, Sp, 3072), np.float16), 7: ((B, self.P), np.float32),
         }
         shape, dt = shapes[buffer]
         out = np.empty(shape, dt)

@@ -152,6 +152,8 @@ struct mv_handle {
   float *wemb = nullptr, *pemb = nullptr, *temb = nullptr, *embg = nullptr, *embb = nullptr;
   std::vector<LayerW> L;
   float *WpT = nullptr, *bp = nullptr, *WhT = nullptr, *bh = nullptr, *Wm = nullptr;
+  int P = MV_PROJ;  // width of the embedding the matcher runs on: 512 = header output (use_header, every reference config),
+                    // 768 = the pooler output itself (use_header = False, model_memory.py:69-73): mv_config.proj_dim
 
   // workspaces: two sets, each with its own stream.  mv_corpus_run alternates the batches of a sweep between them,
   // so two batches are in flight on the GPU at once: the persistent kernels of one batch fill the CUs the other
@@ -351,8 +353,9 @@ int launch_small(mv_handle* h, int cls, const GemmArgs& a) {
 int pool_head(mv_handle* h, const float* x, size_t row_stride, int B, float* u_out) {
   const unsigned gx = (unsigned)((B + 31) / 32);
   hipLaunchKernelGGL(dense768_kernel<0>, dim3(gx, MV_HIDDEN / 32), dim3(512), 0, h->w->stream, x, row_stride, B, h->WpT, h->bp,
-                     MV_HIDDEN, h->w->pooled);
+                     MV_HIDDEN, h->P == MV_HIDDEN ? u_out : h->w->pooled);
   if (int rc = launch_check(h, "pooler")) return rc;
+  if (h->P == MV_HIDDEN) return MV_OK;  // use_header = False: the pooler output is the embedding
   hipLaunchKernelGGL(dense768_kernel<1>, dim3(gx, MV_PROJ / 32), dim3(512), 0, h->w->stream, h->w->pooled, (size_t)MV_HIDDEN, B, h->WhT,
                      h->bh, MV_PROJ, u_out);
   return launch_check(h, "header");
@@ -588,10 +591,13 @@ int match_dev(mv_handle* h, const float* u_dev, int B, float* logits, float* pro
   {
     ProfScope ps(h, KC_MATCH);
     const dim3 grid(small ? 1 : a.nchunk, (B + 3) / 4);
-    if (small && a.logits) hipLaunchKernelGGL((match_topk_kernel<2, 128, 64, 1, 2>), grid, dim3(256), 0, h->w->stream, u_dev, h->anchors, h->Wm, a);
-    else if (small) hipLaunchKernelGGL((match_topk_kernel<2, 128, 64, 0, 2>), grid, dim3(256), 0, h->w->stream, u_dev, h->anchors, h->Wm, a);
-    else if (a.logits) hipLaunchKernelGGL((match_topk_kernel<2, 256, 32, 1, 2>), grid, dim3(512), 0, h->w->stream, u_dev, h->anchors, h->Wm, a);
-    else hipLaunchKernelGGL((match_topk_kernel<2, 256, 32, 0, 2>), grid, dim3(512), 0, h->w->stream, u_dev, h->anchors, h->Wm, a);
+#define MV_MATCH(PD)                                                                                                                          \
+    if (small && a.logits) hipLaunchKernelGGL((match_topk_kernel<2, 128, 64, 1, 2, PD>), grid, dim3(256), 0, h->w->stream, u_dev, h->anchors, h->Wm, a); \
+    else if (small) hipLaunchKernelGGL((match_topk_kernel<2, 128, 64, 0, 2, PD>), grid, dim3(256), 0, h->w->stream, u_dev, h->anchors, h->Wm, a);        \
+    else if (a.logits) hipLaunchKernelGGL((match_topk_kernel<2, 256, 32, 1, 2, PD>), grid, dim3(512), 0, h->w->stream, u_dev, h->anchors, h->Wm, a);     \
+    else hipLaunchKernelGGL((match_topk_kernel<2, 256, 32, 0, 2, PD>), grid, dim3(512), 0, h->w->stream, u_dev, h->anchors, h->Wm, a)
+    if (h->P == MV_PROJ) { MV_MATCH(MV_PROJ); } else { MV_MATCH(MV_HIDDEN); }
+#undef MV_MATCH
     if (int rc = launch_check(h, "match_topk")) return rc;
   }
   if (a.nchunk > 1 && k > 0) {
@@ -756,8 +762,10 @@ const char* mv_kernel_class_name(int cls) {
 
 int mv_create(int device, const mv_config* cfg, mv_handle** out) {
   if (!cfg || !out) return fail(nullptr, MV_ERR_INVALID, "null argument");
-  if (cfg->hidden != MV_HIDDEN || cfg->heads != MV_HEADS || cfg->intermediate != MV_INTER || cfg->proj_dim != MV_PROJ)
-    return fail(nullptr, MV_ERR_INVALID, "kernels are specialised to hidden=768, heads=12, intermediate=3072, proj_dim=512");
+  if (cfg->hidden != MV_HIDDEN || cfg->heads != MV_HEADS || cfg->intermediate != MV_INTER ||
+      (cfg->proj_dim != MV_PROJ && cfg->proj_dim != MV_HIDDEN))
+    return fail(nullptr, MV_ERR_INVALID, "kernels are specialised to hidden=768, heads=12, intermediate=3072, proj_dim=512 (header) "
+                                         "or 768 (use_header = False: no header)");
   if (cfg->layers < 0 || cfg->vocab_size <= 0 || cfg->max_pos <= 0 || cfg->max_pos > 512 || cfg->max_tokens <= 0 ||
       cfg->max_batch <= 0 || cfg->max_anchors <= 0 || cfg->type_vocab <= 0 || (cfg->same_idx != 0 && cfg->same_idx != 1))
     return fail(nullptr, MV_ERR_INVALID, "bad mv_config field");
@@ -772,6 +780,7 @@ int mv_create(int device, const mv_config* cfg, mv_handle** out) {
   if (!h) return fail(nullptr, MV_ERR_NOMEM, "out of host memory");
   h->device = device;
   h->cfg = *cfg;
+  h->P = cfg->proj_dim;
   if (const char* ev = getenv("MEMVUL_STREAMS")) h->n_streams = h->n_alloc = (atoi(ev) == 1 ? 1 : 2);
   for (int wi = 0; wi < h->n_alloc; ++wi) {
     e = hipStreamCreateWithFlags(&h->work[wi].stream, hipStreamNonBlocking);
@@ -832,9 +841,9 @@ int mv_create(int device, const mv_config* cfg, mv_handle** out) {
     A(dev_alloc(h, &h->w->c16, Bp * MV_HIDDEN));
     A(dev_alloc(h, &h->w->cctx, Bp * MV_HIDDEN));
     A(dev_alloc(h, &h->w->ch16, Bp * MV_INTER));
-    A(dev_alloc(h, &h->w->u, (int64_t)cfg->max_batch * MV_PROJ));
+    A(dev_alloc(h, &h->w->u, (int64_t)cfg->max_batch * h->P));
     A(dev_alloc(h, &h->w->pooled, (int64_t)cfg->max_batch * MV_HIDDEN));
-    A(dev_alloc(h, &h->w->u_in, (int64_t)cfg->max_batch * MV_PROJ));
+    A(dev_alloc(h, &h->w->u_in, (int64_t)cfg->max_batch * h->P));
     A(dev_alloc(h, &h->w->logits, BG * 2));
     A(dev_alloc(h, &h->w->probs, BG * 2));
     A(dev_alloc(h, &h->w->psame, BG));
@@ -852,7 +861,7 @@ int mv_create(int device, const mv_config* cfg, mv_handle** out) {
     if (rc == MV_OK && hipStreamSynchronize(h->w->stream) != hipSuccess) rc = MV_ERR_HIP;
   }
   h->w = &h->work[0];
-  A(dev_alloc(h, &h->anchors, (int64_t)cfg->max_anchors * MV_PROJ));
+  A(dev_alloc(h, &h->anchors, (int64_t)cfg->max_anchors * h->P));
   if (rc == MV_OK && hipStreamSynchronize(h->w->stream) != hipSuccess) rc = MV_ERR_HIP;
   if (rc != MV_OK) {
     g_create_error = h->err.empty() ? "workspace allocation failed" : h->err;
@@ -1032,16 +1041,18 @@ int mv_finalize_weights(mv_handle* h, int compute_dtype) {
   }
   NEED("_bert_pooler.pooler.dense.bias", H);
   if ((rc = upload_f32(h, &h->bp, t->data.data(), H))) return rc;
-  NEED("_projector_single._linear_layers.0.weight", MV_PROJ, H);
-  {
-    std::vector<float> tr((size_t)(H * MV_PROJ));
-    for (int64_t n = 0; n < MV_PROJ; ++n) for (int64_t k = 0; k < H; ++k) tr[(size_t)(k * MV_PROJ + n)] = t->data[(size_t)(n * H + k)];
-    if ((rc = upload_f32(h, &h->WhT, tr.data(), H * MV_PROJ))) return rc;
+  if (h->P == MV_PROJ) {  // use_header (model_memory.py:69-71); with proj_dim = 768 the model has no _projector_single
+    NEED("_projector_single._linear_layers.0.weight", MV_PROJ, H);
+    {
+      std::vector<float> tr((size_t)(H * MV_PROJ));
+      for (int64_t n = 0; n < MV_PROJ; ++n) for (int64_t k = 0; k < H; ++k) tr[(size_t)(k * MV_PROJ + n)] = t->data[(size_t)(n * H + k)];
+      if ((rc = upload_f32(h, &h->WhT, tr.data(), H * MV_PROJ))) return rc;
+    }
+    NEED("_projector_single._linear_layers.0.bias", MV_PROJ);
+    if ((rc = upload_f32(h, &h->bh, t->data.data(), MV_PROJ))) return rc;
   }
-  NEED("_projector_single._linear_layers.0.bias", MV_PROJ);
-  if ((rc = upload_f32(h, &h->bh, t->data.data(), MV_PROJ))) return rc;
-  NEED("_projector.weight", 2, 3 * MV_PROJ);
-  if ((rc = upload_f32(h, &h->Wm, t->data.data(), 2 * 3 * MV_PROJ))) return rc;
+  NEED("_projector.weight", 2, 3 * (int64_t)h->P);
+  if ((rc = upload_f32(h, &h->Wm, t->data.data(), 2 * 3 * (int64_t)h->P))) return rc;
 #undef NEED
   if (precise) {  // fp8 planes [lo8 | hi8] of the three activations that are GEMM A operands
     if (h->gemm_tile == 128) return fail(h, MV_ERR_STATE, "MV_F16X8 runs on the persistent GEMM path: MEMVUL_GEMM_TILE=128 excludes it");
@@ -1083,7 +1094,7 @@ int mv_anchor_append(mv_handle* h, const int32_t* ids, const int32_t* lens, int 
     const int nb = (n - off < rows) ? (n - off) : rows;
     HIPCHK(h, hipMemcpyAsync(h->w->d_ids, ids + (size_t)off * S, (size_t)nb * S * 4, hipMemcpyHostToDevice, h->w->stream));
     HIPCHK(h, hipMemcpyAsync(h->w->d_lens, lens + off, (size_t)nb * 4, hipMemcpyHostToDevice, h->w->stream));
-    if (int rc = encode_dev(h, h->w->d_ids, h->w->d_lens, nb, S, -1, h->anchors + (size_t)(h->n_anchors + off) * MV_PROJ)) return rc;
+    if (int rc = encode_dev(h, h->w->d_ids, h->w->d_lens, nb, S, -1, h->anchors + (size_t)(h->n_anchors + off) * h->P)) return rc;
     HIPCHK(h, hipStreamSynchronize(h->w->stream));
   }
   h->n_anchors += n;
@@ -1092,7 +1103,7 @@ int mv_anchor_append(mv_handle* h, const int32_t* ids, const int32_t* lens, int 
 
 int mv_anchor_get(mv_handle* h, float* out) {
   if (!h || !out) return MV_ERR_INVALID;
-  HIPCHK(h, hipMemcpyAsync(out, h->anchors, (size_t)h->n_anchors * MV_PROJ * 4, hipMemcpyDeviceToHost, h->w->stream));
+  HIPCHK(h, hipMemcpyAsync(out, h->anchors, (size_t)h->n_anchors * h->P * 4, hipMemcpyDeviceToHost, h->w->stream));
   HIPCHK(h, hipStreamSynchronize(h->w->stream));
   return MV_OK;
 }
@@ -1100,7 +1111,7 @@ int mv_anchor_get(mv_handle* h, float* out) {
 int mv_anchor_set(mv_handle* h, const float* v, int G) {
   if (!h || !v || G <= 0) return fail(h, MV_ERR_INVALID, "mv_anchor_set: bad argument");
   if (G > h->cfg.max_anchors) return fail(h, MV_ERR_CAPACITY, "anchor bank capacity (mv_config.max_anchors) exceeded");
-  HIPCHK(h, hipMemcpyAsync(h->anchors, v, (size_t)G * MV_PROJ * 4, hipMemcpyHostToDevice, h->w->stream));
+  HIPCHK(h, hipMemcpyAsync(h->anchors, v, (size_t)G * h->P * 4, hipMemcpyHostToDevice, h->w->stream));
   HIPCHK(h, hipStreamSynchronize(h->w->stream));
   h->n_anchors = G;
   return MV_OK;
@@ -1118,7 +1129,7 @@ int mv_encode(mv_handle* h, const int32_t* ids, const int32_t* lens, int B, int 
     HIPCHK(h, hipMemcpyAsync(h->w->d_ids, ids + (size_t)off * S, (size_t)nb * S * 4, hipMemcpyHostToDevice, h->w->stream));
     HIPCHK(h, hipMemcpyAsync(h->w->d_lens, lens + off, (size_t)nb * 4, hipMemcpyHostToDevice, h->w->stream));
     if (int rc = encode_dev(h, h->w->d_ids, h->w->d_lens, nb, S, -1, h->w->u)) return rc;
-    if (embed) HIPCHK(h, hipMemcpyAsync(embed + (size_t)off * MV_PROJ, h->w->u, (size_t)nb * MV_PROJ * 4, hipMemcpyDeviceToHost, h->w->stream));
+    if (embed) HIPCHK(h, hipMemcpyAsync(embed + (size_t)off * h->P, h->w->u, (size_t)nb * h->P * 4, hipMemcpyDeviceToHost, h->w->stream));
     HIPCHK(h, hipStreamSynchronize(h->w->stream));
   }
   return MV_OK;
@@ -1147,7 +1158,7 @@ int mv_forward(mv_handle* h, const int32_t* ids, const int32_t* lens, int B, int
     if (probs) HIPCHK(h, hipMemcpyAsync(probs + (size_t)off * G * 2, h->w->probs, bg * 8, hipMemcpyDeviceToHost, h->w->stream));
     if (best) HIPCHK(h, hipMemcpyAsync(best + (size_t)off * 2, h->w->best, (size_t)nb * 8, hipMemcpyDeviceToHost, h->w->stream));
     if (best_idx) HIPCHK(h, hipMemcpyAsync(best_idx + off, h->w->best_idx, (size_t)nb * 4, hipMemcpyDeviceToHost, h->w->stream));
-    if (embed) HIPCHK(h, hipMemcpyAsync(embed + (size_t)off * MV_PROJ, h->w->u, (size_t)nb * MV_PROJ * 4, hipMemcpyDeviceToHost, h->w->stream));
+    if (embed) HIPCHK(h, hipMemcpyAsync(embed + (size_t)off * h->P, h->w->u, (size_t)nb * h->P * 4, hipMemcpyDeviceToHost, h->w->stream));
     HIPCHK(h, hipStreamSynchronize(h->w->stream));
   }
   return MV_OK;
@@ -1159,7 +1170,7 @@ int mv_match(mv_handle* h, const float* u, int B, float* logits, float* probs, f
   if (B > h->cfg.max_batch) return fail(h, MV_ERR_CAPACITY, "B exceeds mv_config.max_batch");
   HIPCHK(h, hipSetDevice(h->device));
   const int G = h->n_anchors;
-  HIPCHK(h, hipMemcpyAsync(h->w->u_in, u, (size_t)B * MV_PROJ * 4, hipMemcpyHostToDevice, h->w->stream));
+  HIPCHK(h, hipMemcpyAsync(h->w->u_in, u, (size_t)B * h->P * 4, hipMemcpyHostToDevice, h->w->stream));
   if (int rc = match_dev(h, h->w->u_in, B, logits ? h->w->logits : nullptr, probs ? h->w->probs : nullptr, nullptr, 1, h->w->best,
                          h->w->best_idx)) return rc;
   const size_t bg = (size_t)B * G;
@@ -1177,7 +1188,7 @@ int mv_topk(mv_handle* h, const float* u, int B, int k, float* topk_p, int32_t* 
   if (B > h->cfg.max_batch) return fail(h, MV_ERR_CAPACITY, "B exceeds mv_config.max_batch");
   if (k > h->n_anchors) return fail(h, MV_ERR_INVALID, "k exceeds the number of anchors");
   HIPCHK(h, hipSetDevice(h->device));
-  HIPCHK(h, hipMemcpyAsync(h->w->u_in, u, (size_t)B * MV_PROJ * 4, hipMemcpyHostToDevice, h->w->stream));
+  HIPCHK(h, hipMemcpyAsync(h->w->u_in, u, (size_t)B * h->P * 4, hipMemcpyHostToDevice, h->w->stream));
   // one fused pass: P(same) [B, G] never reaches HBM, only 8 B k bytes of results do
   if (int rc = match_dev(h, h->w->u_in, B, nullptr, nullptr, nullptr, k, nullptr, nullptr, h->w->topk_p, h->w->topk_idx)) return rc;
   HIPCHK(h, hipMemcpyAsync(topk_p, h->w->topk_p, (size_t)B * k * 4, hipMemcpyDeviceToHost, h->w->stream));
@@ -1422,7 +1433,7 @@ int mv_debug_read(mv_handle* h, int buffer, void* dst, int64_t bytes) {
     case 4: src = h->w->vt; avail = T * MV_HIDDEN * 2; break;
     case 5: src = h->w->ctx; avail = T * MV_HIDDEN * 2; break;
     case 6: src = h->w->h16; avail = T * MV_INTER * 2; break;
-    case 7: src = h->w->u; avail = (int64_t)h->dbg_B * MV_PROJ * 4; break;
+    case 7: src = h->w->u; avail = (int64_t)h->dbg_B * h->P * 4; break;
     default: return fail(h, MV_ERR_INVALID, "mv_debug_read: unknown buffer");
   }
   if (bytes > avail) return fail(h, MV_ERR_INVALID, "mv_debug_read: more bytes requested than the buffer holds");

@@ -160,11 +160,13 @@ __device__ __forceinline__ void mk_merge_row_any(const MatchArgs& a, int b, int 
 // Measured (tools/match_probe.hip, profiles/r02_i_match_probe.txt): B = 256, G = 124: 15.7 us (round 1: 43 + 6; start of
 // round 2: 24); B = 256, G = 1000, k = 10: 24.7 + 5.0 us merge (round 1: 73 + 11; start of round 2: 42 + 13).  What the
 // probe's in-kernel stamps and ablations ruled out on the way is recorded at the main loop below.
-template <int RB, int GC, int MI, int LOGITS, int RW>
+// P = the embedding width the matcher runs on: 512 (header output, every reference config) or 768 (use_header = False: the
+// pooler output itself, model_memory.py:69-73).
+template <int RB, int GC, int MI, int LOGITS, int RW, int P = MV_PROJ>
 __global__ __launch_bounds__(GC * RW) void match_topk_kernel(const float* __restrict__ u, const float* __restrict__ v,
                                                          const float* __restrict__ Wm, MatchArgs a) {
   constexpr int AW = GC / 64, NW = AW * RW, NT = 64 * NW, NR = RW * RB, STRIDE = MI + 4;  // row stride = 4 mod 64 floats: conflict-free b128
-  static_assert((NW == 4 || NW == 8) && (MI % 4) == 0 && MV_PROJ % MI == 0 && (GC * MI / 4) % NT == 0, "wave split");
+  static_assert((NW == 4 || NW == 8) && (MI % 4) == 0 && P % MI == 0 && (GC * MI / 4) % NT == 0, "wave split");
   __shared__ __attribute__((aligned(16))) float sv[GC * STRIDE];      // anchor chunk x MI features; later P(same) / P(other) [2][NR][GC]
   // Two classes: the probabilities depend only on delta = logit_0 - logit_1, so the loop accumulates ONE chain per (row, anchor)
   // with the class-difference weights (2 instructions per (row, feature) instead of 3); the class-0 chain is added only when the
@@ -172,7 +174,7 @@ __global__ __launch_bounds__(GC * RW) void match_topk_kernel(const float* __rest
   // wave-uniform operands, interleaved per feature quad: [W_b delta | W_c delta | W_b[0] | W_c[0] | u_0 | .. | u_{NR-1}] x float4,
   // so that one base address + immediate offsets serve every read of a step
   constexpr int XQ = 4 + NR;
-  __shared__ __attribute__((aligned(16))) float sx[(MV_PROJ / 4) * XQ * 4];
+  __shared__ __attribute__((aligned(16))) float sx[(P / 4) * XQ * 4];
   __shared__ float sa[NR][2];                                         // (W_a[0] - W_a[1]) . u_r, W_a[0] . u_r
   static_assert(2 * NR * GC <= GC * STRIDE, "P(same) / P(other) reuse the staging buffer");
   const int tid = threadIdx.x, lane = tid & 63;
@@ -193,7 +195,7 @@ __global__ __launch_bounds__(GC * RW) void match_topk_kernel(const float* __rest
     /* rows past G read the last anchor (never ranked, never stored): an `in range ? load : 0` select makes hipcc */ \
     /* branch around every load and wait for each in turn (cdna_hip_programming.md §5 trap (c))                    */ \
     const int gr = g0 + r < a.G ? g0 + r : a.G - 1;                                                               \
-    stage[ST][j] = *(const mk_f4*)(v + (size_t)gr * MV_PROJ + (I0) + 4 * c4);                                    \
+    stage[ST][j] = *(const mk_f4*)(v + (size_t)gr * P + (I0) + 4 * c4);                                    \
   }
 #define MK_STORE_CHUNK(ST)                                                                                        \
   _Pragma("unroll") for (int j = 0; j < NST; ++j) {                                                               \
@@ -202,17 +204,17 @@ __global__ __launch_bounds__(GC * RW) void match_topk_kernel(const float* __rest
   }
   MK_LOAD_CHUNK(0, 0)
   MK_LOAD_CHUNK(1, MI)
-  for (int e = tid; e < NR * (MV_PROJ / 4); e += NT) {  // rows past B repeat the last valid one; never stored
-    const int r = e / (MV_PROJ / 4), c4 = e % (MV_PROJ / 4);
+  for (int e = tid; e < NR * (P / 4); e += NT) {  // rows past B repeat the last valid one; never stored
+    const int r = e / (P / 4), c4 = e % (P / 4);
     const int b = b0 + r < a.B ? b0 + r : a.B - 1;
-    *(float4*)(sx + (c4 * XQ + 4 + r) * 4) = *(const float4*)(u + (size_t)b * MV_PROJ + 4 * c4);
+    *(float4*)(sx + (c4 * XQ + 4 + r) * 4) = *(const float4*)(u + (size_t)b * P + 4 * c4);
   }
-  for (int e = tid; e < 4 * (MV_PROJ / 4); e += NT) {  // slots: W_b delta, W_c delta, W_b[0], W_c[0]  (delta = class 0 - class 1)
-    const int c = e / (MV_PROJ / 4), c4 = e % (MV_PROJ / 4);
+  for (int e = tid; e < 4 * (P / 4); e += NT) {  // slots: W_b delta, W_c delta, W_b[0], W_c[0]  (delta = class 0 - class 1)
+    const int c = e / (P / 4), c4 = e % (P / 4);
     const int row = (c & 1) ? 2 : 1;  // W_m rows: [W_a | W_b | W_c] of class 0, then of class 1
-    float4 ww = *(const float4*)(Wm + (size_t)row * MV_PROJ + 4 * c4);
+    float4 ww = *(const float4*)(Wm + (size_t)row * P + 4 * c4);
     if (c < 2) {
-      const float4 w1 = *(const float4*)(Wm + (size_t)(row + 3) * MV_PROJ + 4 * c4);
+      const float4 w1 = *(const float4*)(Wm + (size_t)(row + 3) * P + 4 * c4);
       ww.x -= w1.x; ww.y -= w1.y; ww.z -= w1.z; ww.w -= w1.w;
     }
     *(float4*)(sx + (c4 * XQ + c) * 4) = ww;
@@ -222,11 +224,11 @@ __global__ __launch_bounds__(GC * RW) void match_topk_kernel(const float* __rest
   for (int r = w; r < NR; r += NW) {
     float s0 = 0.f, s1 = 0.f;
 #pragma unroll
-    for (int j = 0; j < MV_PROJ / 64; ++j) {
+    for (int j = 0; j < P / 64; ++j) {
       const int i = lane + 64 * j;
       const float uu = sx[((i >> 2) * XQ + 4 + r) * 4 + (i & 3)];
       const float wa0 = Wm[lane + 64 * j];
-      s0 = fmaf(wa0 - Wm[3 * MV_PROJ + lane + 64 * j], uu, s0);  // delta chain
+      s0 = fmaf(wa0 - Wm[3 * P + lane + 64 * j], uu, s0);  // delta chain
       s1 = fmaf(wa0, uu, s1);                                     // class-0 chain (LOGITS)
     }
     s0 = mk_wave_sum(s0);
@@ -302,10 +304,10 @@ __global__ __launch_bounds__(GC * RW) void match_topk_kernel(const float* __rest
   }
   static_assert(RB == 4 || RB == 2, "the quad statement is written out for 4 and for 2 rows per wave");
 #pragma unroll  // fully: `stage` then has only compile-time indices and no loop-carried copy (it stays in registers)
-  for (int i0 = 0; i0 < MV_PROJ; i0 += MI) {
+  for (int i0 = 0; i0 < P; i0 += MI) {
     if ((i0 / MI) & 1) { MK_STORE_CHUNK(1) } else { MK_STORE_CHUNK(0) }
     __syncthreads();
-    if (i0 + 2 * MI < MV_PROJ) {  // in flight while this chunk and the next are consumed
+    if (i0 + 2 * MI < P) {  // in flight while this chunk and the next are consumed
       if ((i0 / MI) & 1) { MK_LOAD_CHUNK(1, i0 + 2 * MI) } else { MK_LOAD_CHUNK(0, i0 + 2 * MI) }
     }
     if (stamp && i0 == 0) a.clk[1] = __builtin_amdgcn_s_memtime();

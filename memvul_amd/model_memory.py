@@ -135,9 +135,6 @@ class ModelMemory(Model):
                  regularizer: Any = None,
                  engine_options: Optional[Dict[str, Any]] = None) -> None:
         super().__init__(vocab, regularizer)
-        if not use_header:
-            raise NotImplementedError("use_header=False (matcher on the raw 768-d pooler output) is not used by any "
-                                      "reference config (config_memory.json:36) and is not built")
         self.device = device
         self._device_index = int(str(device).split(":")[1]) if ":" in str(device) else 0
         self._use_header = use_header
@@ -167,6 +164,13 @@ class ModelMemory(Model):
         type_vocab = sd[PFX_BERT + "embeddings.token_type_embeddings.weight"].shape[0]
         opts = dict(max_tokens=128 * 512, max_batch=512, max_anchors=1024)
         opts.update(self._engine_options)
+        # use_header (model_memory.py:69-73): with the header the matcher runs on its 512-d output; without it the model has
+        # no _projector_single and `_projector` is Linear(3 * 768, 2) on the pooler output -> mv_config.proj_dim = 768
+        has_header = "_projector_single._linear_layers.0.weight" in sd
+        if has_header != bool(self._use_header):
+            raise ValueError(f"use_header={self._use_header} but the state dict {'has' if has_header else 'lacks'} "
+                             "_projector_single (model_memory.py:69-71)")
+        opts["proj_dim"] = 512 if self._use_header else 768
         # compute dtype: MV_F16 (default, the benchmarked path) or MV_F16X8 ("precise": + one fp8 correction sweep per GEMM, the mode
         # that holds 1e-3 on trained-like logits; include/memvul_hip.h); engine_options["compute_dtype"] or $MEMVUL_COMPUTE =
         # f16 | f16x8 | precise.  An unknown name raises here (ValueError), not inside ctypes.
@@ -222,7 +226,8 @@ class ModelMemory(Model):
         return ids * mask, lens
 
     def _instance_forward(self, sample, use_header: bool = False) -> np.ndarray:
-        assert use_header, "only the header path is built (config_memory.json:36)"
+        # (the reference passes self._use_header at every call site, l.112, 133; the engine was created for that choice)
+        assert bool(use_header) == bool(self._use_header), "the engine was built for use_header=%s" % self._use_header
         ids, lens = self._ids_lens(sample)
         return self.engine.encode(ids, lens)
 

@@ -58,6 +58,7 @@ def make_weights(
     plain_init: bool = False,
     ln_outliers: bool = False,
     trained_like: bool = False,
+    use_header: bool = True,
 ) -> Dict[str, np.ndarray]:
     """Random-init weights of the reference architecture, fp32.
 
@@ -74,7 +75,8 @@ def make_weights(
     same two dimensions carry offsets -4 / +3 at gains 0.6 / 0.8 in every LayerNorm — a stable fixed point, |hidden| up
     to ~12 against a unit-variance bulk as in trained BERT checkpoints — so that, together with ``qk_scale`` >= 2 and a
     ``match_scale`` that puts |logit| near 3 (training temperature 0.1, config_memory.json:38), the 1e-3 logit tolerance
-    is tested where it is hardest.
+    is tested where it is hardest.  ``use_header=False``: the state dict of a model built without the
+    512-d header (no ``_projector_single``; ``_projector.weight`` is ``[2, 3 * 768]``).
     """
     rng = np.random.Generator(np.random.PCG64(seed))
     H, I, P = dims.hidden, dims.intermediate, dims.proj_dim
@@ -122,8 +124,11 @@ def make_weights(
         w[p + "output.LayerNorm.bias"] = beta(H)
     w[KEY_POOL_W] = normal((H, H))
     w[KEY_POOL_B] = bias(H)
-    w[KEY_HEAD_W] = uniform_linear(P, H)
-    w[KEY_HEAD_B] = rng.uniform(-1 / np.sqrt(H), 1 / np.sqrt(H), size=(P,)).astype(np.float32)
+    if use_header:
+        w[KEY_HEAD_W] = uniform_linear(P, H)
+        w[KEY_HEAD_B] = rng.uniform(-1 / np.sqrt(H), 1 / np.sqrt(H), size=(P,)).astype(np.float32)
+    else:  # model_memory.py:69-73 with use_header=False: no _projector_single, the matcher runs on the 768-d pooler output
+        P = H
     w[KEY_MATCH_W] = uniform_linear(2, 3 * P) * np.float32(match_scale)
     if ln_outliers:  # applied after generation: the random stream (and every golden vector) is unchanged without it
         for k in w:

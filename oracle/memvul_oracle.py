@@ -123,10 +123,16 @@ def encode(
 
 
 def instance_forward(w, ids, mask, heads=12, eps=1e-12, dtype=np.float32, taps=None, stream_round=None) -> np.ndarray:
-    """model_memory.py:90-103 with use_header=True -> ``u [B,512]``."""
+    """model_memory.py:90-103 -> ``u [B,512]`` with use_header=True (every reference config); a state dict WITHOUT
+    ``_projector_single`` is a model built with use_header=False (l.69-73): the embedding is then the pooler output [B,768]."""
     h = encode(w, ids, mask, heads, eps, dtype, taps, stream_round)
     cls = h[:, 0]
     pooled = np.tanh(cls @ w["_bert_pooler.pooler.dense.weight"].astype(dtype).T + w["_bert_pooler.pooler.dense.bias"].astype(dtype))
+    if "_projector_single._linear_layers.0.weight" not in w:
+        if taps is not None:
+            taps["pooled"] = pooled.copy()
+            taps["u"] = pooled.copy()
+        return pooled
     u = np.maximum(
         pooled @ w["_projector_single._linear_layers.0.weight"].astype(dtype).T
         + w["_projector_single._linear_layers.0.bias"].astype(dtype),

@@ -46,16 +46,19 @@ def _text(rng, n):
     return " ".join(rng.choice(WORDS, size=n))
 
 
-def make_fixture(n_irs=40, n_anchors=8, layers=2, seed=7, body_words=(5, 70)):
-    """Returns (dir, archive_dir, golden_path, test_path, weights, dims)."""
+def make_fixture(n_irs=40, n_anchors=8, layers=2, seed=7, body_words=(5, 70), use_header=True):
+    """Returns (dir, archive_dir, golden_path, test_path, weights, dims).  use_header=False: the archive of a model built
+    without the 512-d header (config `use_header: false`, no _projector_single in the weights; model_memory.py:69-73)."""
     rng = np.random.default_rng(seed)
     root = tempfile.mkdtemp(prefix="mvplumb")  # no "test_"/"golden" in the directory name (reader dispatches on substrings)
     arch = os.path.join(root, "archive")
     os.makedirs(os.path.join(arch, "vocabulary"))
     dims = synth.BertDims(layers=layers)
-    w = synth.make_weights(dims, qk_scale=2.0, match_scale=6.0)
+    w = synth.make_weights(dims, qk_scale=2.0, match_scale=6.0, use_header=use_header)
     np.savez(os.path.join(arch, "weights.npz"), **w)
-    json.dump(CONFIG, open(os.path.join(arch, "config.json"), "w"))
+    config = json.loads(json.dumps(CONFIG))
+    config["model"]["use_header"] = bool(use_header)
+    json.dump(config, open(os.path.join(arch, "config.json"), "w"))
     open(os.path.join(arch, "vocabulary", "labels.txt"), "w").write("same\ndiff\n")
     open(os.path.join(arch, "vocabulary", "non_padded_namespaces.txt"), "w").write("*labels\n*tags\n")
     cwes = [f"CWE-{100 + i}" for i in range(n_anchors)]
@@ -81,7 +84,8 @@ class OracleEngine:
     def __init__(self, device=0, **kw):
         OracleEngine.last_device = device
         self.same_idx = kw.get("same_idx", 0)
-        self.v = np.zeros((0, 512), np.float32)
+        self.P = kw.get("proj_dim", 512)
+        self.v = np.zeros((0, self.P), np.float32)
         self.w = None
 
     def load_state_dict(self, sd, compute_dtype=1):
@@ -91,7 +95,7 @@ class OracleEngine:
         pass
 
     def anchor_reset(self):
-        self.v = np.zeros((0, 512), np.float32)
+        self.v = np.zeros((0, self.P), np.float32)
 
     @property
     def n_anchors(self):

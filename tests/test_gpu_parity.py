@@ -357,6 +357,44 @@ def test_edge_shapes_against_the_oracle(gu, gemm_tile):
         eng.forward(one, np.array([1], np.int32))                              # empty anchor bank
 
 
+@pytest.mark.parametrize("compute", ["f16", "precise"])
+def test_use_header_false_matches_the_oracle(gu, compute):
+    """`use_header: false` (model_memory.py:69-73): mv_config.proj_dim = 768 — no header launch, the pooler output is the
+    embedding, the fused matcher runs its 768-wide instantiation (anchors [G, 768], W_m [2, 2304]); checked against the oracle
+    on the same header-less weights, plus the matcher's own consistency (best = row of probs at the first arg-max, top-k)."""
+    dk, wk = dict(layers=2, vocab_size=2048), dict(qk_scale=3.0, match_scale=4.0, use_header=False)
+    dims, w = gu.weights_for(dk, wk)
+    assert synth.KEY_HEAD_W not in w and w[synth.KEY_MATCH_W].shape == (2, 3 * 768)
+    eng = gu.engine_for(dk, wk, compute_dtype=compute, proj_dim=768, max_tokens=16384, max_batch=64, max_anchors=300)
+    aids, alens = synth.make_ids(7, 96, dims.vocab_size, seed=synth.SEED + 1, ragged=True, min_len=8)
+    ids, lens = synth.make_ids(9, 128, dims.vocab_size, ragged=True, min_len=5)
+    eng.anchor_reset(); eng.anchor_append(aids, alens)
+    v = eng.anchor_get()
+    out = eng.forward(ids, lens, want_embed=True)
+    assert v.shape == (7, 768) and out["embed"].shape == (9, 768)
+    v_ref = orc.build_anchor_bank(w, [aids[i, : alens[i]].astype(np.int64) for i in range(7)])
+    u, logits, p, best, idx = orc.predict(w, ids.astype(np.int64), synth.mask_from_lens(lens, 128), v_ref)
+    errs = dict(v=float(np.abs(v - v_ref).max()), u=float(np.abs(out["embed"] - u).max()), logits=float(np.abs(out["logits"] - logits).max()))
+    gu.record("use_header_false", compute=compute, **errs)
+    assert errs["logits"] <= LOGIT_TOL and errs["u"] < 2e-3, errs
+    # the matcher alone at this width, also through the 256-anchor chunks + merge (G = 300)
+    rng = np.random.default_rng(11)
+    uu = np.tanh(rng.standard_normal((37, 768))).astype(np.float32)
+    vv = np.tanh(rng.standard_normal((300, 768))).astype(np.float32)
+    eng.anchor_set(vv)
+    o = eng.match(uu)
+    lg, pp, bb, ii = orc.match(uu, vv, w[synth.KEY_MATCH_W], same_idx=0)
+    assert np.abs(o["logits"] - lg).max() < 5e-5 and np.abs(o["probs"] - pp).max() < 1e-5
+    ps = o["probs"][:, :, 0]
+    assert np.array_equal(o["best_idx"], np.argmax(ps, axis=1).astype(np.int32))
+    tp, ti = eng.topk(uu, 5)
+    rp, ri = orc.topk_match(ps, 5)
+    assert np.array_equal(ti, ri.astype(np.int32)) and np.array_equal(tp, rp)
+    with pytest.raises(ValueError):
+        eng.anchor_set(np.zeros((3, 512), np.float32))  # a 512-wide bank on a 768-wide engine
+    eng.anchor_reset()
+
+
 def test_sweeps_chunk_batches_larger_than_one_pass(gu):
     """batch_size = 512 (the reference __main__ value, predict_memory.py:207) with issue reports longer than
     max_tokens / 512 used to fail with MV_ERR_CAPACITY on the resident sweeps.  mv_corpus_run_len now walks such a batch in

@@ -56,6 +56,28 @@ def test_plumbing_cpu_with_oracle_engine(monkeypatch):
     _check_format_and_metrics(fx, metrics, records, "oracle")
 
 
+def test_use_header_false_plumbing_cpu(monkeypatch):
+    """model_memory.py:69-73 with `use_header: false` (no reference config sets it, but it is a constructor argument of the
+    registered model): no _projector_single, the matcher is Linear(3 * 768, 2) on the pooler output.  The drop-in flow builds
+    the engine with proj_dim = 768, and a state dict that contradicts the flag is rejected."""
+    fx = pu.make_fixture(use_header=False)
+    seen = {}
+
+    class Spy(pu.OracleEngine):
+        def __init__(self, device=0, **kw):
+            seen.update(kw)
+            super().__init__(device, **kw)
+
+    monkeypatch.setattr(model_memory, "Engine", Spy)
+    metrics, records, _ = _run(fx, "nohdr")
+    assert seen["proj_dim"] == 768
+    _check_format_and_metrics(fx, metrics, records, "nohdr")
+    # the same archive read with use_header forced on: the weights lack the header -> a clear error, not garbage
+    from memvul_amd.archive import load_archive
+    with pytest.raises(ValueError, match="_projector_single"):
+        load_archive(fx[1], cuda_device=0, overrides={"model": {"use_header": True}})
+
+
 def test_sweep_driver_writes_the_same_files_cpu(monkeypatch):
     """test_siamese(sweep=True): one resident length-bucketed sweep instead of a forward per batch — same records in
     the same order with the same per-batch line grouping, same metrics (oracle-backed engine: exactly the same)."""
