@@ -7,6 +7,7 @@ mkdir -p $O
 export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 note() { echo "== $* ($(date +%H:%M:%S))"; }
+python -m memvul_amd.build > /dev/null || exit 1   # no-op when the binary that travelled matches the sources; never profile a stale one
 Q="--cpu-sample 0 --sustain-s 0 --no-precise"
 : > $O/r03_f_bench_lines.jsonl
 note "cfg 3: S=512, B=128 (f16, precise)"

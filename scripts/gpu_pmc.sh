@@ -11,6 +11,7 @@ mkdir -p $O
 export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 note() { echo "== $* ($(date +%H:%M:%S))"; }
+python -m memvul_amd.build > /dev/null || exit 1   # no-op when the binary that travelled matches the sources; never profile a stale one
 COMMON="--cpu-sample 0 --sustain-s 0 --matcher-anchors 0 --streams 1 --no-precise"
 SQ="SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE"
 rm -rf $O/p_stats $O/p_sq $O/p_fetch $O/p_write

@@ -6,6 +6,7 @@ O=gpurun_out
 mkdir -p $O
 export TMPDIR=/tmp
 note() { echo "== $* ($(date +%H:%M:%S))"; }
+python -m memvul_amd.build > /dev/null || exit 1   # no-op when the binary that travelled matches the sources; never profile a stale one
 note "focused: persistent GEMM (fp16 / fp8 correction sweep), tile variants"
 ( timeout 600 python -m pytest tests/test_gpu_kernels.py -q -x -k "persistent_gemm or gemm_variants" > $O/pytest_focus.log 2>&1; echo "rc=$?" >> $O/pytest_focus.log ); tail -15 $O/pytest_focus.log
 note "GPU suite"
