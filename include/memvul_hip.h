@@ -38,7 +38,8 @@ typedef enum mv_status {
   MV_ERR_STATE = -3,          /* call order violated (e.g. forward before finalize / no anchors) */
   MV_ERR_MISSING_WEIGHT = -4, /* mv_finalize_weights: a state-dict key was never loaded */
   MV_ERR_CAPACITY = -5,       /* B*S, B or G exceeds what mv_create reserved */
-  MV_ERR_NOMEM = -6
+  MV_ERR_NOMEM = -6,          /* host or device allocation failed */
+  MV_ERR_INTERNAL = -7        /* a C++ exception was caught at the ABI boundary (never propagated to the caller) */
 } mv_status;
 
 typedef enum mv_dtype { MV_F32 = 0, MV_F16 = 1, MV_BF16 = 2, MV_I32 = 3, MV_I64 = 4,

@@ -216,6 +216,27 @@ int fail(mv_handle* h, int code, const std::string& msg) {
   return code;
 }
 
+// No C++ exception crosses the ABI (include/memvul_hip.h): every entry point is a function-try-block whose handler lands here
+// (std::bad_alloc of the host-side staging vectors / maps -> MV_ERR_NOMEM, anything else -> MV_ERR_INTERNAL).
+int on_exception(mv_handle* h) noexcept {
+  int code = MV_ERR_INTERNAL;
+  const char* what = "unknown C++ exception";
+  try {
+    throw;
+  } catch (const std::bad_alloc&) {
+    code = MV_ERR_NOMEM;
+    what = "out of host memory";
+  } catch (const std::exception& e) {
+    what = e.what();
+  } catch (...) {
+  }
+  try {
+    fail(h, code, std::string("internal: ") + what);
+  } catch (...) {  // not even the message could be stored
+  }
+  return code;
+}
+
 #define HIPCHK(h, expr)                                                                             \
   do {                                                                                              \
     hipError_t _e = (expr);                                                                         \
@@ -760,7 +781,7 @@ const char* mv_kernel_class_name(int cls) {
   return (cls >= 0 && cls < MV_NUM_KERNEL_CLASSES) ? kKernelClassNames[cls] : "";
 }
 
-int mv_create(int device, const mv_config* cfg, mv_handle** out) {
+int mv_create(int device, const mv_config* cfg, mv_handle** out) try {
   if (!cfg || !out) return fail(nullptr, MV_ERR_INVALID, "null argument");
   if (cfg->hidden != MV_HIDDEN || cfg->heads != MV_HEADS || cfg->intermediate != MV_INTER ||
       (cfg->proj_dim != MV_PROJ && cfg->proj_dim != MV_HIDDEN))
@@ -870,7 +891,7 @@ int mv_create(int device, const mv_config* cfg, mv_handle** out) {
   }
   *out = h;
   return MV_OK;
-}
+} catch (...) { return on_exception(nullptr); }
 
 void mv_destroy(mv_handle* h) {
   if (!h) return;
@@ -886,12 +907,13 @@ void mv_destroy(mv_handle* h) {
   delete h;
 }
 
-int mv_sync(mv_handle* h) {
+int mv_sync(mv_handle* h) try {
   if (!h) return MV_ERR_INVALID;
+  HIPCHK(h, hipSetDevice(h->device));
   return sync_all(h);
-}
+} catch (...) { return on_exception(h); }
 
-int mv_load_tensor(mv_handle* h, const char* name, const void* host_ptr, int dtype, const int64_t* shape, int ndim) {
+int mv_load_tensor(mv_handle* h, const char* name, const void* host_ptr, int dtype, const int64_t* shape, int ndim) try {
   if (!h || !name || !host_ptr || !shape || ndim < 1 || ndim > 4) return fail(h, MV_ERR_INVALID, "mv_load_tensor: bad argument");
   if (h->finalized) return fail(h, MV_ERR_STATE, "weights already finalized");
   int64_t n = 1;
@@ -909,9 +931,9 @@ int mv_load_tensor(mv_handle* h, const char* name, const void* host_ptr, int dty
   else return fail(h, MV_ERR_INVALID, "mv_load_tensor: unsupported dtype");
   h->staged[name] = std::move(t);
   return MV_OK;
-}
+} catch (...) { return on_exception(h); }
 
-int mv_finalize_weights(mv_handle* h, int compute_dtype) {
+int mv_finalize_weights(mv_handle* h, int compute_dtype) try {
   if (!h) return MV_ERR_INVALID;
   if (h->finalized) return fail(h, MV_ERR_STATE, "weights already finalized");
   if (compute_dtype != MV_F16 && compute_dtype != MV_F16X8)
@@ -1073,16 +1095,16 @@ int mv_finalize_weights(mv_handle* h, int compute_dtype) {
   h->compute_dtype = compute_dtype;
   h->finalized = true;
   return MV_OK;
-}
+} catch (...) { return on_exception(h); }
 
-int mv_anchor_reset(mv_handle* h) {
+int mv_anchor_reset(mv_handle* h) try {
   if (!h) return MV_ERR_INVALID;
   h->n_anchors = 0;
   return MV_OK;
-}
+} catch (...) { return on_exception(h); }
 int mv_anchor_count(mv_handle* h) { return h ? h->n_anchors : MV_ERR_INVALID; }
 
-int mv_anchor_append(mv_handle* h, const int32_t* ids, const int32_t* lens, int n, int S) {
+int mv_anchor_append(mv_handle* h, const int32_t* ids, const int32_t* lens, int n, int S) try {
   if (int rc = check_ready(h)) return rc;
   if (!ids || !lens || n <= 0 || S <= 0 || S > h->cfg.max_pos) return fail(h, MV_ERR_INVALID, "mv_anchor_append: bad argument");
   if (h->n_anchors + n > h->cfg.max_anchors) return fail(h, MV_ERR_CAPACITY, "anchor bank capacity (mv_config.max_anchors) exceeded");
@@ -1099,25 +1121,31 @@ int mv_anchor_append(mv_handle* h, const int32_t* ids, const int32_t* lens, int 
   }
   h->n_anchors += n;
   return MV_OK;
-}
+} catch (...) { return on_exception(h); }
 
-int mv_anchor_get(mv_handle* h, float* out) {
+int mv_anchor_get(mv_handle* h, float* out) try {
   if (!h || !out) return MV_ERR_INVALID;
+  HIPCHK(h, hipSetDevice(h->device));
+  if (int rc = sync_all(h)) return rc;  // a sweep may still be appending / reading on the other stream
+  h->w = &h->work[0];
   HIPCHK(h, hipMemcpyAsync(out, h->anchors, (size_t)h->n_anchors * h->P * 4, hipMemcpyDeviceToHost, h->w->stream));
   HIPCHK(h, hipStreamSynchronize(h->w->stream));
   return MV_OK;
-}
+} catch (...) { return on_exception(h); }
 
-int mv_anchor_set(mv_handle* h, const float* v, int G) {
+int mv_anchor_set(mv_handle* h, const float* v, int G) try {
   if (!h || !v || G <= 0) return fail(h, MV_ERR_INVALID, "mv_anchor_set: bad argument");
   if (G > h->cfg.max_anchors) return fail(h, MV_ERR_CAPACITY, "anchor bank capacity (mv_config.max_anchors) exceeded");
+  HIPCHK(h, hipSetDevice(h->device));
+  if (int rc = sync_all(h)) return rc;  // batches of a resident sweep in flight read the bank
+  h->w = &h->work[0];
   HIPCHK(h, hipMemcpyAsync(h->anchors, v, (size_t)G * h->P * 4, hipMemcpyHostToDevice, h->w->stream));
   HIPCHK(h, hipStreamSynchronize(h->w->stream));
   h->n_anchors = G;
   return MV_OK;
-}
+} catch (...) { return on_exception(h); }
 
-int mv_encode(mv_handle* h, const int32_t* ids, const int32_t* lens, int B, int S, float* embed) {
+int mv_encode(mv_handle* h, const int32_t* ids, const int32_t* lens, int B, int S, float* embed) try {
   if (int rc = check_ready(h)) return rc;
   if (!ids || !lens || B <= 0 || S <= 0 || S > h->cfg.max_pos) return fail(h, MV_ERR_INVALID, "mv_encode: bad argument");
   if (int rc = check_ids(h, ids, (int64_t)B * S, "mv_encode")) return rc;
@@ -1133,10 +1161,10 @@ int mv_encode(mv_handle* h, const int32_t* ids, const int32_t* lens, int B, int 
     HIPCHK(h, hipStreamSynchronize(h->w->stream));
   }
   return MV_OK;
-}
+} catch (...) { return on_exception(h); }
 
 int mv_forward(mv_handle* h, const int32_t* ids, const int32_t* lens, int B, int S, float* logits, float* probs, float* best,
-               int32_t* best_idx, float* embed) {
+               int32_t* best_idx, float* embed) try {
   if (int rc = check_ready(h)) return rc;
   if (!ids || !lens || B <= 0 || S <= 0 || S > h->cfg.max_pos) return fail(h, MV_ERR_INVALID, "mv_forward: bad argument");
   if (h->n_anchors <= 0) return fail(h, MV_ERR_STATE, "anchor bank is empty (call mv_anchor_append / mv_anchor_set first)");
@@ -1162,9 +1190,9 @@ int mv_forward(mv_handle* h, const int32_t* ids, const int32_t* lens, int B, int
     HIPCHK(h, hipStreamSynchronize(h->w->stream));
   }
   return MV_OK;
-}
+} catch (...) { return on_exception(h); }
 
-int mv_match(mv_handle* h, const float* u, int B, float* logits, float* probs, float* best, int32_t* best_idx) {
+int mv_match(mv_handle* h, const float* u, int B, float* logits, float* probs, float* best, int32_t* best_idx) try {
   if (int rc = check_ready(h)) return rc;
   if (!u || B <= 0) return fail(h, MV_ERR_INVALID, "mv_match: bad argument");
   if (B > h->cfg.max_batch) return fail(h, MV_ERR_CAPACITY, "B exceeds mv_config.max_batch");
@@ -1180,9 +1208,9 @@ int mv_match(mv_handle* h, const float* u, int B, float* logits, float* probs, f
   if (best_idx) HIPCHK(h, hipMemcpyAsync(best_idx, h->w->best_idx, (size_t)B * 4, hipMemcpyDeviceToHost, h->w->stream));
   HIPCHK(h, hipStreamSynchronize(h->w->stream));
   return MV_OK;
-}
+} catch (...) { return on_exception(h); }
 
-int mv_topk(mv_handle* h, const float* u, int B, int k, float* topk_p, int32_t* topk_idx) {
+int mv_topk(mv_handle* h, const float* u, int B, int k, float* topk_p, int32_t* topk_idx) try {
   if (int rc = check_ready(h)) return rc;
   if (!u || B <= 0 || k <= 0 || k > 64 || !topk_p || !topk_idx) return fail(h, MV_ERR_INVALID, "mv_topk: bad argument (1 <= k <= 64)");
   if (B > h->cfg.max_batch) return fail(h, MV_ERR_CAPACITY, "B exceeds mv_config.max_batch");
@@ -1195,10 +1223,10 @@ int mv_topk(mv_handle* h, const float* u, int B, int k, float* topk_p, int32_t* 
   HIPCHK(h, hipMemcpyAsync(topk_idx, h->w->topk_idx, (size_t)B * k * 4, hipMemcpyDeviceToHost, h->w->stream));
   HIPCHK(h, hipStreamSynchronize(h->w->stream));
   return MV_OK;
-}
+} catch (...) { return on_exception(h); }
 
 // ---- resident corpus ---------------------------------------------------------------------------
-int mv_corpus_upload(mv_handle* h, const int32_t* ids, const int32_t* lens, int64_t n, int S) {
+int mv_corpus_upload(mv_handle* h, const int32_t* ids, const int32_t* lens, int64_t n, int S) try {
   if (int rc = check_ready(h)) return rc;
   if (!ids || !lens || n <= 0 || S <= 0 || S > h->cfg.max_pos) return fail(h, MV_ERR_INVALID, "mv_corpus_upload: bad argument");
   if (int rc = check_ids(h, ids, n * S, "mv_corpus_upload")) return rc;
@@ -1217,13 +1245,13 @@ int mv_corpus_upload(mv_handle* h, const int32_t* ids, const int32_t* lens, int6
   h->c_n = n;
   h->c_S = S;
   return MV_OK;
-}
+} catch (...) { return on_exception(h); }
 
-int mv_corpus_run(mv_handle* h, int64_t first, int64_t count, int batch, int keep_probs) {
+int mv_corpus_run(mv_handle* h, int64_t first, int64_t count, int batch, int keep_probs) try {
   return mv_corpus_run_len(h, first, count, batch, keep_probs, 0);
-}
+} catch (...) { return on_exception(h); }
 
-int mv_corpus_run_len(mv_handle* h, int64_t first, int64_t count, int batch, int keep_probs, int s_eff) {
+int mv_corpus_run_len(mv_handle* h, int64_t first, int64_t count, int batch, int keep_probs, int s_eff) try {
   if (!h) return MV_ERR_INVALID;
   if (!h->finalized) return fail(h, MV_ERR_STATE, "weights not finalized (mv_finalize_weights)");
   if (!h->c_ids) return fail(h, MV_ERR_STATE, "no resident corpus (mv_corpus_upload)");
@@ -1264,12 +1292,13 @@ int mv_corpus_run_len(mv_handle* h, int64_t first, int64_t count, int batch, int
   }
   h->w = &h->work[0];
   return rc;
-}
+} catch (...) { return on_exception(h); }
 
-int mv_corpus_results(mv_handle* h, int64_t first, int64_t count, float* best, int32_t* best_idx, float* p_same) {
+int mv_corpus_results(mv_handle* h, int64_t first, int64_t count, float* best, int32_t* best_idx, float* p_same) try {
   if (!h) return MV_ERR_INVALID;
   if (!h->c_ids) return fail(h, MV_ERR_STATE, "no resident corpus (mv_corpus_upload)");
   if (first < 0 || count <= 0 || first + count > h->c_n) return fail(h, MV_ERR_INVALID, "mv_corpus_results: bad range");
+  HIPCHK(h, hipSetDevice(h->device));
   h->w = &h->work[0];
   if (int rc = sync_all(h)) return rc;
   if (best) HIPCHK(h, hipMemcpyAsync(best, h->c_best + (size_t)first * 2, (size_t)count * 8, hipMemcpyDeviceToHost, h->w->stream));
@@ -1280,13 +1309,13 @@ int mv_corpus_results(mv_handle* h, int64_t first, int64_t count, float* best, i
   }
   HIPCHK(h, hipStreamSynchronize(h->w->stream));
   return MV_OK;
-}
+} catch (...) { return on_exception(h); }
 
 // ---- multi-GPU exchange: RCCL bound directly ---------------------------------------------------
 // librccl.so is opened at run time (never linked).  The unique id is drawn by rank 0 (mv_comm_unique_id) and handed to every
 // rank's mv_comm_init as BYTES: how they travel is the host's business (memvul_amd/distributed.py broadcasts them over its
 // rendezvous socket — no id file in a shared temp directory, no single-node assumption).
-int mv_comm_prepare(mv_handle* h) {
+int mv_comm_prepare(mv_handle* h) try {
   if (!h) return MV_ERR_INVALID;
   if (h->rccl_lib) return MV_OK;
   for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
@@ -1304,9 +1333,9 @@ int mv_comm_prepare(mv_handle* h) {
   RCCL_SYM(ncclGetErrorString);
 #undef RCCL_SYM
   return MV_OK;
-}
+} catch (...) { return on_exception(h); }
 
-int mv_comm_unique_id(mv_handle* h, void* id_out, int capacity) {
+int mv_comm_unique_id(mv_handle* h, void* id_out, int capacity) try {
   if (!h || !id_out) return MV_ERR_INVALID;
   if (capacity < (int)sizeof(ncclUniqueId)) return fail(h, MV_ERR_INVALID, "mv_comm_unique_id: buffer smaller than ncclUniqueId (128 bytes)");
   if (int rc = mv_comm_prepare(h)) return rc;
@@ -1316,9 +1345,9 @@ int mv_comm_unique_id(mv_handle* h, void* id_out, int capacity) {
   if (r != ncclSuccess) return fail(h, MV_ERR_HIP, std::string("ncclGetUniqueId: ") + h->p_ncclGetErrorString(r));
   std::memcpy(id_out, &id, sizeof(id));
   return (int)sizeof(id);
-}
+} catch (...) { return on_exception(h); }
 
-int mv_comm_init(mv_handle* h, int rank, int world, const void* id, int id_bytes) {
+int mv_comm_init(mv_handle* h, int rank, int world, const void* id, int id_bytes) try {
   if (!h || world < 1 || rank < 0 || rank >= world) return fail(h, MV_ERR_INVALID, "mv_comm_init: bad rank / world");
   if (h->comm) return fail(h, MV_ERR_STATE, "mv_comm_init: communicator already initialised");
   h->comm_rank = rank;
@@ -1332,9 +1361,9 @@ int mv_comm_init(mv_handle* h, int rank, int world, const void* id, int id_bytes
   ncclResult_t r = h->p_ncclCommInitRank(&h->comm, world, uid, rank);
   if (r != ncclSuccess) { h->comm = nullptr; return fail(h, MV_ERR_HIP, std::string("ncclCommInitRank: ") + h->p_ncclGetErrorString(r)); }
   return MV_OK;
-}
+} catch (...) { return on_exception(h); }
 
-int mv_comm_allgather(mv_handle* h, const void* send, void* recv, int64_t bytes_per_rank) {
+int mv_comm_allgather(mv_handle* h, const void* send, void* recv, int64_t bytes_per_rank) try {
   if (!h || !send || !recv || bytes_per_rank <= 0) return fail(h, MV_ERR_INVALID, "mv_comm_allgather: bad argument");
   if (h->comm_world == 1 && !h->comm) { std::memcpy(recv, send, (size_t)bytes_per_rank); return MV_OK; }
   if (!h->comm) return fail(h, MV_ERR_STATE, "mv_comm_allgather: mv_comm_init first");
@@ -1360,40 +1389,41 @@ int mv_comm_allgather(mv_handle* h, const void* send, void* recv, int64_t bytes_
   HIPCHK(h, hipMemcpyAsync(recv, h->comm_recv, (size_t)total, hipMemcpyDeviceToHost, st));
   HIPCHK(h, hipStreamSynchronize(st));
   return MV_OK;
-}
+} catch (...) { return on_exception(h); }
 
-int mv_comm_destroy(mv_handle* h) {
+int mv_comm_destroy(mv_handle* h) try {
   if (!h) return MV_ERR_INVALID;
+  (void)hipSetDevice(h->device);
   if (h->comm) { h->p_ncclCommDestroy(h->comm); h->comm = nullptr; }
   if (h->comm_send) { hipFree(h->comm_send); h->comm_send = nullptr; h->comm_send_cap = 0; }
   if (h->comm_recv) { hipFree(h->comm_recv); h->comm_recv = nullptr; h->comm_recv_cap = 0; }
   h->comm_world = 1; h->comm_rank = 0;
   return MV_OK;
-}
+} catch (...) { return on_exception(h); }
 
 // ---- measurement / debug -----------------------------------------------------------------------
-int mv_profile_enable(mv_handle* h, int on) {
+int mv_profile_enable(mv_handle* h, int on) try {
   if (!h) return MV_ERR_INVALID;
   h->prof = on != 0;
   return MV_OK;
-}
+} catch (...) { return on_exception(h); }
 
-int mv_set_streams(mv_handle* h, int n) {
+int mv_set_streams(mv_handle* h, int n) try {
   if (!h || (n != 1 && n != 2)) return fail(h, MV_ERR_INVALID, "mv_set_streams: 1 or 2");
   if (n == 2 && !h->work[1].stream) return fail(h, MV_ERR_STATE, "mv_set_streams: the second workspace set was not created (MEMVUL_STREAMS=1)");
   if (int rc = sync_all(h)) return rc;
   h->n_streams = n;
   h->rr = 0;
   return MV_OK;
-}
+} catch (...) { return on_exception(h); }
 
-int mv_profile_select(mv_handle* h, uint32_t class_mask) {
+int mv_profile_select(mv_handle* h, uint32_t class_mask) try {
   if (!h) return MV_ERR_INVALID;
   h->prof_mask = class_mask;
   return MV_OK;
-}
+} catch (...) { return on_exception(h); }
 
-int mv_profile_read(mv_handle* h, double* ms, int64_t* launches, int n) {
+int mv_profile_read(mv_handle* h, double* ms, int64_t* launches, int n) try {
   if (!h || !ms || !launches || n < MV_NUM_KERNEL_CLASSES) return fail(h, MV_ERR_INVALID, "mv_profile_read: bad argument");
   if (int rc = sync_all(h)) return rc;
   for (int i = 0; i < n; ++i) { ms[i] = 0; launches[i] = 0; }
@@ -1405,9 +1435,9 @@ int mv_profile_read(mv_handle* h, double* ms, int64_t* launches, int n) {
   }
   h->recs.clear();
   return MV_OK;
-}
+} catch (...) { return on_exception(h); }
 
-int mv_debug_encode(mv_handle* h, const int32_t* ids, const int32_t* lens, int B, int S, int n_layers) {
+int mv_debug_encode(mv_handle* h, const int32_t* ids, const int32_t* lens, int B, int S, int n_layers) try {
   if (int rc = check_ready(h)) return rc;
   if (!ids || !lens || B <= 0 || S <= 0 || S > h->cfg.max_pos) return fail(h, MV_ERR_INVALID, "mv_debug_encode: bad argument");
   if (B > max_rows_for(h, S)) return fail(h, MV_ERR_CAPACITY, "mv_debug_encode: batch too large for one pass");
@@ -1418,9 +1448,9 @@ int mv_debug_encode(mv_handle* h, const int32_t* ids, const int32_t* lens, int B
   if (int rc = encode_dev(h, h->w->d_ids, h->w->d_lens, B, S, n_layers < 0 ? h->cfg.layers : n_layers, h->w->u, /*full=*/true)) return rc;
   HIPCHK(h, hipStreamSynchronize(h->w->stream));
   return MV_OK;
-}
+} catch (...) { return on_exception(h); }
 
-int mv_debug_read(mv_handle* h, int buffer, void* dst, int64_t bytes) {
+int mv_debug_read(mv_handle* h, int buffer, void* dst, int64_t bytes) try {
   if (!h || !dst || bytes <= 0) return MV_ERR_INVALID;
   const int64_t T = (int64_t)h->dbg_B * h->dbg_Sp;
   const void* src = nullptr;
@@ -1440,10 +1470,10 @@ int mv_debug_read(mv_handle* h, int buffer, void* dst, int64_t bytes) {
   HIPCHK(h, hipMemcpyAsync(dst, src, (size_t)bytes, hipMemcpyDeviceToHost, h->w->stream));
   HIPCHK(h, hipStreamSynchronize(h->w->stream));
   return MV_OK;
-}
+} catch (...) { return on_exception(h); }
 
 int mv_test_gemm(mv_handle* h, int variant, int M, int N, int K, const uint16_t* A, const uint16_t* W, const float* bias,
-                 float* C, int iters, float* ms) {
+                 float* C, int iters, float* ms) try {
   if (!h || !A || !W || M <= 0 || N <= 0 || K <= 0) return fail(h, MV_ERR_INVALID, "mv_test_gemm: bad argument");
   if (variant != 0 && variant != 19) return fail(h, MV_ERR_INVALID, "mv_test_gemm: variant 0 (128^2 tile) or 19 (64^2 ring)");
   if (variant == 0 && (M % 128 || N % 128 || K % 64)) return fail(h, MV_ERR_INVALID, "mv_test_gemm: M,N % 128 and K % 64 required");
@@ -1484,14 +1514,14 @@ int mv_test_gemm(mv_handle* h, int variant, int M, int N, int K, const uint16_t*
   }
   dev_free(h, dA); dev_free(h, dW); dev_free(h, dB); dev_free(h, dC);
   return rc;
-}
+} catch (...) { return on_exception(h); }
 
 // The FFN-1 kernel of the persistent path (gemm_pp_kernel<PP_GELU, RAW>) on caller-provided fp32 operands with unit row
 // statistics: out16 = fp16(gelu(A W^T + bias)) [M][N]; x8 != 0: the MV_F16X8 build (fp16 sweep + fp8 correction sweep) and, with
 // out8, the [lo8 | hi8] planes of the output [M][2 N].  A / W are split into their planes on the host exactly as
 // mv_finalize_weights does for weights (W) and as the producing epilogues do for activations (A: shift MV_X8_ACT_SHIFT).
 int mv_test_gemm_pp(mv_handle* h, int x8, int M, int N, int K, const float* A, const float* W, const float* bias, uint16_t* out16,
-                    uint8_t* out8, int iters, float* ms) {
+                    uint8_t* out8, int iters, float* ms) try {
   if (!h || !A || !W || !bias || !out16 || M <= 0 || N <= 0 || K <= 0) return fail(h, MV_ERR_INVALID, "mv_test_gemm_pp: bad argument");
   if (M % 256 || N % 256 || K % 128 || K < 256 || N > MV_INTER)
     return fail(h, MV_ERR_INVALID, "mv_test_gemm_pp: M,N % 256, K % 128, K >= 256, N <= 3072 required");
@@ -1562,13 +1592,13 @@ int mv_test_gemm_pp(mv_handle* h, int x8, int M, int N, int K, const float* A, c
   dev_free(h, dA); dev_free(h, dW); dev_free(h, dO); dev_free(h, dB); dev_free(h, dS);
   dev_free(h, dA8); dev_free(h, dW8); dev_free(h, dO8);
   return rc;
-}
+} catch (...) { return on_exception(h); }
 
 // host-side e4m3 encoder of the MV_F16X8 weight planes (no GPU needed): tests pin it to the oracle's rounding model
-int mv_test_e4m3(const float* in, uint8_t* out, int64_t n) {
+int mv_test_e4m3(const float* in, uint8_t* out, int64_t n) try {
   if (!in || !out || n < 0) return MV_ERR_INVALID;
   for (int64_t i = 0; i < n; ++i) out[i] = f32_to_e4m3_bits(in[i]);
   return MV_OK;
-}
+} catch (...) { return on_exception(nullptr); }
 
 }  // extern "C"

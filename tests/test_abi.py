@@ -60,3 +60,16 @@ def test_product_code_never_imports_the_oracle():
             if fn.endswith(".py"):
                 txt = open(os.path.join(dp, fn)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", txt, flags=re.M), os.path.join(dp, fn)
+
+
+def test_no_cpp_exception_can_cross_the_abi():
+    """include/memvul_hip.h promises that no C++ exception leaves the library: every `int mv_*` entry of engine.hip that has a
+    body of its own is a function-try-block whose handler translates to a status (engine.hip on_exception); only one-line
+    accessors that cannot throw are exempt."""
+    src = open(os.path.join(ROOT, "memvul_amd", "csrc", "engine.hip")).read()
+    block = src[src.index('extern "C" {'):src.index('}  // extern "C"')]
+    heads = re.findall(r"^int (mv_\w+)\(([^{;]*?)\)\s*(try\s*)?\{(.*)$", block, flags=re.M)
+    assert len(heads) >= 30
+    unguarded = [name for name, _, guard, rest in heads if not guard and not rest.rstrip().endswith("}")]
+    assert not unguarded, unguarded
+    assert block.count("catch (...) { return on_exception(") == sum(1 for _, _, guard, _ in heads if guard)
