@@ -180,6 +180,21 @@ def init_transport(engine=None, rank: Optional[int] = None, world: Optional[int]
     addr = addr or os.environ.get("MASTER_ADDR", "127.0.0.1")
     port = port if port is not None else int(os.environ.get("MASTER_PORT", "29500")) + 1
     hub = _Hub(rank, world, addr, port)
+    try:
+        return _agree_on_transport(hub, engine, rank, world, prefer, addr, port)
+    except BaseException:  # a peer vanished mid-agreement (ConnectionError), Ctrl-C ...: leave no socket and no half-made communicator behind
+        hub.comm_destroy()
+        if engine is not None:
+            try:
+                engine.comm_destroy()
+            except RuntimeError:
+                pass
+        _comm, _comm_note = None, "none"
+        raise
+
+
+def _agree_on_transport(hub, engine, rank: int, world: int, prefer: str, addr: str, port: int) -> str:
+    global _comm, _comm_note
     why = "requested" if prefer != "rccl" else ""
     if prefer == "rccl" and engine is None:
         why = "no engine given"

@@ -147,6 +147,39 @@ def test_hub_rejects_strangers_and_bad_ranks():
         os.environ.pop("MEMVUL_RUN_TOKEN", None)
 
 
+def test_transport_agreement_cleans_up_when_a_peer_vanishes():
+    """A rank that dies between the handshake and the agreement must not leave rank 0 with an open hub or a half-made
+    communicator: init_transport raises, the module is back at "no transport", the engine's communicator is destroyed."""
+    import threading
+
+    port = 31050 + (os.getpid() % 300)
+    os.environ["MEMVUL_RUN_TOKEN"] = "vanish-test"
+
+    class FakeEngine:  # RCCL "usable" here, so rank 0 enters the agreement's first all-gather
+        destroyed = 0
+
+        def comm_prepare(self):
+            pass
+
+        def comm_destroy(self):
+            FakeEngine.destroyed += 1
+
+    def peer():
+        h = mvdist._Hub(1, 2, "127.0.0.1", port, timeout_s=30.0)
+        h.comm_destroy()  # gone before the agreement starts
+
+    try:
+        t = threading.Thread(target=peer)
+        t.start()
+        with pytest.raises((ConnectionError, OSError)):
+            mvdist.init_transport(FakeEngine(), rank=0, world=2, prefer="rccl", addr="127.0.0.1", port=port)
+        t.join(timeout=30)
+        assert mvdist._comm is None and mvdist.transport_note() == "none" and FakeEngine.destroyed >= 1
+    finally:
+        os.environ.pop("MEMVUL_RUN_TOKEN", None)
+        mvdist.shutdown()
+
+
 def test_bench_two_ranks_control_flow_and_json_contract(tmp_path):
     """the REAL bench.py under `torch.distributed.run --nproc-per-node 2` with a numpy stand-in engine
     (MEMVUL_BENCH_STUB_ENGINE; no GPU, not a measurement): rendezvous, agreed transport, barrier + max-over-ranks timing, the
