@@ -51,18 +51,26 @@ LIB_STAMP = os.path.join(ROOT, "memvul_amd", "lib", "libmemvul_hip.so.stamp")
 def load_pmc():
     """Counter-derived figures of the GEMM classes (HBM bytes per launch = 2 x FETCH_SIZE + WRITE_SIZE per the gfx950 correction;
     matrix-pipe busy fraction; effective shader clock) from the separate rocprofv3 --pmc passes of this workload
-    (scripts/gpu_pmc.sh writes profiles/pmc_current.json together with the build stamp of the library it profiled).  They are
-    reported ONLY when that stamp equals the stamp of the library loaded now — a kernel edit can never leave stale counter
-    numbers in a bench line (VERDICT r2 next #4); otherwise `traffic` is null and the note says why."""
+    (scripts/gpu_pmc.sh writes profiles/pmc_current.json together with the stamp of the library it profiled).  They are
+    reported ONLY when the DEVICE CODE profiled is the device code loaded now (the stamp's `dev` line: sha256 of the gfx950
+    code object in the .so; stamps without it are compared whole) — a kernel edit can never leave stale counter numbers in a
+    bench line, a host-only edit of the library does not throw them away; otherwise `traffic` is null and
+    the note says why."""
+    def lines(stamp):
+        return dict(line.split(" ", 1) for line in str(stamp).strip().splitlines() if " " in line)
+
     try:
         pmc = json.load(open(PMC_FILE))
         stamp = open(LIB_STAMP).read().strip()
     except Exception as e:  # no counter pass on record / no stamp next to the library
         return {}, "no counter pass on record (%s)" % type(e).__name__
-    if pmc.get("lib_stamp") != stamp:
-        return {}, "profiles/pmc_current.json was taken on another build of libmemvul_hip.so (stamp %s..., loaded %s...): not reported" % (
-            str(pmc.get("lib_stamp"))[:12], stamp[:12])
-    return pmc.get("classes", {}), "profiles/pmc_current.json (rocprofv3 --pmc, same workload, separate passes, library stamp %s...)" % stamp[:12]
+    have, want = lines(pmc.get("lib_stamp")), lines(stamp)
+    same = have.get("dev") == want["dev"] if ("dev" in have and "dev" in want) else pmc.get("lib_stamp") == stamp
+    if not same:
+        return {}, "profiles/pmc_current.json was taken on other device code than the loaded libmemvul_hip.so (%s..., loaded %s...): not reported" % (
+            str(have.get("dev") or have.get("src"))[:12], str(want.get("dev") or want.get("src"))[:12])
+    return pmc.get("classes", {}), "profiles/pmc_current.json (rocprofv3 --pmc, same workload, separate passes, device code %s...)" % str(
+        want.get("dev") or want.get("src"))[:12]
 
 
 def flops_per_ir(S: int, G: int, layers: int = 12) -> float:

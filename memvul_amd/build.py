@@ -58,6 +58,41 @@ def build_fingerprint(extra_flags=()) -> str:
     return "src %s\ncc %s" % (source_fingerprint(extra_flags), hashlib.sha256(cc).hexdigest() if cc is not None else "unknown")
 
 
+def device_code_fingerprint(lib_path: str = None) -> str:
+    """sha256 of the gfx950 code object(s) embedded in the shared library (the clang offload bundle inside .hip_fatbin): what the
+    GPU executes.  Host-only edits of engine.hip leave it unchanged, any kernel change moves it — bench.py keys the counter
+    figures of profiles/pmc_current.json on this line of the stamp."""
+    import hashlib
+    import struct
+
+    data = open(lib_path or LIB_PATH, "rb").read()
+    magic = b"__CLANG_OFFLOAD_BUNDLE__"
+    h = hashlib.sha256()
+    found = 0
+    i = data.find(magic)
+    while i >= 0:
+        (n,) = struct.unpack_from("<Q", data, i + 24)
+        off = i + 32
+        for _ in range(n):
+            o, size, tsz = struct.unpack_from("<QQQ", data, off)
+            off += 24
+            triple = data[off:off + tsz]
+            off += tsz
+            if ARCH.encode() in triple:
+                h.update(data[i + o:i + o + size])
+                found += 1
+        i = data.find(magic, i + len(magic))
+    if not found:
+        raise RuntimeError(f"no {ARCH} code object found in {lib_path or LIB_PATH}")
+    return h.hexdigest()
+
+
+def read_stamp() -> dict:
+    """The stamp next to the library as a dict: src / cc (what it was built from) and dev (the device code it contains)."""
+    with open(STAMP_PATH) as f:
+        return dict(line.split(" ", 1) for line in f.read().strip().splitlines() if " " in line)
+
+
 def is_stale(extra_flags=()) -> bool:
     """True when the library must be rebuilt: no binary / stamp, other sources or flags, or — where a compiler exists to
     compare with — another compiler.  On a box WITHOUT hipcc only the source line is compared (the binary that travelled with
@@ -88,7 +123,7 @@ def build(force: bool = False, verbose: bool = True, extra_flags=()) -> str:
     subprocess.run(cmd, check=True)
     os.replace(LIB_PATH + ".tmp", LIB_PATH)
     with open(STAMP_PATH, "w") as f:
-        f.write(build_fingerprint(extra_flags) + "\n")
+        f.write(build_fingerprint(extra_flags) + "\ndev " + device_code_fingerprint(LIB_PATH) + "\n")
     return LIB_PATH
 
 

@@ -73,3 +73,22 @@ def test_no_cpp_exception_can_cross_the_abi():
     unguarded = [name for name, _, guard, rest in heads if not guard and not rest.rstrip().endswith("}")]
     assert not unguarded, unguarded
     assert block.count("catch (...) { return on_exception(") == sum(1 for _, _, guard, _ in heads if guard)
+
+
+def test_stamp_carries_the_device_code_fingerprint(lib):
+    """bench.py keys the counter figures of profiles/pmc_current.json on the stamp's `dev` line = sha256 of the gfx950 code
+    object inside the .so: it must describe the binary next to it, and the committed counter file must be readable."""
+    import json
+
+    import bench
+    from memvul_amd import build
+
+    st = build.read_stamp()
+    assert set(st) >= {"src", "cc", "dev"}
+    assert st["dev"] == build.device_code_fingerprint() and st["src"] == build.source_fingerprint()
+    classes, note = bench.load_pmc()
+    pmc = json.load(open(bench.PMC_FILE))
+    if "dev " + st["dev"] in pmc["lib_stamp"]:
+        assert classes and "gemm_ffn2" in classes and classes["gemm_ffn2"]["traffic_bytes"] > 0, note
+    else:  # kernels changed since the last counter pass: the bench must say so instead of quoting the old figures
+        assert classes == {} and "not reported" in note
