@@ -145,7 +145,10 @@ def main():
     if multi:
         # the N > 1 transport: the ranks agree over a rendezvous hub whether RCCL bound inside libmemvul_hip.so (mv_comm_*,
         # collective on the engine's stream, no torch in the process) carries the statistics or the hub itself does
-        transport = mvdist.init_transport(eng, rank, world, prefer="tcp" if (one_gpu_smoke or stub) else "rccl")
+        # (MEMVUL_BENCH_ONE_GPU_SMOKE=rccl lets the shared-GPU ranks TRY RCCL: ncclCommInitRank refuses two ranks on one device,
+        # so the run exercises the agreement's fall-back — every rank reports the failure, all move to the hub together)
+        skip_rccl = stub or (one_gpu_smoke and os.environ.get("MEMVUL_BENCH_ONE_GPU_SMOKE") != "rccl")
+        transport = mvdist.init_transport(eng, rank, world, prefer="tcp" if skip_rccl else "rccl")
 
     # anchor memory: G synthetic CWE descriptions of up to 512 tokens, built once per process (untimed;
     # predict_memory.py:81-83 forwards them in chunks of 128)
