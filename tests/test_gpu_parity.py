@@ -142,12 +142,13 @@ def test_ref12_logits_against_the_reference_run(gu, compute):
     eng.anchor_reset()
 
 
-def test_anchor_chunking_and_padding_invariance(gu):
+@pytest.mark.parametrize("compute", ["f16", "precise"])
+def test_anchor_chunking_and_padding_invariance(gu, compute):
     """Anchors appended in two chunks (128 + rest in the reference, predict_memory.py:81-83) equal one
-    append; extra zero padding columns do not change an embedding (masked keys)."""
+    append; extra zero padding columns do not change an embedding (masked keys).  Both compute dtypes."""
     dk, wk = dict(layers=2, vocab_size=2048), dict(qk_scale=3.0)
     dims, w = gu.weights_for(dk, wk)
-    eng = gu.engine_for(dk, wk)
+    eng = gu.engine_for(dk, wk, compute_dtype=compute)
     ids, lens = synth.make_ids(9, 96, dims.vocab_size, ragged=True, min_len=5)
     eng.anchor_reset(); eng.anchor_append(ids, lens); v1 = eng.anchor_get()
     eng.anchor_reset(); eng.anchor_append(ids[:4], lens[:4]); eng.anchor_append(ids[4:], lens[4:]); v2 = eng.anchor_get()
@@ -166,13 +167,14 @@ def test_anchor_chunking_and_padding_invariance(gu):
     eng.anchor_reset()
 
 
-def test_full_batch_properties(gu):
+@pytest.mark.parametrize("compute", ["f16", "precise"])
+def test_full_batch_properties(gu, compute):
     """BASELINE.json configs[1] shape (B=256, S=256, G=124) on the 12-layer model: properties that need
     no CPU reference at this size, plus agreement of the resident-corpus path with mv_forward and an
-    oracle spot-check of a few rows."""
+    oracle spot-check of a few rows.  Both compute dtypes (the bench runs both at this shape)."""
     dk, wk = dict(layers=12), dict()
     dims, w = gu.weights_for(dk, wk)
-    eng = gu.engine_for(dk, wk, max_tokens=65536, max_batch=256, max_anchors=128)
+    eng = gu.engine_for(dk, wk, compute_dtype=compute, max_tokens=65536, max_batch=256, max_anchors=128)
     B, S, G = 256, 256, 124
     ids, lens = synth.make_ids(B, S, dims.vocab_size, ragged=False)
     aids, alens = synth.make_ids(G, 64, dims.vocab_size, seed=synth.SEED + 1, ragged=True, min_len=8)
