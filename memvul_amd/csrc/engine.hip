@@ -799,6 +799,10 @@ int mv_create(int device, const mv_config* cfg, mv_handle** out) try {
   if (e != hipSuccess) return fail(nullptr, MV_ERR_HIP, std::string("hipSetDevice: ") + hipGetErrorString(e));
   mv_handle* h = new (std::nothrow) mv_handle();
   if (!h) return fail(nullptr, MV_ERR_NOMEM, "out of host memory");
+  struct Guard {  // an exception below (caught by this function's handler) must not leak the half-built handle
+    mv_handle* h;
+    ~Guard() { if (h) mv_destroy(h); }
+  } guard{h};
   h->device = device;
   h->cfg = *cfg;
   h->P = cfg->proj_dim;
@@ -807,8 +811,7 @@ int mv_create(int device, const mv_config* cfg, mv_handle** out) try {
     e = hipStreamCreateWithFlags(&h->work[wi].stream, hipStreamNonBlocking);
     if (e != hipSuccess) {
       g_create_error = std::string("hipStreamCreate: ") + hipGetErrorString(e);
-      mv_destroy(h);
-      return MV_ERR_HIP;
+      return MV_ERR_HIP;  // the guard destroys the handle
     }
   }
   // dynamic LDS above 64 KiB needs an explicit opt-in — per device, so here and not behind a process-wide flag
@@ -886,9 +889,9 @@ int mv_create(int device, const mv_config* cfg, mv_handle** out) try {
   if (rc == MV_OK && hipStreamSynchronize(h->w->stream) != hipSuccess) rc = MV_ERR_HIP;
   if (rc != MV_OK) {
     g_create_error = h->err.empty() ? "workspace allocation failed" : h->err;
-    mv_destroy(h);
-    return rc;
+    return rc;  // the guard destroys the handle
   }
+  guard.h = nullptr;
   *out = h;
   return MV_OK;
 } catch (...) { return on_exception(nullptr); }
