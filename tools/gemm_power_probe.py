@@ -3,9 +3,13 @@ launch) on random operands, on operands of small dynamic range (few toggling man
 stream, LDS / DMA traffic and synchronisation are identical, only the switching activity of the data differs.
     python tools/gemm_power_probe.py
 """
+import os
+import sys
+
 import numpy as np
 
-from memvul_amd.binding import Engine
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from memvul_amd.binding import Engine  # noqa: E402
 
 M, N, K = 65536, 3072, 768
 rng = np.random.default_rng(2021)
