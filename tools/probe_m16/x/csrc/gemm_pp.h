@@ -1,0 +1,809 @@
+// Persistent ping-pong MFMA GEMM for the BERT projections at bench scale:
+//   C[M,N] = A[M,K] (fp16) x W[N,K]^T (fp16, torch Linear.weight layout) + bias, fp32 accumulate,
+// with the reference's elementwise work fused (HF BertSelfAttention / BertSelfOutput / BertIntermediate /
+// BertOutput as invoked from custom_PTM_embedder.py:228).
+//
+// Structure (cdna_hip_programming.md §5 "256^2 8-phase template", T1-T5; MI355X_MICROARCH.md "Two waves per SIMD"):
+//   * 256x256x64 tile, 512 threads = 8 waves as 2(M) x 4(N), 128x64 of C per wave (128 accumulator VGPRs),
+//     v_mfma_f32_32x32x16_f16, ONE workgroup per CU, grid = #CUs, each workgroup walks a strided list of
+//     output tiles (persistent): the K-tile stream never drains between output tiles, so the next tile's
+//     operands are already in flight while the epilogue stores.
+//   * ONE s_barrier per phase; the first M-half of the workgroup (waves 0-3) runs [MFMA(j), read fragments(j+1)] and
+//     the second (waves 4-7: one wave of each half per SIMD) [read fragments(j), MFMA(j)] inside the same barrier
+//     interval, so each SIMD's matrix pipe is handed from one wave to the other in the middle of the interval.
+//   * A K-tile is 4 phases = the 4 quadrants (64 x 32) of the wave's C block in the order (a0,b0) (a0,b1) (a1,b1)
+//     (a1,b0): each phase reads at most ONE operand half-tile (8 or 4 ds_read_b128 per wave).
+//   * Operand half-tiles (128 rows x 128 B = 16 KiB = 2 LDS-DMA instructions per wave) are the unit of staging: LDS
+//     holds two K-tiles x {a0,a1,b0,b1} = 128 KiB; F = 4 half-tiles are kept in flight across every barrier (half-tile
+//     H is issued in interval H-3-F, is landed for every wave at the barrier that ends interval H-3, and its LDS region
+//     was last read in interval H-8 or H-9) with one counted `s_waitcnt vmcnt(2 F)` per interval; loads stay in
+//     flight across barriers (raw s_barrier, never __syncthreads).
+//   * LDS image of a half-tile is lane-linear per DMA instruction (1 KiB = 8 rows x 128 B); the bank swizzle
+//     (16-B chunk c of row r at slot c ^ ((r >> 1) & 7)) is applied on the per-lane SOURCE address and on the
+//     ds_read_b128 (rule 21).  The DMA uses the SGPR-base + 32-bit-VGPR-offset form.
+//   * Orientation: C^T fragments (W rows as the MFMA A operand), so a lane holds 4 CONSECUTIVE output columns of one
+//     token row per register group; every 32x32 fragment goes through a wave-private LDS transposition so that each
+//     global store / residual load instruction covers 16 rows x 64 contiguous bytes.
+//   * Tile order: logical tile sequence = (column group of GN tiles) > tile_m > tile_n-in-group; per persistent
+//     iteration the 256 concurrent tiles are consecutive in it and each XCD takes a contiguous run of 32 (the
+//     group's W panels stay in that XCD's L2 while it sweeps the A row panels).
+//
+// Three kernel kinds (the encoder layer's four GEMMs; what rounds 1-2 also carried — fp32-stream epilogues, the two-barrier
+// schedule, timing ablations — lives in tools/legacy/ with its A/B records in profiles/):
+//   PP_QK   (RAW)  Q, K (head-major) and V^T in ONE launch: the V tiles go through the wave's LDS image transposed.
+//   PP_GELU (RAW)  FFN-1 + exact-erf GELU.
+//   PP_RESLN3      attention-output projection / FFN-2: + bias + LayerNorm(residual), in place on the raw stream.
+// "Virtual LayerNorm": no LayerNorm kernel between the GEMMs.  By linearity
+//   W LN(r) + b = rstd * (W'' r) + b',  W''[n][k] = W[n][k] gamma[k] - mean_k(W[n][.] gamma[.]),  b' = b + W beta
+// (the row mean of r drops out against the row-centred weights), so a RAW consumer takes the raw stream rounded to fp16 as
+// its A operand and the folded weights W'' (prepared once on the host), starts its accumulators from zero and applies
+// fma(rstd_row, acc, b'_col) in the epilogue; its next tile's row statistics and bias' arrive by seven LDS-DMA pieces.  The
+// producer (PP_RESLN3) normalises the residual tile it loads anyway while initialising the accumulators and writes the new raw
+// stream as TWO fp16 planes  hi = fp16(r)  (the operand of the RAW consumers),  lo = fp16(r - hi)  (r ~= hi + lo to 2^-22)
+// plus the rows' "vstats": per row and 256-column tile the (sum, sum of squares); every consumer turns the three pairs of a
+// row into (mean, rstd) itself (common.h ln_from_partials).
+//
+// X8 = 1 (compute dtype MV_F16X8, "precise"): every GEMM adds a SECOND sweep on the fp8 matrix path into the same fp32
+// accumulators:  A W ~= A_hi W_hi + 2^-s (A_lo8 W_hi8 + A_hi8 W_lo8),  A_hi = fp16(A), A_lo8 = e4m3((A - A_hi) 2^(11 + sa)),
+// A_hi8 = e4m3(A_hi 2^sa), W likewise with its own shift sw, s = 11 + sa + sw — the first-order correction terms of the
+// split-operand product, which only need ~4 significant bits, as ONE v_mfma_scale_f32_32x32x64_f8f6f4 sweep (OCP e4m3, uniform
+// E8M0 scales = the exact power of two 2^-s) over a virtual K of 2 K: the fp8 operands are rows [lo8 (K bytes) | hi8 (K bytes)]
+// for A and [hi8 | lo8] for W, so row pitch (2 K bytes), K-tile width (128 bytes) and K-tile count (K / 64) equal the fp16
+// sweep's and the staging code is shared; an fp8 K-tile covers 128 products per row pair in the matrix-pipe time the fp16
+// tile needs for 64.  Cost: 2x the main loop (a three-sweep fp16 split: 3x); error: operand rounding 2^-12 -> ~2^-15.5
+// (oracle/precision_model.py "f16x8").  The producers (PP_GELU, PP_RESLN3; embedding, attention) write the [lo8 | hi8] planes.
+#pragma once
+#include "common.h"
+#include <type_traits>
+
+#include "gemm.h"
+
+enum { PP_QK = 1, PP_GELU = 3, PP_RESLN3 = 8 };
+constexpr int PP_F = 4;  // half-tiles kept in flight across each barrier
+
+#define PP_LDS_A 0           // [par][a][wr][64 rows][128 B]
+#define PP_LDS_B 65536       // [par][b][wc][32 rows][128 B]
+#define PP_LDS_BIAS 131072   // PP_RESLN3: bias | gamma | beta, 3 x 768 fp32
+#define PP_LDS_SCR (PP_LDS_BIAS + MV_INTER * 4)  // 8 waves x 2 KiB: wave-private transposition scratch
+#define PP_LDS_BYTES (PP_LDS_SCR + 8 * 2048)     // 159,744 of 163,840
+// RAW kernels re-partition everything above the operand ring: [2][256] bias' of the tile | [2][256 rows][3][sum, sumsq] | scratch
+#define PP_LDS_BIAS_T PP_LDS_BIAS                  // 2 x 1 KiB
+#define PP_LDS_STATS (PP_LDS_BIAS + 2048)          // 2 x 6 KiB
+#define PP_LDS_SCR_RAW (PP_LDS_STATS + 2 * 6144)   // 8 waves x 2 KiB
+#define PP_LDS_RSTD (PP_LDS_SCR_RAW + 8 * 2048)    // 2 x 256 rstd of the tile's rows (computed once per workgroup, in the main loop)
+#define PP_LDS_BYTES_RAW (PP_LDS_RSTD + 2048)      // 163,840 = all of the CU's LDS
+
+__device__ __forceinline__ uint32_t pack_h2(float a, float b) {
+  const half2_t h = {(half_t)a, (half_t)b};
+  return __builtin_bit_cast(uint32_t, h);
+}
+
+// (hipcc/ROCm 7.2: __builtin_bit_cast applied directly to an ext_vector ELEMENT expression reads element 0 —
+// always go through a scalar copy)
+__device__ __forceinline__ uint32_t f2u(float x) { return __float_as_uint(x); }
+__device__ __forceinline__ float u2f(uint32_t x) { return __uint_as_float(x); }
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef int intx4 __attribute__((ext_vector_type(4)));
+typedef int intx8 __attribute__((ext_vector_type(8)));
+
+// Wave-private transposition through a [32 rows][64 B] LDS image (16-B chunk c of row r at slot c ^ ((r >> 2) & 3)):
+// the MFMA C/D layout gives a lane 8 or 16 contiguous bytes of ONE row (lane = row), so storing it directly makes
+// every wave-store touch 64 scattered 16-B pieces (measured: ~64 cycles of address processing per instruction,
+// 3.6 us per 256^2 tile).  Through the image each store covers 16 rows x 64 contiguous bytes.  Inline asm keeps
+// these LDS accesses out of hipcc's LDS-DMA alias bookkeeping (it would put `s_waitcnt vmcnt(0)` before them and
+// wait for the epilogue's own stores); LDS executes a wave's instructions in order, so the read-after-write
+// needs no wait, only the read results do (same statement, guide §5.7 form i).  Two fp16 fragments (j = 0, 1) per statement:
+// the second fragment's writes may follow the first one's reads into the same image without a wait in between.
+__device__ __forceinline__ void scr_f16x2(uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3, const u32x2 (&da)[4],
+                                          const u32x2 (&db)[4], uint32_t r, u32x4 (&o)[4]) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm volatile(
+      "ds_write_b64 %4, %8\n\tds_write_b64 %5, %9\n\tds_write_b64 %6, %10\n\tds_write_b64 %7, %11\n\t"
+      "ds_read_b128 %0, %16\n\tds_read_b128 %1, %16 offset:1024\n\t"
+      "ds_write_b64 %4, %12\n\tds_write_b64 %5, %13\n\tds_write_b64 %6, %14\n\tds_write_b64 %7, %15\n\t"
+      "ds_read_b128 %2, %16\n\tds_read_b128 %3, %16 offset:1024\n\ts_waitcnt lgkmcnt(0)"
+      : "=&v"(o[0]), "=&v"(o[1]), "=&v"(o[2]), "=&v"(o[3])
+      : "v"(w0), "v"(w1), "v"(w2), "v"(w3), "v"(da[0]), "v"(da[1]), "v"(da[2]), "v"(da[3]), "v"(db[0]), "v"(db[1]),
+        "v"(db[2]), "v"(db[3]), "v"(r)
+      : "memory");
+#endif
+}
+// Two fp8 planes (MV_F16X8: lo8, then hi8) of one 32-row x 64-column block (fragments j = 0, 1) through the same image:
+// a plane is [32 rows][64 B], the lane's dword (j, g) = columns 32 j + 8 g + 4 hi ..+3 goes to slot 2 j + (g >> 1) of its
+// row (swizzled like the fp16 image) at byte 8 (g & 1) + 4 hi; w0..w3 = the lane's slot addresses (+ 4 hi), da / db index
+// 4 j + g.  The read side is the fp16 one: rows lane >> 2 and + 16, 16-B chunk lane & 3.
+__device__ __forceinline__ void scr_f8x2(uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3, const uint32_t (&da)[8],
+                                         const uint32_t (&db)[8], uint32_t r, u32x4 (&o)[4]) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm volatile(
+      "ds_write_b32 %4, %8\n\tds_write_b32 %4, %9 offset:8\n\tds_write_b32 %5, %10\n\tds_write_b32 %5, %11 offset:8\n\t"
+      "ds_write_b32 %6, %12\n\tds_write_b32 %6, %13 offset:8\n\tds_write_b32 %7, %14\n\tds_write_b32 %7, %15 offset:8\n\t"
+      "ds_read_b128 %0, %24\n\tds_read_b128 %1, %24 offset:1024\n\t"
+      "ds_write_b32 %4, %16\n\tds_write_b32 %4, %17 offset:8\n\tds_write_b32 %5, %18\n\tds_write_b32 %5, %19 offset:8\n\t"
+      "ds_write_b32 %6, %20\n\tds_write_b32 %6, %21 offset:8\n\tds_write_b32 %7, %22\n\tds_write_b32 %7, %23 offset:8\n\t"
+      "ds_read_b128 %2, %24\n\tds_read_b128 %3, %24 offset:1024\n\ts_waitcnt lgkmcnt(0)"
+      : "=&v"(o[0]), "=&v"(o[1]), "=&v"(o[2]), "=&v"(o[3])
+      : "v"(w0), "v"(w1), "v"(w2), "v"(w3), "v"(da[0]), "v"(da[1]), "v"(da[2]), "v"(da[3]), "v"(da[4]), "v"(da[5]), "v"(da[6]),
+        "v"(da[7]), "v"(db[0]), "v"(db[1]), "v"(db[2]), "v"(db[3]), "v"(db[4]), "v"(db[5]), "v"(db[6]), "v"(db[7]), "v"(r)
+      : "memory");
+#endif
+}
+// The V block of a merged Q,K,V launch (lane = token, registers = 4 consecutive head dims) goes
+// through the image TRANSPOSED - image rows = head dims, image columns = tokens - so that the read side and the
+// stores are the V^T ones: 16 two-byte writes per fragment (row 8 g + 4 hi + e at a0 / a1 = a0 ^ 32 plus
+// 512 g + 64 e; the slot swizzle (row >> 2) & 3 = (2 g + hi) & 3 alternates between hi and hi ^ 2).
+__device__ __forceinline__ void scr_f16x2_t(uint32_t a0, uint32_t a1, const u32x2 (&da)[4], const u32x2 (&db)[4], uint32_t r,
+                                            u32x4 (&o)[4]) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  const uint32_t a00 = da[0][0], a01 = da[0][1], a10 = da[1][0], a11 = da[1][1], a20 = da[2][0], a21 = da[2][1], a30 = da[3][0],
+                 a31 = da[3][1];
+  const uint32_t b00 = db[0][0], b01 = db[0][1], b10 = db[1][0], b11 = db[1][1], b20 = db[2][0], b21 = db[2][1], b30 = db[3][0],
+                 b31 = db[3][1];
+#define MV_T16(A, LO, HI, OFF)                                                                            \
+  "ds_write_b16 " A ", " LO " offset:" #OFF "+0\n\tds_write_b16_d16_hi " A ", " LO " offset:" #OFF "+64\n\t" \
+  "ds_write_b16 " A ", " HI " offset:" #OFF "+128\n\tds_write_b16_d16_hi " A ", " HI " offset:" #OFF "+192\n\t"
+  asm volatile(
+      MV_T16("%4", "%6", "%7", 0) MV_T16("%5", "%8", "%9", 512) MV_T16("%4", "%10", "%11", 1024) MV_T16("%5", "%12", "%13", 1536)
+      "ds_read_b128 %0, %22\n\tds_read_b128 %1, %22 offset:1024\n\t"
+      MV_T16("%4", "%14", "%15", 0) MV_T16("%5", "%16", "%17", 512) MV_T16("%4", "%18", "%19", 1024) MV_T16("%5", "%20", "%21", 1536)
+      "ds_read_b128 %2, %22\n\tds_read_b128 %3, %22 offset:1024\n\ts_waitcnt lgkmcnt(0)"
+      : "=&v"(o[0]), "=&v"(o[1]), "=&v"(o[2]), "=&v"(o[3])
+      : "v"(a0), "v"(a1), "v"(a00), "v"(a01), "v"(a10), "v"(a11), "v"(a20), "v"(a21), "v"(a30), "v"(a31), "v"(b00), "v"(b01),
+        "v"(b10), "v"(b11), "v"(b20), "v"(b21), "v"(b30), "v"(b31), "v"(r)
+      : "memory");
+#undef MV_T16
+#endif
+}
+// The reverse direction for two fp16 planes of one 32 x 32 fragment: coalesced 16-byte pieces (rows lane >> 2 and + 16, chunk
+// lane & 3) are written into the image, the C/D-layout units (row lane & 31, columns 8 g + 4 hi .. + 3) are read back.
+__device__ __forceinline__ void scr_f16_rev2(uint32_t wc, const u32x4& a0, const u32x4& a1, const u32x4& b0, const u32x4& b1, uint32_t r0,
+                                             uint32_t r1, uint32_t r2, uint32_t r3, u32x2 (&oa)[4], u32x2 (&ob)[4]) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm volatile(
+      "ds_write_b128 %8, %9\n\tds_write_b128 %8, %10 offset:1024\n\t"
+      "ds_read_b64 %0, %13\n\tds_read_b64 %1, %14\n\tds_read_b64 %2, %15\n\tds_read_b64 %3, %16\n\t"
+      "ds_write_b128 %8, %11\n\tds_write_b128 %8, %12 offset:1024\n\t"
+      "ds_read_b64 %4, %13\n\tds_read_b64 %5, %14\n\tds_read_b64 %6, %15\n\tds_read_b64 %7, %16\n\ts_waitcnt lgkmcnt(0)"
+      : "=&v"(oa[0]), "=&v"(oa[1]), "=&v"(oa[2]), "=&v"(oa[3]), "=&v"(ob[0]), "=&v"(ob[1]), "=&v"(ob[2]), "=&v"(ob[3])
+      : "v"(wc), "v"(a0), "v"(a1), "v"(b0), "v"(b1), "v"(r0), "v"(r1), "v"(r2), "v"(r3)
+      : "memory");
+  __builtin_amdgcn_sched_barrier(0);
+#endif
+}
+
+// PP_RESLN3 accumulator init: one float4 of each of the bias, gamma and beta images (gamma at +3072 B, beta at +6144 B).
+__device__ __forceinline__ void lds_read_bgb1(uint32_t addr, float4& bi, float4& ga, float4& be) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm volatile("ds_read_b128 %0, %3\n\tds_read_b128 %1, %3 offset:3072\n\tds_read_b128 %2, %3 offset:6144\n\ts_waitcnt lgkmcnt(0)"
+               : "=&v"(bi), "=&v"(ga), "=&v"(be)
+               : "v"(addr)
+               : "memory");
+  __builtin_amdgcn_sched_barrier(0);
+#endif
+}
+
+template <int EPI, int RAW = 0, int X8 = 0>
+__global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmArgs a) {
+  static_assert(EPI == PP_QK || EPI == PP_GELU || EPI == PP_RESLN3, "kernel kinds of the encoder layer");
+  static_assert(RAW == (EPI != PP_RESLN3), "PP_QK / PP_GELU consume the raw stream (virtual LayerNorm), PP_RESLN3 produces it");
+  constexpr bool IS_RES = (EPI == PP_RESLN3);
+  constexpr int WAITN = 2 * PP_F;
+  constexpr int LDS_SCR = RAW ? PP_LDS_SCR_RAW : PP_LDS_SCR;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int hi = lane >> 5, l31 = lane & 31;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 2, wc = wave & 3;
+  const int K = a.K, nk0 = K >> 6;                 // K-tiles of one sweep
+  constexpr int nseg = X8 ? 2 : 1;                  // X8: the fp16 sweep, then the fp8 correction sweep (same K-tile count)
+  const int nk = nk0 * nseg;                        // K-tiles per output tile
+  const int tm_count = a.M >> 8, tn_count = a.N >> 8;
+  const int ntiles = tm_count * tn_count;
+  const int G = gridDim.x;
+  const int bslot = xcd_remap(blockIdx.x, G);
+
+  // ---- bias -> LDS (once per workgroup; RAW kernels: per tile, issue_stats)
+  if constexpr (!RAW) {
+    float* lb = (float*)(smem + PP_LDS_BIAS);
+    for (int n = tid; n < a.N; n += 512) lb[n] = a.bias ? a.bias[n] : 0.f;
+    for (int n = tid; n < MV_HIDDEN; n += 512) {  // N == 768: gamma at [768, 1536), beta at [1536, 2304) of the same image
+      lb[MV_HIDDEN + n] = a.lng[n];
+      lb[2 * MV_HIDDEN + n] = a.lnb[n];
+    }
+  }
+
+  // ---- staging geometry: wave w fills slabs 2w, 2w+1 (8 rows x 128 B each) of every half-tile
+  uint32_t offA[2], offB[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int rho = (2 * wave + j) * 8 + (lane >> 3);
+    const int c = (lane & 7) ^ ((rho >> 1) & 7);
+    const int rowA = (rho >> 6) * 128 + (rho & 63);
+    const int rowB = (rho >> 5) * 64 + (rho & 31);
+    offA[j] = (uint32_t)(rowA * K + c * 8) * 2u;
+    offB[j] = (uint32_t)(rowB * K + c * 8) * 2u;
+  }
+  // issue cursor (wave-uniform): output tile being staged, its operand panels and K-tile index
+  int i_it = 0, i_kt = 0, i_seg = 0;
+  const char* iA = (const char*)a.A;
+  const char* iW = (const char*)a.W;
+  size_t tA = 0, tW = 0;  // X8: byte offsets of the issue tile's operand panels (the fp8 panels have the same row pitch, 2 K bytes)
+  auto set_issue_seg = [&]() {  // X8, sweep 0: A_hi W_hi (fp16), 1: [A_lo8 | A_hi8] x [W_hi8 | W_lo8] (fp8)
+    iA = (i_seg ? (const char*)a.A8 : (const char*)a.A) + tA;
+    iW = (i_seg ? (const char*)a.W8 : (const char*)a.W) + tW;
+  };
+  auto set_issue_tile = [&](int it) {
+    const int L = it * G + bslot;
+    if (L < ntiles) {  // past the end: keep staging the last valid tile (never read, keeps the vmcnt ledger exact)
+      int tm, tn;
+      raster(L, tm_count, tn_count, a.GN, tm, tn);
+      if constexpr (X8) {
+        tA = (size_t)tm * 256 * K * 2;
+        tW = (size_t)tn * 256 * K * 2;
+      } else {
+        iA = (const char*)a.A + (size_t)tm * 256 * K * 2;
+        iW = (const char*)a.W + (size_t)tn * 256 * K * 2;
+      }
+    }
+    if constexpr (X8) set_issue_seg();
+  };
+  set_issue_tile(0);
+  // kind: 0 = a0, 1 = a1, 2 = b0, 3 = b1; issue order per K-tile: b0, a0, b1, a1 (= read order)
+  auto issue = [&](auto kindc, auto parc) {
+    constexpr int kind = decltype(kindc)::value;
+    constexpr int par = decltype(parc)::value;
+    const char* src;
+    char* dst;
+    if constexpr (kind < 2) {
+      src = iA + (size_t)(kind * 64) * K * 2 + i_kt * 128;
+      dst = smem + PP_LDS_A + par * 32768 + kind * 16384 + wave * 2048;
+      glds16((const half_t*)(src + offA[0]), dst);
+      glds16((const half_t*)(src + offA[1]), dst + 1024);
+    } else {
+      src = iW + (size_t)((kind - 2) * 32) * K * 2 + i_kt * 128;
+      dst = smem + PP_LDS_B + par * 32768 + (kind - 2) * 16384 + wave * 2048;
+      glds16((const half_t*)(src + offB[0]), dst);
+      glds16((const half_t*)(src + offB[1]), dst + 1024);
+    }
+    if constexpr (kind == 1) {  // last half-tile of this K-tile: advance the cursor
+      if (++i_kt == nk0) {
+        i_kt = 0;
+        if constexpr (X8) {
+          if (++i_seg == nseg) {
+            i_seg = 0;
+            set_issue_tile(++i_it);
+          } else {
+            set_issue_seg();
+          }
+        } else {
+          set_issue_tile(++i_it);
+        }
+      }
+    }
+  };
+  // psi-th half-tile of the stream (psi = phase + 1): psi % 4 -> kind, (psi / 4) & 1 -> LDS parity
+  auto issue_psi = [&](auto psic) {
+    constexpr int psi = decltype(psic)::value;
+    constexpr int q = psi & 3;
+    constexpr int kind = (q == 0) ? 2 : (q == 1) ? 0 : (q == 2) ? 3 : 1;
+    issue(std::integral_constant<int, kind>{}, std::integral_constant<int, (psi >> 2) & 1>{});
+  };
+
+  // ---- fragment read addresses
+  const int swz = (lane >> 1) & 7;
+  int rdA[4], rdB[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) {
+    const int o = l31 * 128 + (((ks * 2 + hi) ^ swz) << 4);
+    rdA[ks] = PP_LDS_A + wr * 8192 + o;
+    rdB[ks] = PP_LDS_B + wc * 4096 + o;
+  }
+  // fragment registers.  X8 builds hold each PAIR of 16-byte chunks (2 kk, 2 kk + 1) as one 8-dword value, because the fp8
+  // matrix instruction takes 32 K-bytes per lane as a 256-bit operand (left as separate 128-bit values hipcc copies them
+  // into fresh 8-register tuples in front of every MFMA and spills); the fp16 instruction reads the halves in place.
+  half8_t Xf[X8 ? 1 : 2][X8 ? 1 : 4], Wx[X8 ? 1 : 4], Wy[X8 ? 1 : 4];
+  intx8 Xp[X8 ? 2 : 1][X8 ? 2 : 1], Wxp[X8 ? 2 : 1], Wyp[X8 ? 2 : 1];
+  auto ld16 = [&](int off) -> intx4 { return *(const intx4*)(smem + off); };
+  auto read_a = [&](int par, int asub) {
+    if constexpr (X8) {
+#pragma unroll
+      for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+          const int o = par * 32768 + asub * 16384 + ii * 4096;
+          Xp[ii][kk] = __builtin_shufflevector(ld16(rdA[2 * kk] + o), ld16(rdA[2 * kk + 1] + o), 0, 1, 2, 3, 4, 5, 6, 7);
+        }
+    } else {
+#pragma unroll
+      for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+          Xf[ii][ks] = *(const half8_t*)(smem + rdA[ks] + par * 32768 + asub * 16384 + ii * 4096);
+    }
+  };
+  auto read_b = [&](half8_t (&Wf)[X8 ? 1 : 4], intx8 (&Wp)[X8 ? 2 : 1], int par, int bsub) {
+    if constexpr (X8) {
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        const int o = par * 32768 + bsub * 16384;
+        Wp[kk] = __builtin_shufflevector(ld16(rdB[2 * kk] + o), ld16(rdB[2 * kk + 1] + o), 0, 1, 2, 3, 4, 5, 6, 7);
+      }
+    } else {
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) Wf[ks] = *(const half8_t*)(smem + rdB[ks] + par * 32768 + bsub * 16384);
+    }
+  };
+
+  floatx16 acc[4][2];
+  // the two fp16 planes of fragment pair i of the residual tile at (mw0, nw0) by full-line loads (16 rows x 64 B per
+  // instruction), parked in the accumulator registers they will be transposed into: [i][j] registers 0-3 / 4-7 = hi rows
+  // crow / crow + 16, 8-11 / 12-15 = lo
+  auto park_residual = [&](int i, int mw0, int nw0) {
+    const int crow = lane >> 2, cchunk = lane & 3;
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int pl = 0; pl < 2; ++pl)
+#pragma unroll
+        for (int x = 0; x < 2; ++x) {
+          const half_t* src = (pl ? a.out16b : a.out16) + (size_t)(mw0 + i * 32 + x * 16 + crow) * MV_HIDDEN + nw0 + j * 32 + 8 * cchunk;
+          const float4 t = *(const float4*)src;
+          acc[i][j][8 * pl + 4 * x + 0] = t.x; acc[i][j][8 * pl + 4 * x + 1] = t.y;
+          acc[i][j][8 * pl + 4 * x + 2] = t.z; acc[i][j][8 * pl + 4 * x + 3] = t.w;
+        }
+  };
+  // One quadrant of a K-tile.  F8 (X8, the correction sweep): the same fragment registers hold fp8 bytes — a lane's four
+  // 16-byte chunks 2 ks + hi (ks = 0..3) of its 128-byte row; MFMA kk takes chunks 4 kk + hi and 4 kk + 2 + hi as its 32
+  // K-bytes, the same assignment for both operands, so every byte column of the tile meets its partner exactly once.
+  auto mma_quadrant = [&](auto asubc, auto bc, auto f8c, const half8_t (&Wf)[X8 ? 1 : 4], const intx8 (&Wp)[X8 ? 2 : 1]) {
+    constexpr int asub = decltype(asubc)::value;
+    constexpr int b = decltype(bc)::value;
+    if constexpr (X8) {
+      if constexpr (decltype(f8c)::value) {
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+          for (int ii = 0; ii < 2; ++ii)
+            acc[asub * 2 + ii][b] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(Wp[kk], Xp[ii][kk], acc[asub * 2 + ii][b], 0, 0, 0,
+                                                                                    a.x8_scale, 0, 0x7f7f7f7f);
+      } else {
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+          const intx4 w4 = (ks & 1) ? __builtin_shufflevector(Wp[ks >> 1], Wp[ks >> 1], 4, 5, 6, 7)
+                                    : __builtin_shufflevector(Wp[ks >> 1], Wp[ks >> 1], 0, 1, 2, 3);
+#pragma unroll
+          for (int ii = 0; ii < 2; ++ii) {
+            const intx4 x4 = (ks & 1) ? __builtin_shufflevector(Xp[ii][ks >> 1], Xp[ii][ks >> 1], 4, 5, 6, 7)
+                                      : __builtin_shufflevector(Xp[ii][ks >> 1], Xp[ii][ks >> 1], 0, 1, 2, 3);
+            acc[asub * 2 + ii][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8_t, w4), __builtin_bit_cast(half8_t, x4),
+                                                                           acc[asub * 2 + ii][b], 0, 0, 0);
+          }
+        }
+      }
+    } else {
+      // TIMING PROBE (numerically meaningless): every 32x32x16 MFMA replaced by two 16x16x32 MFMAs on the same operand registers
+      // and on halves of the same accumulator registers — same FLOPs, same matrix-pipe time, same LDS / DMA traffic
+      typedef float f4v __attribute__((ext_vector_type(4)));
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+        for (int ii = 0; ii < 2; ++ii) {
+          floatx16& c = acc[asub * 2 + ii][b];
+          constexpr int dummy = 0; (void)dummy;
+          const int o = (ks & 1) * 8;
+          f4v c0 = {c[o + 0], c[o + 1], c[o + 2], c[o + 3]}, c1 = {c[o + 4], c[o + 5], c[o + 6], c[o + 7]};
+          c0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(Wf[ks], Xf[ii][ks], c0, 0, 0, 0);
+          c1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(Wf[ks], Xf[ii][ks], c1, 0, 0, 0);
+          c[o + 0] = c0[0]; c[o + 1] = c0[1]; c[o + 2] = c0[2]; c[o + 3] = c0[3];
+          c[o + 4] = c1[0]; c[o + 5] = c1[1]; c[o + 6] = c1[2]; c[o + 7] = c1[3];
+        }
+    }
+  };
+
+  // ---- building blocks: fragment set / quadrant of phase s (P = s & 3, LDS parity = s >> 2)
+  auto read_set = [&](auto sc) {
+    constexpr int s = decltype(sc)::value & 7;
+    constexpr int P = s & 3, par = s >> 2;
+    if constexpr (P == 0) { read_a(par, 0); read_b(Wx, Wxp, par, 0); }
+    if constexpr (P == 1) read_b(Wy, Wyp, par, 1);
+    if constexpr (P == 2) read_a(par, 1);
+  };
+  auto mma_set = [&](auto sc, auto f8c) {
+    constexpr int P = decltype(sc)::value & 3;
+    if constexpr (P == 0) mma_quadrant(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, f8c, Wx, Wxp);
+    if constexpr (P == 1) mma_quadrant(std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{}, f8c, Wy, Wyp);
+    if constexpr (P == 2) mma_quadrant(std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{}, f8c, Wy, Wyp);
+    if constexpr (P == 3) mma_quadrant(std::integral_constant<int, 1>{}, std::integral_constant<int, 0>{}, f8c, Wx, Wxp);
+  };
+  auto interval = [&](auto sc, auto grpc, auto f8c, bool last_of_tile = false) {
+    constexpr int s = decltype(sc)::value;
+    constexpr int grp = decltype(grpc)::value;
+    if constexpr (grp == 0) {  // matrix pipe first, then the NEXT phase's fragments
+      __builtin_amdgcn_s_setprio(1);
+      mma_set(sc, f8c);
+      __builtin_amdgcn_s_setprio(0);
+      __builtin_amdgcn_sched_barrier(0);
+      // the next OUTPUT tile's first fragments are read after its accumulator init instead (run_tiles): keeping
+      // 48 fragment VGPRs live across the epilogue + init costs more than one exposed LDS read per tile
+      if (!(s == 7 && last_of_tile)) read_set(std::integral_constant<int, (s + 1) & 7>{});
+      issue_psi(std::integral_constant<int, (s + 3 + PP_F) & 7>{});
+    } else {  // this phase's fragments first, then the matrix pipe as the other half releases it
+      read_set(sc);
+      issue_psi(std::integral_constant<int, (s + 3 + PP_F) & 7>{});
+      __builtin_amdgcn_sched_barrier(0);
+      mma_set(sc, f8c);
+    }
+    if constexpr (X8) {
+      // pin this interval's accumulators here: the scaled-MFMA builtin is a pure function to hipcc's IR passes, which otherwise
+      // sink four intervals' worth of them across the barriers into one block (20 + 0 + 0 ... per interval instead of 4 each,
+      // 18 fragment tuples live at once, 400-600 bytes of scratch per lane)
+#if defined(__HIP_DEVICE_COMPILE__)
+      constexpr int P = s & 3, a0 = (P >= 2) ? 2 : 0, bq = (P == 1 || P == 2) ? 1 : 0;  // the quadrant of phase P (mma_set)
+      asm volatile("" : "+v"(acc[a0][bq]), "+v"(acc[a0 + 1][bq]));
+#endif
+    }
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WAITN) : "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+  };
+
+  // ---- RAW: vstats of the 256 token rows (6 KiB) and the 256 bias' values (1 KiB) of persistent iteration `itn` -> LDS
+  // images itn & 1.  Seven 1-KiB LDS-DMA pieces, two per wave 0..3, riding in the same vmcnt ledger: a piece only pushes
+  // OLDER operand pieces out of a counted wait's window, so every wait stays conservative.  (tm, tn) = the tile's
+  // coordinates (computed at the START of the previous tile: the raster's integer divisions stay out of the main loop).
+  auto issue_stats = [&](int itn, int tm, int tn) {
+    if (itn * G + bslot < ntiles && wave < 4) {
+#pragma unroll
+      for (int pc = 0; pc < 2; ++pc) {
+        const int piece = 2 * wave + pc;  // 0..5: vstats, 6: bias', 7: none
+        if (piece < 6) {
+          const char* src = (const char*)a.lnstats + (size_t)tm * 6144 + piece * 1024 + lane * 16;
+          glds16((const half_t*)src, smem + PP_LDS_STATS + (itn & 1) * 6144 + piece * 1024);
+        } else if (piece == 6) {
+          const char* src = (const char*)a.bias + (size_t)tn * 1024 + lane * 16;
+          glds16((const half_t*)src, smem + PP_LDS_BIAS_T + (itn & 1) * 1024);
+        }
+      }
+    }
+  };
+  if constexpr (RAW) {
+    int tm = 0, tn = 0;
+    if (bslot < ntiles) raster(bslot, tm_count, tn_count, a.GN, tm, tn);
+    issue_stats(0, tm, tn);
+  }
+
+  // ---- prologue: half-tiles psi = 0 .. 2 + F in flight, psi 0 .. 2 landed
+  issue_psi(std::integral_constant<int, 0>{});
+  issue_psi(std::integral_constant<int, 1>{});
+  issue_psi(std::integral_constant<int, 2>{});
+  issue_psi(std::integral_constant<int, 3>{});
+  issue_psi(std::integral_constant<int, 4>{});
+  issue_psi(std::integral_constant<int, 5>{});
+  issue_psi(std::integral_constant<int, 6>{});
+  asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(WAITN) : "memory");  // lgkmcnt: the bias image writes
+  __builtin_amdgcn_sched_barrier(0);
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_sched_barrier(0);
+
+  auto run_tiles = [&](auto grpc) {
+  for (int it = 0;; ++it) {
+    const int L = it * G + bslot;
+    if (L >= ntiles) break;
+    int tile_m, tile_n;
+    raster(L, tm_count, tn_count, a.GN, tile_m, tile_n);
+    int next_m = 0, next_n = 0;  // RAW: the workgroup's next tile (issue_stats); PP_RESLN3: its residual tile is requested
+    const bool has_next = L + G < ntiles;  // during this tile's epilogue
+    if (has_next) raster(L + G, tm_count, tn_count, a.GN, next_m, next_n);
+    const int mw = (tile_m << 8) + wr * 128;  // first token row of this wave
+    const int nw = (tile_n << 8) + wc * 64;   // first output column of this wave
+
+    // ---- accumulator init: zero (RAW) or bias + LayerNorm(residual).  The images are read with inline-asm ds_reads: hipcc
+    // would put `s_waitcnt vmcnt(0)` in front of a compiler-visible LDS load here (LDS-DMA in flight) and drain the
+    // operand pipeline once per output tile.  Loads and their lgkmcnt wait are one statement (guide §5.7 form i).
+    {
+      const uint32_t baddr = (uint32_t)(PP_LDS_BIAS + (nw + 4 * hi) * 4);
+      // scratch addresses of this lane: MFMA layout (row = lane & 31) and coalesced layout (row = lane >> 2)
+      const uint32_t scr = (uint32_t)(LDS_SCR + wave * 2048);
+      const uint32_t sf = (uint32_t)((l31 >> 2) & 3);
+      const uint32_t scr_c = scr + (lane >> 2) * 64 + ((((uint32_t)lane & 3) ^ (((uint32_t)lane >> 4) & 3)) << 4);
+      if constexpr (IS_RES) {
+        // residual tile by full-line loads (16 rows x 64 B per instruction), transposed into the C/D layout
+        // (the raw lines are parked in the accumulator registers they will be transposed into)
+        float2 lnst[4];    // (mean, rstd) of this lane's four token rows
+        float2 lnp[4][3];  // the rows' vstats, loaded here and turned into (mean, rstd) only AFTER the residual tile's loads
+                           // are issued (in source order hipcc waits for these loads first and the two memory latencies add
+                           // up: +1.3 us per tile)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float2* pp = (const float2*)(a.lnstats + 6 * (size_t)(mw + i * 32 + l31));
+          lnp[i][0] = pp[0]; lnp[i][1] = pp[1]; lnp[i][2] = pp[2];
+        }
+        const uint32_t wbase = scr + l31 * 64 + hi * 8 + (sf << 4);
+        // (tiles after the workgroup's first: the lines were requested fragment pair by fragment pair during the PREVIOUS
+        //  tile's epilogue, each as soon as its accumulator registers had been stored — park_residual below — so the read
+        //  phase of this tile runs under the write phase of the last one instead of after it)
+        if (it == 0) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) park_residual(i, mw, nw);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) lnst[i] = ln_from_partials(lnp[i][0], lnp[i][1], lnp[i][2], a.ln_eps);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+#pragma clang fp contract(off)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            u32x4 p[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+              for (int e = 0; e < 4; ++e) p[q][e] = f2u(acc[i][j][4 * q + e]);
+            u32x2 oh[4], ol[4];
+            scr_f16_rev2(scr_c, p[0], p[1], p[2], p[3], wbase, wbase ^ 16u, wbase ^ 32u, wbase ^ 48u, oh, ol);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+              float4 bi, ga, be;
+              lds_read_bgb1(baddr + j * 128 + g * 32, bi, ga, be);
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                const uint32_t wh = oh[g][e >> 1], wl = ol[g][e >> 1];  // scalar copies before the bit casts (see f2u)
+                const half2_t h2 = __builtin_bit_cast(half2_t, wh);
+                const half2_t l2 = __builtin_bit_cast(half2_t, wl);
+                const float r = (float)h2[e & 1] + (float)l2[e & 1];
+                const float t = (r - lnst[i].x) * lnst[i].y;
+                acc[i][j][4 * g + e] = __builtin_fmaf(t, ((const float*)&ga)[e], ((const float*)&be)[e]) + ((const float*)&bi)[e];
+              }
+            }
+          }
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              acc[i][j][4 * g + 0] = 0.f; acc[i][j][4 * g + 1] = 0.f; acc[i][j][4 * g + 2] = 0.f; acc[i][j][4 * g + 3] = 0.f;
+            }
+      }
+    }
+
+    if constexpr (decltype(grpc)::value == 0) read_set(std::integral_constant<int, 0>{});
+    auto two_ktiles = [&](auto f8c, bool last) {
+      interval(std::integral_constant<int, 0>{}, grpc, f8c);
+      interval(std::integral_constant<int, 1>{}, grpc, f8c);
+      interval(std::integral_constant<int, 2>{}, grpc, f8c);
+      interval(std::integral_constant<int, 3>{}, grpc, f8c);
+      interval(std::integral_constant<int, 4>{}, grpc, f8c);
+      interval(std::integral_constant<int, 5>{}, grpc, f8c);
+      interval(std::integral_constant<int, 6>{}, grpc, f8c);
+      interval(std::integral_constant<int, 7>{}, grpc, f8c, last);
+    };
+    for (int kt = 0; kt < nk0; kt += 2) {
+      if constexpr (RAW) {  // every wave has left the previous tile's epilogue (>= 8 barriers ago): its stats image is free
+        if (kt == 2) {
+          issue_stats(it + 1, next_m, next_n);
+          // rstd of THIS tile's 256 rows -> LDS, once per workgroup (waves 4..7, one row per lane; in the epilogue, per column
+          // wave, the three pairs + rsq of four rows per lane cost 0.4 us per tile)
+          if (wave >= 4) {
+            const int row = (wave - 4) * 64 + lane;
+            const uint32_t saddr = (uint32_t)(PP_LDS_STATS + (it & 1) * 6144 + row * 24);
+            float2 p0, p1, p2;
+            asm volatile("ds_read_b64 %0, %3\n\tds_read_b64 %1, %3 offset:8\n\tds_read_b64 %2, %3 offset:16\n\ts_waitcnt lgkmcnt(0)"
+                         : "=&v"(p0), "=&v"(p1), "=&v"(p2)
+                         : "v"(saddr)
+                         : "memory");
+            const float rs = ln_from_partials(p0, p1, p2, a.ln_eps).y;
+            const uint32_t waddr = (uint32_t)(PP_LDS_RSTD + (it & 1) * 1024 + row * 4);
+            asm volatile("ds_write_b32 %0, %1" ::"v"(waddr), "v"(rs) : "memory");
+          }
+        }
+      }
+      two_ktiles(std::false_type{}, !X8 && kt + 2 >= nk0);
+    }
+    if constexpr (X8) {  // the correction sweep: the same intervals on the fp8 matrix path
+      for (int kt = nk0; kt < nk; kt += 2) two_ktiles(std::true_type{}, kt + 2 >= nk);
+    }
+
+    // ---- epilogue (store only): every 32x32 fragment goes through the wave's [32][64 B] LDS image
+    {
+      const uint32_t scr = (uint32_t)(LDS_SCR + wave * 2048);
+      const uint32_t sf = (uint32_t)((l31 >> 2) & 3);
+      const uint32_t scr_c = scr + (lane >> 2) * 64 + ((((uint32_t)lane & 3) ^ (((uint32_t)lane >> 4) & 3)) << 4);
+      const int crow = lane >> 2, cchunk = lane & 3;  // coalesced layout: row (+16 for the second read), 16-B chunk
+      if constexpr (IS_RES) {
+        // vstats of the new raw rows: (sum, sum of squares) over this TILE's 256 columns.  Each wave reduces its 64 columns
+        // (lane = token row, the two half-waves hold disjoint column sets), parks the 128 pairs in its own scratch, and after
+        // a workgroup barrier the first column wave of each M-half adds the four shares in wave order (deterministic) and
+        // writes slot tile_n of the rows' three pairs.  A second barrier keeps the scratch intact until it has been read.
+        // (inline asm: compiler-visible LDS accesses would wait for the LDS-DMA in flight, see the accumulator init)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const float v = acc[i][j][r];
+              s1 += v;
+              s2 = __builtin_fmaf(v, v, s2);
+            }
+          const auto t1 = __builtin_amdgcn_permlane32_swap(f2u(s1), f2u(s1), false, false);
+          const auto t2 = __builtin_amdgcn_permlane32_swap(f2u(s2), f2u(s2), false, false);
+          float2 st;
+          st.x = u2f(t1[0]) + u2f(t1[1]);
+          st.y = u2f(t2[0]) + u2f(t2[1]);
+          const uint32_t waddr = scr + (uint32_t)(i * 32 + l31) * 8;  // both half-waves write the same pair
+          asm volatile("ds_write_b64 %0, %1" ::"v"(waddr), "v"(st) : "memory");
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        if (wc == 0) {  // rows i * 32 + l31 of this M-half: the lower half-wave takes i = 0, 1, the upper one i = 2, 3
+#pragma unroll
+          for (int ii = 0; ii < 2; ++ii) {
+            const int row = (2 * hi + ii) * 32 + l31;
+            const uint32_t raddr = (uint32_t)(LDS_SCR + wr * 4 * 2048) + (uint32_t)row * 8;
+            float2 q0, q1, q2, q3;
+            asm volatile("ds_read_b64 %0, %4\n\tds_read_b64 %1, %4 offset:2048\n\tds_read_b64 %2, %4 offset:4096\n\t"
+                         "ds_read_b64 %3, %4 offset:6144\n\ts_waitcnt lgkmcnt(0)"
+                         : "=&v"(q0), "=&v"(q1), "=&v"(q2), "=&v"(q3)
+                         : "v"(raddr)
+                         : "memory");
+            float2 st;
+            st.x = ((q0.x + q1.x) + q2.x) + q3.x;
+            st.y = ((q0.y + q1.y) + q2.y) + q3.y;
+            *(float2*)(a.lnpart + ((size_t)(mw + row) * 3 + tile_n) * 2) = st;
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      {
+        // fp16 outputs: 8-B units (4 values) of the C/D layout -> chunk g, half hi of the row
+        // (PP_RESLN3: the hi plane of the raw stream, the A operand of the next RAW consumer)
+        const uint32_t wbase = scr + l31 * 64 + hi * 8 + (sf << 4);
+        const uint32_t wbase8 = scr + l31 * 64 + hi * 4 + (sf << 4);  // fp8 planes (scr_f8x2)
+        half_t* obase;    // pointer of (row crow, chunk cchunk) of fragment (i = 0, j = 0)
+        size_t rstride;   // elements between image rows in the output
+        size_t istride;   // elements between i blocks (32 C/D rows along the register axis or the lane axis)
+        size_t jstride;   // elements between j blocks
+        bool live = true;
+        bool vtile = false;  // PP_QK: this tile belongs to the V block and is stored as V^T
+        const uint32_t tbase = scr + hi * 256 + (((uint32_t)(l31 >> 3) ^ (uint32_t)hi) << 4) + (uint32_t)(l31 & 7) * 2;
+        if constexpr (EPI == PP_GELU || IS_RES) {
+          obase = a.out16 + (size_t)(mw + crow) * a.N + nw + 8 * cchunk;
+          rstride = a.N; istride = (size_t)32 * a.N; jstride = 32;
+        } else {  // PP_QK: one head per wave; S % 64 == 0 so a 128-row block may span two batch rows
+          // columns [0,768) -> Q, [768,1536) -> K, [1536,2304) -> V^T (a merged launch); col0 = 768: K (and V) only
+          const int colg = nw + a.col0;
+          const int which = colg >= 2 * MV_HIDDEN ? 2 : (colg >= MV_HIDDEN ? 1 : 0);
+          const int head = (colg - which * MV_HIDDEN) >> 6;
+          vtile = which == 2;
+          if (vtile) {  // image rows = head dims, image columns = tokens (scr_f16x2_t)
+            obase = a.vt + ((size_t)head * MV_HEAD_DIM + crow) * a.S + 8 * cchunk;
+            rstride = a.S; istride = 0; jstride = (size_t)32 * a.S;
+          } else {
+            obase = (which ? a.k : a.q) + (size_t)head * a.S * MV_HEAD_DIM + (size_t)crow * MV_HEAD_DIM + 8 * cchunk;
+            rstride = MV_HEAD_DIM; istride = 0; jstride = 32;  // the batch-row part is added per i below
+          }
+        }
+        // RAW: bias' of this wave's columns (per-tile LDS image) and rstd of its token rows (from the vstats image, one row
+        // per lane and i), applied as fma(rstd, acc, bias')
+        float4 rbv[2][4];
+        float rrs[4];
+        if constexpr (RAW) {
+          const uint32_t baddr = (uint32_t)(PP_LDS_BIAS_T + (it & 1) * 1024 + (wc * 64 + 4 * hi) * 4);
+          const uint32_t saddr = (uint32_t)(PP_LDS_RSTD + (it & 1) * 1024 + (wr * 128 + l31) * 4);  // this wave's 128 rows
+          asm volatile(
+              "ds_read_b128 %0, %12\n\tds_read_b128 %1, %12 offset:32\n\tds_read_b128 %2, %12 offset:64\n\t"
+              "ds_read_b128 %3, %12 offset:96\n\tds_read_b128 %4, %12 offset:128\n\tds_read_b128 %5, %12 offset:160\n\t"
+              "ds_read_b128 %6, %12 offset:192\n\tds_read_b128 %7, %12 offset:224\n\t"
+              "ds_read_b32 %8, %13\n\tds_read_b32 %9, %13 offset:128\n\tds_read_b32 %10, %13 offset:256\n\t"
+              "ds_read_b32 %11, %13 offset:384\n\ts_waitcnt lgkmcnt(0)"
+              : "=&v"(rbv[0][0]), "=&v"(rbv[0][1]), "=&v"(rbv[0][2]), "=&v"(rbv[0][3]), "=&v"(rbv[1][0]), "=&v"(rbv[1][1]),
+                "=&v"(rbv[1][2]), "=&v"(rbv[1][3]), "=&v"(rrs[0]), "=&v"(rrs[1]), "=&v"(rrs[2]), "=&v"(rrs[3])
+              : "v"(baddr), "v"(saddr)
+              : "memory");
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        (void)wbase8;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int mb = mw + i * 32;
+          half_t* ob = obase + i * istride;
+          const float rrs_i = RAW ? rrs[i] : 1.f;  // RAW: rstd of token row 32 i + l31
+          (void)rrs_i;
+          if constexpr (EPI == PP_QK) {
+            live = mb < a.Mreal;
+            const int b = mb / a.S, s0 = mb - b * a.S;
+            if (!vtile) ob = obase + ((size_t)b * MV_HEADS * a.S + s0) * MV_HEAD_DIM;
+            else ob = obase + (size_t)b * MV_HEADS * MV_HEAD_DIM * a.S + s0;
+          }
+          u32x2 d[2][4];
+          u32x4 o[4];
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+              float v0 = acc[i][j][4 * g + 0], v1 = acc[i][j][4 * g + 1], v2 = acc[i][j][4 * g + 2], v3 = acc[i][j][4 * g + 3];
+              if constexpr (RAW) {  // lane = token row 32 i + l31, registers = 4 consecutive columns
+                v0 = __builtin_fmaf(rrs_i, v0, rbv[j][g].x); v1 = __builtin_fmaf(rrs_i, v1, rbv[j][g].y);
+                v2 = __builtin_fmaf(rrs_i, v2, rbv[j][g].z); v3 = __builtin_fmaf(rrs_i, v3, rbv[j][g].w);
+              }
+              if constexpr (EPI == PP_GELU) {
+                float2_t a01, a23;
+                a01.x = v0; a01.y = v1; a23.x = v2; a23.y = v3;
+                a01 = gelu_erf2(a01);
+                a23 = gelu_erf2(a23);
+                v0 = a01.x; v1 = a01.y; v2 = a23.x; v3 = a23.y;
+                if constexpr (X8) {  // the fp8 planes below are taken from the activated values
+                  acc[i][j][4 * g + 0] = v0; acc[i][j][4 * g + 1] = v1; acc[i][j][4 * g + 2] = v2; acc[i][j][4 * g + 3] = v3;
+                }
+              }
+              d[j][g][0] = pack_h2(v0, v1);
+              d[j][g][1] = pack_h2(v2, v3);
+            }
+          if (EPI == PP_QK && vtile) scr_f16x2_t(tbase, tbase ^ 32u, d[0], d[1], scr_c, o);
+          else scr_f16x2(wbase, wbase ^ 16u, wbase ^ 32u, wbase ^ 48u, d[0], d[1], scr_c, o);
+          if (live) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+              half_t* op = ob + j * jstride;
+              *(u32x4*)op = o[2 * j];
+              *(u32x4*)(op + 16 * rstride) = o[2 * j + 1];
+            }
+          }
+          if constexpr (IS_RES) {  // second plane: lo = fp16(r - hi), same addresses in the lo buffer
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+              for (int g = 0; g < 4; ++g) {
+                const float v0 = acc[i][j][4 * g + 0], v1 = acc[i][j][4 * g + 1], v2 = acc[i][j][4 * g + 2], v3 = acc[i][j][4 * g + 3];
+                d[j][g][0] = pack_h2(v0 - (float)(half_t)v0, v1 - (float)(half_t)v1);
+                d[j][g][1] = pack_h2(v2 - (float)(half_t)v2, v3 - (float)(half_t)v3);
+              }
+            scr_f16x2(wbase, wbase ^ 16u, wbase ^ 32u, wbase ^ 48u, d[0], d[1], scr_c, o);
+            half_t* ol = ob + (a.out16b - a.out16);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+              half_t* op = ol + j * jstride;
+              *(u32x4*)op = o[2 * j];
+              *(u32x4*)(op + 16 * rstride) = o[2 * j + 1];
+            }
+          }
+          if constexpr (X8 && (IS_RES || EPI == PP_GELU)) {
+            // MV_F16X8: the [lo8 | hi8] planes of this output (the A8 operand of the next GEMM's correction sweep): rows of
+            // 2 N bytes, lo8 of column n at byte n, hi8 at byte N + n; one 16-B store per lane, plane and 16-row half
+            uint32_t dl[8], dh[8];
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+              for (int g = 0; g < 4; ++g)
+                x8_planes4(acc[i][j][4 * g + 0], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3], dh[4 * j + g], dl[4 * j + g]);
+            scr_f8x2(wbase8, wbase8 ^ 16u, wbase8 ^ 32u, wbase8 ^ 48u, dl, dh, scr_c, o);
+            uint8_t* o8 = a.out8 + (size_t)(mb + crow) * (2 * a.N) + nw + 16 * cchunk;
+            *(u32x4*)o8 = o[0];
+            *(u32x4*)(o8 + (size_t)16 * (2 * a.N)) = o[1];
+            *(u32x4*)(o8 + a.N) = o[2];
+            *(u32x4*)(o8 + a.N + (size_t)16 * (2 * a.N)) = o[3];
+          }
+          if constexpr (IS_RES) {  // fragment pair i is out: request pair i of the NEXT tile's residual into its registers
+            if (has_next) park_residual(i, (next_m << 8) + wr * 128, (next_n << 8) + wc * 64);
+          }
+        }
+      }
+    }
+  }
+
+  };  // run_tiles
+  if (wr == 0) run_tiles(std::integral_constant<int, 0>{});
+  else run_tiles(std::integral_constant<int, 1>{});
+
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // no LDS-DMA may outlive the workgroup's LDS allocation
+}
