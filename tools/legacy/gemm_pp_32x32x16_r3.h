@@ -4,18 +4,15 @@
 // BertOutput as invoked from custom_PTM_embedder.py:228).
 //
 // Structure (cdna_hip_programming.md §5 "256^2 8-phase template", T1-T5; MI355X_MICROARCH.md "Two waves per SIMD"):
-//   * 256x256x64 tile, 512 threads = 8 waves as 2(M) x 4(N), 128x64 of C per wave = 8 token blocks x 4 column blocks of 16 x 16
-//     (128 accumulator VGPRs), **v_mfma_f32_16x16x32_f16**: these kernels are power-bound and this shape costs less
-//     energy per FLOP than 32x32x16 (half the accumulator traffic): chip-wide 1.82-1.85 PF against 1.46-1.50
-//     (tools/mfma_shape_probe.hip), +6 % on every launch; the 32x32x16 form of this file is tools/legacy/gemm_pp_32x32x16_r3.h.
-//     ONE workgroup per CU, grid = #CUs, each workgroup walks a strided list of output tiles (persistent): the K-tile stream
-//     never drains between output tiles, so the next tile's operands are already in flight while the epilogue stores.
+//   * 256x256x64 tile, 512 threads = 8 waves as 2(M) x 4(N), 128x64 of C per wave (128 accumulator VGPRs),
+//     v_mfma_f32_32x32x16_f16, ONE workgroup per CU, grid = #CUs, each workgroup walks a strided list of
+//     output tiles (persistent): the K-tile stream never drains between output tiles, so the next tile's
+//     operands are already in flight while the epilogue stores.
 //   * ONE s_barrier per phase; the first M-half of the workgroup (waves 0-3) runs [MFMA(j), read fragments(j+1)] and
 //     the second (waves 4-7: one wave of each half per SIMD) [read fragments(j), MFMA(j)] inside the same barrier
 //     interval, so each SIMD's matrix pipe is handed from one wave to the other in the middle of the interval.
-//   * A K-tile is 4 phases = the 4 quadrants (64 tokens x 32 columns: 16 MFMAs) of the wave's C block in the order (a0,b0) (a0,b1)
-//     (a1,b1) (a1,b0): each phase reads at most ONE operand half-tile (8 or 4 ds_read_b128 per wave).  Operand lane (row = lane & 15,
-//     kg = lane >> 4) holds the 8 halves k = 32 kk + 8 kg .. + 7 of its row = 16-byte chunk 4 kk + kg of the 128-byte K-tile row.
+//   * A K-tile is 4 phases = the 4 quadrants (64 x 32) of the wave's C block in the order (a0,b0) (a0,b1) (a1,b1)
+//     (a1,b0): each phase reads at most ONE operand half-tile (8 or 4 ds_read_b128 per wave).
 //   * Operand half-tiles (128 rows x 128 B = 16 KiB = 2 LDS-DMA instructions per wave) are the unit of staging: LDS
 //     holds two K-tiles x {a0,a1,b0,b1} = 128 KiB; F = 4 half-tiles are kept in flight across every barrier (half-tile
 //     H is issued in interval H-3-F, is landed for every wave at the barrier that ends interval H-3, and its LDS region
@@ -24,9 +21,9 @@
 //   * LDS image of a half-tile is lane-linear per DMA instruction (1 KiB = 8 rows x 128 B); the bank swizzle
 //     (16-B chunk c of row r at slot c ^ ((r >> 1) & 7)) is applied on the per-lane SOURCE address and on the
 //     ds_read_b128 (rule 21).  The DMA uses the SGPR-base + 32-bit-VGPR-offset form.
-//   * Orientation: C^T fragments (W rows as the MFMA A operand): acc[tb][cb] (4 registers) = token 16 tb + (lane & 15), columns
-//     16 cb + 4 (lane >> 4) .. + 3; every 32 x 32 block (4 accumulators) goes through a wave-private LDS transposition so that
-//     each global store / residual load instruction covers 16 rows x 64 contiguous bytes.
+//   * Orientation: C^T fragments (W rows as the MFMA A operand), so a lane holds 4 CONSECUTIVE output columns of one
+//     token row per register group; every 32x32 fragment goes through a wave-private LDS transposition so that each
+//     global store / residual load instruction covers 16 rows x 64 contiguous bytes.
 //   * Tile order: logical tile sequence = (column group of GN tiles) > tile_m > tile_n-in-group; per persistent
 //     iteration the 256 concurrent tiles are consecutive in it and each XCD takes a contiguous run of 32 (the
 //     group's W panels stay in that XCD's L2 while it sweeps the A row panels).
@@ -49,7 +46,7 @@
 // X8 = 1 (compute dtype MV_F16X8, "precise"): every GEMM adds a SECOND sweep on the fp8 matrix path into the same fp32
 // accumulators:  A W ~= A_hi W_hi + 2^-s (A_lo8 W_hi8 + A_hi8 W_lo8),  A_hi = fp16(A), A_lo8 = e4m3((A - A_hi) 2^(11 + sa)),
 // A_hi8 = e4m3(A_hi 2^sa), W likewise with its own shift sw, s = 11 + sa + sw — the first-order correction terms of the
-// split-operand product, which only need ~4 significant bits, as ONE v_mfma_scale_f32_16x16x128_f8f6f4 sweep (OCP e4m3, uniform
+// split-operand product, which only need ~4 significant bits, as ONE v_mfma_scale_f32_32x32x64_f8f6f4 sweep (OCP e4m3, uniform
 // E8M0 scales = the exact power of two 2^-s) over a virtual K of 2 K: the fp8 operands are rows [lo8 (K bytes) | hi8 (K bytes)]
 // for A and [hi8 | lo8] for W, so row pitch (2 K bytes), K-tile width (128 bytes) and K-tile count (K / 64) equal the fp16
 // sweep's and the staging code is shared; an fp8 K-tile covers 128 products per row pair in the matrix-pipe time the fp16
@@ -58,6 +55,7 @@
 #pragma once
 #include "common.h"
 #include <type_traits>
+
 #include "gemm.h"
 
 enum { PP_QK = 1, PP_GELU = 3, PP_RESLN3 = 8 };
@@ -90,11 +88,13 @@ typedef int intx4 __attribute__((ext_vector_type(4)));
 typedef int intx8 __attribute__((ext_vector_type(8)));
 
 // Wave-private transposition through a [32 rows][64 B] LDS image (16-B chunk c of row r at slot c ^ ((r >> 2) & 3)):
-// the C/D layout gives a lane 8 contiguous bytes of a row; stored directly every wave-store touches 64 scattered pieces (~64 cycles
-// of address processing per instruction, 3.6 us per 256^2 tile), through the image each store covers 16 rows x 64 contiguous
-// bytes.  Inline asm keeps these LDS accesses out of hipcc's LDS-DMA alias bookkeeping (it would put `s_waitcnt vmcnt(0)` before
-// them); LDS executes a wave's instructions in order, so the read-after-write needs no wait, only the read results do (guide
-// §5.7 form i).  Two blocks (j = 0, 1) per statement: the second's writes may follow the first's reads without a wait in between.
+// the MFMA C/D layout gives a lane 8 or 16 contiguous bytes of ONE row (lane = row), so storing it directly makes
+// every wave-store touch 64 scattered 16-B pieces (measured: ~64 cycles of address processing per instruction,
+// 3.6 us per 256^2 tile).  Through the image each store covers 16 rows x 64 contiguous bytes.  Inline asm keeps
+// these LDS accesses out of hipcc's LDS-DMA alias bookkeeping (it would put `s_waitcnt vmcnt(0)` before them and
+// wait for the epilogue's own stores); LDS executes a wave's instructions in order, so the read-after-write
+// needs no wait, only the read results do (same statement, guide §5.7 form i).  Two fp16 fragments (j = 0, 1) per statement:
+// the second fragment's writes may follow the first one's reads into the same image without a wait in between.
 __device__ __forceinline__ void scr_f16x2(uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3, const u32x2 (&da)[4],
                                           const u32x2 (&db)[4], uint32_t r, u32x4 (&o)[4]) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -109,18 +109,19 @@ __device__ __forceinline__ void scr_f16x2(uint32_t w0, uint32_t w1, uint32_t w2,
       : "memory");
 #endif
 }
-// Two fp8 planes (MV_F16X8: lo8, then hi8) of one 32-row x 64-column block through the wave's [32 rows][64 B] image, 16x16 C/D layout:
-// the lane's dword (tbl, s) = token 16 tbl + m16, columns 16 s + 4 q4 .. + 3 goes to slot s of row 16 tbl + m16 at byte 4 q4;
-// w0..w3 = the lane's (swizzled) slot addresses of row m16, da / db index 4 tbl + s.  The read side is the fp16 one: rows lane >> 2 and + 16, 16-B chunk lane & 3.
+// Two fp8 planes (MV_F16X8: lo8, then hi8) of one 32-row x 64-column block (fragments j = 0, 1) through the same image:
+// a plane is [32 rows][64 B], the lane's dword (j, g) = columns 32 j + 8 g + 4 hi ..+3 goes to slot 2 j + (g >> 1) of its
+// row (swizzled like the fp16 image) at byte 8 (g & 1) + 4 hi; w0..w3 = the lane's slot addresses (+ 4 hi), da / db index
+// 4 j + g.  The read side is the fp16 one: rows lane >> 2 and + 16, 16-B chunk lane & 3.
 __device__ __forceinline__ void scr_f8x2(uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3, const uint32_t (&da)[8],
-                                           const uint32_t (&db)[8], uint32_t r, u32x4 (&o)[4]) {
+                                         const uint32_t (&db)[8], uint32_t r, u32x4 (&o)[4]) {
 #if defined(__HIP_DEVICE_COMPILE__)
   asm volatile(
-      "ds_write_b32 %4, %8\n\tds_write_b32 %5, %9\n\tds_write_b32 %6, %10\n\tds_write_b32 %7, %11\n\t"
-      "ds_write_b32 %4, %12 offset:1024\n\tds_write_b32 %5, %13 offset:1024\n\tds_write_b32 %6, %14 offset:1024\n\tds_write_b32 %7, %15 offset:1024\n\t"
+      "ds_write_b32 %4, %8\n\tds_write_b32 %4, %9 offset:8\n\tds_write_b32 %5, %10\n\tds_write_b32 %5, %11 offset:8\n\t"
+      "ds_write_b32 %6, %12\n\tds_write_b32 %6, %13 offset:8\n\tds_write_b32 %7, %14\n\tds_write_b32 %7, %15 offset:8\n\t"
       "ds_read_b128 %0, %24\n\tds_read_b128 %1, %24 offset:1024\n\t"
-      "ds_write_b32 %4, %16\n\tds_write_b32 %5, %17\n\tds_write_b32 %6, %18\n\tds_write_b32 %7, %19\n\t"
-      "ds_write_b32 %4, %20 offset:1024\n\tds_write_b32 %5, %21 offset:1024\n\tds_write_b32 %6, %22 offset:1024\n\tds_write_b32 %7, %23 offset:1024\n\t"
+      "ds_write_b32 %4, %16\n\tds_write_b32 %4, %17 offset:8\n\tds_write_b32 %5, %18\n\tds_write_b32 %5, %19 offset:8\n\t"
+      "ds_write_b32 %6, %20\n\tds_write_b32 %6, %21 offset:8\n\tds_write_b32 %7, %22\n\tds_write_b32 %7, %23 offset:8\n\t"
       "ds_read_b128 %2, %24\n\tds_read_b128 %3, %24 offset:1024\n\ts_waitcnt lgkmcnt(0)"
       : "=&v"(o[0]), "=&v"(o[1]), "=&v"(o[2]), "=&v"(o[3])
       : "v"(w0), "v"(w1), "v"(w2), "v"(w3), "v"(da[0]), "v"(da[1]), "v"(da[2]), "v"(da[3]), "v"(da[4]), "v"(da[5]), "v"(da[6]),
@@ -128,10 +129,12 @@ __device__ __forceinline__ void scr_f8x2(uint32_t w0, uint32_t w1, uint32_t w2, 
       : "memory");
 #endif
 }
-// The V block of a merged Q,K,V launch in the 16x16 C/D layout (lane = token 16 tbl + m16, registers = 4 consecutive head dims
-// 16 cbl + 4 q4 + e of unit k = 2 tbl + cbl) through the image TRANSPOSED - image rows = head dims, image columns = tokens: 16 two-byte
-// writes per fragment at t0 (tbl = 0) / t1 (tbl = 1) + 1024 cbl + 64 e (t = q4 * 256 + swizzled token chunk + 2 (m16 & 7)).
-__device__ __forceinline__ void scr_f16x2_t(uint32_t t0, uint32_t t1, const u32x2 (&da)[4], const u32x2 (&db)[4], uint32_t r, u32x4 (&o)[4]) {
+// The V block of a merged Q,K,V launch (lane = token, registers = 4 consecutive head dims) goes
+// through the image TRANSPOSED - image rows = head dims, image columns = tokens - so that the read side and the
+// stores are the V^T ones: 16 two-byte writes per fragment (row 8 g + 4 hi + e at a0 / a1 = a0 ^ 32 plus
+// 512 g + 64 e; the slot swizzle (row >> 2) & 3 = (2 g + hi) & 3 alternates between hi and hi ^ 2).
+__device__ __forceinline__ void scr_f16x2_t(uint32_t a0, uint32_t a1, const u32x2 (&da)[4], const u32x2 (&db)[4], uint32_t r,
+                                            u32x4 (&o)[4]) {
 #if defined(__HIP_DEVICE_COMPILE__)
   const uint32_t a00 = da[0][0], a01 = da[0][1], a10 = da[1][0], a11 = da[1][1], a20 = da[2][0], a21 = da[2][1], a30 = da[3][0],
                  a31 = da[3][1];
@@ -141,12 +144,12 @@ __device__ __forceinline__ void scr_f16x2_t(uint32_t t0, uint32_t t1, const u32x
   "ds_write_b16 " A ", " LO " offset:" #OFF "+0\n\tds_write_b16_d16_hi " A ", " LO " offset:" #OFF "+64\n\t" \
   "ds_write_b16 " A ", " HI " offset:" #OFF "+128\n\tds_write_b16_d16_hi " A ", " HI " offset:" #OFF "+192\n\t"
   asm volatile(
-      MV_T16("%4", "%6", "%7", 0) MV_T16("%4", "%8", "%9", 1024) MV_T16("%5", "%10", "%11", 0) MV_T16("%5", "%12", "%13", 1024)
+      MV_T16("%4", "%6", "%7", 0) MV_T16("%5", "%8", "%9", 512) MV_T16("%4", "%10", "%11", 1024) MV_T16("%5", "%12", "%13", 1536)
       "ds_read_b128 %0, %22\n\tds_read_b128 %1, %22 offset:1024\n\t"
-      MV_T16("%4", "%14", "%15", 0) MV_T16("%4", "%16", "%17", 1024) MV_T16("%5", "%18", "%19", 0) MV_T16("%5", "%20", "%21", 1024)
+      MV_T16("%4", "%14", "%15", 0) MV_T16("%5", "%16", "%17", 512) MV_T16("%4", "%18", "%19", 1024) MV_T16("%5", "%20", "%21", 1536)
       "ds_read_b128 %2, %22\n\tds_read_b128 %3, %22 offset:1024\n\ts_waitcnt lgkmcnt(0)"
       : "=&v"(o[0]), "=&v"(o[1]), "=&v"(o[2]), "=&v"(o[3])
-      : "v"(t0), "v"(t1), "v"(a00), "v"(a01), "v"(a10), "v"(a11), "v"(a20), "v"(a21), "v"(a30), "v"(a31), "v"(b00), "v"(b01),
+      : "v"(a0), "v"(a1), "v"(a00), "v"(a01), "v"(a10), "v"(a11), "v"(a20), "v"(a21), "v"(a30), "v"(a31), "v"(b00), "v"(b01),
         "v"(b10), "v"(b11), "v"(b20), "v"(b21), "v"(b30), "v"(b31), "v"(r)
       : "memory");
 #undef MV_T16
@@ -288,51 +291,55 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmArgs a) {
     issue(std::integral_constant<int, kind>{}, std::integral_constant<int, (psi >> 2) & 1>{});
   };
 
-  // ---- fragment read addresses: operand row lane & 15 of a 16-row block, 16-byte chunk 4 kk + (lane >> 4) of its 128-byte K-tile row
-  // (conflict-free on the unchanged half-tile image: each ds_read_b128 lane group covers the 16 slots mod 256 B once)
-  const int m16 = lane & 15, q4 = lane >> 4;
-  int rdA[2], rdB[2];
+  // ---- fragment read addresses
+  const int swz = (lane >> 1) & 7;
+  int rdA[4], rdB[4];
 #pragma unroll
-  for (int kk = 0; kk < 2; ++kk) {
-    const int o = m16 * 128 + (((4 * kk + q4) ^ ((m16 >> 1) & 7)) << 4);
-    rdA[kk] = PP_LDS_A + wr * 8192 + o;
-    rdB[kk] = PP_LDS_B + wc * 4096 + o;
+  for (int ks = 0; ks < 4; ++ks) {
+    const int o = l31 * 128 + (((ks * 2 + hi) ^ swz) << 4);
+    rdA[ks] = PP_LDS_A + wr * 8192 + o;
+    rdB[ks] = PP_LDS_B + wc * 4096 + o;
   }
-  // fragment registers: A sub-tile = 4 token blocks x 2 K-steps, a W sub-tile = 2 column blocks x 2 K-steps.  X8 builds hold the
-  // two chunks (q4, 4 + q4) of a row as ONE 8-dword value: the fp8 instruction (16x16x128) takes them as its 32 K-bytes — the same
-  // assignment for both operands, so every byte column meets its partner once — and the fp16 sweep uses the halves as K-steps 0 / 1.
-  half8_t Xf[X8 ? 1 : 4][X8 ? 1 : 2], Wx[X8 ? 1 : 2][X8 ? 1 : 2], Wy[X8 ? 1 : 2][X8 ? 1 : 2];
-  intx8 Xp[X8 ? 4 : 1], Wxp[X8 ? 2 : 1], Wyp[X8 ? 2 : 1];
+  // fragment registers.  X8 builds hold each PAIR of 16-byte chunks (2 kk, 2 kk + 1) as one 8-dword value, because the fp8
+  // matrix instruction takes 32 K-bytes per lane as a 256-bit operand (left as separate 128-bit values hipcc copies them
+  // into fresh 8-register tuples in front of every MFMA and spills); the fp16 instruction reads the halves in place.
+  half8_t Xf[X8 ? 1 : 2][X8 ? 1 : 4], Wx[X8 ? 1 : 4], Wy[X8 ? 1 : 4];
+  intx8 Xp[X8 ? 2 : 1][X8 ? 2 : 1], Wxp[X8 ? 2 : 1], Wyp[X8 ? 2 : 1];
   auto ld16 = [&](int off) -> intx4 { return *(const intx4*)(smem + off); };
   auto read_a = [&](int par, int asub) {
+    if constexpr (X8) {
 #pragma unroll
-    for (int t4 = 0; t4 < 4; ++t4) {
-      const int o = par * 32768 + asub * 16384 + t4 * 2048;
-      if constexpr (X8) {
-        Xp[t4] = __builtin_shufflevector(ld16(rdA[0] + o), ld16(rdA[1] + o), 0, 1, 2, 3, 4, 5, 6, 7);
-      } else {
+      for (int ii = 0; ii < 2; ++ii)
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk) Xf[t4][kk] = *(const half8_t*)(smem + rdA[kk] + o);
-      }
+        for (int kk = 0; kk < 2; ++kk) {
+          const int o = par * 32768 + asub * 16384 + ii * 4096;
+          Xp[ii][kk] = __builtin_shufflevector(ld16(rdA[2 * kk] + o), ld16(rdA[2 * kk + 1] + o), 0, 1, 2, 3, 4, 5, 6, 7);
+        }
+    } else {
+#pragma unroll
+      for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+          Xf[ii][ks] = *(const half8_t*)(smem + rdA[ks] + par * 32768 + asub * 16384 + ii * 4096);
     }
   };
-  auto read_b = [&](half8_t (&Wf)[X8 ? 1 : 2][X8 ? 1 : 2], intx8 (&Wp)[X8 ? 2 : 1], int par, int bsub) {
+  auto read_b = [&](half8_t (&Wf)[X8 ? 1 : 4], intx8 (&Wp)[X8 ? 2 : 1], int par, int bsub) {
+    if constexpr (X8) {
 #pragma unroll
-    for (int c2 = 0; c2 < 2; ++c2) {
-      const int o = par * 32768 + bsub * 16384 + c2 * 2048;
-      if constexpr (X8) {
-        Wp[c2] = __builtin_shufflevector(ld16(rdB[0] + o), ld16(rdB[1] + o), 0, 1, 2, 3, 4, 5, 6, 7);
-      } else {
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk) Wf[c2][kk] = *(const half8_t*)(smem + rdB[kk] + o);
+      for (int kk = 0; kk < 2; ++kk) {
+        const int o = par * 32768 + bsub * 16384;
+        Wp[kk] = __builtin_shufflevector(ld16(rdB[2 * kk] + o), ld16(rdB[2 * kk + 1] + o), 0, 1, 2, 3, 4, 5, 6, 7);
       }
+    } else {
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) Wf[ks] = *(const half8_t*)(smem + rdB[ks] + par * 32768 + bsub * 16384);
     }
   };
 
-  floatx4 acc[8][4];  // [token block of 16][column block of 16]
-  // the two fp16 planes of the 32 x 32 block i (token rows) x j (columns) of the residual tile at (mw0, nw0) by full-line loads
-  // (16 rows x 64 B per instruction), parked in the four accumulators of that block: acc[2 i + pl][2 j + x] = plane pl (hi, lo),
-  // rows crow + 16 x — the accumulator init transposes them into the C/D layout
+  floatx16 acc[4][2];
+  // the two fp16 planes of fragment pair i of the residual tile at (mw0, nw0) by full-line loads (16 rows x 64 B per
+  // instruction), parked in the accumulator registers they will be transposed into: [i][j] registers 0-3 / 4-7 = hi rows
+  // crow / crow + 16, 8-11 / 12-15 = lo
   auto park_residual = [&](int i, int mw0, int nw0) {
     const int crow = lane >> 2, cchunk = lane & 3;
 #pragma unroll
@@ -343,44 +350,44 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmArgs a) {
         for (int x = 0; x < 2; ++x) {
           const half_t* src = (pl ? a.out16b : a.out16) + (size_t)(mw0 + i * 32 + x * 16 + crow) * MV_HIDDEN + nw0 + j * 32 + 8 * cchunk;
           const float4 t = *(const float4*)src;
-          acc[2 * i + pl][2 * j + x][0] = t.x; acc[2 * i + pl][2 * j + x][1] = t.y;
-          acc[2 * i + pl][2 * j + x][2] = t.z; acc[2 * i + pl][2 * j + x][3] = t.w;
+          acc[i][j][8 * pl + 4 * x + 0] = t.x; acc[i][j][8 * pl + 4 * x + 1] = t.y;
+          acc[i][j][8 * pl + 4 * x + 2] = t.z; acc[i][j][8 * pl + 4 * x + 3] = t.w;
         }
   };
-  // One quadrant (64 tokens x 32 columns) of a K-tile: 16 MFMAs of 16x16x32 (fp16) or 8 of 16x16x128 (the fp8 correction sweep).
-  auto mma_quadrant = [&](auto asubc, auto bc, auto f8c, const half8_t (&Wf)[X8 ? 1 : 2][X8 ? 1 : 2], const intx8 (&Wp)[X8 ? 2 : 1]) {
+  // One quadrant of a K-tile.  F8 (X8, the correction sweep): the same fragment registers hold fp8 bytes — a lane's four
+  // 16-byte chunks 2 ks + hi (ks = 0..3) of its 128-byte row; MFMA kk takes chunks 4 kk + hi and 4 kk + 2 + hi as its 32
+  // K-bytes, the same assignment for both operands, so every byte column of the tile meets its partner exactly once.
+  auto mma_quadrant = [&](auto asubc, auto bc, auto f8c, const half8_t (&Wf)[X8 ? 1 : 4], const intx8 (&Wp)[X8 ? 2 : 1]) {
     constexpr int asub = decltype(asubc)::value;
     constexpr int b = decltype(bc)::value;
     if constexpr (X8) {
       if constexpr (decltype(f8c)::value) {
 #pragma unroll
-        for (int c2 = 0; c2 < 2; ++c2)
-#pragma unroll
-          for (int t4 = 0; t4 < 4; ++t4)
-            acc[asub * 4 + t4][b * 2 + c2] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(Wp[c2], Xp[t4], acc[asub * 4 + t4][b * 2 + c2], 0, 0, 0,
-                                                                                            a.x8_scale, 0, 0x7f7f7f7f);
-      } else {
-#pragma unroll
         for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
-          for (int c2 = 0; c2 < 2; ++c2) {
-            const intx4 w4 = kk ? __builtin_shufflevector(Wp[c2], Wp[c2], 4, 5, 6, 7) : __builtin_shufflevector(Wp[c2], Wp[c2], 0, 1, 2, 3);
+          for (int ii = 0; ii < 2; ++ii)
+            acc[asub * 2 + ii][b] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(Wp[kk], Xp[ii][kk], acc[asub * 2 + ii][b], 0, 0, 0,
+                                                                                    a.x8_scale, 0, 0x7f7f7f7f);
+      } else {
 #pragma unroll
-            for (int t4 = 0; t4 < 4; ++t4) {
-              const intx4 x4 = kk ? __builtin_shufflevector(Xp[t4], Xp[t4], 4, 5, 6, 7) : __builtin_shufflevector(Xp[t4], Xp[t4], 0, 1, 2, 3);
-              acc[asub * 4 + t4][b * 2 + c2] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8_t, w4), __builtin_bit_cast(half8_t, x4),
-                                                                                   acc[asub * 4 + t4][b * 2 + c2], 0, 0, 0);
-            }
+        for (int ks = 0; ks < 4; ++ks) {
+          const intx4 w4 = (ks & 1) ? __builtin_shufflevector(Wp[ks >> 1], Wp[ks >> 1], 4, 5, 6, 7)
+                                    : __builtin_shufflevector(Wp[ks >> 1], Wp[ks >> 1], 0, 1, 2, 3);
+#pragma unroll
+          for (int ii = 0; ii < 2; ++ii) {
+            const intx4 x4 = (ks & 1) ? __builtin_shufflevector(Xp[ii][ks >> 1], Xp[ii][ks >> 1], 4, 5, 6, 7)
+                                      : __builtin_shufflevector(Xp[ii][ks >> 1], Xp[ii][ks >> 1], 0, 1, 2, 3);
+            acc[asub * 2 + ii][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8_t, w4), __builtin_bit_cast(half8_t, x4),
+                                                                           acc[asub * 2 + ii][b], 0, 0, 0);
           }
+        }
       }
     } else {
 #pragma unroll
-      for (int kk = 0; kk < 2; ++kk)
+      for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
-        for (int c2 = 0; c2 < 2; ++c2)
-#pragma unroll
-          for (int t4 = 0; t4 < 4; ++t4)
-            acc[asub * 4 + t4][b * 2 + c2] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Wf[c2][kk], Xf[t4][kk], acc[asub * 4 + t4][b * 2 + c2], 0, 0, 0);
+        for (int ii = 0; ii < 2; ++ii)
+          acc[asub * 2 + ii][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Wf[ks], Xf[ii][ks], acc[asub * 2 + ii][b], 0, 0, 0);
     }
   };
 
@@ -422,9 +429,8 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmArgs a) {
       // sink four intervals' worth of them across the barriers into one block (20 + 0 + 0 ... per interval instead of 4 each,
       // 18 fragment tuples live at once, 400-600 bytes of scratch per lane)
 #if defined(__HIP_DEVICE_COMPILE__)
-      constexpr int P = s & 3, a0 = (P >= 2) ? 4 : 0, bq = (P == 1 || P == 2) ? 2 : 0;  // the quadrant of phase P (mma_set)
-      asm volatile("" : "+v"(acc[a0][bq]), "+v"(acc[a0 + 1][bq]), "+v"(acc[a0 + 2][bq]), "+v"(acc[a0 + 3][bq]), "+v"(acc[a0][bq + 1]),
-                   "+v"(acc[a0 + 1][bq + 1]), "+v"(acc[a0 + 2][bq + 1]), "+v"(acc[a0 + 3][bq + 1]));
+      constexpr int P = s & 3, a0 = (P >= 2) ? 2 : 0, bq = (P == 1 || P == 2) ? 1 : 0;  // the quadrant of phase P (mma_set)
+      asm volatile("" : "+v"(acc[a0][bq]), "+v"(acc[a0 + 1][bq]));
 #endif
     }
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WAITN) : "memory");
@@ -483,71 +489,74 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmArgs a) {
     const int mw = (tile_m << 8) + wr * 128;  // first token row of this wave
     const int nw = (tile_n << 8) + wc * 64;   // first output column of this wave
 
-    // ---- accumulator init: zero (RAW) or bias + LayerNorm(residual).  The images are read with inline-asm ds_reads: hipcc would put
-    // `s_waitcnt vmcnt(0)` in front of a compiler-visible LDS load here (LDS-DMA in flight) and drain the operand pipeline once per tile.
+    // ---- accumulator init: zero (RAW) or bias + LayerNorm(residual).  The images are read with inline-asm ds_reads: hipcc
+    // would put `s_waitcnt vmcnt(0)` in front of a compiler-visible LDS load here (LDS-DMA in flight) and drain the
+    // operand pipeline once per output tile.  Loads and their lgkmcnt wait are one statement (guide §5.7 form i).
     {
-      const uint32_t baddr = (uint32_t)(PP_LDS_BIAS + (nw + 4 * q4) * 4);  // + 64 cb: this lane's four columns of column block cb
-      // scratch addresses of this lane: C/D-layout units (token 16 tbl + m16 of a 32 x 32 block, columns 16 cbl + 4 q4 .. + 3 = slot
-      // 2 cbl + (q4 >> 1), half q4 & 1 of the [32 rows][64 B] image) and coalesced layout (row = lane >> 2)
+      const uint32_t baddr = (uint32_t)(PP_LDS_BIAS + (nw + 4 * hi) * 4);
+      // scratch addresses of this lane: MFMA layout (row = lane & 31) and coalesced layout (row = lane >> 2)
       const uint32_t scr = (uint32_t)(LDS_SCR + wave * 2048);
-      const uint32_t sf = (uint32_t)((m16 >> 2) & 3);
+      const uint32_t sf = (uint32_t)((l31 >> 2) & 3);
       const uint32_t scr_c = scr + (lane >> 2) * 64 + ((((uint32_t)lane & 3) ^ (((uint32_t)lane >> 4) & 3)) << 4);
       if constexpr (IS_RES) {
-        // residual tile by full-line loads (16 rows x 64 B per instruction), parked in the accumulators and transposed into the C/D layout
-        float2 lnst[8];    // (mean, rstd) of this lane's eight token rows 16 tb + m16
-        float2 lnp[8][3];  // the rows' vstats, loaded here and turned into (mean, rstd) only AFTER the residual tile's loads are issued
-                           // (in source order hipcc waits for these loads first and the two memory latencies add up: +1.3 us per tile)
+        // residual tile by full-line loads (16 rows x 64 B per instruction), transposed into the C/D layout
+        // (the raw lines are parked in the accumulator registers they will be transposed into)
+        float2 lnst[4];    // (mean, rstd) of this lane's four token rows
+        float2 lnp[4][3];  // the rows' vstats, loaded here and turned into (mean, rstd) only AFTER the residual tile's loads
+                           // are issued (in source order hipcc waits for these loads first and the two memory latencies add
+                           // up: +1.3 us per tile)
 #pragma unroll
-        for (int tb = 0; tb < 8; ++tb) {
-          const float2* pp = (const float2*)(a.lnstats + 6 * (size_t)(mw + tb * 16 + m16));
-          lnp[tb][0] = pp[0]; lnp[tb][1] = pp[1]; lnp[tb][2] = pp[2];
+        for (int i = 0; i < 4; ++i) {
+          const float2* pp = (const float2*)(a.lnstats + 6 * (size_t)(mw + i * 32 + l31));
+          lnp[i][0] = pp[0]; lnp[i][1] = pp[1]; lnp[i][2] = pp[2];
         }
-        const uint32_t ub = scr + m16 * 64 + (q4 & 1) * 8;  // unit (tbl, cbl) at ub + 1024 tbl, slot (2 cbl + (q4 >> 1)) ^ sf
-        const uint32_t u00 = ub + ((((uint32_t)(q4 >> 1)) ^ sf) << 4), u01 = ub + (((2u + (uint32_t)(q4 >> 1)) ^ sf) << 4);
-        // (tiles after the workgroup's first: the lines were requested block row by block row during the PREVIOUS tile's epilogue, each
-        //  as soon as its accumulators had been stored — park_residual — so this tile's read phase runs under the last one's writes)
+        const uint32_t wbase = scr + l31 * 64 + hi * 8 + (sf << 4);
+        // (tiles after the workgroup's first: the lines were requested fragment pair by fragment pair during the PREVIOUS
+        //  tile's epilogue, each as soon as its accumulator registers had been stored — park_residual below — so the read
+        //  phase of this tile runs under the write phase of the last one instead of after it)
         if (it == 0) {
 #pragma unroll
           for (int i = 0; i < 4; ++i) park_residual(i, mw, nw);
         }
 #pragma unroll
-        for (int tb = 0; tb < 8; ++tb) lnst[tb] = ln_from_partials(lnp[tb][0], lnp[tb][1], lnp[tb][2], a.ln_eps);
+        for (int i = 0; i < 4; ++i) lnst[i] = ln_from_partials(lnp[i][0], lnp[i][1], lnp[i][2], a.ln_eps);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
 #pragma clang fp contract(off)
 #pragma unroll
           for (int j = 0; j < 2; ++j) {
-            u32x4 p[4];  // p[2 pl + x] = plane pl, rows crow + 16 x (park_residual)
+            u32x4 p[4];
 #pragma unroll
-            for (int qq = 0; qq < 4; ++qq)
+            for (int q = 0; q < 4; ++q)
 #pragma unroll
-              for (int e = 0; e < 4; ++e) p[qq][e] = f2u(acc[2 * i + (qq >> 1)][2 * j + (qq & 1)][e]);
-            u32x2 oh[4], ol[4];  // unit k = 2 tbl + cbl
-            scr_f16_rev2(scr_c, p[0], p[1], p[2], p[3], u00, u01, u00 + 1024u, u01 + 1024u, oh, ol);
+              for (int e = 0; e < 4; ++e) p[q][e] = f2u(acc[i][j][4 * q + e]);
+            u32x2 oh[4], ol[4];
+            scr_f16_rev2(scr_c, p[0], p[1], p[2], p[3], wbase, wbase ^ 16u, wbase ^ 32u, wbase ^ 48u, oh, ol);
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-              const int tbl = k >> 1, cbl = k & 1;
+            for (int g = 0; g < 4; ++g) {
               float4 bi, ga, be;
-              lds_read_bgb1(baddr + (2 * j + cbl) * 64, bi, ga, be);
+              lds_read_bgb1(baddr + j * 128 + g * 32, bi, ga, be);
 #pragma unroll
               for (int e = 0; e < 4; ++e) {
-                const uint32_t wh = oh[k][e >> 1], wl = ol[k][e >> 1];  // scalar copies before the bit casts (see f2u)
+                const uint32_t wh = oh[g][e >> 1], wl = ol[g][e >> 1];  // scalar copies before the bit casts (see f2u)
                 const half2_t h2 = __builtin_bit_cast(half2_t, wh);
                 const half2_t l2 = __builtin_bit_cast(half2_t, wl);
                 const float r = (float)h2[e & 1] + (float)l2[e & 1];
-                const float t = (r - lnst[2 * i + tbl].x) * lnst[2 * i + tbl].y;
-                acc[2 * i + tbl][2 * j + cbl][e] = __builtin_fmaf(t, ((const float*)&ga)[e], ((const float*)&be)[e]) + ((const float*)&bi)[e];
+                const float t = (r - lnst[i].x) * lnst[i].y;
+                acc[i][j][4 * g + e] = __builtin_fmaf(t, ((const float*)&ga)[e], ((const float*)&be)[e]) + ((const float*)&bi)[e];
               }
             }
           }
         }
       } else {
 #pragma unroll
-        for (int tb = 0; tb < 8; ++tb)
+        for (int j = 0; j < 2; ++j)
 #pragma unroll
-          for (int cb = 0; cb < 4; ++cb) {
-            acc[tb][cb][0] = 0.f; acc[tb][cb][1] = 0.f; acc[tb][cb][2] = 0.f; acc[tb][cb][3] = 0.f;
-          }
+          for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              acc[i][j][4 * g + 0] = 0.f; acc[i][j][4 * g + 1] = 0.f; acc[i][j][4 * g + 2] = 0.f; acc[i][j][4 * g + 3] = 0.f;
+            }
       }
     }
 
@@ -588,38 +597,35 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmArgs a) {
       for (int kt = nk0; kt < nk; kt += 2) two_ktiles(std::true_type{}, kt + 2 >= nk);
     }
 
-    // ---- epilogue (store only): every 32 x 32 block (i, j) = accumulators (2 i + tbl, 2 j + cbl) goes through the wave's [32][64 B] image
+    // ---- epilogue (store only): every 32x32 fragment goes through the wave's [32][64 B] LDS image
     {
       const uint32_t scr = (uint32_t)(LDS_SCR + wave * 2048);
-      const uint32_t sf = (uint32_t)((m16 >> 2) & 3);
+      const uint32_t sf = (uint32_t)((l31 >> 2) & 3);
       const uint32_t scr_c = scr + (lane >> 2) * 64 + ((((uint32_t)lane & 3) ^ (((uint32_t)lane >> 4) & 3)) << 4);
       const int crow = lane >> 2, cchunk = lane & 3;  // coalesced layout: row (+16 for the second read), 16-B chunk
       if constexpr (IS_RES) {
-        // vstats of the new raw rows: (sum, sum of squares) over this TILE's 256 columns.  Each wave reduces its 64 columns (a token
-        // row's 64 values sit in the four lanes m16 + 16 q4), parks the 128 pairs in its own scratch, and after a workgroup barrier
-        // the first column wave of each M-half adds the four shares in wave order (deterministic) and writes slot tile_n of the
-        // rows' three pairs.  A second barrier keeps the scratch intact until it has been read (inline asm: see the accumulator init).
+        // vstats of the new raw rows: (sum, sum of squares) over this TILE's 256 columns.  Each wave reduces its 64 columns
+        // (lane = token row, the two half-waves hold disjoint column sets), parks the 128 pairs in its own scratch, and after
+        // a workgroup barrier the first column wave of each M-half adds the four shares in wave order (deterministic) and
+        // writes slot tile_n of the rows' three pairs.  A second barrier keeps the scratch intact until it has been read.
+        // (inline asm: compiler-visible LDS accesses would wait for the LDS-DMA in flight, see the accumulator init)
 #pragma unroll
-        for (int tb = 0; tb < 8; ++tb) {
+        for (int i = 0; i < 4; ++i) {
           float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-          for (int cb = 0; cb < 4; ++cb)
+          for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              const float v = acc[tb][cb][e];
+            for (int r = 0; r < 16; ++r) {
+              const float v = acc[i][j][r];
               s1 += v;
               s2 = __builtin_fmaf(v, v, s2);
             }
-          // q4 pairs (0,1) / (2,3): rows of 16 lanes swapped; then the two halves of the wave
-          const auto a1 = __builtin_amdgcn_permlane16_swap(f2u(s1), f2u(s1), false, false);
-          const auto a2 = __builtin_amdgcn_permlane16_swap(f2u(s2), f2u(s2), false, false);
-          const float h1 = u2f(a1[0]) + u2f(a1[1]), h2 = u2f(a2[0]) + u2f(a2[1]);
-          const auto t1 = __builtin_amdgcn_permlane32_swap(f2u(h1), f2u(h1), false, false);
-          const auto t2 = __builtin_amdgcn_permlane32_swap(f2u(h2), f2u(h2), false, false);
+          const auto t1 = __builtin_amdgcn_permlane32_swap(f2u(s1), f2u(s1), false, false);
+          const auto t2 = __builtin_amdgcn_permlane32_swap(f2u(s2), f2u(s2), false, false);
           float2 st;
           st.x = u2f(t1[0]) + u2f(t1[1]);
           st.y = u2f(t2[0]) + u2f(t2[1]);
-          const uint32_t waddr = scr + (uint32_t)(tb * 16 + m16) * 8;  // the four lanes of a row write the same pair
+          const uint32_t waddr = scr + (uint32_t)(i * 32 + l31) * 8;  // both half-waves write the same pair
           asm volatile("ds_write_b64 %0, %1" ::"v"(waddr), "v"(st) : "memory");
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -648,20 +654,17 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmArgs a) {
         __builtin_amdgcn_sched_barrier(0);
       }
       {
-        // unit (tbl, cbl) of a block: token 16 tbl + m16, columns 16 cbl + 4 q4 .. + 3 -> image row 16 tbl + m16, slot 2 cbl + (q4 >> 1),
-        // half q4 & 1.  fp16: 8-byte units; fp8 planes: 4-byte units at byte 4 q4 of slot cbl (columns 16 cbl .. + 15 of a 32-column half)
-        const uint32_t ub = scr + m16 * 64 + (q4 & 1) * 8;
-        const uint32_t u00 = ub + ((((uint32_t)(q4 >> 1)) ^ sf) << 4), u01 = ub + (((2u + (uint32_t)(q4 >> 1)) ^ sf) << 4);
-        const uint32_t ub8 = scr + m16 * 64 + q4 * 4;  // + ((slot ^ sf) << 4), slot = 2 j + cbl of the 64-byte plane row
-        half_t* obase;    // pointer of (row crow, chunk cchunk) of block (i = 0, j = 0)
+        // fp16 outputs: 8-B units (4 values) of the C/D layout -> chunk g, half hi of the row
+        // (PP_RESLN3: the hi plane of the raw stream, the A operand of the next RAW consumer)
+        const uint32_t wbase = scr + l31 * 64 + hi * 8 + (sf << 4);
+        const uint32_t wbase8 = scr + l31 * 64 + hi * 4 + (sf << 4);  // fp8 planes (scr_f8x2)
+        half_t* obase;    // pointer of (row crow, chunk cchunk) of fragment (i = 0, j = 0)
         size_t rstride;   // elements between image rows in the output
-        size_t istride;   // elements between i blocks (32 token rows)
+        size_t istride;   // elements between i blocks (32 C/D rows along the register axis or the lane axis)
         size_t jstride;   // elements between j blocks
         bool live = true;
         bool vtile = false;  // PP_QK: this tile belongs to the V block and is stored as V^T
-        // V^T image: rows = head dims 16 cbl + 4 q4 + e, columns = tokens 16 tbl + m16 (2 bytes), 16-B chunk (token >> 3) ^ q4
-        const uint32_t tb0 = scr + q4 * 256 + (m16 & 7) * 2;
-        const uint32_t tt0 = tb0 + ((((uint32_t)(m16 >> 3)) ^ (uint32_t)q4) << 4), tt1 = tb0 + (((2u + (uint32_t)(m16 >> 3)) ^ (uint32_t)q4) << 4);
+        const uint32_t tbase = scr + hi * 256 + (((uint32_t)(l31 >> 3) ^ (uint32_t)hi) << 4) + (uint32_t)(l31 & 7) * 2;
         if constexpr (EPI == PP_GELU || IS_RES) {
           obase = a.out16 + (size_t)(mw + crow) * a.N + nw + 8 * cchunk;
           rstride = a.N; istride = (size_t)32 * a.N; jstride = 32;
@@ -679,47 +682,48 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmArgs a) {
             rstride = MV_HEAD_DIM; istride = 0; jstride = 32;  // the batch-row part is added per i below
           }
         }
-        // RAW: bias' of this lane's columns (per-tile LDS image: one float4 per column block) and rstd of its eight token rows
-        // (from the vstats image), applied as fma(rstd, acc, bias')
-        float4 rbv[4];
-        float rrs[8];
+        // RAW: bias' of this wave's columns (per-tile LDS image) and rstd of its token rows (from the vstats image, one row
+        // per lane and i), applied as fma(rstd, acc, bias')
+        float4 rbv[2][4];
+        float rrs[4];
         if constexpr (RAW) {
-          const uint32_t baddr = (uint32_t)(PP_LDS_BIAS_T + (it & 1) * 1024 + (wc * 64 + 4 * q4) * 4);
-          const uint32_t saddr = (uint32_t)(PP_LDS_RSTD + (it & 1) * 1024 + (wr * 128 + m16) * 4);  // this wave's 128 rows
+          const uint32_t baddr = (uint32_t)(PP_LDS_BIAS_T + (it & 1) * 1024 + (wc * 64 + 4 * hi) * 4);
+          const uint32_t saddr = (uint32_t)(PP_LDS_RSTD + (it & 1) * 1024 + (wr * 128 + l31) * 4);  // this wave's 128 rows
           asm volatile(
-              "ds_read_b128 %0, %12\n\tds_read_b128 %1, %12 offset:64\n\tds_read_b128 %2, %12 offset:128\n\t"
-              "ds_read_b128 %3, %12 offset:192\n\t"
-              "ds_read_b32 %4, %13\n\tds_read_b32 %5, %13 offset:64\n\tds_read_b32 %6, %13 offset:128\n\t"
-              "ds_read_b32 %7, %13 offset:192\n\tds_read_b32 %8, %13 offset:256\n\tds_read_b32 %9, %13 offset:320\n\t"
-              "ds_read_b32 %10, %13 offset:384\n\tds_read_b32 %11, %13 offset:448\n\ts_waitcnt lgkmcnt(0)"
-              : "=&v"(rbv[0]), "=&v"(rbv[1]), "=&v"(rbv[2]), "=&v"(rbv[3]), "=&v"(rrs[0]), "=&v"(rrs[1]), "=&v"(rrs[2]), "=&v"(rrs[3]),
-                "=&v"(rrs[4]), "=&v"(rrs[5]), "=&v"(rrs[6]), "=&v"(rrs[7])
+              "ds_read_b128 %0, %12\n\tds_read_b128 %1, %12 offset:32\n\tds_read_b128 %2, %12 offset:64\n\t"
+              "ds_read_b128 %3, %12 offset:96\n\tds_read_b128 %4, %12 offset:128\n\tds_read_b128 %5, %12 offset:160\n\t"
+              "ds_read_b128 %6, %12 offset:192\n\tds_read_b128 %7, %12 offset:224\n\t"
+              "ds_read_b32 %8, %13\n\tds_read_b32 %9, %13 offset:128\n\tds_read_b32 %10, %13 offset:256\n\t"
+              "ds_read_b32 %11, %13 offset:384\n\ts_waitcnt lgkmcnt(0)"
+              : "=&v"(rbv[0][0]), "=&v"(rbv[0][1]), "=&v"(rbv[0][2]), "=&v"(rbv[0][3]), "=&v"(rbv[1][0]), "=&v"(rbv[1][1]),
+                "=&v"(rbv[1][2]), "=&v"(rbv[1][3]), "=&v"(rrs[0]), "=&v"(rrs[1]), "=&v"(rrs[2]), "=&v"(rrs[3])
               : "v"(baddr), "v"(saddr)
               : "memory");
           __builtin_amdgcn_sched_barrier(0);
         }
-        (void)ub8;
+        (void)wbase8;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           const int mb = mw + i * 32;
           half_t* ob = obase + i * istride;
+          const float rrs_i = RAW ? rrs[i] : 1.f;  // RAW: rstd of token row 32 i + l31
+          (void)rrs_i;
           if constexpr (EPI == PP_QK) {
             live = mb < a.Mreal;
             const int b = mb / a.S, s0 = mb - b * a.S;
             if (!vtile) ob = obase + ((size_t)b * MV_HEADS * a.S + s0) * MV_HEAD_DIM;
             else ob = obase + (size_t)b * MV_HEADS * MV_HEAD_DIM * a.S + s0;
           }
-          u32x2 d[2][4];  // [j][k = 2 tbl + cbl]
+          u32x2 d[2][4];
           u32x4 o[4];
 #pragma unroll
           for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-              const int tb = 2 * i + (k >> 1), cb = 2 * j + (k & 1);
-              float v0 = acc[tb][cb][0], v1 = acc[tb][cb][1], v2 = acc[tb][cb][2], v3 = acc[tb][cb][3];
-              if constexpr (RAW) {  // lane = token row 16 tb + m16, registers = 4 consecutive columns
-                v0 = __builtin_fmaf(rrs[tb], v0, rbv[cb].x); v1 = __builtin_fmaf(rrs[tb], v1, rbv[cb].y);
-                v2 = __builtin_fmaf(rrs[tb], v2, rbv[cb].z); v3 = __builtin_fmaf(rrs[tb], v3, rbv[cb].w);
+            for (int g = 0; g < 4; ++g) {
+              float v0 = acc[i][j][4 * g + 0], v1 = acc[i][j][4 * g + 1], v2 = acc[i][j][4 * g + 2], v3 = acc[i][j][4 * g + 3];
+              if constexpr (RAW) {  // lane = token row 32 i + l31, registers = 4 consecutive columns
+                v0 = __builtin_fmaf(rrs_i, v0, rbv[j][g].x); v1 = __builtin_fmaf(rrs_i, v1, rbv[j][g].y);
+                v2 = __builtin_fmaf(rrs_i, v2, rbv[j][g].z); v3 = __builtin_fmaf(rrs_i, v3, rbv[j][g].w);
               }
               if constexpr (EPI == PP_GELU) {
                 float2_t a01, a23;
@@ -728,14 +732,14 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmArgs a) {
                 a23 = gelu_erf2(a23);
                 v0 = a01.x; v1 = a01.y; v2 = a23.x; v3 = a23.y;
                 if constexpr (X8) {  // the fp8 planes below are taken from the activated values
-                  acc[tb][cb][0] = v0; acc[tb][cb][1] = v1; acc[tb][cb][2] = v2; acc[tb][cb][3] = v3;
+                  acc[i][j][4 * g + 0] = v0; acc[i][j][4 * g + 1] = v1; acc[i][j][4 * g + 2] = v2; acc[i][j][4 * g + 3] = v3;
                 }
               }
-              d[j][k][0] = pack_h2(v0, v1);
-              d[j][k][1] = pack_h2(v2, v3);
+              d[j][g][0] = pack_h2(v0, v1);
+              d[j][g][1] = pack_h2(v2, v3);
             }
-          if (EPI == PP_QK && vtile) scr_f16x2_t(tt0, tt1, d[0], d[1], scr_c, o);
-          else scr_f16x2(u00, u01, u00 + 1024u, u01 + 1024u, d[0], d[1], scr_c, o);
+          if (EPI == PP_QK && vtile) scr_f16x2_t(tbase, tbase ^ 32u, d[0], d[1], scr_c, o);
+          else scr_f16x2(wbase, wbase ^ 16u, wbase ^ 32u, wbase ^ 48u, d[0], d[1], scr_c, o);
           if (live) {
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
@@ -748,13 +752,12 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmArgs a) {
 #pragma unroll
             for (int j = 0; j < 2; ++j)
 #pragma unroll
-              for (int k = 0; k < 4; ++k) {
-                const int tb = 2 * i + (k >> 1), cb = 2 * j + (k & 1);
-                const float v0 = acc[tb][cb][0], v1 = acc[tb][cb][1], v2 = acc[tb][cb][2], v3 = acc[tb][cb][3];
-                d[j][k][0] = pack_h2(v0 - (float)(half_t)v0, v1 - (float)(half_t)v1);
-                d[j][k][1] = pack_h2(v2 - (float)(half_t)v2, v3 - (float)(half_t)v3);
+              for (int g = 0; g < 4; ++g) {
+                const float v0 = acc[i][j][4 * g + 0], v1 = acc[i][j][4 * g + 1], v2 = acc[i][j][4 * g + 2], v3 = acc[i][j][4 * g + 3];
+                d[j][g][0] = pack_h2(v0 - (float)(half_t)v0, v1 - (float)(half_t)v1);
+                d[j][g][1] = pack_h2(v2 - (float)(half_t)v2, v3 - (float)(half_t)v3);
               }
-            scr_f16x2(u00, u01, u00 + 1024u, u01 + 1024u, d[0], d[1], scr_c, o);
+            scr_f16x2(wbase, wbase ^ 16u, wbase ^ 32u, wbase ^ 48u, d[0], d[1], scr_c, o);
             half_t* ol = ob + (a.out16b - a.out16);
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
@@ -766,31 +769,27 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmArgs a) {
           if constexpr (X8 && (IS_RES || EPI == PP_GELU)) {
             // MV_F16X8: the [lo8 | hi8] planes of this output (the A8 operand of the next GEMM's correction sweep): rows of
             // 2 N bytes, lo8 of column n at byte n, hi8 at byte N + n; one 16-B store per lane, plane and 16-row half
-            uint32_t dl[8], dh[8];  // [4 tbl + 2 j + cbl]: the dword of token 16 tbl + m16, columns 32 j + 16 cbl + 4 q4 .. + 3
+            uint32_t dl[8], dh[8];
 #pragma unroll
-            for (int tbl = 0; tbl < 2; ++tbl)
+            for (int j = 0; j < 2; ++j)
 #pragma unroll
-              for (int j = 0; j < 2; ++j)
-#pragma unroll
-                for (int cbl = 0; cbl < 2; ++cbl) {
-                  const int tb = 2 * i + tbl, cb = 2 * j + cbl;
-                  x8_planes4(acc[tb][cb][0], acc[tb][cb][1], acc[tb][cb][2], acc[tb][cb][3], dh[4 * tbl + 2 * j + cbl], dl[4 * tbl + 2 * j + cbl]);
-                }
-            const uint32_t w8 = ub8 + (sf << 4);
-            scr_f8x2(w8, w8 ^ 16u, w8 ^ 32u, w8 ^ 48u, dl, dh, scr_c, o);
+              for (int g = 0; g < 4; ++g)
+                x8_planes4(acc[i][j][4 * g + 0], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3], dh[4 * j + g], dl[4 * j + g]);
+            scr_f8x2(wbase8, wbase8 ^ 16u, wbase8 ^ 32u, wbase8 ^ 48u, dl, dh, scr_c, o);
             uint8_t* o8 = a.out8 + (size_t)(mb + crow) * (2 * a.N) + nw + 16 * cchunk;
             *(u32x4*)o8 = o[0];
             *(u32x4*)(o8 + (size_t)16 * (2 * a.N)) = o[1];
             *(u32x4*)(o8 + a.N) = o[2];
             *(u32x4*)(o8 + a.N + (size_t)16 * (2 * a.N)) = o[3];
           }
-          if constexpr (IS_RES) {  // block row i is out: request block row i of the NEXT tile's residual into its registers
+          if constexpr (IS_RES) {  // fragment pair i is out: request pair i of the NEXT tile's residual into its registers
             if (has_next) park_residual(i, (next_m << 8) + wr * 128, (next_n << 8) + wc * 64);
           }
         }
       }
     }
   }
+
   };  // run_tiles
   if (wr == 0) run_tiles(std::integral_constant<int, 0>{});
   else run_tiles(std::integral_constant<int, 1>{});
