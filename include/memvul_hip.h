@@ -44,7 +44,7 @@ typedef enum mv_status {
 
 typedef enum mv_dtype { MV_F32 = 0, MV_F16 = 1, MV_BF16 = 2, MV_I32 = 3, MV_I64 = 4,
                         /* compute dtype only ("precise"): the fp16 MFMA sweep of every encoder GEMM plus ONE correction sweep on the
-                         * fp8 matrix path (OCP e4m3, v_mfma_scale_f32_32x32x64_f8f6f4) over the first-order terms of the split-operand
+                         * fp8 matrix path (OCP e4m3, v_mfma_scale_f32_16x16x128_f8f6f4) over the first-order terms of the split-operand
                          * product, A_lo8 W_hi8 + A_hi8 W_lo8 — ~15.5-bit operands at 2x the GEMM main loop: the mode that holds 1e-3 on
                          * the logits in the trained-like regime.  (5 was MV_F16X2, the three-sweep fp16 split
                          * of round 2 that this mode replaces; it is rejected now.) */
