@@ -152,8 +152,8 @@ __device__ __forceinline__ void scr_f16x2_t(uint32_t t0, uint32_t t1, const u32x
 #undef MV_T16
 #endif
 }
-// The reverse direction for two fp16 planes of one 32 x 32 fragment: coalesced 16-byte pieces (rows lane >> 2 and + 16, chunk
-// lane & 3) are written into the image, the C/D-layout units (row lane & 31, columns 8 g + 4 hi .. + 3) are read back.
+// The reverse direction for two fp16 planes of one 32 x 32 block: coalesced 16-byte pieces (rows lane >> 2 and + 16, chunk
+// lane & 3) are written into the image, the four C/D-layout units (tbl, cbl) of the lane (addresses r0..r3) are read back.
 __device__ __forceinline__ void scr_f16_rev2(uint32_t wc, const u32x4& a0, const u32x4& a1, const u32x4& b0, const u32x4& b1, uint32_t r0,
                                              uint32_t r1, uint32_t r2, uint32_t r3, u32x2 (&oa)[4], u32x2 (&ob)[4]) {
 #if defined(__HIP_DEVICE_COMPILE__)
