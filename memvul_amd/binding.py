@@ -16,11 +16,23 @@ LIB_PATH = os.path.join(_HERE, "lib", "libmemvul_hip.so")
 
 MV_F32, MV_F16, MV_BF16, MV_I32, MV_I64 = 0, 1, 2, 3, 4
 MV_F16X8 = 6  # compute dtype only ("precise"): fp16 MFMA sweep + one fp8 (e4m3) correction sweep per GEMM (include/memvul_hip.h)
-COMPUTE_DTYPES = {"f16": MV_F16, "f16x8": MV_F16X8, "precise": MV_F16X8}
+COMPUTE_DTYPES = {"f16": MV_F16, "fast": MV_F16, "f16x8": MV_F16X8, "precise": MV_F16X8}
+# The product's default is the compute dtype that holds the reference's 1e-3 logit tolerance on trained-like weights
+# (model_memory.py:133-147 at config_memory.json:38's temperature): MV_F16X8.  MV_F16 ("fast") is an explicit opt-in:
+# ~1.7x the rate, logits within 1e-3 only on small-logit models (measured 3.0-5.6e-3 at |logit| ~ 3).
+DEFAULT_COMPUTE = "precise"
+
+
+def default_compute() -> str:
+    """$MEMVUL_COMPUTE (f16 | fast | f16x8 | precise) or the contract-holding default."""
+    return os.environ.get("MEMVUL_COMPUTE", DEFAULT_COMPUTE)
 
 
 def compute_dtype_of(name_or_code) -> int:
-    """"f16" | "f16x8" (alias "precise") or the numeric mv_dtype -> the code mv_finalize_weights takes; anything else raises."""
+    """"f16" (alias "fast") | "f16x8" (alias "precise") or the numeric mv_dtype -> the code mv_finalize_weights takes; None = the
+    default (default_compute()); anything else raises."""
+    if name_or_code is None:
+        name_or_code = default_compute()
     if isinstance(name_or_code, str):
         if name_or_code.lower() not in COMPUTE_DTYPES:
             raise ValueError(f"unknown compute dtype {name_or_code!r}: expected one of {sorted(COMPUTE_DTYPES)}")
@@ -178,7 +190,7 @@ class Engine:
         shape = (C.c_int64 * arr.ndim)(*arr.shape)
         self._check(self._lib.mv_load_tensor(self._h, name.encode(), _ptr(arr), dt, shape, arr.ndim), f"mv_load_tensor({name})")
 
-    def load_state_dict(self, sd: Dict[str, np.ndarray], compute_dtype=MV_F16):
+    def load_state_dict(self, sd: Dict[str, np.ndarray], compute_dtype=None):
         """``sd``: reference ``state_dict`` keys -> arrays (torch tensors are converted by the caller)."""
         for k, v in sd.items():
             a = np.asarray(v)

@@ -171,10 +171,11 @@ class ModelMemory(Model):
             raise ValueError(f"use_header={self._use_header} but the state dict {'has' if has_header else 'lacks'} "
                              "_projector_single (model_memory.py:69-71)")
         opts["proj_dim"] = 512 if self._use_header else 768
-        # compute dtype: MV_F16 (default, the benchmarked path) or MV_F16X8 ("precise": + one fp8 correction sweep per GEMM, the mode
-        # that holds 1e-3 on trained-like logits; include/memvul_hip.h); engine_options["compute_dtype"] or $MEMVUL_COMPUTE =
-        # f16 | f16x8 | precise.  An unknown name raises here (ValueError), not inside ctypes.
-        cd = compute_dtype_of(opts.pop("compute_dtype", os.environ.get("MEMVUL_COMPUTE", "f16")))
+        # compute dtype: MV_F16X8 ("precise", the DEFAULT: fp16 sweep + one fp8 correction sweep per GEMM — the mode that holds the
+        # reference's 1e-3 on trained-like logits; include/memvul_hip.h) or MV_F16 ("fast": explicit opt-in, 3.0-5.6e-3 there);
+        # engine_options["compute_dtype"] or $MEMVUL_COMPUTE = precise | f16x8 | f16 | fast.  An unknown name raises here
+        # (ValueError), not inside ctypes.
+        cd = compute_dtype_of(opts.pop("compute_dtype", None))
         if self._engine is not None:
             self._engine.close()
         self._engine = Engine(self._device_index, vocab_size=vocab_size, layers=layers, max_pos=max_pos, type_vocab=type_vocab,

@@ -17,7 +17,7 @@ from typing import Any, Dict, List, Optional
 
 import numpy as np
 
-from .binding import Engine, MV_F16
+from .binding import Engine, compute_dtype_of
 from .model_memory import PFX_BERT, _ClassificationCounts, _np
 from .registry import Model, TextFieldEmbedder, Vocabulary
 
@@ -64,12 +64,13 @@ class ModelSingle(Model):
         eng_sd["_projector.weight"] = np.zeros((2, 3 * 512), np.float32)
         opts = dict(max_tokens=128 * 512, max_batch=512, max_anchors=1)
         opts.update(self._engine_options)
+        opts_compute = opts.pop("compute_dtype", None)  # None: binding.default_compute() — precise unless $MEMVUL_COMPUTE says otherwise
         if self._engine is not None:
             self._engine.close()
         self._engine = Engine(self._device_index, vocab_size=sd[PFX_BERT + "embeddings.word_embeddings.weight"].shape[0], layers=layers,
                               max_pos=min(512, sd[PFX_BERT + "embeddings.position_embeddings.weight"].shape[0]),
                               type_vocab=sd[PFX_BERT + "embeddings.token_type_embeddings.weight"].shape[0], **opts)
-        self._engine.load_state_dict(eng_sd, MV_F16)
+        self._engine.load_state_dict(eng_sd, compute_dtype_of(opts_compute))
         return self
 
     @property

@@ -86,9 +86,12 @@ def test_stamp_carries_the_device_code_fingerprint(lib):
     st = build.read_stamp()
     assert set(st) >= {"src", "cc", "dev"}
     assert st["dev"] == build.device_code_fingerprint() and st["src"] == build.source_fingerprint()
-    classes, note = bench.load_pmc()
     pmc = json.load(open(bench.PMC_FILE))
+    modes = sorted(pmc.get("classes_by_mode", {}))
+    assert modes, "profiles/pmc_current.json: one counter pass per compute dtype under classes_by_mode"
+    classes, note = bench.load_pmc(modes[0])
     if "dev " + st["dev"] in pmc["lib_stamp"]:
         assert classes and "gemm_ffn2" in classes and classes["gemm_ffn2"]["traffic_bytes"] > 0, note
+        assert bench.load_pmc("no such mode")[0] == {}
     else:  # kernels changed since the last counter pass: the bench must say so instead of quoting the old figures
         assert classes == {} and "not reported" in note
