@@ -165,7 +165,7 @@ def main():
                  max_batch=max(B, 256), max_anchors=max(G, 1024))
     eng.load_state_dict(weights, mode)
     eng.set_streams(args.streams)
-    transport = "none (one rank)"
+    transport, comm_info = "none (one rank)", {}
     if multi:
         # the N > 1 transport: the ranks agree over a rendezvous hub whether RCCL bound inside libmemvul_hip.so (mv_comm_*,
         # collective on the engine's stream, no torch in the process) carries the statistics or the hub itself does
@@ -173,6 +173,10 @@ def main():
         # so the run exercises the agreement's fall-back — every rank reports the failure, all move to the hub together)
         skip_rccl = stub or (one_gpu_smoke and os.environ.get("MEMVUL_BENCH_ONE_GPU_SMOKE") != "rccl")
         transport = mvdist.init_transport(eng, rank, world, prefer="tcp" if skip_rccl else "rccl")
+        # what RCCL itself says about the communicator the statistics travel over (mv_comm_info: ncclCommCount / ncclGetVersion)
+        comm_info = eng.comm_info() if hasattr(eng, "comm_info") else {}
+        if transport.startswith("rccl") and comm_info.get("rccl_ranks") != world:
+            raise SystemExit(f"transport says RCCL but ncclCommCount reports {comm_info.get('rccl_ranks')} ranks for WORLD_SIZE={world}")
 
     # anchor memory: G synthetic CWE descriptions of up to 512 tokens, built once per process (untimed;
     # predict_memory.py:81-83 forwards them in chunks of 128)
@@ -275,7 +279,9 @@ def main():
                                                                                                  "MV_F16" if mode == "f16" else "MV_F16X8"),
                    "compute": mode,
                    "global_batch": world * B, "seq_len": S, "anchors": G, "parallelism": "dp%d (corpus shards, one "
-                   "all-gather of (score,label) stats)" % world, "stats_transport": transport},
+                   "all-gather of (score,label) stats)" % world, "stats_transport": transport,
+                   **({"comm_world": comm_info.get("rccl_ranks") or comm_info.get("world", world), "rccl_ranks": comm_info.get("rccl_ranks", 0),
+                       "rccl_version": comm_info.get("rccl_version", 0)} if multi else {})},
         # executed FLOPs (with last-layer [CLS] pruning the fraction is priced on what runs)
         "e2e_tflops_per_gpu": round(value / world * fpi_exec / 1e12, 2),
         "e2e_mfma_frac": round(value / world * fpi_exec / 1e12 / MFMA_PEAK_TFLOPS, 4),
@@ -286,9 +292,14 @@ def main():
     }
     if one_gpu_smoke:
         out["config"]["note"] = "MEMVUL_BENCH_ONE_GPU_SMOKE: all ranks share ONE GPU, exchange over the rendezvous hub: control-flow check, not a measurement"
-    if stub:
+    if stub:  # never a number that could be mistaken for a measurement: `value` is null, the stand-in's rate sits under its own name
         out["data"] = "stub"
         out["config"]["note"] = "MEMVUL_BENCH_STUB_ENGINE: numpy stand-in engine, NO GPU — a test of this file's control flow and JSON contract, not a measurement"
+        out["stub_rate_not_a_measurement"] = out["value"]
+        out["value"] = None
+        for k in ("e2e_tflops_per_gpu", "e2e_mfma_frac"):
+            out[k] = None
+        prof = {}
     if prof:
         kernels = {}
         for name, (ms, n) in breakdown.items():
@@ -368,7 +379,9 @@ def corpus_shard_leg(eng, dims, B, S, rank, world, shard_irs):
     mvdist.barrier()
     t0 = time.perf_counter()
     eng.corpus_run(0, n, B, keep_probs=False)
-    best, idx, _ = eng.corpus_results(0, n)
+    eng.sync()
+    t_compute = time.perf_counter() - t0
+    best, idx, _ = eng.corpus_results(0, n)  # the one download of the shard's per-IR results (12 B per issue report)
     t_sweep = time.perf_counter() - t0
     tg = time.perf_counter()
     all_s, all_l = mvdist.all_gather_stats(best[:, 0], lab)
@@ -378,7 +391,8 @@ def corpus_shard_leg(eng, dims, B, S, rank, world, shard_irs):
     rates = mvdist.all_gather_rows(np.array([[n / t_sweep]], np.float32))[:, 0]  # every rank's own sweep rate, no collective in it
     total = int(len(all_s))
     return {"irs_per_rank": n, "irs_total": total, "value_corpus": round(total / elapsed, 2), "unit": "issue-reports/s",
-            "seconds": round(elapsed, 3), "allgather_ms": round(gather_ms, 3), "allgather_bytes_per_rank": int(n * 8),
+            "seconds": round(elapsed, 3), "sweep_ms": round(t_compute * 1e3, 2), "results_d2h_ms": round((t_sweep - t_compute) * 1e3, 3),
+            "allgather_ms": round(gather_ms, 3), "allgather_bytes_per_rank": int(n * 8),
             "fixed_overhead_frac": round(gather_ms * 1e-3 / elapsed, 5),
             "sum_of_rank_sweep_rates": round(float(rates.sum()), 2),
             "scaling_vs_sum_of_ranks": round(total / elapsed / float(rates.sum()), 4),

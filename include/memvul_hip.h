@@ -169,6 +169,13 @@ int mv_comm_unique_id(mv_handle* h, void* id_out, int capacity);
 int mv_comm_init(mv_handle* h, int rank, int world, const void* id, int id_bytes);
 int mv_comm_allgather(mv_handle* h, const void* send, void* recv, int64_t bytes_per_rank);
 int mv_comm_destroy(mv_handle* h);
+/* What the transport is, as RCCL reports it: info[0] = ranks of the live communicator (ncclCommCount; 0 = no communicator),
+ * info[1] = this rank in it (ncclCommUserRank), info[2] = RCCL version code (ncclGetVersion; 0 while librccl.so is not open),
+ * info[3] = the world mv_comm_allgather gathers over.  bench.py --gpus N records it in its line. */
+int mv_comm_info(mv_handle* h, int* info, int n);
+/* GPUs visible to this process (hipGetDeviceCount; 0 without one; <= 0 means none): lets a test or a launcher decide whether a
+ * two-rank RCCL run is possible here. */
+int mv_device_count(void);
 
 /* ---- measurement / test hooks ---------------------------------------------------------------- */
 

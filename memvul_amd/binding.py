@@ -51,7 +51,7 @@ ABI_SYMBOLS = [
     "mv_forward", "mv_encode", "mv_match", "mv_topk", "mv_corpus_upload", "mv_corpus_run", "mv_corpus_run_len",
     "mv_corpus_results", "mv_set_streams", "mv_profile_enable", "mv_profile_select", "mv_profile_read", "mv_kernel_class_name",
     "mv_debug_encode", "mv_debug_read", "mv_test_gemm", "mv_test_gemm_pp", "mv_test_e4m3", "mv_comm_prepare", "mv_comm_unique_id", "mv_comm_init", "mv_comm_allgather",
-    "mv_comm_destroy",
+    "mv_comm_destroy", "mv_comm_info", "mv_device_count",
 ]
 
 
@@ -120,6 +120,8 @@ def load_library(path: Optional[str] = None):
         "mv_comm_init": (C.c_int, [vp, C.c_int, C.c_int, vp, C.c_int]),
         "mv_comm_allgather": (C.c_int, [vp, vp, vp, C.c_int64]),
         "mv_comm_destroy": (C.c_int, [vp]),
+        "mv_comm_info": (C.c_int, [vp, P(C.c_int), C.c_int]),
+        "mv_device_count": (C.c_int, []),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)  # AttributeError if the .so does not export a declared symbol
@@ -333,6 +335,13 @@ class Engine:
         self._check(self._lib.mv_comm_destroy(self._h), "mv_comm_destroy")
         self.comm_rank, self.comm_world = 0, 1
 
+    def comm_info(self) -> Dict[str, int]:
+        """What RCCL itself says about the live communicator: its rank count (0 = none), this rank, the RCCL version code, and
+        the world mv_comm_allgather gathers over."""
+        info = (C.c_int * 4)()
+        self._check(self._lib.mv_comm_info(self._h, info, 4), "mv_comm_info")
+        return {"rccl_ranks": int(info[0]), "rccl_rank": int(info[1]), "rccl_version": int(info[2]), "world": int(info[3])}
+
     # -- measurement / debug
     def set_streams(self, n: int):
         """Batches of the resident sweep in flight at once (1 or 2)."""
@@ -387,9 +396,10 @@ class Engine:
                                            C.byref(ms)), "mv_test_gemm")
         return out, float(ms.value)
 
-    def test_gemm_pp(self, A: np.ndarray, W: np.ndarray, bias: np.ndarray, x8: bool = False, iters: int = 1):
+    def test_gemm_pp(self, A: np.ndarray, W: np.ndarray, bias: np.ndarray, x8=False, iters: int = 1):
         """The persistent FFN-1 kernel on fp32 operands (unit row statistics): fp16 gelu(A W^T + bias) [M][N]; x8: the MV_F16X8
-        build, also returning the [lo8 | hi8] e4m3 planes of the output as uint8 [M][2 N]."""
+        build (True / 1: both correction terms, 2: the weight-side term A_hi8 W_lo8 only, the QKV projection's form), also returning
+        the [lo8 | hi8] e4m3 planes of the output as uint8 [M][2 N]."""
         A, W, bias = _as(A, np.float32), _as(W, np.float32), _as(bias, np.float32)
         M, K = A.shape
         N = W.shape[0]
@@ -399,6 +409,11 @@ class Engine:
         self._check(self._lib.mv_test_gemm_pp(self._h, int(x8), M, N, K, _ptr(A), _ptr(W), _ptr(bias), _ptr(out), _ptr(out8), iters,
                                               C.byref(ms)), "mv_test_gemm_pp")
         return out, out8, float(ms.value)
+
+
+def device_count() -> int:
+    """GPUs visible to this process (0 without one)."""
+    return max(0, int(load_library().mv_device_count()))
 
 
 def e4m3_bits(x: np.ndarray) -> np.ndarray:

@@ -4,6 +4,7 @@ from __future__ import annotations
 import os
 import shutil
 import subprocess
+from struct import error as struct_error
 import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
@@ -71,11 +72,19 @@ def device_code_fingerprint(lib_path: str = None) -> str:
     found = 0
     i = data.find(magic)
     while i >= 0:
+        if i + 32 > len(data):
+            raise RuntimeError("truncated offload bundle header")
         (n,) = struct.unpack_from("<Q", data, i + 24)
         off = i + 32
+        if n > 64:  # a handful of targets at most: anything else is not a bundle header we understand (e.g. a compressed one)
+            raise RuntimeError(f"offload bundle with {n} entries: not a plain clang offload bundle")
         for _ in range(n):
+            if off + 24 > len(data):
+                raise RuntimeError("truncated offload bundle entry table")
             o, size, tsz = struct.unpack_from("<QQQ", data, off)
             off += 24
+            if tsz > 256 or off + tsz > len(data) or i + o + size > len(data):  # never trust offsets read from the file
+                raise RuntimeError("offload bundle entry points outside the file")
             triple = data[off:off + tsz]
             off += tsz
             if ARCH.encode() in triple:
@@ -121,9 +130,19 @@ def build(force: bool = False, verbose: bool = True, extra_flags=()) -> str:
     if verbose:
         print("[memvul_amd.build]", " ".join(cmd), flush=True)
     subprocess.run(cmd, check=True)
+    # the stamp describes the NEW binary and is written from it before either file is moved into place; a fatbin this parser does
+    # not understand (compressed bundle, no gfx950 entry) yields `dev unknown` — bench.load_pmc then compares whole stamps — instead
+    # of a successful compile left without a stamp (and rebuilt, and failing again, on every load)
+    try:
+        dev = device_code_fingerprint(LIB_PATH + ".tmp")
+    except (RuntimeError, OSError, ValueError, struct_error) as e:
+        dev = "unknown"
+        if verbose:
+            print(f"[memvul_amd.build] device-code fingerprint unavailable ({e}); stamp carries `dev unknown`", flush=True)
+    with open(STAMP_PATH + ".tmp", "w") as f:
+        f.write(build_fingerprint(extra_flags) + "\ndev " + dev + "\n")
     os.replace(LIB_PATH + ".tmp", LIB_PATH)
-    with open(STAMP_PATH, "w") as f:
-        f.write(build_fingerprint(extra_flags) + "\ndev " + device_code_fingerprint(LIB_PATH) + "\n")
+    os.replace(STAMP_PATH + ".tmp", STAMP_PATH)
     return LIB_PATH
 
 

@@ -24,20 +24,22 @@ typedef float floatx16 __attribute__((ext_vector_type(16)));
 // its hi8 / lo8 in range; larger values only lose the correction term of that element (graceful: fp16-level accuracy there).
 #define MV_X8_ACT_SHIFT 2
 typedef short shortx2_t __attribute__((ext_vector_type(2)));
-// four values -> one dword of e4m3(v / scale), each value clamped to +-bound (= 448 scale) first
-__device__ __forceinline__ uint32_t pack_fp8x4_scaled(float a, float b, float c, float d, float scale, float bound) {
-  a = __builtin_amdgcn_fmed3f(a, -bound, bound); b = __builtin_amdgcn_fmed3f(b, -bound, bound);
-  c = __builtin_amdgcn_fmed3f(c, -bound, bound); d = __builtin_amdgcn_fmed3f(d, -bound, bound);
+// four values (already inside the format's range after the scale) -> one dword of e4m3(v / scale)
+__device__ __forceinline__ uint32_t pack_fp8x4_scaled(float a, float b, float c, float d, float scale) {
   shortx2_t v = {0, 0};
   v = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(v, a, b, scale, false);
   v = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(v, c, d, scale, true);
   return __builtin_bit_cast(uint32_t, v);
 }
-// four consecutive values -> (hi8 dword, lo8 dword)
+// four consecutive values -> (hi8 dword, lo8 dword).  ONE clamp per value (to +-448 / 2^shift = +-112) serves both planes: the
+// rounding residual of a clamped value c is at most 2^-5 (c below 128), i.e. 2^8 after the lo plane's 2^(11 + shift) — inside
+// e4m3's range — and a clamped-away value (exactly +-112, representable) has residual 0: it loses its correction term, nothing else.
 __device__ __forceinline__ void x8_planes4(float v0, float v1, float v2, float v3, uint32_t& hi8, uint32_t& lo8) {
-  constexpr float SH = 1.0f / (float)(1 << MV_X8_ACT_SHIFT), SL = 1.0f / (float)(2048 << MV_X8_ACT_SHIFT);
-  hi8 = pack_fp8x4_scaled(v0, v1, v2, v3, SH, 448.f * SH);
-  lo8 = pack_fp8x4_scaled(v0 - (float)(half_t)v0, v1 - (float)(half_t)v1, v2 - (float)(half_t)v2, v3 - (float)(half_t)v3, SL, 448.f * SL);
+  constexpr float SH = 1.0f / (float)(1 << MV_X8_ACT_SHIFT), SL = 1.0f / (float)(2048 << MV_X8_ACT_SHIFT), BOUND = 448.f * SH;
+  v0 = __builtin_amdgcn_fmed3f(v0, -BOUND, BOUND); v1 = __builtin_amdgcn_fmed3f(v1, -BOUND, BOUND);
+  v2 = __builtin_amdgcn_fmed3f(v2, -BOUND, BOUND); v3 = __builtin_amdgcn_fmed3f(v3, -BOUND, BOUND);
+  hi8 = pack_fp8x4_scaled(v0, v1, v2, v3, SH);
+  lo8 = pack_fp8x4_scaled(v0 - (float)(half_t)v0, v1 - (float)(half_t)v1, v2 - (float)(half_t)v2, v3 - (float)(half_t)v3, SL);
 }
 
 // Sum / max over the 64 lanes of a wave (all lanes receive the result).

@@ -181,6 +181,10 @@ struct mv_handle {
 
   // last-layer pruning ([CLS] rows only after the last layer's K / V projection) and its compact buffers
   bool cls_prune = true;   // env MEMVUL_CLS_PRUNE=0 disables
+  int pp_gn_max = 4;       // raster group width cap of the persistent GEMM (env MEMVUL_GN_MAX: the A/B of profiles/r04_*)
+  int pp_raster = 0;       // env MEMVUL_RASTER=1: the A-stationary raster where it applies (FFN-1, QKV at full-size grids)
+  int qkv_x8_terms = 1;    // MV_F16X8: the QKV projection sweeps only the weight-side correction term (gemm_pp.h x8_terms); env
+                           // MEMVUL_QKV_X8_TERMS=2 restores both terms (the A/B switch of profiles/r04_*)
 
   // profiling
   uint32_t prof_mask = 0xffffffffu;  // kernel classes that get HIP events while profiling is on
@@ -205,6 +209,9 @@ struct mv_handle {
   decltype(&ncclAllGather) p_ncclAllGather = nullptr;
   decltype(&ncclCommDestroy) p_ncclCommDestroy = nullptr;
   decltype(&ncclGetErrorString) p_ncclGetErrorString = nullptr;
+  decltype(&ncclGetVersion) p_ncclGetVersion = nullptr;      // optional (mv_comm_info)
+  decltype(&ncclCommCount) p_ncclCommCount = nullptr;        // optional
+  decltype(&ncclCommUserRank) p_ncclCommUserRank = nullptr;  // optional
   void *comm_send = nullptr, *comm_recv = nullptr;
   int64_t comm_send_cap = 0, comm_recv_cap = 0;
 };
@@ -341,9 +348,11 @@ int launch_pp(mv_handle* h, int cls, GemmArgs a) {
     return fail(h, MV_ERR_INVALID, "gemm_pp: M,N % 256, K % 128, K >= 256, N <= 3072 required");  // K >= 256: the RAW kernels stage the
                                                                                               // next tile's statistics at K-tile 2
   if (!a.bias || !a.lnstats) return fail(h, MV_ERR_STATE, "internal: gemm_pp without bias / row statistics");
-  a.GN = choose_gn(a.N / 256, 4);  // widths 2 / 3 / 6 / 12 measured: 4 (or the largest divisor below it) is the fastest
+  a.GN = choose_gn(a.N / 256, h->pp_gn_max);  // widths 2 / 3 / 6 / 12 measured: 4 (or the largest divisor below it) is the fastest
   const int tiles = (a.M / 256) * (a.N / 256);
   const int grid = tiles < h->num_cu ? tiles : h->num_cu;
+  // the A-stationary raster (gemm_pp.h raster_pp; MEMVUL_RASTER=1): only where its windows tile the sequence exactly
+  a.raster_mode = (h->pp_raster == 1 && a.N / 256 > a.GN && ((a.M / 256) * a.GN) % grid == 0) ? 1 : 0;
   const int lds = RAW ? PP_LDS_BYTES_RAW : PP_LDS_BYTES;
   ProfScope ps(h, cls);
   if (a.A8) {
@@ -484,7 +493,7 @@ int encode_dev(mv_handle* h, const int32_t* d_ids, const int32_t* d_lens, int B,
       g.col0 = MV_HIDDEN;
       if (big) {
         g.lnstats = st_in;
-        if (x8) { g.A8 = h->w->x8; g.W8 = w.wqkv_f8 + (size_t)MV_HIDDEN * 2 * MV_HIDDEN; g.x8_scale = w.sc_qkv; }
+        if (x8) { g.A8 = h->w->x8; g.W8 = w.wqkv_f8 + (size_t)MV_HIDDEN * 2 * MV_HIDDEN; g.x8_scale = w.sc_qkv; g.x8_terms = h->qkv_x8_terms; }
         if (int rc = launch_pp<PP_QK>(h, KC_GEMM_KV_LAST, g)) return rc;
       } else if (int rc = launch_small<EPI_QKV>(h, KC_GEMM_KV_LAST, g)) return rc;
       ProfScope tail(h, KC_CLS_TAIL);
@@ -542,25 +551,25 @@ int encode_dev(mv_handle* h, const int32_t* d_ids, const int32_t* d_lens, int B,
     if (big) {
       // K2: Q, K, V^T projection of the raw stream (LayerNorm folded into W'' / b')
       g.A = h->w->x16; g.W = wqkv; g.bias = bqkv; g.N = 3 * MV_HIDDEN; g.K = MV_HIDDEN; g.lnstats = st_in;
-      if (x8) { g.A8 = h->w->x8; g.W8 = w.wqkv_f8; g.x8_scale = w.sc_qkv; }
+      if (x8) { g.A8 = h->w->x8; g.W8 = w.wqkv_f8; g.x8_scale = w.sc_qkv; g.x8_terms = h->qkv_x8_terms; }
       if (int rc = launch_pp<PP_QK>(h, KC_GEMM_QKV, g)) return rc;
       // K3: attention
       if (int rc = launch_attention(h, d_lens, B, Sp, x8)) return rc;
       // K4: attention output projection + bias + LayerNorm(residual), in place on the raw stream; + vstats of the new rows
       g.A = h->w->ctx; g.W = w.wo; g.bias = w.bo; g.N = MV_HIDDEN; g.K = MV_HIDDEN;
       g.lnstats = st_in; g.lng = pend_g; g.lnb = pend_b; g.lnpart = st_mid; g.out16 = h->w->x16; g.out16b = h->w->xlo;
-      if (x8) { g.A8 = h->w->ctx8; g.W8 = w.wo8; g.x8_scale = w.sc_o; g.out8 = h->w->x8; }
+      if (x8) { g.A8 = h->w->ctx8; g.W8 = w.wo8; g.x8_scale = w.sc_o; g.out8 = h->w->x8; g.x8_terms = 2; }
       if (int rc = launch_pp<PP_RESLN3>(h, KC_GEMM_OUT, g)) return rc;
       pend_g = w.ln1g; pend_b = w.ln1b;
       // K5: FFN-1 + exact-erf GELU
       g.A = h->w->x16; g.W = w.w1_f; g.bias = w.b1_f; g.N = MV_INTER; g.K = MV_HIDDEN; g.lnstats = st_mid; g.out16 = h->w->h16;
       g.out16b = nullptr; g.lnpart = nullptr;
-      if (x8) { g.A8 = h->w->x8; g.W8 = w.w1_f8; g.x8_scale = w.sc_1; g.out8 = h->w->h8; }
+      if (x8) { g.A8 = h->w->x8; g.W8 = w.w1_f8; g.x8_scale = w.sc_1; g.out8 = h->w->h8; g.x8_terms = 2; }
       if (int rc = launch_pp<PP_GELU>(h, KC_GEMM_FFN1, g)) return rc;
       // K6: FFN-2 + bias + LayerNorm(residual)
       g.A = h->w->h16; g.W = w.w2; g.bias = w.b2; g.N = MV_HIDDEN; g.K = MV_INTER;
       g.lnstats = st_mid; g.lng = pend_g; g.lnb = pend_b; g.lnpart = st_in; g.out16 = h->w->x16; g.out16b = h->w->xlo;
-      if (x8) { g.A8 = h->w->h8; g.W8 = w.w28; g.x8_scale = w.sc_2; g.out8 = h->w->x8; }
+      if (x8) { g.A8 = h->w->h8; g.W8 = w.w28; g.x8_scale = w.sc_2; g.out8 = h->w->x8; g.x8_terms = 2; }
       if (int rc = launch_pp<PP_RESLN3>(h, KC_GEMM_FFN2, g)) return rc;
       pend_g = w.ln2g; pend_b = w.ln2b;
       if (last) { if (int rc = final_ln(w.ln2g, w.ln2b)) return rc; }  // the pooler reads a normalised stream
@@ -833,6 +842,9 @@ int mv_create(int device, const mv_config* cfg, mv_handle** out) try {
   (void)hipGetLastError();
   if (const char* e = getenv("MEMVUL_GEMM_TILE")) h->gemm_tile = atoi(e);
   if (const char* e = getenv("MEMVUL_CLS_PRUNE")) h->cls_prune = atoi(e) != 0;
+  if (const char* e = getenv("MEMVUL_QKV_X8_TERMS")) h->qkv_x8_terms = atoi(e) == 2 ? 2 : 1;
+  if (const char* e = getenv("MEMVUL_GN_MAX")) { const int v = atoi(e); if (v >= 1 && v <= 12) h->pp_gn_max = v; }
+  if (const char* e = getenv("MEMVUL_RASTER")) h->pp_raster = atoi(e) == 1 ? 1 : 0;
   {
     int ncu = 0;
     if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && ncu > 0) h->num_cu = ncu;
@@ -1335,6 +1347,9 @@ int mv_comm_prepare(mv_handle* h) try {
   RCCL_SYM(ncclCommDestroy);
   RCCL_SYM(ncclGetErrorString);
 #undef RCCL_SYM
+  h->p_ncclGetVersion = (decltype(&ncclGetVersion))dlsym(h->rccl_lib, "ncclGetVersion");
+  h->p_ncclCommCount = (decltype(&ncclCommCount))dlsym(h->rccl_lib, "ncclCommCount");
+  h->p_ncclCommUserRank = (decltype(&ncclCommUserRank))dlsym(h->rccl_lib, "ncclCommUserRank");
   return MV_OK;
 } catch (...) { return on_exception(h); }
 
@@ -1353,9 +1368,9 @@ int mv_comm_unique_id(mv_handle* h, void* id_out, int capacity) try {
 int mv_comm_init(mv_handle* h, int rank, int world, const void* id, int id_bytes) try {
   if (!h || world < 1 || rank < 0 || rank >= world) return fail(h, MV_ERR_INVALID, "mv_comm_init: bad rank / world");
   if (h->comm) return fail(h, MV_ERR_STATE, "mv_comm_init: communicator already initialised");
-  h->comm_rank = rank;
-  h->comm_world = world;
-  if (world == 1 && !id) return MV_OK;  // no transport needed (with an id: a real 1-rank communicator, the GPU-box test)
+  // rank / world are recorded only once the init has SUCCEEDED: a failed init leaves the handle in its one-rank state (the
+  // gather is then a copy) instead of a world without a communicator
+  if (world == 1 && !id) { h->comm_rank = 0; h->comm_world = 1; return MV_OK; }  // no transport needed (with an id: a real 1-rank communicator, the GPU-box test)
   if (!id || id_bytes != (int)sizeof(ncclUniqueId)) return fail(h, MV_ERR_INVALID, "mv_comm_init: the 128-byte unique id of rank 0 (mv_comm_unique_id) is required");
   if (int rc = mv_comm_prepare(h)) return rc;
   HIPCHK(h, hipSetDevice(h->device));
@@ -1363,8 +1378,33 @@ int mv_comm_init(mv_handle* h, int rank, int world, const void* id, int id_bytes
   std::memcpy(&uid, id, sizeof(uid));
   ncclResult_t r = h->p_ncclCommInitRank(&h->comm, world, uid, rank);
   if (r != ncclSuccess) { h->comm = nullptr; return fail(h, MV_ERR_HIP, std::string("ncclCommInitRank: ") + h->p_ncclGetErrorString(r)); }
+  h->comm_rank = rank;
+  h->comm_world = world;
   return MV_OK;
 } catch (...) { return on_exception(h); }
+
+// What the transport IS, as RCCL itself reports it: info[0] = ranks of the live communicator by ncclCommCount (0: no
+// communicator — one rank, or the run is on another transport), info[1] = this rank in it by ncclCommUserRank, info[2] = the
+// RCCL version code of ncclGetVersion (0 while librccl.so is not open), info[3] = the world mv_comm_allgather will gather over.
+int mv_comm_info(mv_handle* h, int* info, int n) try {
+  if (!h || !info || n < 4) return fail(h, MV_ERR_INVALID, "mv_comm_info: int[4] required");
+  info[0] = info[1] = info[2] = 0;
+  info[3] = h->comm_world;
+  if (h->rccl_lib && h->p_ncclGetVersion) { int v = 0; if (h->p_ncclGetVersion(&v) == ncclSuccess) info[2] = v; }
+  if (h->comm) {
+    int c = -1, r = -1;
+    if (h->p_ncclCommCount && h->p_ncclCommCount(h->comm, &c) == ncclSuccess) info[0] = c;
+    if (h->p_ncclCommUserRank && h->p_ncclCommUserRank(h->comm, &r) == ncclSuccess) info[1] = r;
+  }
+  return MV_OK;
+} catch (...) { return on_exception(h); }
+
+// GPUs visible to this process (hipGetDeviceCount): 0 on a box without one (a HIP error there is "none", not a failure).
+int mv_device_count(void) try {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; }
+  return n;
+} catch (...) { return on_exception(nullptr); }
 
 int mv_comm_allgather(mv_handle* h, const void* send, void* recv, int64_t bytes_per_rank) try {
   if (!h || !send || !recv || bytes_per_rank <= 0) return fail(h, MV_ERR_INVALID, "mv_comm_allgather: bad argument");
@@ -1528,6 +1568,7 @@ int mv_test_gemm_pp(mv_handle* h, int x8, int M, int N, int K, const float* A, c
   if (!h || !A || !W || !bias || !out16 || M <= 0 || N <= 0 || K <= 0) return fail(h, MV_ERR_INVALID, "mv_test_gemm_pp: bad argument");
   if (M % 256 || N % 256 || K % 128 || K < 256 || N > MV_INTER)
     return fail(h, MV_ERR_INVALID, "mv_test_gemm_pp: M,N % 256, K % 128, K >= 256, N <= 3072 required");
+  if (x8 == 2 && K % 256) return fail(h, MV_ERR_INVALID, "mv_test_gemm_pp: the weight-side-only sweep walks K / 128 K-tiles in pairs: K % 256 required");
   HIPCHK(h, hipSetDevice(h->device));
   std::vector<uint16_t> a16((size_t)M * K), w16((size_t)N * K);
   for (size_t i = 0; i < a16.size(); ++i) a16[i] = f32_to_f16_bits(A[i]);
@@ -1569,6 +1610,7 @@ int mv_test_gemm_pp(mv_handle* h, int x8, int M, int N, int K, const float* A, c
     HIPCHK(h, hipMemcpyAsync(dA8, a8.data(), a8.size(), hipMemcpyHostToDevice, h->w->stream));
     HIPCHK(h, hipMemcpyAsync(dW8, w8.data(), w8.size(), hipMemcpyHostToDevice, h->w->stream));
     g.A8 = dA8; g.W8 = dW8; g.out8 = dO8; g.x8_scale = scale_word;
+    g.x8_terms = (x8 == 2) ? 1 : 2;  // x8 = 2: the weight-side term only (the QKV projection's form)
   }
   if (iters < 1) iters = 1;
   hipEvent_t e0, e1;

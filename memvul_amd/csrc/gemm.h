@@ -55,6 +55,9 @@ struct GemmArgs {
   const uint8_t* W8;     // [N][2 K]:    row = [hi8 | lo8] of W, pre-scaled by 2^sw / 2^(11 + sw)
   uint8_t* out8;         // PP_GELU / PP_RESLN3: [M][2 N] = [lo8 | hi8] planes of this GEMM's output (the next GEMM's A8)
   int x8_scale;          // E8M0 byte of 2^-(11 + sa + sw), replicated in the four bytes (the other scale operand is 1.0)
+  int x8_terms;          // 0 / 2: both first-order terms; 1: only A_hi8 W_lo8 (the second halves of the rows: K bytes, K / 128 K-tiles)
+  int raster_mode;       // gemm_pp: 0 = column group > tile_m > tile_n; 1 = "A-stationary": consecutive persistent iterations of a workgroup
+                         // keep its tile_m and walk the column groups (the XCD's A panels stay in its L2 across the whole N sweep)
 };
 
 // logical tile index -> (tile_m, tile_n) under the grouped raster

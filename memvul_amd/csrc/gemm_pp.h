@@ -46,7 +46,7 @@
 // plus the rows' "vstats": per row and 256-column tile the (sum, sum of squares); every consumer turns the three pairs of a
 // row into (mean, rstd) itself (common.h ln_from_partials).
 //
-// X8 = 1 (compute dtype MV_F16X8, "precise"): every GEMM adds a SECOND sweep on the fp8 matrix path into the same fp32
+// X8 = 1 (compute dtype MV_F16X8, "precise"): every GEMM adds a SECOND sweep (x8_terms = 1: its weight-side half only) on the fp8 matrix path into the same fp32
 // accumulators:  A W ~= A_hi W_hi + 2^-s (A_lo8 W_hi8 + A_hi8 W_lo8),  A_hi = fp16(A), A_lo8 = e4m3((A - A_hi) 2^(11 + sa)),
 // A_hi8 = e4m3(A_hi 2^sa), W likewise with its own shift sw, s = 11 + sa + sw — the first-order correction terms of the
 // split-operand product, which only need ~4 significant bits, as ONE v_mfma_scale_f32_16x16x128_f8f6f4 sweep (OCP e4m3, uniform
@@ -180,6 +180,24 @@ __device__ __forceinline__ void lds_read_bgb1(uint32_t addr, float4& bi, float4&
 #endif
 }
 
+// logical tile L of a persistent grid of G workgroups -> (tile_m, tile_n).  Mode 0: the grouped raster of gemm.h (all tile_m of a
+// column group, then the next group: an A panel is fetched once per group).  Mode 1 (host: only when tm_count * GN % G == 0): window
+// w = L / G of the sequence is (block b = w / ngroups of G consecutive (tile_m, tile_n-in-group) positions, column group g = w % ngroups),
+// so a workgroup — and with the XCD remap a whole XCD's contiguous run of 32 positions — meets the SAME tile_m in ngroups consecutive
+// iterations: its A panels can stay in that XCD's L2 across the whole N sweep while the W panels of the groups pass through.
+__device__ __forceinline__ void raster_pp(const GemmArgs& a, int L, int G, int tm_count, int tn_count, int& tile_m, int& tile_n) {
+  if (a.raster_mode == 1) {
+    const int ngroups = tn_count / a.GN;
+    const int w = L / G, r = L - w * G;
+    const int b = w / ngroups, g = w - b * ngroups;
+    const int p = b * G + r;
+    tile_m = p / a.GN;
+    tile_n = g * a.GN + (p - tile_m * a.GN);
+  } else {
+    raster(L, tm_count, tn_count, a.GN, tile_m, tile_n);
+  }
+}
+
 template <int EPI, int RAW = 0, int X8 = 0>
 __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmArgs a) {
   static_assert(EPI == PP_QK || EPI == PP_GELU || EPI == PP_RESLN3, "kernel kinds of the encoder layer");
@@ -194,8 +212,14 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmArgs a) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wave >> 2, wc = wave & 3;
   const int K = a.K, nk0 = K >> 6;                 // K-tiles of one sweep
-  constexpr int nseg = X8 ? 2 : 1;                  // X8: the fp16 sweep, then the fp8 correction sweep (same K-tile count)
-  const int nk = nk0 * nseg;                        // K-tiles per output tile
+  constexpr int nseg = X8 ? 2 : 1;                  // X8: the fp16 sweep, then the fp8 correction sweep
+  // K-tiles of the fp8 sweep: K / 64 for both first-order terms (virtual K = 2 K), K / 128 when only the weight-side term
+  // A_hi8 W_lo8 is swept (a.x8_terms == 1: the SECOND halves of both operand rows, byte offset K) — the QKV projection, whose
+  // A-side term is below the resolution of the fp16 Q / K / V it writes (oracle/precision_model.py: dropping it moves the
+  // trained-like logit error 3.4e-4 -> 2.7e-4, i.e. nowhere)
+  const int nk8 = X8 ? (a.x8_terms == 1 ? nk0 >> 1 : nk0) : 0;
+  const size_t off8 = (X8 && a.x8_terms == 1) ? (size_t)K : 0;
+  const int nk = nk0 + nk8;                         // K-tiles per output tile
   const int tm_count = a.M >> 8, tn_count = a.N >> 8;
   const int ntiles = tm_count * tn_count;
   const int G = gridDim.x;
@@ -228,14 +252,14 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmArgs a) {
   const char* iW = (const char*)a.W;
   size_t tA = 0, tW = 0;  // X8: byte offsets of the issue tile's operand panels (the fp8 panels have the same row pitch, 2 K bytes)
   auto set_issue_seg = [&]() {  // X8, sweep 0: A_hi W_hi (fp16), 1: [A_lo8 | A_hi8] x [W_hi8 | W_lo8] (fp8)
-    iA = (i_seg ? (const char*)a.A8 : (const char*)a.A) + tA;
-    iW = (i_seg ? (const char*)a.W8 : (const char*)a.W) + tW;
+    iA = (i_seg ? (const char*)a.A8 + off8 : (const char*)a.A) + tA;
+    iW = (i_seg ? (const char*)a.W8 + off8 : (const char*)a.W) + tW;
   };
   auto set_issue_tile = [&](int it) {
     const int L = it * G + bslot;
     if (L < ntiles) {  // past the end: keep staging the last valid tile (never read, keeps the vmcnt ledger exact)
       int tm, tn;
-      raster(L, tm_count, tn_count, a.GN, tm, tn);
+      raster_pp(a, L, G, tm_count, tn_count, tm, tn);
       if constexpr (X8) {
         tA = (size_t)tm * 256 * K * 2;
         tW = (size_t)tn * 256 * K * 2;
@@ -265,7 +289,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmArgs a) {
       glds16((const half_t*)(src + offB[1]), dst + 1024);
     }
     if constexpr (kind == 1) {  // last half-tile of this K-tile: advance the cursor
-      if (++i_kt == nk0) {
+      if (++i_kt == ((X8 && i_seg) ? nk8 : nk0)) {
         i_kt = 0;
         if constexpr (X8) {
           if (++i_seg == nseg) {
@@ -454,7 +478,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmArgs a) {
   };
   if constexpr (RAW) {
     int tm = 0, tn = 0;
-    if (bslot < ntiles) raster(bslot, tm_count, tn_count, a.GN, tm, tn);
+    if (bslot < ntiles) raster_pp(a, bslot, G, tm_count, tn_count, tm, tn);
     issue_stats(0, tm, tn);
   }
 
@@ -476,10 +500,10 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmArgs a) {
     const int L = it * G + bslot;
     if (L >= ntiles) break;
     int tile_m, tile_n;
-    raster(L, tm_count, tn_count, a.GN, tile_m, tile_n);
+    raster_pp(a, L, G, tm_count, tn_count, tile_m, tile_n);
     int next_m = 0, next_n = 0;  // RAW: the workgroup's next tile (issue_stats); PP_RESLN3: its residual tile is requested
     const bool has_next = L + G < ntiles;  // during this tile's epilogue
-    if (has_next) raster(L + G, tm_count, tn_count, a.GN, next_m, next_n);
+    if (has_next) raster_pp(a, L + G, G, tm_count, tn_count, next_m, next_n);
     const int mw = (tile_m << 8) + wr * 128;  // first token row of this wave
     const int nw = (tile_n << 8) + wc * 64;   // first output column of this wave
 

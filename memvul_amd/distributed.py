@@ -17,7 +17,8 @@ Transport (``init_transport``), torch-free:
    ``mv_comm_init`` and reports the outcome — only when ALL ranks succeeded does the run use RCCL bound inside
    libmemvul_hip.so (collective on the engine's stream, over xGMI); otherwise ALL ranks use the hub itself as the
    transport.  No rank decides alone, there is no id file in a shared temp directory and no single-node assumption.
-   (A rank that dies INSIDE the collective ncclCommInitRank still strands the others until RCCL's own timeout.)
+   (A rank that dies INSIDE the collective ncclCommInitRank strands the others until RCCL's own timeout; the hub sockets
+   themselves never block longer than HUB_IO_TIMEOUT_S, so a hung peer ends in a RuntimeError on every rank, not in a hang.)
 3. ``shutdown()`` tears the transport down; a later ``init_transport`` starts from scratch.
 
 The data path has no collective, only 8 B per issue report of statistics cross ranks, so a run on the hub is still a
@@ -33,6 +34,9 @@ from typing import Optional, Tuple
 import numpy as np
 
 RENDEZVOUS_TIMEOUT_S = 180.0
+# no hub socket ever blocks for ever: a peer that hangs without closing its socket (or a rank stranded inside a collective
+# ncclCommInitRank that another rank failed out of) surfaces as a RuntimeError on every waiting rank after this long
+HUB_IO_TIMEOUT_S = float(os.environ.get("MEMVUL_HUB_TIMEOUT_S", "900"))
 
 
 def shard_range(n: int, rank: int, world: int) -> Tuple[int, int]:
@@ -88,10 +92,10 @@ class _Hub:
                     r = int.from_bytes(hello[:4], "little")
                     if hello[4:] != token or not (0 < r < world) or r in by_rank:
                         raise ConnectionError("bad handshake")
-                except (OSError, ConnectionError):
-                    c.close()  # not one of this run's ranks: drop it and keep listening
+                except (OSError, ConnectionError, RuntimeError):
+                    c.close()  # not one of this run's ranks (or silent): drop it and keep listening
                     continue
-                c.settimeout(None)
+                c.settimeout(HUB_IO_TIMEOUT_S)
                 c.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
                 by_rank[r] = c
             srv.close()
@@ -106,16 +110,21 @@ class _Hub:
                     if time.time() - t0 > timeout_s:
                         raise RuntimeError(f"rendezvous: rank 0 not reachable at {addr}:{port} within {timeout_s:.0f} s")
                     time.sleep(0.05)
-            c.settimeout(None)
+            c.settimeout(HUB_IO_TIMEOUT_S)
             c.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
             c.sendall(int(rank).to_bytes(4, "little") + token)
             self.sock = c
 
     @staticmethod
     def _recvn(c, n: int) -> bytes:
+        import socket
+
         buf = bytearray()
         while len(buf) < n:
-            part = c.recv(min(1 << 20, n - len(buf)))
+            try:
+                part = c.recv(min(1 << 20, n - len(buf)))
+            except socket.timeout:
+                raise RuntimeError(f"rendezvous hub: a peer stayed silent for {HUB_IO_TIMEOUT_S:.0f} s (hung rank?) — giving up instead of waiting for ever")
             if not part:
                 raise ConnectionError("peer closed the rendezvous socket")
             buf += part
@@ -230,8 +239,10 @@ def _agree_on_transport(hub, engine, rank: int, world: int, prefer: str, addr: s
                     _comm = engine
                     _comm_note = "rccl (bound in libmemvul_hip.so, engine stream; unique id over the rendezvous socket)"
                     return _comm_note
-                if ok:
+                try:  # EVERY rank leaves the attempt behind (a rank whose own init failed too: its handle goes back to one rank)
                     engine.comm_destroy()
+                except RuntimeError:
+                    pass
                 why = "ncclCommInitRank failed on a rank" + (f" (here: {err[:100]})" if err else "")
     _comm = hub
     _comm_note = f"tcp hub on {addr}:{port} ({why or 'fallback'})"

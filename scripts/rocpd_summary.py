@@ -2,7 +2,7 @@
 
     python scripts/rocpd_summary.py stats <results.db>          # == --kernel-trace --stats summary
     python scripts/rocpd_summary.py pmc <results.db> [<results.db> ...]   # per-kernel mean counter values
-    python scripts/rocpd_summary.py json <lib stamp file> <results.db> [...]   # the GEMM classes' counter figures as
+    python scripts/rocpd_summary.py json <lib stamp file> [--mode f16|precise] [--into old.json] <results.db> [...]   # the GEMM classes' counter figures as
                                                                               # profiles/pmc_current.json (bench.py load_pmc)
 """
 import sqlite3
@@ -102,13 +102,15 @@ def pmc(dbs):
         print(line)
 
 
-# kernel symbol (+ duration class for the residual GEMM, which serves two shapes) -> bench.py kernel class
-CLASS_OF = (("gemm_pp_kernel<1, 1, 0>", None, "gemm_qkv"), ("gemm_pp_kernel<3, 1, 0>", None, "gemm_ffn1_gelu"),
-            ("gemm_pp_kernel<8, 0, 0>", "long", "gemm_ffn2"), ("gemm_pp_kernel<8, 0, 0>", "short", "gemm_attn_out"),
-            ("attention_v2_kernel<4, 1, 0>", None, "attention"))
+# kernel symbol (+ duration class for the residual GEMM, which serves two shapes) -> bench.py kernel class; X = 0 (MV_F16) / 1 (MV_F16X8)
+def class_of(mode):
+    x = "1" if mode == "precise" else "0"
+    return ((f"gemm_pp_kernel<1, 1, {x}>", None, "gemm_qkv"), (f"gemm_pp_kernel<3, 1, {x}>", None, "gemm_ffn1_gelu"),
+            (f"gemm_pp_kernel<8, 0, {x}>", "long", "gemm_ffn2"), (f"gemm_pp_kernel<8, 0, {x}>", "short", "gemm_attn_out"),
+            (f"attention_v2_kernel<4, 1, {x}>", None, "attention"), (f"attention_v2_kernel<2, 4, {x}>", None, "attention"))
 
 
-def pmc_json(stamp_file, dbs):
+def pmc_json(stamp_file, dbs, mode="f16", into=None):
     """Mean per-dispatch counters of the encoder's kernel classes at the default bench workload -> JSON with the stamp of the
     library that was profiled: traffic_bytes = 2 x FETCH_SIZE + WRITE_SIZE (KiB -> bytes; the gfx950 FETCH correction of
     MI355X_MICROARCH.md), mfma_busy_frac = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8), effective clock =
@@ -123,7 +125,7 @@ def pmc_json(stamp_file, dbs):
     for name, gx, cname, val, d in rows:
         by_sym[name].append(d)
     out = {}
-    for sym, dclass, cls in CLASS_OF:
+    for sym, dclass, cls in class_of(mode):
         names = [n for n in by_sym if sym in n]
         if not names:
             continue
@@ -154,14 +156,31 @@ def pmc_json(stamp_file, dbs):
             if "SQ_VALU_MFMA_BUSY_CYCLES" in mean:
                 rec["mfma_busy_frac"] = round(mean["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024 * cyc), 4)
         out[cls] = rec
-    print(json.dumps({"lib_stamp": open(stamp_file).read().strip(), "workload": "bench.py default (S=256, B=256, G=124, 12 layers, MV_F16), one batch in flight",
-                      "source": "rocprofv3 --kernel-trace --pmc, one counter group per pass (scripts/gpu_pmc.sh)", "classes": out}, indent=1))
+    stamp = open(stamp_file).read().strip()
+    doc = {"lib_stamp": stamp, "workload": "bench.py default (S=256, B=256, G=124, 12 layers), one batch in flight; one entry per compute dtype profiled",
+           "source": "rocprofv3 --kernel-trace --pmc, one counter group per pass (scripts/gpu_pmc.sh)", "classes_by_mode": {}}
+    if into:
+        try:
+            old = json.load(open(into))
+            if old.get("lib_stamp") == stamp:  # same binary: add this mode's pass to the record
+                doc["classes_by_mode"] = old.get("classes_by_mode", {})
+        except (OSError, ValueError):
+            pass
+    doc["classes_by_mode"][mode] = out
+    print(json.dumps(doc, indent=1))
 
 
 if __name__ == "__main__":
     if sys.argv[1] == "stats":
         stats(sys.argv[2])
-    elif sys.argv[1] == "json":
-        pmc_json(sys.argv[2], sys.argv[3:])
+    elif sys.argv[1] == "json":  # json <stamp> [--mode f16|precise] [--into existing.json] <dbs...>
+        args, mode, into = sys.argv[3:], "f16", None
+        while args and args[0].startswith("--"):
+            if args[0] == "--mode":
+                mode = args[1]
+            elif args[0] == "--into":
+                into = args[1]
+            args = args[2:]
+        pmc_json(sys.argv[2], args, mode, into)
     else:
         pmc(sys.argv[2:])

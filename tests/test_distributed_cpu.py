@@ -197,8 +197,12 @@ def test_bench_two_ranks_control_flow_and_json_contract(tmp_path):
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config"):
         assert k in d, k
     assert d["n_gpus"] == 2 and d["steps"] == 6 and d["warmup"] == 2 and d["scaling"] == "weak" and d["higher_is_better"] is True
-    assert d["value"] == pytest.approx(2 * 6 * 32 / (d["ms_per_step"] * 6e-3), rel=1e-3)   # whole-job aggregate over both ranks
+    # the stand-in engine never yields a `value`: null, no roofline / kernels; its rate sits under a name of its own
+    assert d["value"] is None and "roofline" not in d and "kernels" not in d and d["e2e_mfma_frac"] is None
+    assert d["stub_rate_not_a_measurement"] == pytest.approx(2 * 6 * 32 / (d["ms_per_step"] * 6e-3), rel=1e-3)   # whole-job aggregate over both ranks
     assert d["data"] == "stub" and "NO GPU" in d["config"]["note"]
+    assert d["config"]["comm_world"] == 2 and d["config"]["rccl_ranks"] == 0 and d["config"]["compute"] == "precise"
+    assert "sweep_ms" in d["corpus_shard"] and "results_d2h_ms" in d["corpus_shard"]
     assert d["config"]["stats_transport"].startswith("tcp hub") and d["config"]["global_batch"] == 64
     assert d["stats_table_sum"] == 2 * 8 * 32 * 40       # both ranks' (score, label) rows reached rank 0: 40 thresholds x rows
     sh = d["corpus_shard"]

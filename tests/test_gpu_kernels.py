@@ -86,6 +86,34 @@ def test_persistent_gemm_fp16_and_fp8_correction_sweep(gu, shape):
     assert (ex <= lo8_res + 2.5e-4 * scale).all(), float(ex.max())      # ... which is ~2^-15.5 operands
     assert ex.max() < 0.5 * max(e16.max(), 1e-4 * scale)                # several times below the fp16 build on the same data
     assert np.abs(hi8 - out_x.astype(np.float64)).max() <= np.abs(out_x.astype(np.float64)).max() * 2.0 ** -4 + 2.0 ** -11
+    # x8_terms = 1 (the QKV projection's form since round 4): the fp8 sweep covers only the weight-side term A_hi8 W_lo8 — the second
+    # halves of both operand rows, K / 128 K-tiles.  Against the SAME product formed on the CPU: agreement at the fp32-accumulation
+    # level; a wrong half / K-tile count / byte offset shows up as the fp16 build's error or as garbage.
+    if K % 256 == 0:
+        out_w, _, ms_w = eng.test_gemm_pp(A, W, bias, x8=2)
+        emul_w = _gelu64(pm._mm("f16x8w", "f16x8", A.astype(np.float64), W.astype(np.float64)) + bias)
+        ew = np.abs(out_w.astype(np.float64) - emul_w) - (np.abs(emul_w) * 2.0 ** -11 + 2.0 ** -25)
+        both = _gelu64(pm._mm("f16x8", "f16x8", A.astype(np.float64), W.astype(np.float64)) + bias)
+        gu.record("gemm_pp_wside", M=M, N=N, K=K, vs_cpu_emulation=float(ew.max()), wside_vs_both=float(np.abs(emul_w - both).max()), ms=ms_w, ms_both=ms8)
+        assert ew.max() <= 3e-5 * scale, float(ew.max())
+
+
+def test_a_stationary_raster_gives_identical_bits(gu):
+    """MEMVUL_RASTER=1 / MEMVUL_GN_MAX (the raster A/B switches of round 4): which workgroup computes a tile, and when, must not
+    change a single bit of it — the FFN-1 kernel at a shape where the A-stationary raster applies (tm_count * GN % grid == 0)."""
+    M, N, K = 16384, 3072, 768
+    rng = np.random.default_rng(99)
+    A = rng.standard_normal((M, K)).astype(np.float32)
+    W = (rng.standard_normal((N, K)) * 0.04).astype(np.float32)
+    bias = (rng.standard_normal(N) * 0.1).astype(np.float32)
+    base, _, _ = gu.engine_for(L2, WK).test_gemm_pp(A, W, bias, x8=False)
+    base8, planes8, _ = gu.engine_for(L2, WK).test_gemm_pp(A, W, bias, x8=True)
+    for env in ({"MEMVUL_RASTER": "1"}, {"MEMVUL_GN_MAX": "12"}, {"MEMVUL_RASTER": "1", "MEMVUL_GN_MAX": "6"}):
+        eng = gu.engine_for(L2, WK, env=env)
+        out, _, _ = eng.test_gemm_pp(A, W, bias, x8=False)
+        assert np.array_equal(out.view(np.uint16), base.view(np.uint16)), env
+        out8, p8, _ = eng.test_gemm_pp(A, W, bias, x8=True)
+        assert np.array_equal(out8.view(np.uint16), base8.view(np.uint16)) and np.array_equal(p8, planes8), env
 
 
 def _taps(gu, B, S, ragged):
