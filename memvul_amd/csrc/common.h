@@ -42,6 +42,13 @@ __device__ __forceinline__ void x8_planes4(float v0, float v1, float v2, float v
   lo8 = pack_fp8x4_scaled(v0 - (float)(half_t)v0, v1 - (float)(half_t)v1, v2 - (float)(half_t)v2, v3 - (float)(half_t)v3, SL);
 }
 
+// the hi8 plane alone (a consumer that sweeps only the weight-side term never reads lo8)
+__device__ __forceinline__ uint32_t x8_hi4(float v0, float v1, float v2, float v3) {
+  constexpr float SH = 1.0f / (float)(1 << MV_X8_ACT_SHIFT), BOUND = 448.f * SH;
+  return pack_fp8x4_scaled(__builtin_amdgcn_fmed3f(v0, -BOUND, BOUND), __builtin_amdgcn_fmed3f(v1, -BOUND, BOUND),
+                           __builtin_amdgcn_fmed3f(v2, -BOUND, BOUND), __builtin_amdgcn_fmed3f(v3, -BOUND, BOUND), SH);
+}
+
 // Sum / max over the 64 lanes of a wave (all lanes receive the result).
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

@@ -183,8 +183,9 @@ struct mv_handle {
   bool cls_prune = true;   // env MEMVUL_CLS_PRUNE=0 disables
   int pp_gn_max = 4;       // raster group width cap of the persistent GEMM (env MEMVUL_GN_MAX: the A/B of profiles/r04_*)
   int pp_raster = 0;       // env MEMVUL_RASTER=1: the A-stationary raster where it applies (FFN-1, QKV at full-size grids)
-  int qkv_x8_terms = 1;    // MV_F16X8: the QKV projection sweeps only the weight-side correction term (gemm_pp.h x8_terms); env
-                           // MEMVUL_QKV_X8_TERMS=2 restores both terms (the A/B switch of profiles/r04_*)
+  int qkv_aside_mask = 1;  // MV_F16X8: which of the Q / K / V blocks of the QKV projection sweep the A-side correction term too (bit 0 / 1 / 2;
+                           // gemm_pp.h x8_aside_mask).  Default: Q only.  env MEMVUL_QKV_ASIDE = a subset of "qkv" ("" / "none" = weight-side
+                           // term only everywhere, "qkv" = round 3's form): the A/B switch of profiles/r04_d_*
 
   // profiling
   uint32_t prof_mask = 0xffffffffu;  // kernel classes that get HIP events while profiling is on
@@ -493,7 +494,7 @@ int encode_dev(mv_handle* h, const int32_t* d_ids, const int32_t* d_lens, int B,
       g.col0 = MV_HIDDEN;
       if (big) {
         g.lnstats = st_in;
-        if (x8) { g.A8 = h->w->x8; g.W8 = w.wqkv_f8 + (size_t)MV_HIDDEN * 2 * MV_HIDDEN; g.x8_scale = w.sc_qkv; g.x8_terms = h->qkv_x8_terms; }
+        if (x8) { g.A8 = h->w->x8; g.W8 = w.wqkv_f8 + (size_t)MV_HIDDEN * 2 * MV_HIDDEN; g.x8_scale = w.sc_qkv; g.x8_terms = 3; g.x8_aside_mask = h->qkv_aside_mask; }
         if (int rc = launch_pp<PP_QK>(h, KC_GEMM_KV_LAST, g)) return rc;
       } else if (int rc = launch_small<EPI_QKV>(h, KC_GEMM_KV_LAST, g)) return rc;
       ProfScope tail(h, KC_CLS_TAIL);
@@ -551,25 +552,25 @@ int encode_dev(mv_handle* h, const int32_t* d_ids, const int32_t* d_lens, int B,
     if (big) {
       // K2: Q, K, V^T projection of the raw stream (LayerNorm folded into W'' / b')
       g.A = h->w->x16; g.W = wqkv; g.bias = bqkv; g.N = 3 * MV_HIDDEN; g.K = MV_HIDDEN; g.lnstats = st_in;
-      if (x8) { g.A8 = h->w->x8; g.W8 = w.wqkv_f8; g.x8_scale = w.sc_qkv; g.x8_terms = h->qkv_x8_terms; }
+      if (x8) { g.A8 = h->w->x8; g.W8 = w.wqkv_f8; g.x8_scale = w.sc_qkv; g.x8_terms = 3; g.x8_aside_mask = h->qkv_aside_mask; }
       if (int rc = launch_pp<PP_QK>(h, KC_GEMM_QKV, g)) return rc;
       // K3: attention
       if (int rc = launch_attention(h, d_lens, B, Sp, x8)) return rc;
       // K4: attention output projection + bias + LayerNorm(residual), in place on the raw stream; + vstats of the new rows
       g.A = h->w->ctx; g.W = w.wo; g.bias = w.bo; g.N = MV_HIDDEN; g.K = MV_HIDDEN;
       g.lnstats = st_in; g.lng = pend_g; g.lnb = pend_b; g.lnpart = st_mid; g.out16 = h->w->x16; g.out16b = h->w->xlo;
-      if (x8) { g.A8 = h->w->ctx8; g.W8 = w.wo8; g.x8_scale = w.sc_o; g.out8 = h->w->x8; g.x8_terms = 2; }
+      if (x8) { g.A8 = h->w->ctx8; g.W8 = w.wo8; g.x8_scale = w.sc_o; g.out8 = h->w->x8; g.x8_terms = 2; g.out8_hi_only = 0; }
       if (int rc = launch_pp<PP_RESLN3>(h, KC_GEMM_OUT, g)) return rc;
       pend_g = w.ln1g; pend_b = w.ln1b;
       // K5: FFN-1 + exact-erf GELU
       g.A = h->w->x16; g.W = w.w1_f; g.bias = w.b1_f; g.N = MV_INTER; g.K = MV_HIDDEN; g.lnstats = st_mid; g.out16 = h->w->h16;
       g.out16b = nullptr; g.lnpart = nullptr;
-      if (x8) { g.A8 = h->w->x8; g.W8 = w.w1_f8; g.x8_scale = w.sc_1; g.out8 = h->w->h8; g.x8_terms = 2; }
+      if (x8) { g.A8 = h->w->x8; g.W8 = w.w1_f8; g.x8_scale = w.sc_1; g.out8 = h->w->h8; g.x8_terms = 2; g.out8_hi_only = 0; }
       if (int rc = launch_pp<PP_GELU>(h, KC_GEMM_FFN1, g)) return rc;
       // K6: FFN-2 + bias + LayerNorm(residual)
       g.A = h->w->h16; g.W = w.w2; g.bias = w.b2; g.N = MV_HIDDEN; g.K = MV_INTER;
       g.lnstats = st_mid; g.lng = pend_g; g.lnb = pend_b; g.lnpart = st_in; g.out16 = h->w->x16; g.out16b = h->w->xlo;
-      if (x8) { g.A8 = h->w->h8; g.W8 = w.w28; g.x8_scale = w.sc_2; g.out8 = h->w->x8; g.x8_terms = 2; }
+      if (x8) { g.A8 = h->w->h8; g.W8 = w.w28; g.x8_scale = w.sc_2; g.out8 = h->w->x8; g.x8_terms = 2; g.out8_hi_only = h->qkv_aside_mask == 0; }
       if (int rc = launch_pp<PP_RESLN3>(h, KC_GEMM_FFN2, g)) return rc;
       pend_g = w.ln2g; pend_b = w.ln2b;
       if (last) { if (int rc = final_ln(w.ln2g, w.ln2b)) return rc; }  // the pooler reads a normalised stream
@@ -842,7 +843,11 @@ int mv_create(int device, const mv_config* cfg, mv_handle** out) try {
   (void)hipGetLastError();
   if (const char* e = getenv("MEMVUL_GEMM_TILE")) h->gemm_tile = atoi(e);
   if (const char* e = getenv("MEMVUL_CLS_PRUNE")) h->cls_prune = atoi(e) != 0;
-  if (const char* e = getenv("MEMVUL_QKV_X8_TERMS")) h->qkv_x8_terms = atoi(e) == 2 ? 2 : 1;
+  if (const char* e = getenv("MEMVUL_QKV_ASIDE")) {
+    h->qkv_aside_mask = 0;
+    for (const char* c = e; *c; ++c) h->qkv_aside_mask |= (*c == 'q' || *c == 'Q') ? 1 : (*c == 'k' || *c == 'K') ? 2 : (*c == 'v' || *c == 'V') ? 4 : 0;
+    if (!strcmp(e, "none")) h->qkv_aside_mask = 0;
+  }
   if (const char* e = getenv("MEMVUL_GN_MAX")) { const int v = atoi(e); if (v >= 1 && v <= 12) h->pp_gn_max = v; }
   if (const char* e = getenv("MEMVUL_RASTER")) h->pp_raster = atoi(e) == 1 ? 1 : 0;
   {

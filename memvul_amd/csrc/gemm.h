@@ -55,7 +55,10 @@ struct GemmArgs {
   const uint8_t* W8;     // [N][2 K]:    row = [hi8 | lo8] of W, pre-scaled by 2^sw / 2^(11 + sw)
   uint8_t* out8;         // PP_GELU / PP_RESLN3: [M][2 N] = [lo8 | hi8] planes of this GEMM's output (the next GEMM's A8)
   int x8_scale;          // E8M0 byte of 2^-(11 + sa + sw), replicated in the four bytes (the other scale operand is 1.0)
-  int x8_terms;          // 0 / 2: both first-order terms; 1: only A_hi8 W_lo8 (the second halves of the rows: K bytes, K / 128 K-tiles)
+  int x8_terms;          // 0 / 2: both first-order terms; 1: only A_hi8 W_lo8 (the second halves of the rows: K bytes, K / 128 K-tiles);
+                         // 3 (PP_QK): per Q / K / V block by x8_aside_mask
+  int x8_aside_mask;     // x8_terms == 3: bit 0 / 1 / 2 set = the Q / K / V block sweeps both terms, clear = the weight-side term only
+  int out8_hi_only;      // PP_RESLN3 X8: write only the hi8 plane of out8 (the consumer sweeps the weight-side term only: FFN-2 -> next QKV)
   int raster_mode;       // gemm_pp: 0 = column group > tile_m > tile_n; 1 = "A-stationary": consecutive persistent iterations of a workgroup
                          // keep its tile_m and walk the column groups (the XCD's A panels stay in its L2 across the whole N sweep)
 };

@@ -128,6 +128,18 @@ __device__ __forceinline__ void scr_f8x2(uint32_t w0, uint32_t w1, uint32_t w2, 
       : "memory");
 #endif
 }
+// ONE fp8 plane of the block (the first half of scr_f8x2): o[0] = rows lane >> 2, o[1] = rows + 16
+__device__ __forceinline__ void scr_f8x1(uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3, const uint32_t (&da)[8], uint32_t r, u32x4 (&o)[4]) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm volatile(
+      "ds_write_b32 %2, %6\n\tds_write_b32 %3, %7\n\tds_write_b32 %4, %8\n\tds_write_b32 %5, %9\n\t"
+      "ds_write_b32 %2, %10 offset:1024\n\tds_write_b32 %3, %11 offset:1024\n\tds_write_b32 %4, %12 offset:1024\n\tds_write_b32 %5, %13 offset:1024\n\t"
+      "ds_read_b128 %0, %14\n\tds_read_b128 %1, %14 offset:1024\n\ts_waitcnt lgkmcnt(0)"
+      : "=&v"(o[0]), "=&v"(o[1])
+      : "v"(w0), "v"(w1), "v"(w2), "v"(w3), "v"(da[0]), "v"(da[1]), "v"(da[2]), "v"(da[3]), "v"(da[4]), "v"(da[5]), "v"(da[6]), "v"(da[7]), "v"(r)
+      : "memory");
+#endif
+}
 // The V block of a merged Q,K,V launch in the 16x16 C/D layout (lane = token 16 tbl + m16, registers = 4 consecutive head dims
 // 16 cbl + 4 q4 + e of unit k = 2 tbl + cbl) through the image TRANSPOSED - image rows = head dims, image columns = tokens: 16 two-byte
 // writes per fragment at t0 (tbl = 0) / t1 (tbl = 1) + 1024 cbl + 64 e (t = q4 * 256 + swizzled token chunk + 2 (m16 & 7)).
@@ -213,13 +225,21 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmArgs a) {
   const int wr = wave >> 2, wc = wave & 3;
   const int K = a.K, nk0 = K >> 6;                 // K-tiles of one sweep
   constexpr int nseg = X8 ? 2 : 1;                  // X8: the fp16 sweep, then the fp8 correction sweep
-  // K-tiles of the fp8 sweep: K / 64 for both first-order terms (virtual K = 2 K), K / 128 when only the weight-side term
-  // A_hi8 W_lo8 is swept (a.x8_terms == 1: the SECOND halves of both operand rows, byte offset K) — the QKV projection, whose
-  // A-side term is below the resolution of the fp16 Q / K / V it writes (oracle/precision_model.py: dropping it moves the
-  // trained-like logit error 3.4e-4 -> 2.7e-4, i.e. nowhere)
-  const int nk8 = X8 ? (a.x8_terms == 1 ? nk0 >> 1 : nk0) : 0;
-  const size_t off8 = (X8 && a.x8_terms == 1) ? (size_t)K : 0;
-  const int nk = nk0 + nk8;                         // K-tiles per output tile
+  // K-tiles of the fp8 sweep of a tile: K / 64 for both first-order terms (virtual K = 2 K), K / 128 when only the weight-side term
+  // A_hi8 W_lo8 is swept (the SECOND halves of both operand rows, byte offset K).  a.x8_terms: 0 / 2 = both terms everywhere,
+  // 1 = weight-side only, 3 = per Q / K / V block of a PP_QK launch by a.x8_aside_mask (bit `which` set = both terms).  The QKV
+  // projection sweeps the A-side term for ONE of its three blocks only (Q): the A-operand rounding is common to Q, K and V, and
+  // restoring it in one of them already brings the trained-like logit error back to the three-block level — measured on the MI355X
+  // over the goldens l12_trained_s256 / _ragged and the reference's own 12-layer run (profiles/r04_d_qkv_aside_errors.txt), max:
+  // all three 3.8e-4, Q only 4.2e-4, K only 4.7e-4, V only 4.4e-4, none 8.1e-4; oracle/precision_model.py predicts the same on the
+  // first case (7.6e-4 / 2.9e-4 / 3.8e-4 for none / Q / all).  QKV launch 388 -> 335 us (310 with none), +2.9 % issue reports/s.
+  auto both_terms = [&](int tn) -> bool {
+    if (a.x8_terms != 3) return a.x8_terms != 1;
+    const int which = (tn * 256 + a.col0) / MV_HIDDEN;  // 0 = Q, 1 = K, 2 = V
+    return (a.x8_aside_mask >> which) & 1;
+  };
+  int i_nk8 = X8 ? nk0 : 0;    // of the tile being STAGED (issue cursor)
+  size_t i_off8 = 0;
   const int tm_count = a.M >> 8, tn_count = a.N >> 8;
   const int ntiles = tm_count * tn_count;
   const int G = gridDim.x;
@@ -252,8 +272,8 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmArgs a) {
   const char* iW = (const char*)a.W;
   size_t tA = 0, tW = 0;  // X8: byte offsets of the issue tile's operand panels (the fp8 panels have the same row pitch, 2 K bytes)
   auto set_issue_seg = [&]() {  // X8, sweep 0: A_hi W_hi (fp16), 1: [A_lo8 | A_hi8] x [W_hi8 | W_lo8] (fp8)
-    iA = (i_seg ? (const char*)a.A8 + off8 : (const char*)a.A) + tA;
-    iW = (i_seg ? (const char*)a.W8 + off8 : (const char*)a.W) + tW;
+    iA = (i_seg ? (const char*)a.A8 + i_off8 : (const char*)a.A) + tA;
+    iW = (i_seg ? (const char*)a.W8 + i_off8 : (const char*)a.W) + tW;
   };
   auto set_issue_tile = [&](int it) {
     const int L = it * G + bslot;
@@ -263,6 +283,9 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmArgs a) {
       if constexpr (X8) {
         tA = (size_t)tm * 256 * K * 2;
         tW = (size_t)tn * 256 * K * 2;
+        const bool both = both_terms(tn);
+        i_nk8 = both ? nk0 : nk0 >> 1;
+        i_off8 = both ? 0 : (size_t)K;
       } else {
         iA = (const char*)a.A + (size_t)tm * 256 * K * 2;
         iW = (const char*)a.W + (size_t)tn * 256 * K * 2;
@@ -289,7 +312,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmArgs a) {
       glds16((const half_t*)(src + offB[1]), dst + 1024);
     }
     if constexpr (kind == 1) {  // last half-tile of this K-tile: advance the cursor
-      if (++i_kt == ((X8 && i_seg) ? nk8 : nk0)) {
+      if (++i_kt == ((X8 && i_seg) ? i_nk8 : nk0)) {
         i_kt = 0;
         if constexpr (X8) {
           if (++i_seg == nseg) {
@@ -609,6 +632,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmArgs a) {
       two_ktiles(std::false_type{}, !X8 && kt + 2 >= nk0);
     }
     if constexpr (X8) {  // the correction sweep: the same intervals on the fp8 matrix path
+      const int nk = nk0 + (both_terms(tile_n) ? nk0 : nk0 >> 1);  // K-tiles of THIS output tile
       for (int kt = nk0; kt < nk; kt += 2) two_ktiles(std::true_type{}, kt + 2 >= nk);
     }
 
@@ -791,22 +815,37 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmArgs a) {
             // MV_F16X8: the [lo8 | hi8] planes of this output (the A8 operand of the next GEMM's correction sweep): rows of
             // 2 N bytes, lo8 of column n at byte n, hi8 at byte N + n; one 16-B store per lane, plane and 16-row half
             uint32_t dl[8], dh[8];  // [4 tbl + 2 j + cbl]: the dword of token 16 tbl + m16, columns 32 j + 16 cbl + 4 q4 .. + 3
-#pragma unroll
-            for (int tbl = 0; tbl < 2; ++tbl)
-#pragma unroll
-              for (int j = 0; j < 2; ++j)
-#pragma unroll
-                for (int cbl = 0; cbl < 2; ++cbl) {
-                  const int tb = 2 * i + tbl, cb = 2 * j + cbl;
-                  x8_planes4(acc[tb][cb][0], acc[tb][cb][1], acc[tb][cb][2], acc[tb][cb][3], dh[4 * tbl + 2 * j + cbl], dl[4 * tbl + 2 * j + cbl]);
-                }
             const uint32_t w8 = ub8 + (sf << 4);
-            scr_f8x2(w8, w8 ^ 16u, w8 ^ 32u, w8 ^ 48u, dl, dh, scr_c, o);
             uint8_t* o8 = a.out8 + (size_t)(mb + crow) * (2 * a.N) + nw + 16 * cchunk;
-            *(u32x4*)o8 = o[0];
-            *(u32x4*)(o8 + (size_t)16 * (2 * a.N)) = o[1];
-            *(u32x4*)(o8 + a.N) = o[2];
-            *(u32x4*)(o8 + a.N + (size_t)16 * (2 * a.N)) = o[3];
+            if (IS_RES && a.out8_hi_only) {  // FFN-2 -> the next layer's QKV projection, which sweeps A_hi8 W_lo8 only: no lo8 plane
+#pragma unroll
+              for (int tbl = 0; tbl < 2; ++tbl)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                  for (int cbl = 0; cbl < 2; ++cbl) {
+                    const int tb = 2 * i + tbl, cb = 2 * j + cbl;
+                    dh[4 * tbl + 2 * j + cbl] = x8_hi4(acc[tb][cb][0], acc[tb][cb][1], acc[tb][cb][2], acc[tb][cb][3]);
+                  }
+              scr_f8x1(w8, w8 ^ 16u, w8 ^ 32u, w8 ^ 48u, dh, scr_c, o);
+              *(u32x4*)(o8 + a.N) = o[0];
+              *(u32x4*)(o8 + a.N + (size_t)16 * (2 * a.N)) = o[1];
+            } else {
+#pragma unroll
+              for (int tbl = 0; tbl < 2; ++tbl)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                  for (int cbl = 0; cbl < 2; ++cbl) {
+                    const int tb = 2 * i + tbl, cb = 2 * j + cbl;
+                    x8_planes4(acc[tb][cb][0], acc[tb][cb][1], acc[tb][cb][2], acc[tb][cb][3], dh[4 * tbl + 2 * j + cbl], dl[4 * tbl + 2 * j + cbl]);
+                  }
+              scr_f8x2(w8, w8 ^ 16u, w8 ^ 32u, w8 ^ 48u, dl, dh, scr_c, o);
+              *(u32x4*)o8 = o[0];
+              *(u32x4*)(o8 + (size_t)16 * (2 * a.N)) = o[1];
+              *(u32x4*)(o8 + a.N) = o[2];
+              *(u32x4*)(o8 + a.N + (size_t)16 * (2 * a.N)) = o[3];
+            }
           }
           if constexpr (IS_RES) {  // block row i is out: request block row i of the NEXT tile's residual into its registers
             if (has_next) park_residual(i, (next_m << 8) + wr * 128, (next_n << 8) + wc * 64);

@@ -12,7 +12,8 @@ rounding function at exactly the tensors the engine rounds:
   ``h``                      GELU output (A operand of FFN-2)
 
 Each knob is a per-layer list of formats: ``"f16"``, ``"f16x2"`` (hi + lo split, 22 bits), ``"bf16"``, ``"bf16x2"``,
-``"bf16x3"``, ``"exact"``, ``"f16x8"`` (the MV_F16X8 planes; as an A-operand format ``"f16x8w"`` = only the weight-side term swept).  ``logit_error_table`` prints what each rounding point costs on the match logits, so a
+``"bf16x3"``, ``"exact"``, ``"f16x8"`` (the MV_F16X8 planes; as an A-operand format ``"f16x8w"`` = only the weight-side term swept,
+``"f16x8q"`` / ``k`` / ``v`` = the A-side term only in that block of the packed QKV projection).  ``logit_error_table`` prints what each rounding point costs on the match logits, so a
 precision change to the engine is chosen by measurement before any kernel is touched (tests/test_precision_model.py).
 Everything else (LayerNorm statistics, softmax, residual adds, pooler, header, matcher) is fp32/fp64-exact here, as
 in the engine (fp32).
@@ -70,12 +71,18 @@ def _w_shift(w):
 def _mm(afmt, wfmt, A, W):
     """A @ W^T as the engine forms it.  Both operands "f16x8" (MV_F16X8): ONE fp16 sweep + two fp8 (e4m3) correction sweeps
     into the same fp32 accumulators,  A_hi W_hi + A_lo8 W_hi8 + A_hi8 W_lo8;  otherwise each operand is rounded on its own."""
-    if afmt in ("f16x8", "f16x8w") and wfmt == "f16x8":
+    if afmt in ("f16x8", "f16x8w", "f16x8q", "f16x8k", "f16x8v") and wfmt == "f16x8":
         ah, ah8, al8 = _x8_planes(A, X8_ACT_SHIFT)
         wh, wh8, wl8 = _x8_planes(W, _w_shift(W))
-        if afmt == "f16x8w":  # the weight-side term only (gemm_pp.h x8_terms = 1: the QKV projection since round 4)
-            return ah @ wh.T + ah8 @ wl8.T
-        return ah @ wh.T + al8 @ wh8.T + ah8 @ wl8.T
+        out = ah @ wh.T + ah8 @ wl8.T
+        if afmt == "f16x8w":  # the weight-side term only (gemm_pp.h x8_terms = 1)
+            return out
+        if afmt != "f16x8":   # packed QKV weight [3 H][K]: the A-side term only in the Q / K / V block (gemm_pp.h x8_aside_mask)
+            Hb = W.shape[0] // 3
+            b = "qkv".index(afmt[-1])
+            out[..., b * Hb:(b + 1) * Hb] += al8 @ wh8[b * Hb:(b + 1) * Hb].T
+            return out
+        return out + al8 @ wh8.T
     return FORMATS[afmt](A) @ FORMATS[wfmt](W).T
 
 
@@ -99,11 +106,12 @@ FORMATS = {
     # one-sided use of the MV_F16X8 planes (the other operand in another format): hi + the de-scaled fp8 lo plane
     "f16x8": lambda x: (lambda p: p[0] + p[2])(_x8_planes(x, X8_ACT_SHIFT)),
     "f16x8w": _f16,  # an A operand whose own correction term is not swept: plain fp16 when paired with a non-x8 weight format
+    "f16x8q": _f16, "f16x8k": _f16, "f16x8v": _f16,
 }
 
 # the knobs of the SHIPPED MV_F16X8 engine (round 4): every GEMM sweeps both first-order terms except the QKV projection, which
-# sweeps the weight-side term only
-X8_ENGINE = dict(w_qkv="f16x8", w_o="f16x8", w_1="f16x8", w_2="f16x8", a_qkv="f16x8w", a_ffn1="f16x8", ctx="f16x8", h="f16x8")
+# sweeps the A-side term in its Q block only (the weight-side term everywhere)
+X8_ENGINE = dict(w_qkv="f16x8", w_o="f16x8", w_1="f16x8", w_2="f16x8", a_qkv="f16x8q", a_ffn1="f16x8", ctx="f16x8", h="f16x8")
 
 KNOBS = ("w_qkv", "w_o", "w_1", "w_2", "a_qkv", "a_ffn1", "qkv", "p", "ctx", "h")
 
