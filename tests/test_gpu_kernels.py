@@ -169,7 +169,7 @@ def test_layer0_stages(gu, B, S, ragged, gemm_tile, compute):
     scale_q = float(np.abs(taps["l0_q"]).max())
     assert errs["q"] < 3e-3 * max(1.0, scale_q), errs
     assert errs["k"] < 3e-3 * max(1.0, float(np.abs(taps["l0_k"]).max())), errs
-    # bounds = ~1.5x the largest error measured over all nine shapes and both GEMM paths (profiles/r04_c_parity_records.jsonl:
+    # bounds = ~1.5x the largest error measured over all nine shapes and both GEMM paths (profiles/r04_f_parity_records.jsonl:
     # v 1.5e-3, ctx 6.8e-3 (MV_F16) / 4.0e-3 (precise), gelu 1.6e-3, layer0 1.6e-3): a regression of a few fp16 ulps in one stage shows here
     assert errs["v"] < 2.5e-3, errs
     assert errs["ctx"] < (6e-3 if compute == "precise" else 9e-3), errs  # peaked attention (qk_scale=4): fp16 rounding of P and V
@@ -190,7 +190,7 @@ def test_attention_persistent_item_loop(gu, B, S, compute):
     ctx = eng.debug_read(5)[:, :S].astype(np.float32)
     err = float(np.abs(ctx - taps["l0_ctx"])[mask].max())
     gu.record("attention_items", B=B, S=S, compute=compute, max_err=err)
-    assert err < (8e-3 if compute == "precise" else 1.2e-2)  # measured 5.4e-3 / 9.4e-3 (profiles/r04_c_parity_records.jsonl)
+    assert err < (8e-3 if compute == "precise" else 1.2e-2)  # measured 5.4e-3 / 9.4e-3 (profiles/r04_f_parity_records.jsonl)
 
 
 def test_match_and_topk_vs_oracle(gu):
