@@ -14,6 +14,36 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 
 def patch(src, mode):
     s = src
+    if mode == "halfbar":  # every other barrier (and counted wait) of the fp8 sweep removed: is the sweep bound by its per-interval synchronisation?
+        old = '''    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WAITN) : "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+  };'''
+        new = '''    if constexpr (!(X8 && decltype(f8c)::value && (s & 1) == 0)) {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WAITN) : "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    }
+  };'''
+        assert old in s
+        return s.replace(old, new)
+    if mode == "nobar8":  # NO barrier / wait in the fp8 sweep at all (timing only)
+        old = '''    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WAITN) : "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+  };'''
+        new = '''    if constexpr (!(X8 && decltype(f8c)::value)) {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WAITN) : "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    }
+  };'''
+        assert old in s
+        return s.replace(old, new)
     if mode == "nocorr":
         s = s.replace("constexpr int nseg = X8 ? 2 : 1;", "constexpr int nseg = 1;")
         s = s.replace("two_ktiles(std::false_type{}, !X8 && kt + 2 >= nk0);", "two_ktiles(std::false_type{}, kt + 2 >= nk0);")
@@ -41,7 +71,7 @@ def patch(src, mode):
 
 def main():
     src = open(os.path.join(ROOT, "memvul_amd/csrc/gemm_pp.h")).read()
-    for mode in ("half", "half6", "nocorr"):
+    for mode in (sys.argv[1:] or ("half", "half6", "nocorr")):
         d = os.path.join(HERE, "x_" + mode)
         shutil.rmtree(d, ignore_errors=True)
         shutil.copytree(os.path.join(ROOT, "memvul_amd/csrc"), os.path.join(d, "x/csrc"))
