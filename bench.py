@@ -177,6 +177,8 @@ def main():
         comm_info = eng.comm_info() if hasattr(eng, "comm_info") else {}
         if transport.startswith("rccl") and comm_info.get("rccl_ranks") != world:
             raise SystemExit(f"transport says RCCL but ncclCommCount reports {comm_info.get('rccl_ranks')} ranks for WORLD_SIZE={world}")
+        if mvdist.transport_world() != world:
+            raise SystemExit(f"the agreed transport spans {mvdist.transport_world()} ranks for WORLD_SIZE={world}")
 
     # anchor memory: G synthetic CWE descriptions of up to 512 tokens, built once per process (untimed;
     # predict_memory.py:81-83 forwards them in chunks of 128)
@@ -280,7 +282,7 @@ def main():
                    "compute": mode,
                    "global_batch": world * B, "seq_len": S, "anchors": G, "parallelism": "dp%d (corpus shards, one "
                    "all-gather of (score,label) stats)" % world, "stats_transport": transport,
-                   **({"comm_world": comm_info.get("rccl_ranks") or comm_info.get("world", world), "rccl_ranks": comm_info.get("rccl_ranks", 0),
+                   **({"comm_world": mvdist.transport_world(), "rccl_ranks": comm_info.get("rccl_ranks", 0),
                        "rccl_version": comm_info.get("rccl_version", 0)} if multi else {})},
         # executed FLOPs (with last-layer [CLS] pruning the fraction is priced on what runs)
         "e2e_tflops_per_gpu": round(value / world * fpi_exec / 1e12, 2),

@@ -264,6 +264,11 @@ def shutdown():
             _comm, _comm_note = None, "none"
 
 
+def transport_world() -> int:
+    """Ranks of the ACTIVE transport (RCCL communicator or hub) — what all_gather_stats gathers over; 0 before init_transport."""
+    return _world()
+
+
 def _world() -> int:
     return getattr(_comm, "comm_world", 1) if _comm is not None else 0
 
