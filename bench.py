@@ -132,11 +132,15 @@ def main():
     ap.add_argument("--matcher-anchors", type=int, default=1000, help="N = 1: anchors of the fused match + top-k measurement (configs[4]; 0 disables)")
     args = ap.parse_args()
 
+    # `--gpus N` is a promise about the line's `n_gpus`: under a launcher WORLD_SIZE must say N too; WITHOUT a launcher this
+    # process becomes the launcher of N ranks (self_launch) — it never runs one rank and reports it as N, or N as one
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        raise SystemExit(self_launch(args.gpus))
     rank, local_rank, world = mvdist.env_world()
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: refusing to run (the line's n_gpus would not be what was asked for)")
     if args.cpu_sample > 0 and world == 1:
         import torch  # noqa: F401  (the CPU baseline leg only; loaded BEFORE the engine: see tests/test_gpu_parity.py)
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     multi = world > 1
     # development check of the N > 1 control flow on a ONE-GPU box (not a measurement): every rank shares device 0 and the
     # exchange runs over the rendezvous hub instead of RCCL (one GPU cannot host two RCCL ranks); the JSON line says so
@@ -283,7 +287,9 @@ def main():
                    "global_batch": world * B, "seq_len": S, "anchors": G, "parallelism": "dp%d (corpus shards, one "
                    "all-gather of (score,label) stats)" % world, "stats_transport": transport,
                    **({"comm_world": mvdist.transport_world(), "rccl_ranks": comm_info.get("rccl_ranks", 0),
-                       "rccl_version": comm_info.get("rccl_version", 0)} if multi else {})},
+                       "rccl_version": comm_info.get("rccl_version", 0),
+                       "launcher": "bench.py self_launch (no WORLD_SIZE in the environment)" if os.environ.get("MEMVUL_SELF_LAUNCHED") else "external (WORLD_SIZE set)"}
+                      if multi else {})},
         # executed FLOPs (with last-layer [CLS] pruning the fraction is priced on what runs)
         "e2e_tflops_per_gpu": round(value / world * fpi_exec / 1e12, 2),
         "e2e_mfma_frac": round(value / world * fpi_exec / 1e12 / MFMA_PEAK_TFLOPS, 4),
@@ -332,7 +338,7 @@ def main():
         out["ragged"] = ragged_leg(eng, dims, B, S, rank)
     if world == 1 and args.matcher_anchors > 0:
         out["matcher"] = matcher_leg(eng, args.matcher_anchors, B)
-    if args.cpu_sample > 0 and world == 1:
+    if args.cpu_sample > 0 and world == 1 and not stub:
         out["cpu_baseline"], out["logit_max_abs_err_vs_cpu"], out["anchor_max_abs_err_vs_cpu"] = cpu_baseline(
             weights, dims, eng, ids, lens, S, args.cpu_sample, aids, alens)
     if contract is not None:
@@ -348,6 +354,65 @@ def main():
         out["fast" if other == "f16" else "precise"] = second_mode_leg(args, other, dims, weights, aids, alens, ids, lens, contract)
     print(json.dumps(out), flush=True)
     mvdist.shutdown()
+
+
+def visible_gpus() -> int:
+    """GPUs this process could open (mv_device_count of the loaded library; the stand-in engine has as many as it is asked for)."""
+    if os.environ.get("MEMVUL_BENCH_STUB_ENGINE"):
+        return 1 << 30
+    from memvul_amd.binding import device_count
+
+    return device_count()
+
+
+def self_launch(n: int) -> int:
+    """`python bench.py --gpus N` with no launcher in the environment: spawn the N ranks ourselves — one process per GPU, the
+    same command line, RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT / MEMVUL_RUN_TOKEN as `torch.distributed.run`
+    would set them (rendezvous on 127.0.0.1) — and return the job's exit code: 0 only if EVERY rank exited 0 (rank 0 prints the
+    one JSON line on this process's stdout; the other ranks' stdout goes to stderr).  Fewer than N visible GPUs: a message and a
+    non-zero code, nothing is run (MEMVUL_BENCH_ONE_GPU_SMOKE, the shared-GPU control-flow check, is the one exception).
+    One failed rank ends the others (by their PIDs) instead of leaving them in the rendezvous."""
+    import secrets
+    import socket
+    import subprocess
+
+    have = visible_gpus()
+    if have < n and not os.environ.get("MEMVUL_BENCH_ONE_GPU_SMOKE"):
+        print(f"bench.py: --gpus {n} but only {have} GPU(s) visible to this process: not running "
+              f"(a {have}-GPU line must be asked for with --gpus {max(have, 1)})", file=sys.stderr)
+        return 2
+    with socket.socket() as s:  # a free port pair (the hub listens on port + 1)
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    if port > 65000:
+        port -= 2000
+    env0 = dict(os.environ, WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), MEMVUL_SELF_LAUNCHED="1")
+    env0.setdefault("MEMVUL_RUN_TOKEN", secrets.token_hex(16))
+    env0.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    procs = []
+    for r in range(n):
+        env = dict(env0, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else sys.stderr))
+    rc, live = 0, set(range(n))
+    try:
+        while live:
+            for r in sorted(live):
+                c = procs[r].poll()
+                if c is None:
+                    continue
+                live.discard(r)
+                if c != 0 and rc == 0:
+                    rc = c if c > 0 else 1
+                    print(f"bench.py: rank {r} of {n} exited with code {c}: ending the other ranks", file=sys.stderr)
+                    for o in live:
+                        procs[o].terminate()
+            time.sleep(0.05)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    return rc
 
 
 def sustained_leg(eng, step, B, seconds):

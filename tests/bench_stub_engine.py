@@ -7,6 +7,10 @@ import numpy as np
 
 class Engine:
     def __init__(self, device=0, **kw):
+        import os
+
+        if os.environ.get("MEMVUL_BENCH_STUB_FAIL_RANK") == os.environ.get("RANK", "0"):
+            raise RuntimeError("stand-in engine: this rank was told to fail (MEMVUL_BENCH_STUB_FAIL_RANK)")
         self.device = device
         self.G = 0
         self.ids = None
@@ -43,6 +47,11 @@ class Engine:
     def corpus_results(self, first, count, with_probs=False):
         return self.best[first:first + count].copy(), self.idx[first:first + count].copy(), None
 
+    def topk(self, u, k):
+        self.n_topk = getattr(self, "n_topk", 0) + 1
+        u = np.asarray(u)
+        return np.zeros((len(u), k), np.float32), np.zeros((len(u), k), np.int32)
+
     def sync(self):
         pass
 
@@ -54,7 +63,9 @@ class Engine:
 
     def profile_read(self):
         n, self.n_launch = self.n_launch, 0
-        return {k: (0.3 * n, 11 * n) for k in ("gemm_qkv", "gemm_attn_out", "gemm_ffn1_gelu", "gemm_ffn2")} | {"attention": (0.1 * n, 11 * n)}
+        t, self.n_topk = getattr(self, "n_topk", 0), 0
+        return {k: (0.3 * n, 11 * n) for k in ("gemm_qkv", "gemm_attn_out", "gemm_ffn1_gelu", "gemm_ffn2")} | {
+            "attention": (0.1 * n, 11 * n), "match": (0.03 * t, t), "topk": (0.005 * t, t)}
 
     def close(self):
         pass
