@@ -47,6 +47,7 @@ else:
 
 MFMA_PEAK_TFLOPS = 2500.0  # MI355X dense fp16/bf16 MFMA peak (MI355X_MICROARCH.md)
 LOGIT_TOL = 1e-3           # BASELINE.json north_star: logits within 1e-3 of the reference CPU path
+AUTO_MARGIN = 0.5          # --compute auto hands `value` to MV_F16 only if its measured trained-like error is <= AUTO_MARGIN * LOGIT_TOL
 MODE_DTYPE = {"f16": "fp16 (MV_F16: fp16 MFMA operands, fp32 accumulate)",
               "precise": "fp16 + fp8 (MV_F16X8: fp16 MFMA sweep + one OCP-e4m3 MFMA correction sweep per GEMM, fp32 accumulate)"}
 H, I, P = 768, 3072, 512
@@ -164,7 +165,9 @@ def main():
     if world == 1 and args.cpu_sample > 0 and not stub:
         contract = trained_like_errors(dims, S)
         if args.compute == "auto":
-            mode = "f16" if contract["logit_max_abs_err_trained_like"]["f16"] <= LOGIT_TOL else "precise"
+            # the sample is small (16 IRs x 8 anchors: a max over 128 logit pairs moves +-40 % with the draw), so the fast mode only
+            # takes the headline with a 2x margin to the tolerance — `value` cannot flip meaning between runs on a borderline reading
+            mode = "f16" if contract["logit_max_abs_err_trained_like"]["f16"] <= AUTO_MARGIN * LOGIT_TOL else "precise"
     eng = Engine(local_rank, vocab_size=dims.vocab_size, layers=dims.layers, max_tokens=max(B * S, 128 * 512),
                  max_batch=max(B, 256), max_anchors=max(G, 1024))
     eng.load_state_dict(weights, mode)
@@ -345,7 +348,9 @@ def main():
         errs = contract["logit_max_abs_err_trained_like"]
         out["logit_max_abs_err_trained_like"] = errs[mode]
         out["contract"] = {"logit_tol": LOGIT_TOL, "headline_mode": mode, "meets": bool(errs[mode] <= LOGIT_TOL),
-                           "selection": ("--compute auto: fastest mode with measured error <= tol" if args.compute == "auto" else "--compute " + args.compute),
+                           "selection": ("--compute auto: MV_F16 if its measured error <= %g x tol, else MV_F16X8" % AUTO_MARGIN if args.compute == "auto"
+                                         else "--compute " + args.compute),
+                           "selection_sample_logits": contract.get("sample_logits"),
                            **contract}
     if world == 1 and not args.no_second and not stub:
         out["cfg3"] = cfg3_leg(eng, dims, mode, min(K, 10), W, args.streams, profile=not args.no_profile)
@@ -641,7 +646,7 @@ def trained_like_errors(dims, S, nt=16, gt=8):
         o = e2.forward(ids, lens)
         errs[mode] = float(np.abs(o["logits"] - lg).max())
         e2.close()
-    return {"logit_max_abs_err_trained_like": errs,
+    return {"logit_max_abs_err_trained_like": errs, "sample_logits": int(lg.size),
             "trained_like_sample": ("%d IRs x %d tokens against %d anchors of up to %d tokens, %d-layer trained-like weights (LayerNorm outlier "
                                     "dims, peaked attention, matcher x29), max |logit| %.2f; CPU leg = oracle/hf_reference.py fp32" % (
                                         nt, S, gt, LA, dims.layers, float(np.abs(lg).max())))}

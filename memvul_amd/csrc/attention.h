@@ -5,7 +5,7 @@
 // Layout in HBM (written by the QKV GEMM epilogue): Q,K [B][12][S][64] fp16 (Q pre-scaled by 1/8),
 // V^T [B][12][64][S] fp16; output ctx [B*S][768] fp16 (head h at columns 64h..64h+63).
 // (The round-1 kernel that staged a head's whole K / V^T per workgroup — the A/B yardstick of rounds 1-2 — is
-// tools/legacy/attention.h; padded lengths 320 / 448 now run as 384 / 512 through attention_v2's 128-key chunks.)
+// git history (rounds 1-2); padded lengths 320 / 448 now run as 384 / 512 through attention_v2's 128-key chunks.)
 #pragma once
 #include "common.h"
 

@@ -34,7 +34,7 @@
 // X8 1 (MV_F16X8, gemm_pp.h): the context is also written as fp8 planes [lo8 (768) | hi8 (768)] per token row to
 // AttnArgs::ctx8 — e4m3 of (O - fp16(O)) 2^(11 + s) and of O 2^s, the A8 operand of the output projection's correction sweep
 // (16 more registers across the unit boundary, a second pass through the O image); a separate instantiation.
-// (The timing ablations of rounds 1-2 — no Q loads / O stores / DMA / exp / MFMA / fragment reads — are tools/legacy/.)
+// (The timing ablations of rounds 1-2 — no Q loads / O stores / DMA / exp / MFMA / fragment reads — were retired: git history before round 5.)
 template <int NKB, int NCH = 1, int X8 = 0>  // chunk = 64 NKB keys = 2 NKB waves x 32 queries; padded length S = 64 NKB NCH
 __global__ __launch_bounds__(NKB * 128) __attribute__((amdgpu_waves_per_eu(2, 2))) void attention_v2_kernel(AttnArgs a, int nunits) {
   constexpr int S = NKB * 64;        // keys per chunk = queries per unit

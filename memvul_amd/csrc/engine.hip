@@ -349,6 +349,10 @@ int launch_pp(mv_handle* h, int cls, GemmArgs a) {
     return fail(h, MV_ERR_INVALID, "gemm_pp: M,N % 256, K % 128, K >= 256, N <= 3072 required");  // K >= 256: the RAW kernels stage the
                                                                                               // next tile's statistics at K-tile 2
   if (!a.bias || !a.lnstats) return fail(h, MV_ERR_STATE, "internal: gemm_pp without bias / row statistics");
+  // a weight-side-only fp8 sweep walks K / 128 K-tiles IN PAIRS (gemm_pp.h two_ktiles): the staging and consume cursors only stay in
+  // step when that count is even
+  if (a.A8 && (a.x8_terms == 1 || a.x8_terms == 3) && a.K % 256)
+    return fail(h, MV_ERR_INVALID, "gemm_pp: a weight-side-only fp8 correction sweep needs K % 256 == 0");
   a.GN = choose_gn(a.N / 256, h->pp_gn_max);  // widths 2 / 3 / 6 / 12 measured: 4 (or the largest divisor below it) is the fastest
   const int tiles = (a.M / 256) * (a.N / 256);
   const int grid = tiles < h->num_cu ? tiles : h->num_cu;
@@ -845,8 +849,16 @@ int mv_create(int device, const mv_config* cfg, mv_handle** out) try {
   if (const char* e = getenv("MEMVUL_CLS_PRUNE")) h->cls_prune = atoi(e) != 0;
   if (const char* e = getenv("MEMVUL_QKV_ASIDE")) {
     h->qkv_aside_mask = 0;
-    for (const char* c = e; *c; ++c) h->qkv_aside_mask |= (*c == 'q' || *c == 'Q') ? 1 : (*c == 'k' || *c == 'K') ? 2 : (*c == 'v' || *c == 'V') ? 4 : 0;
-    if (!strcmp(e, "none")) h->qkv_aside_mask = 0;
+    if (strcmp(e, "none")) {
+      for (const char* c = e; *c; ++c) {
+        const int bit = (*c == 'q' || *c == 'Q') ? 1 : (*c == 'k' || *c == 'K') ? 2 : (*c == 'v' || *c == 'V') ? 4 : 0;
+        if (!bit) {  // a typo must not silently change the numerics
+          g_create_error = std::string("MEMVUL_QKV_ASIDE=\"") + e + "\": expected a subset of \"qkv\", \"\" or \"none\"";
+          return MV_ERR_INVALID;  // the guard destroys the handle
+        }
+        h->qkv_aside_mask |= bit;
+      }
+    }
   }
   if (const char* e = getenv("MEMVUL_GN_MAX")) { const int v = atoi(e); if (v >= 1 && v <= 12) h->pp_gn_max = v; }
   if (const char* e = getenv("MEMVUL_RASTER")) h->pp_raster = atoi(e) == 1 ? 1 : 0;

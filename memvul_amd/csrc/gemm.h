@@ -21,7 +21,7 @@
 //          one barrier per K-step ("step-3" structure of the guide).  The mid-size path (passes too small to fill the
 //          chip with 256^2 tiles); the bench-scale path is gemm_pp.h, the skinny-M path ([CLS] tail) gemm_ring below.
 //          (The round-1/2 library also carried a 256^2 one-tile-per-workgroup kernel, a register-staged 128^2 form and a
-//          sweep of ring geometries: tools/legacy/, A/B records in profiles/r01_d_gemm_ablation.txt.)
+//          sweep of ring geometries: retired (git history), A/B records in profiles/r01_d_gemm_ablation.txt.)
 #pragma once
 #include "common.h"
 

@@ -7,7 +7,7 @@
 //   * 256x256x64 tile, 512 threads = 8 waves as 2(M) x 4(N), 128x64 of C per wave = 8 token blocks x 4 column blocks of 16 x 16
 //     (128 accumulator VGPRs), **v_mfma_f32_16x16x32_f16**: these kernels are power-bound and this shape costs less
 //     energy per FLOP than 32x32x16 (half the accumulator traffic): chip-wide 1.82-1.85 PF against 1.46-1.50
-//     (tools/mfma_shape_probe.hip), +6 % on every launch; the 32x32x16 form of this file is tools/legacy/gemm_pp_32x32x16_r3.h.
+//     (tools/mfma_shape_probe.hip), +6 % on every launch; the 32x32x16 form of this file is in the history (git show 5bc1d9a^:memvul_amd/csrc/gemm_pp.h).
 //     ONE workgroup per CU, grid = #CUs, each workgroup walks a strided list of output tiles (persistent): the K-tile stream
 //     never drains between output tiles, so the next tile's operands are already in flight while the epilogue stores.
 //   * ONE s_barrier per phase; the first M-half of the workgroup (waves 0-3) runs [MFMA(j), read fragments(j+1)] and
@@ -32,7 +32,7 @@
 //     group's W panels stay in that XCD's L2 while it sweeps the A row panels).
 //
 // Three kernel kinds (the encoder layer's four GEMMs; what rounds 1-2 also carried — fp32-stream epilogues, the two-barrier
-// schedule, timing ablations — lives in tools/legacy/ with its A/B records in profiles/):
+// schedule, timing ablations — was retired (git history before round 5; A/B records in profiles/):
 //   PP_QK   (RAW)  Q, K (head-major) and V^T in ONE launch: the V tiles go through the wave's LDS image transposed.
 //   PP_GELU (RAW)  FFN-1 + exact-erf GELU.
 //   PP_RESLN3      attention-output projection / FFN-2: + bias + LayerNorm(residual), in place on the raw stream.

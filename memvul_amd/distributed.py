@@ -18,7 +18,8 @@ Transport (``init_transport``), torch-free:
    libmemvul_hip.so (collective on the engine's stream, over xGMI); otherwise ALL ranks use the hub itself as the
    transport.  No rank decides alone, there is no id file in a shared temp directory and no single-node assumption.
    (A rank that dies INSIDE the collective ncclCommInitRank strands the others until RCCL's own timeout; the hub sockets
-   themselves never block longer than HUB_IO_TIMEOUT_S, so a hung peer ends in a RuntimeError on every rank, not in a hang.)
+   themselves never block longer than HUB_IO_TIMEOUT_S during the agreement and HUB_DATA_TIMEOUT_S — the limit on rank skew — once the
+   hub is the data transport, so a hung peer ends in a RuntimeError on every rank, not in a hang.)
 3. ``shutdown()`` tears the transport down; a later ``init_transport`` starts from scratch.
 
 The data path has no collective, only 8 B per issue report of statistics cross ranks, so a run on the hub is still a
@@ -34,9 +35,13 @@ from typing import Optional, Tuple
 import numpy as np
 
 RENDEZVOUS_TIMEOUT_S = 180.0
-# no hub socket ever blocks for ever: a peer that hangs without closing its socket (or a rank stranded inside a collective
-# ncclCommInitRank that another rank failed out of) surfaces as a RuntimeError on every waiting rank after this long
+# no hub socket ever blocks for ever.  Two limits: during the transport AGREEMENT (rendezvous, RCCL probe, unique-id broadcast,
+# ncclCommInitRank outcome) a peer that hangs without closing its socket — or a rank stranded inside a collective ncclCommInitRank
+# that another rank failed out of — surfaces as a RuntimeError on every waiting rank after HUB_IO_TIMEOUT_S; once the hub IS the data
+# transport its collectives wait up to HUB_DATA_TIMEOUT_S, the hard limit on legitimate rank skew (a rank that finishes its shard
+# early waits for the slowest one inside the barrier / all-gather; rank 0 concatenating part files between two barriers)
 HUB_IO_TIMEOUT_S = float(os.environ.get("MEMVUL_HUB_TIMEOUT_S", "900"))
+HUB_DATA_TIMEOUT_S = float(os.environ.get("MEMVUL_HUB_DATA_TIMEOUT_S", str(6 * 3600)))
 
 
 def shard_range(n: int, rank: int, world: int) -> Tuple[int, int]:
@@ -124,11 +129,26 @@ class _Hub:
             try:
                 part = c.recv(min(1 << 20, n - len(buf)))
             except socket.timeout:
-                raise RuntimeError(f"rendezvous hub: a peer stayed silent for {HUB_IO_TIMEOUT_S:.0f} s (hung rank?) — giving up instead of waiting for ever")
+                raise RuntimeError(f"rendezvous hub: a peer stayed silent for {c.gettimeout() or 0:.0f} s (hung rank?) — giving up instead of waiting for ever")
             if not part:
                 raise ConnectionError("peer closed the rendezvous socket")
             buf += part
         return bytes(buf)
+
+    @staticmethod
+    def _send(c, data: bytes):
+        """sendall with the same failure surface as _recvn: a peer that stopped reading is a RuntimeError, not a bare socket.timeout."""
+        import socket
+
+        try:
+            c.sendall(data)
+        except socket.timeout:
+            raise RuntimeError(f"rendezvous hub: a peer accepted no data for {c.gettimeout() or 0:.0f} s (hung rank?) — giving up instead of waiting for ever")
+
+    def set_timeout(self, seconds: float):
+        """The limit every later send / receive on the hub's sockets waits for (agreement: HUB_IO_TIMEOUT_S; data phase: HUB_DATA_TIMEOUT_S)."""
+        for c in self.peers + ([self.sock] if self.sock is not None else []):
+            c.settimeout(seconds)
 
     def comm_allgather(self, arr: np.ndarray) -> np.ndarray:
         arr = np.ascontiguousarray(arr)
@@ -139,9 +159,9 @@ class _Hub:
             blocks = [arr.tobytes()] + [self._recvn(c, nb) for c in self.peers]
             whole = b"".join(blocks)
             for c in self.peers:
-                c.sendall(whole)
+                self._send(c, whole)
         else:
-            self.sock.sendall(arr.tobytes())
+            self._send(self.sock, arr.tobytes())
             whole = self._recvn(self.sock, nb * self.comm_world)
         return np.frombuffer(whole, arr.dtype).reshape((self.comm_world,) + arr.shape).copy()
 
@@ -152,7 +172,7 @@ class _Hub:
         if self.rank == 0:
             assert payload is not None and len(payload) == nbytes
             for c in self.peers:
-                c.sendall(payload)
+                self._send(c, payload)
             return payload
         return self._recvn(self.sock, nbytes)
 
@@ -245,6 +265,7 @@ def _agree_on_transport(hub, engine, rank: int, world: int, prefer: str, addr: s
                     pass
                 why = "ncclCommInitRank failed on a rank" + (f" (here: {err[:100]})" if err else "")
     _comm = hub
+    hub.set_timeout(HUB_DATA_TIMEOUT_S)  # from here on the sockets carry the job's barriers and its one all-gather: the skew limit applies
     _comm_note = f"tcp hub on {addr}:{port} ({why or 'fallback'})"
     return _comm_note
 

@@ -22,7 +22,7 @@ def gu():
 def test_gemm_variants(gu, variant, shape):
     """0: the 128^2-tile LDS-DMA kernel of small passes, 19: the 64^2-tile ring kernel of the [CLS] tail (mv_test_gemm).  Both
     accumulate over K in the same order, so they must agree bit-for-bit with each other and with fp32 numpy to rounding.
-    (The ring-geometry sweep, the 256^2 one-tile kernel and the register-staged form of rounds 1-2 live in tools/legacy/.)"""
+    (The ring-geometry sweep, the 256^2 one-tile kernel and the register-staged form of rounds 1-2 are retired (git history).)"""
     M, N, K = shape
     rng = np.random.default_rng(M + N + K)
     A = rng.standard_normal((M, K)).astype(np.float16)

@@ -86,7 +86,11 @@ def test_trained_like_logits(gu, golden_dir, name, gemm_tile):
     eng.anchor_reset()
 
 
-@pytest.mark.parametrize("name", ["l12_trained_s256", "l12_trained_ragged", "l12_base_ragged", "l12_base_s256"])
+PRECISE_TRAINED_LIKE_REGRESSION_BOUND = 5.5e-4  # the shipped default on the trained-like goldens measures 3.7 - 4.2e-4: a bound tight enough to
+                                                 # catch erosion of the margin to the 1e-3 contract, not the contract itself
+
+
+@pytest.mark.parametrize("name", ["l12_trained_s256", "l12_trained_ragged", "l12_base_ragged", "l12_base_s256", "l2_peaky_full", "l2_ragged"])
 def test_precise_mode_holds_1e3_in_the_trained_like_regime(gu, golden_dir, name):
     """MV_F16X8 (compute dtype "precise"): every GEMM of the encoder adds ONE correction sweep on the fp8 matrix path —
     A_lo8 W_hi8 + A_hi8 W_lo8, the first-order terms of the split-operand product in OCP e4m3 — to its fp16 sweep
@@ -109,9 +113,23 @@ def test_precise_mode_holds_1e3_in_the_trained_like_regime(gu, golden_dir, name)
                 logits=float(np.abs(out["logits"] - g["logits"]).max()), p=float(np.abs(out["probs"] - g["p"]).max()),
                 logit_scale=float(np.abs(g["logits"]).max()))
     gu.record("precise_mode", case=name, **errs)
-    assert errs["logits"] <= LOGIT_TOL, errs
+    assert errs["logits"] <= (PRECISE_TRAINED_LIKE_REGRESSION_BOUND if "trained" in name else LOGIT_TOL), errs
     assert errs["p"] <= 1e-4, errs
     eng.anchor_reset()
+
+
+def test_small_pass_kernels_exclude_the_default_compute_dtype(gu):
+    """the product default is MV_F16X8, which only exists on the persistent GEMM path — MEMVUL_GEMM_TILE=128 (the small-pass
+    kernels forced) must fail at mv_finalize_weights with a message that names the switch, not compute something else."""
+    dk, wk = dict(layers=1), dict()
+    with pytest.raises(RuntimeError, match="MEMVUL_GEMM_TILE=128"):
+        gu.engine_for(dk, wk, gemm_tile=128, compute_dtype="precise")
+
+
+def test_unknown_qkv_aside_characters_are_rejected(gu):
+    """a typo in MEMVUL_QKV_ASIDE must not silently change the numerics."""
+    with pytest.raises(RuntimeError, match="MEMVUL_QKV_ASIDE"):
+        gu.engine_for(dict(layers=1), dict(), env={"MEMVUL_QKV_ASIDE": "qx"}, compute_dtype="precise")
 
 
 @pytest.mark.parametrize("compute", ["f16", "precise"])
