@@ -13,49 +13,52 @@ from typing import Any, Dict, Iterable, Iterator, List, Optional
 
 import numpy as np
 
+from .registry import HAVE_ALLENNLP
 
-@dataclass
-class Token:
-    text: str = None
-    text_id: Optional[int] = None
-    type_id: Optional[int] = None
+if HAVE_ALLENNLP:
+    # AllenNLP is importable: the reader emits AllenNLP's OWN Instances / Fields, so AllenNLP's DataLoader, Batch and
+    # `evaluate` (predict_memory.py:92-110) can index and collate them (registry.py; tests/test_reference_driver_over_plugin.py)
+    from allennlp.data import Instance, Token  # type: ignore
+    from allennlp.data.fields import Field, LabelField, MetadataField, TextField  # type: ignore
+else:
+    @dataclass
+    class Token:
+        text: str = None
+        text_id: Optional[int] = None
+        type_id: Optional[int] = None
 
+    class Field:
+        pass
 
-class Field:
-    pass
+    class TextField(Field):
+        def __init__(self, tokens: List[Token], token_indexers: Optional[Dict[str, Any]] = None) -> None:
+            self.tokens = tokens
+            self._token_indexers = token_indexers
 
+        def __len__(self):
+            return len(self.tokens)
 
-class TextField(Field):
-    def __init__(self, tokens: List[Token], token_indexers: Optional[Dict[str, Any]] = None) -> None:
-        self.tokens = tokens
-        self._token_indexers = token_indexers
+    class LabelField(Field):
+        def __init__(self, label: str, label_namespace: str = "labels") -> None:
+            self.label = label
+            self._label_namespace = label_namespace
 
-    def __len__(self):
-        return len(self.tokens)
+    class MetadataField(Field):
+        def __init__(self, metadata: Any) -> None:
+            self.metadata = metadata
 
+    class Instance:
+        def __init__(self, fields: Dict[str, Field]) -> None:
+            self.fields = fields
 
-class LabelField(Field):
-    def __init__(self, label: str, label_namespace: str = "labels") -> None:
-        self.label = label
-        self._label_namespace = label_namespace
-
-
-class MetadataField(Field):
-    def __init__(self, metadata: Any) -> None:
-        self.metadata = metadata
-
-
-class Instance:
-    def __init__(self, fields: Dict[str, Field]) -> None:
-        self.fields = fields
-
-    def __getitem__(self, k):
-        return self.fields[k]
+        def __getitem__(self, k):
+            return self.fields[k]
 
 
 def collate(instances: List[Instance], vocab=None) -> Dict[str, Any]:
     """``allennlp_collate``: every TextField padded with 0 to the longest in the batch, labels indexed
-    through the ``labels`` namespace, metadata passed through as a list."""
+    through the ``labels`` namespace, metadata passed through as a list.  (Same arrays from AllenNLP's own Instances and
+    from the stand-in's: only ``tokens`` / ``text_id`` / ``type_id`` / ``label`` / ``metadata`` are read.)"""
     out: Dict[str, Any] = {}
     names = list(instances[0].fields.keys())
     for name in names:

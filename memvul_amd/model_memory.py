@@ -29,11 +29,21 @@ import numpy as np
 from .binding import Engine, compute_dtype_of
 from .custom_metric import SiameseMeasureV1
 from .data import Instance, collate
-from .registry import Model, TextFieldEmbedder, TokenEmbedder, Vocabulary
+from .registry import HAVE_ALLENNLP, Model, TextFieldEmbedder, TokenEmbedder, Vocabulary, register_builtin
 
 logger = logging.getLogger(__name__)
 
 PFX_BERT = "_text_field_embedder.token_embedder_tokens.transformer_model."
+
+
+class _LoadResult(tuple):
+    """``(missing_keys, unexpected_keys)`` of ``torch.nn.Module.load_state_dict``."""
+
+    def __new__(cls, missing, unexpected):
+        return super().__new__(cls, (list(missing), list(unexpected)))
+
+    missing_keys = property(lambda self: self[0])
+    unexpected_keys = property(lambda self: self[1])
 
 
 def _np(x):
@@ -55,6 +65,7 @@ class CustomPretrainedTransformerEmbedder(TokenEmbedder):
                  override_weights_strip_prefix: Optional[str] = None, gradient_checkpointing: Optional[bool] = None,
                  tokenizer_kwargs: Optional[Dict[str, Any]] = None, transformer_kwargs: Optional[Dict[str, Any]] = None,
                  pretrained_model_path: str = "out_wwm/") -> None:
+        super().__init__()  # AllenNLP's TokenEmbedder is a torch.nn.Module (BasicTextFieldEmbedder registers it as a sub-module)
         if max_length is not None:
             raise NotImplementedError("segment folding (custom_PTM_embedder.py:244-381) is dead code in every reference config")
         if not last_layer_only:
@@ -66,7 +77,7 @@ class CustomPretrainedTransformerEmbedder(TokenEmbedder):
         return self.output_dim
 
 
-@TokenEmbedder.register("pretrained_transformer")
+@register_builtin(TokenEmbedder, "pretrained_transformer")
 class _PlainPretrainedTransformerEmbedder(CustomPretrainedTransformerEmbedder):
     """config_no_pretrain.json uses the stock embedder type; same inference path."""
 
@@ -75,9 +86,10 @@ class _PlainPretrainedTransformerEmbedder(CustomPretrainedTransformerEmbedder):
         super().__init__(model_name, **kw)
 
 
-@TextFieldEmbedder.register("basic")
+@register_builtin(TextFieldEmbedder, "basic")
 class BasicTextFieldEmbedder(TextFieldEmbedder):
     def __init__(self, token_embedders: Dict[str, TokenEmbedder]) -> None:
+        super().__init__()
         self.token_embedders = token_embedders
 
     def get_output_dim(self):
@@ -181,7 +193,10 @@ class ModelMemory(Model):
         self._engine = Engine(self._device_index, vocab_size=vocab_size, layers=layers, max_pos=max_pos, type_vocab=type_vocab,
                               same_idx=self._same_idx, **opts)
         self._engine.load_state_dict(sd, cd)
-        return self
+        # torch's contract (AllenNLP's Model._load unpacks it): every tensor the engine needs was found by mv_load_tensor /
+        # mv_finalize_weights (they fail otherwise); keys it has no use for — the BertModel's own pooler copy, position_ids — are
+        # not "unexpected" to a model that declares no parameters of its own
+        return _LoadResult([], [])
 
     @property
     def engine(self) -> Engine:

@@ -137,7 +137,15 @@ class ReaderMemory(DatasetReader):
 
             first, count = shard_range(n_total, int(shard[0]), int(shard[1]))
             all_data = all_data[first:first + count]
-        ids, lens = self._tokenizer.batch_ids([self._text_of(s) for s in all_data], workers=workers)
+        texts = [self._text_of(s) for s in all_data]
+        if hasattr(self._tokenizer, "batch_ids"):
+            ids, lens = self._tokenizer.batch_ids(texts, workers=workers)
+        else:  # AllenNLP's own PretrainedTransformerTokenizer (registry.HAVE_ALLENNLP): text by text, same ids
+            rows = [[t.text_id for t in self._tokenizer.tokenize(x)] for x in texts]
+            lens = np.fromiter((len(r) for r in rows), dtype=np.int32, count=len(rows))
+            ids = np.zeros((len(rows), int(lens.max()) if len(rows) else 0), np.int32)
+            for i, r in enumerate(rows):
+                ids[i, :len(r)] = r
         same = np.fromiter((s[self._target] == "pos" for s in all_data), dtype=bool, count=len(all_data))
         labels = [s["CWE_ID"] if s[self._target] == "pos" else s[self._target] for s in all_data]
         return {"type": type_, "ids": ids, "lens": lens, "same": same, "labels": labels,

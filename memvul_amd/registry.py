@@ -5,16 +5,21 @@ reader_memory.py:35, ``Model.register("model_memory")`` model_memory.py:39,
 
 When AllenNLP is importable the real base classes are re-exported, so the classes of this package
 register into AllenNLP's own registry and ``load_archive``/``evaluate`` find them by the names the
-reference's configs use.  AllenNLP is absent from this image, so a small stand-in with the same
-``register`` / ``by_name`` / ``from_params`` behaviour is provided: construction by ``"type"`` key,
-nested construction of annotated/registered sub-objects, unknown keys rejected.
+reference's configs use: the reference's UNMODIFIED driver runs over this plugin with
+``test_siamese(..., package="memvul_amd")`` (predict_memory.py:49,59) — executed by
+tests/test_reference_driver_over_plugin.py against the AllenNLP stand-in of oracle/ref_harness/stubs.
+Names AllenNLP itself owns (the ``pretrained_transformer`` tokenizer / indexer / embedder, the ``basic``
+text-field embedder) are then served by AllenNLP's own classes (``register_builtin``).  AllenNLP is absent
+from this image, so otherwise a small stand-in with the same ``register`` / ``by_name`` / ``from_params``
+behaviour is provided: construction by ``"type"`` key, nested construction of annotated/registered
+sub-objects, unknown keys rejected.
 """
 from __future__ import annotations
 
 import inspect
 from typing import Any, Callable, Dict, Optional, Type
 
-try:  # pragma: no cover - not installed in this image
+try:
     from allennlp.common import Registrable  # type: ignore
     from allennlp.data import DatasetReader, Vocabulary  # type: ignore
     from allennlp.data.token_indexers import TokenIndexer  # type: ignore
@@ -187,3 +192,13 @@ except Exception:
                         for line in f:
                             v.add_token_to_namespace(line.rstrip("\n"), ns)
             return v
+
+
+def register_builtin(base, name: str):
+    """Class decorator: register under a name that AllenNLP ITSELF owns (its ``pretrained_transformer`` tokenizer /
+    indexer / embedder, its ``basic`` text-field embedder).  Stand-in mode: a plain ``base.register(name)``; with AllenNLP
+    importable: a no-op — AllenNLP's own implementation serves the name (re-registering it is a ConfigurationError there),
+    and this package's class stays importable for direct use."""
+    if HAVE_ALLENNLP:
+        return lambda cls: cls
+    return base.register(name)

@@ -18,7 +18,7 @@ import zlib
 from typing import Dict, List, Optional
 
 from .data import Token
-from .registry import Tokenizer, TokenIndexer
+from .registry import Tokenizer, TokenIndexer, register_builtin
 
 logger = logging.getLogger(__name__)
 CLS_ID, SEP_ID, PAD_ID, UNK_ID = 101, 102, 0, 100
@@ -35,7 +35,7 @@ def _find_vocab(model_name: str) -> Optional[str]:
     return None
 
 
-@Tokenizer.register("pretrained_transformer")
+@register_builtin(Tokenizer, "pretrained_transformer")
 class PretrainedTransformerTokenizer(Tokenizer):
     def __init__(self, model_name: str = "bert-base-uncased", add_special_tokens: bool = True, max_length: Optional[int] = None,
                  tokenizer_kwargs: Optional[Dict] = None, vocab_size: int = 30522) -> None:
@@ -138,7 +138,7 @@ class PretrainedTransformerTokenizer(Tokenizer):
         return [Token(str(i), i, 0) for i in self._hash_encode(text)]
 
 
-@TokenIndexer.register("pretrained_transformer")
+@register_builtin(TokenIndexer, "pretrained_transformer")
 class PretrainedTransformerIndexer(TokenIndexer):
     """Tokens already carry their wordpiece ids; indexing is the identity (``namespace`` is only where
     AllenNLP would mirror the HF vocabulary)."""
