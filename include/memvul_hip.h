@@ -152,6 +152,13 @@ int mv_corpus_run_len(mv_handle* h, int64_t first, int64_t count, int batch, int
 int mv_set_streams(mv_handle* h, int n);
 /* best fp32 [count,2], best_idx int32 [count], p_same fp32 [count,G] (NULL unless kept). Synchronises. */
 int mv_corpus_results(mv_handle* h, int64_t first, int64_t count, float* best, int32_t* best_idx, float* p_same);
+/* MV_F16X8 only (always 0 in MV_F16).  The fp8 planes of the activations (raw residual stream, attention context, GELU output) use ONE
+ * static scale: |x| <= 112 is representable; an element beyond it keeps its fp16 accuracy but loses its correction term (the precision of
+ * MV_F16 for that element) — the computation never fails over it.  *clamped = the number of such elements since the handle was created
+ * (or since the last call with reset != 0), saturating at 2^32 - 1; synchronises.  A non-zero count on a real checkpoint means the 1e-3
+ * logit contract of model_memory.py:141 is no longer backed by the measurements in DESIGN.md section 2 for that model: the Python
+ * wrapper warns once (binding.Engine).  No reference counterpart (the reference computes in fp32). */
+int mv_x8_saturation(mv_handle* h, int64_t* clamped, int reset);
 
 /* ---- multi-GPU exchange (the reference is single-process, predict_memory.py:103) --------------------
  * One process per GPU, contiguous corpus shards, no data-path collective; the ONE exchange is an all-gather of the

@@ -7,6 +7,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import warnings
 from typing import Dict, Iterable, Optional, Tuple
 
 import numpy as np
@@ -49,7 +50,7 @@ ABI_SYMBOLS = [
     "mv_create", "mv_destroy", "mv_last_error", "mv_sync", "mv_load_tensor", "mv_finalize_weights",
     "mv_anchor_reset", "mv_anchor_append", "mv_anchor_count", "mv_anchor_get", "mv_anchor_set",
     "mv_forward", "mv_encode", "mv_match", "mv_topk", "mv_corpus_upload", "mv_corpus_run", "mv_corpus_run_len",
-    "mv_corpus_results", "mv_set_streams", "mv_profile_enable", "mv_profile_select", "mv_profile_read", "mv_kernel_class_name",
+    "mv_corpus_results", "mv_x8_saturation", "mv_set_streams", "mv_profile_enable", "mv_profile_select", "mv_profile_read", "mv_kernel_class_name",
     "mv_debug_encode", "mv_debug_read", "mv_test_gemm", "mv_test_gemm_pp", "mv_test_e4m3", "mv_comm_prepare", "mv_comm_unique_id", "mv_comm_init", "mv_comm_allgather",
     "mv_comm_destroy", "mv_comm_info", "mv_device_count",
 ]
@@ -105,6 +106,7 @@ def load_library(path: Optional[str] = None):
         "mv_corpus_run": (C.c_int, [vp, C.c_int64, C.c_int64, C.c_int, C.c_int]),
         "mv_corpus_run_len": (C.c_int, [vp, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_int]),
         "mv_corpus_results": (C.c_int, [vp, C.c_int64, C.c_int64, vp, vp, vp]),
+        "mv_x8_saturation": (C.c_int, [vp, C.POINTER(C.c_int64), C.c_int]),
         "mv_set_streams": (C.c_int, [vp, C.c_int]),
         "mv_profile_enable": (C.c_int, [vp, C.c_int]),
         "mv_profile_select": (C.c_int, [vp, C.c_uint32]),
@@ -200,6 +202,26 @@ class Engine:
                 continue
             self.load_tensor(k, a)
         self._check(self._lib.mv_finalize_weights(self._h, compute_dtype_of(compute_dtype)), "mv_finalize_weights")
+        self._precise = compute_dtype_of(compute_dtype) == MV_F16X8
+        self._sat_warned = False
+
+    def x8_saturation(self, reset: bool = False) -> int:
+        """MV_F16X8: activation elements (raw stream, attention context, GELU output) that fell outside the +-112 range of the fp8
+        correction planes since the engine was created / last reset (mv_x8_saturation; synchronises).  Such an element keeps fp16
+        accuracy and loses its correction term."""
+        n = C.c_int64(0)
+        self._check(self._lib.mv_x8_saturation(self._h, C.byref(n), int(bool(reset))), "mv_x8_saturation")
+        return int(n.value)
+
+    def _check_saturation(self):
+        """Called after the host-synchronous entry points of the precise mode: warn ONCE when the fp8 planes clamped anything."""
+        if getattr(self, "_precise", False) and not self._sat_warned:
+            n = self.x8_saturation()
+            if n:
+                self._sat_warned = True
+                warnings.warn(f"MV_F16X8: {n} activation element(s) exceeded the +-112 range of the fp8 correction planes and were "
+                              "computed at fp16 accuracy; the 1e-3 logit tolerance is not backed by measurement for this model "
+                              "(include/memvul_hip.h mv_x8_saturation; Engine.x8_saturation())", RuntimeWarning, stacklevel=3)
 
     # -- anchors
     def anchor_reset(self):
@@ -208,6 +230,7 @@ class Engine:
     def anchor_append(self, ids: np.ndarray, lens: np.ndarray):
         ids, lens = _as(ids, np.int32), _as(lens, np.int32)
         self._check(self._lib.mv_anchor_append(self._h, _ptr(ids), _ptr(lens), ids.shape[0], ids.shape[1]), "mv_anchor_append")
+        self._check_saturation()
 
     @property
     def n_anchors(self) -> int:
@@ -239,12 +262,14 @@ class Engine:
         embed = np.empty((B, self.P), np.float32) if want_embed else None
         self._check(self._lib.mv_forward(self._h, _ptr(ids), _ptr(lens), B, S, _ptr(logits), _ptr(probs), _ptr(best),
                                          _ptr(idx), _ptr(embed)), "mv_forward")
+        self._check_saturation()
         return {"logits": logits, "probs": probs, "best": best, "best_idx": idx, "embed": embed}
 
     def encode(self, ids: np.ndarray, lens: np.ndarray) -> np.ndarray:
         ids, lens = _as(ids, np.int32), _as(lens, np.int32)
         out = np.empty((ids.shape[0], self.P), np.float32)
         self._check(self._lib.mv_encode(self._h, _ptr(ids), _ptr(lens), ids.shape[0], ids.shape[1], _ptr(out)), "mv_encode")
+        self._check_saturation()
         return out
 
     def match(self, u: np.ndarray):
@@ -300,6 +325,7 @@ class Engine:
         idx = np.empty((count,), np.int32)
         ps = np.empty((count, self.n_anchors), np.float32) if with_probs else None
         self._check(self._lib.mv_corpus_results(self._h, first, count, _ptr(best), _ptr(idx), _ptr(ps)), "mv_corpus_results")
+        self._check_saturation()
         return best, idx, ps
 
     # -- multi-GPU exchange (RCCL bound inside the library; no torch in the process)

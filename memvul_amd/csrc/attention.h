@@ -18,6 +18,7 @@ struct AttnArgs {
   int S;                // padded length: 64, 128, 192, 256, 384 or 512
   int B;
   uint8_t* ctx8;        // MV_F16X8 (attention_v2_kernel<.., X8 = 1>): [B*S][1536] = [lo8 (768) | hi8 (768)] planes of ctx (gemm_pp.h)
+  unsigned int* x8_sat; // MV_F16X8: device counter of context elements beyond the fp8 planes' range (common.h x8_planes4)
 };
 
 // Last encoder layer: only the [CLS] query (token 0) of each issue report is consumed downstream

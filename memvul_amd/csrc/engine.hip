@@ -168,6 +168,7 @@ struct mv_handle {
   int rr = 0;                 // workspace set of the next resident-sweep batch
   float* anchors = nullptr;
   int n_anchors = 0;
+  unsigned int* x8_sat = nullptr;  // MV_F16X8: device counter of activation elements beyond the fp8 planes' range (mv_x8_saturation)
 
   // resident corpus
   int32_t *c_ids = nullptr, *c_lens = nullptr;
@@ -400,7 +401,7 @@ int pool_head(mv_handle* h, const float* x, size_t row_stride, int B, float* u_o
 inline int padded_len(int S_in) { return (int)round_up(S_in, S_in <= 256 ? 64 : 128); }
 
 int launch_attention(mv_handle* h, const int32_t* d_lens, int B, int Sp, bool x8) {
-  AttnArgs a{h->w->q, h->w->k, h->w->vt, d_lens, h->w->ctx, Sp, B, x8 ? h->w->ctx8 : nullptr};
+  AttnArgs a{h->w->q, h->w->k, h->w->vt, d_lens, h->w->ctx, Sp, B, x8 ? h->w->ctx8 : nullptr, h->x8_sat};
   ProfScope ps(h, KC_ATTENTION);
   if (Sp <= 256) {
     const int nkb = Sp / 64, items = B * MV_HEADS;
@@ -458,11 +459,11 @@ int encode_dev(mv_handle* h, const int32_t* d_ids, const int32_t* d_lens, int B,
     if (big)
       hipLaunchKernelGGL(embed_ln_kernel<true>, dim3(ln_grid), dim3(256), 0, h->w->stream, d_ids, pitch, S_in, Sp, (int)M, c.vocab_size,
                          h->wemb, h->pemb, h->temb, h->embg, h->embb, c.ln_eps, h->w->xres, h->w->x16, h->w->lnstats, h->w->xlo,
-                         x8 ? h->w->x8 : (uint8_t*)nullptr);
+                         x8 ? h->w->x8 : (uint8_t*)nullptr, h->x8_sat);
     else
       hipLaunchKernelGGL(embed_ln_kernel<false>, dim3(ln_grid), dim3(256), 0, h->w->stream, d_ids, pitch, S_in, Sp, (int)M, c.vocab_size,
                          h->wemb, h->pemb, h->temb, h->embg, h->embb, c.ln_eps, h->w->xres, h->w->x16, (float*)nullptr,
-                         (half_t*)nullptr, (uint8_t*)nullptr);
+                         (half_t*)nullptr, (uint8_t*)nullptr, (unsigned int*)nullptr);
     if (int rc = launch_check(h, "embed_ln")) return rc;
   }
   // big: the LayerNorm whose statistics are pending in the vstats buffers — gamma / beta the next residual GEMM applies
@@ -475,7 +476,8 @@ int encode_dev(mv_handle* h, const int32_t* d_ids, const int32_t* d_lens, int B,
   };
   auto final_ln = [&](const float* g, const float* b) -> int {  // two-plane raw stream -> normalised fp32 rows (pooler / debug taps)
     const size_t n4 = (size_t)M * MV_HIDDEN / 4;
-    hipLaunchKernelGGL(hilo_to_f32_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, h->w->stream, h->w->x16, h->w->xlo, n4, h->w->xres);
+    hipLaunchKernelGGL(hilo_to_f32_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, h->w->stream, h->w->x16, x8 ? (const half_t*)nullptr : h->w->xlo,
+                       x8 ? (const uint8_t*)h->w->x8 : (const uint8_t*)nullptr, n4, h->w->xres);
     if (int rc = launch_check(h, "hilo_to_f32")) return rc;
     return run_ln(h->w->xres, h->w->x16, (int)M, g, b);
   };
@@ -487,7 +489,7 @@ int encode_dev(mv_handle* h, const int32_t* d_ids, const int32_t* d_lens, int B,
     const LayerW& w = h->L[l];
     const bool last = (l == n_layers - 1);
     GemmArgs g{};
-    g.M = (int)Mpad; g.Mreal = (int)M; g.S = Sp; g.ln_eps = c.ln_eps;
+    g.M = (int)Mpad; g.Mreal = (int)M; g.S = Sp; g.ln_eps = c.ln_eps; g.x8_sat = h->x8_sat;
     g.q = h->w->q; g.k = h->w->k; g.vt = h->w->vt;
     const half_t* wqkv = big ? w.wqkv_f : w.wqkv;
     const float* bqkv = big ? w.bqkv_f : w.bqkv;
@@ -507,7 +509,7 @@ int encode_dev(mv_handle* h, const int32_t* d_ids, const int32_t* d_lens, int B,
       auto tail_rc = [&]() -> int {
         hipLaunchKernelGGL(cls_gather_kernel, dim3((B + 3) / 4), dim3(256), 0, h->w->stream, h->w->xres, h->w->x16, Sp, B,
                            big ? st_in : (const float*)nullptr, pend_g, pend_b, h->w->c32, h->w->c16, big ? 1 : 0,
-                           big ? h->w->xlo : (const half_t*)nullptr, big ? 1 : 0, c.ln_eps);
+                           big ? h->w->xlo : (const half_t*)nullptr, big ? 1 : 0, c.ln_eps, x8 ? (const uint8_t*)h->w->x8 : (const uint8_t*)nullptr);
         if (int rc = launch_check(h, "cls_gather")) return rc;
         if (x8) {
           // MV_F16X8: the B [CLS] rows in full fp32 on the fp32-input matrix cores (their operand rounding would reach the
@@ -563,18 +565,18 @@ int encode_dev(mv_handle* h, const int32_t* d_ids, const int32_t* d_lens, int B,
       // K4: attention output projection + bias + LayerNorm(residual), in place on the raw stream; + vstats of the new rows
       g.A = h->w->ctx; g.W = w.wo; g.bias = w.bo; g.N = MV_HIDDEN; g.K = MV_HIDDEN;
       g.lnstats = st_in; g.lng = pend_g; g.lnb = pend_b; g.lnpart = st_mid; g.out16 = h->w->x16; g.out16b = h->w->xlo;
-      if (x8) { g.A8 = h->w->ctx8; g.W8 = w.wo8; g.x8_scale = w.sc_o; g.out8 = h->w->x8; g.x8_terms = 2; g.out8_hi_only = 0; }
+      if (x8) { g.A8 = h->w->ctx8; g.W8 = w.wo8; g.x8_scale = w.sc_o; g.out8 = h->w->x8; g.x8_terms = 2; }
       if (int rc = launch_pp<PP_RESLN3>(h, KC_GEMM_OUT, g)) return rc;
       pend_g = w.ln1g; pend_b = w.ln1b;
       // K5: FFN-1 + exact-erf GELU
       g.A = h->w->x16; g.W = w.w1_f; g.bias = w.b1_f; g.N = MV_INTER; g.K = MV_HIDDEN; g.lnstats = st_mid; g.out16 = h->w->h16;
       g.out16b = nullptr; g.lnpart = nullptr;
-      if (x8) { g.A8 = h->w->x8; g.W8 = w.w1_f8; g.x8_scale = w.sc_1; g.out8 = h->w->h8; g.x8_terms = 2; g.out8_hi_only = 0; }
+      if (x8) { g.A8 = h->w->x8; g.W8 = w.w1_f8; g.x8_scale = w.sc_1; g.out8 = h->w->h8; g.x8_terms = 2; }
       if (int rc = launch_pp<PP_GELU>(h, KC_GEMM_FFN1, g)) return rc;
       // K6: FFN-2 + bias + LayerNorm(residual)
       g.A = h->w->h16; g.W = w.w2; g.bias = w.b2; g.N = MV_HIDDEN; g.K = MV_INTER;
       g.lnstats = st_mid; g.lng = pend_g; g.lnb = pend_b; g.lnpart = st_in; g.out16 = h->w->x16; g.out16b = h->w->xlo;
-      if (x8) { g.A8 = h->w->h8; g.W8 = w.w28; g.x8_scale = w.sc_2; g.out8 = h->w->x8; g.x8_terms = 2; g.out8_hi_only = h->qkv_aside_mask == 0; }
+      if (x8) { g.A8 = h->w->h8; g.W8 = w.w28; g.x8_scale = w.sc_2; g.out8 = h->w->x8; g.x8_terms = 2; }  // (the lo8 plane is the stream's own lo since round 5: always written)
       if (int rc = launch_pp<PP_RESLN3>(h, KC_GEMM_FFN2, g)) return rc;
       pend_g = w.ln2g; pend_b = w.ln2b;
       if (last) { if (int rc = final_ln(w.ln2g, w.ln2b)) return rc; }  // the pooler reads a normalised stream
@@ -915,6 +917,8 @@ int mv_create(int device, const mv_config* cfg, mv_handle** out) try {
   }
   h->w = &h->work[0];
   A(dev_alloc(h, &h->anchors, (int64_t)cfg->max_anchors * h->P));
+  A(dev_alloc(h, &h->x8_sat, 4));
+  if (rc == MV_OK && hipMemset(h->x8_sat, 0, 4 * sizeof(unsigned int)) != hipSuccess) rc = fail(h, MV_ERR_HIP, "hipMemset(x8_sat)");
   if (rc == MV_OK && hipStreamSynchronize(h->w->stream) != hipSuccess) rc = MV_ERR_HIP;
   if (rc != MV_OK) {
     g_create_error = h->err.empty() ? "workspace allocation failed" : h->err;
@@ -1474,6 +1478,17 @@ int mv_set_streams(mv_handle* h, int n) try {
   if (int rc = sync_all(h)) return rc;
   h->n_streams = n;
   h->rr = 0;
+  return MV_OK;
+} catch (...) { return on_exception(h); }
+
+int mv_x8_saturation(mv_handle* h, int64_t* clamped, int reset) try {
+  if (!h || !clamped) return fail(h, MV_ERR_INVALID, "mv_x8_saturation: bad argument");
+  HIPCHK(h, hipSetDevice(h->device));
+  if (int rc = sync_all(h)) return rc;
+  unsigned int v = 0;
+  HIPCHK(h, hipMemcpy(&v, h->x8_sat, sizeof(v), hipMemcpyDeviceToHost));
+  if (reset) HIPCHK(h, hipMemset(h->x8_sat, 0, sizeof(v)));
+  *clamped = (int64_t)v;
   return MV_OK;
 } catch (...) { return on_exception(h); }
 

@@ -181,6 +181,27 @@ __device__ __forceinline__ void scr_f16_rev2(uint32_t wc, const u32x4& a0, const
 #endif
 }
 
+// MV_F16X8 form of the same: the residual block is the hi fp16 plane (a0, a1: rows lane >> 2 and + 16, 16-B chunk lane & 3) and the lo8
+// plane of the stream's fp8 planes (l0, l1: the same rows, the 8 bytes of columns 8 (lane & 3) .. + 7).  The lo8 image is [32 rows][32 B]
+// at the base of the wave's scratch (a lane writes its 8 bytes at lane * 8 [+ 512]: linear), written after the hi units have been read
+// (LDS executes a wave's instructions in order); unit (tbl, cbl) of the lane = the 4 bytes of token 16 tbl + m16, columns
+// 16 cbl + 4 q4 .. + 3 at rl + 512 tbl + 16 cbl.
+__device__ __forceinline__ void scr_f16_lo8_rev(uint32_t wc, const u32x4& a0, const u32x4& a1, const u32x2& l0, const u32x2& l1, uint32_t r0,
+                                                uint32_t r1, uint32_t r2, uint32_t r3, uint32_t wl, uint32_t rl, u32x2 (&oa)[4], uint32_t (&ol)[4]) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm volatile(
+      "ds_write_b128 %8, %9\n\tds_write_b128 %8, %10 offset:1024\n\t"
+      "ds_read_b64 %0, %13\n\tds_read_b64 %1, %14\n\tds_read_b64 %2, %15\n\tds_read_b64 %3, %16\n\t"
+      "ds_write_b64 %17, %11\n\tds_write_b64 %17, %12 offset:512\n\t"
+      "ds_read_b32 %4, %18\n\tds_read_b32 %5, %18 offset:16\n\tds_read_b32 %6, %18 offset:512\n\tds_read_b32 %7, %18 offset:528\n\t"
+      "s_waitcnt lgkmcnt(0)"
+      : "=&v"(oa[0]), "=&v"(oa[1]), "=&v"(oa[2]), "=&v"(oa[3]), "=&v"(ol[0]), "=&v"(ol[1]), "=&v"(ol[2]), "=&v"(ol[3])
+      : "v"(wc), "v"(a0), "v"(a1), "v"(l0), "v"(l1), "v"(r0), "v"(r1), "v"(r2), "v"(r3), "v"(wl), "v"(rl)
+      : "memory");
+  __builtin_amdgcn_sched_barrier(0);
+#endif
+}
+
 // PP_RESLN3 accumulator init: one float4 of each of the bias, gamma and beta images (gamma at +3072 B, beta at +6144 B).
 __device__ __forceinline__ void lds_read_bgb1(uint32_t addr, float4& bi, float4& ga, float4& be) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -238,6 +259,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmArgs a) {
     const int which = (tn * 256 + a.col0) / MV_HIDDEN;  // 0 = Q, 1 = K, 2 = V
     return (a.x8_aside_mask >> which) & 1;
   };
+  int x8_sat = 0;              // elements of this wave's outputs beyond the fp8 planes' range (common.h x8_planes4; wave-uniform -> an SGPR)
   int i_nk8 = X8 ? nk0 : 0;    // of the tile being STAGED (issue cursor)
   size_t i_off8 = 0;
   const int tm_count = a.M >> 8, tn_count = a.N >> 8;
@@ -380,6 +402,10 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmArgs a) {
   // the two fp16 planes of the 32 x 32 block i (token rows) x j (columns) of the residual tile at (mw0, nw0) by full-line loads
   // (16 rows x 64 B per instruction), parked in the four accumulators of that block: acc[2 i + pl][2 j + x] = plane pl (hi, lo),
   // rows crow + 16 x — the accumulator init transposes them into the C/D layout
+  // MV_F16X8 (round 5): the stream is hi fp16 + the lo8 plane of its fp8 planes (out8: rows [lo8 (768) | hi8 (768)]) — the SAME bytes the
+  // next consumer's correction sweep reads as A_lo8, so the stream has no lo fp16 plane of its own: r ~= hi + lo8 2^-(11 + shift)
+  // (2^-15 of the element instead of 2^-22; oracle/precision_model.py knob "res": +1.2e-4 on trained-like logits on its own, lost in
+  // the 3e-4 of the fp16 Q / K / V / P storage).  The lo8 lines (16 rows x 32 B per instruction) park in registers 0, 1 of the lo slot.
   auto park_residual = [&](int i, int mw0, int nw0) {
     const int crow = lane >> 2, cchunk = lane & 3;
 #pragma unroll
@@ -388,7 +414,15 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmArgs a) {
       for (int pl = 0; pl < 2; ++pl)
 #pragma unroll
         for (int x = 0; x < 2; ++x) {
-          const half_t* src = (pl ? a.out16b : a.out16) + (size_t)(mw0 + i * 32 + x * 16 + crow) * MV_HIDDEN + nw0 + j * 32 + 8 * cchunk;
+          const size_t row = (size_t)(mw0 + i * 32 + x * 16 + crow);
+          if constexpr (X8) {
+            if (pl) {
+              const float2 t = *(const float2*)(a.out8 + row * (2 * MV_HIDDEN) + nw0 + j * 32 + 8 * cchunk);
+              acc[2 * i + 1][2 * j + x][0] = t.x; acc[2 * i + 1][2 * j + x][1] = t.y;
+              continue;
+            }
+          }
+          const half_t* src = (pl ? a.out16b : a.out16) + row * MV_HIDDEN + nw0 + j * 32 + 8 * cchunk;
           const float4 t = *(const float4*)src;
           acc[2 * i + pl][2 * j + x][0] = t.x; acc[2 * i + pl][2 * j + x][1] = t.y;
           acc[2 * i + pl][2 * j + x][2] = t.z; acc[2 * i + pl][2 * j + x][3] = t.w;
@@ -570,18 +604,38 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmArgs a) {
 #pragma unroll
               for (int e = 0; e < 4; ++e) p[qq][e] = f2u(acc[2 * i + (qq >> 1)][2 * j + (qq & 1)][e]);
             u32x2 oh[4], ol[4];  // unit k = 2 tbl + cbl
-            scr_f16_rev2(scr_c, p[0], p[1], p[2], p[3], u00, u01, u00 + 1024u, u01 + 1024u, oh, ol);
+            uint32_t ol8[4];     // MV_F16X8: the unit's four lo8 bytes
+            if constexpr (X8) {
+              const u32x2 l0 = {p[2][0], p[2][1]}, l1 = {p[3][0], p[3][1]};
+              scr_f16_lo8_rev(scr_c, p[0], p[1], l0, l1, u00, u01, u00 + 1024u, u01 + 1024u, scr + (uint32_t)lane * 8u,
+                              scr + (uint32_t)m16 * 32u + (uint32_t)q4 * 4u, oh, ol8);
+            } else {
+              scr_f16_rev2(scr_c, p[0], p[1], p[2], p[3], u00, u01, u00 + 1024u, u01 + 1024u, oh, ol);
+            }
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
               const int tbl = k >> 1, cbl = k & 1;
               float4 bi, ga, be;
               lds_read_bgb1(baddr + (2 * j + cbl) * 64, bi, ga, be);
+              float2_t lf01, lf23;  // MV_F16X8: e4m3 -> fp32 of the four lo8 bytes (the plane's 2^(11 + shift) pre-scale is undone in the add)
+              if constexpr (X8) {
+                lf01 = __builtin_amdgcn_cvt_scalef32_pk_f32_fp8(ol8[k], 1.0f, false);
+                lf23 = __builtin_amdgcn_cvt_scalef32_pk_f32_fp8(ol8[k], 1.0f, true);
+              }
 #pragma unroll
               for (int e = 0; e < 4; ++e) {
-                const uint32_t wh = oh[k][e >> 1], wl = ol[k][e >> 1];  // scalar copies before the bit casts (see f2u)
+                const uint32_t wh = oh[k][e >> 1];  // scalar copies before the bit casts (see f2u)
                 const half2_t h2 = __builtin_bit_cast(half2_t, wh);
-                const half2_t l2 = __builtin_bit_cast(half2_t, wl);
-                const float r = (float)h2[e & 1] + (float)l2[e & 1];
+                float r;
+                if constexpr (X8) {
+                  constexpr float SLO = 1.0f / (float)(2048 << MV_X8_ACT_SHIFT);
+                  const float lo = (e == 0) ? lf01.x : (e == 1) ? lf01.y : (e == 2) ? lf23.x : lf23.y;
+                  r = (float)h2[e & 1] + lo * SLO;  // (the product is exact: a power-of-two scale)
+                } else {
+                  const uint32_t wl = ol[k][e >> 1];
+                  const half2_t l2 = __builtin_bit_cast(half2_t, wl);
+                  r = (float)h2[e & 1] + (float)l2[e & 1];
+                }
                 const float t = (r - lnst[2 * i + tbl].x) * lnst[2 * i + tbl].y;
                 acc[2 * i + tbl][2 * j + cbl][e] = __builtin_fmaf(t, ((const float*)&ga)[e], ((const float*)&be)[e]) + ((const float*)&bi)[e];
               }
@@ -792,7 +846,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmArgs a) {
               *(u32x4*)(op + 16 * rstride) = o[2 * j + 1];
             }
           }
-          if constexpr (IS_RES) {  // second plane: lo = fp16(r - hi), same addresses in the lo buffer
+          if constexpr (IS_RES && !X8) {  // second plane: lo = fp16(r - hi), same addresses in the lo buffer (MV_F16X8: the lo8 plane below IS the stream's lo)
 #pragma unroll
             for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -817,35 +871,20 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmArgs a) {
             uint32_t dl[8], dh[8];  // [4 tbl + 2 j + cbl]: the dword of token 16 tbl + m16, columns 32 j + 16 cbl + 4 q4 .. + 3
             const uint32_t w8 = ub8 + (sf << 4);
             uint8_t* o8 = a.out8 + (size_t)(mb + crow) * (2 * a.N) + nw + 16 * cchunk;
-            if (IS_RES && a.out8_hi_only) {  // FFN-2 -> the next layer's QKV projection, which sweeps A_hi8 W_lo8 only: no lo8 plane
 #pragma unroll
-              for (int tbl = 0; tbl < 2; ++tbl)
+            for (int tbl = 0; tbl < 2; ++tbl)
 #pragma unroll
-                for (int j = 0; j < 2; ++j)
+              for (int j = 0; j < 2; ++j)
 #pragma unroll
-                  for (int cbl = 0; cbl < 2; ++cbl) {
-                    const int tb = 2 * i + tbl, cb = 2 * j + cbl;
-                    dh[4 * tbl + 2 * j + cbl] = x8_hi4(acc[tb][cb][0], acc[tb][cb][1], acc[tb][cb][2], acc[tb][cb][3]);
-                  }
-              scr_f8x1(w8, w8 ^ 16u, w8 ^ 32u, w8 ^ 48u, dh, scr_c, o);
-              *(u32x4*)(o8 + a.N) = o[0];
-              *(u32x4*)(o8 + a.N + (size_t)16 * (2 * a.N)) = o[1];
-            } else {
-#pragma unroll
-              for (int tbl = 0; tbl < 2; ++tbl)
-#pragma unroll
-                for (int j = 0; j < 2; ++j)
-#pragma unroll
-                  for (int cbl = 0; cbl < 2; ++cbl) {
-                    const int tb = 2 * i + tbl, cb = 2 * j + cbl;
-                    x8_planes4(acc[tb][cb][0], acc[tb][cb][1], acc[tb][cb][2], acc[tb][cb][3], dh[4 * tbl + 2 * j + cbl], dl[4 * tbl + 2 * j + cbl]);
-                  }
-              scr_f8x2(w8, w8 ^ 16u, w8 ^ 32u, w8 ^ 48u, dl, dh, scr_c, o);
-              *(u32x4*)o8 = o[0];
-              *(u32x4*)(o8 + (size_t)16 * (2 * a.N)) = o[1];
-              *(u32x4*)(o8 + a.N) = o[2];
-              *(u32x4*)(o8 + a.N + (size_t)16 * (2 * a.N)) = o[3];
-            }
+                for (int cbl = 0; cbl < 2; ++cbl) {
+                  const int tb = 2 * i + tbl, cb = 2 * j + cbl;
+                  x8_planes4(acc[tb][cb][0], acc[tb][cb][1], acc[tb][cb][2], acc[tb][cb][3], dh[4 * tbl + 2 * j + cbl], dl[4 * tbl + 2 * j + cbl], x8_sat);
+                }
+            scr_f8x2(w8, w8 ^ 16u, w8 ^ 32u, w8 ^ 48u, dl, dh, scr_c, o);
+            *(u32x4*)o8 = o[0];
+            *(u32x4*)(o8 + (size_t)16 * (2 * a.N)) = o[1];
+            *(u32x4*)(o8 + a.N) = o[2];
+            *(u32x4*)(o8 + a.N + (size_t)16 * (2 * a.N)) = o[3];
           }
           if constexpr (IS_RES) {  // block row i is out: request block row i of the NEXT tile's residual into its registers
             if (has_next) park_residual(i, (next_m << 8) + wr * 128, (next_n << 8) + wc * 64);
@@ -858,5 +897,6 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmArgs a) {
   if (wr == 0) run_tiles(std::integral_constant<int, 0>{});
   else run_tiles(std::integral_constant<int, 1>{});
 
+  if constexpr (X8 && EPI != PP_QK) x8_sat_flush(a.x8_sat, x8_sat);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // no LDS-DMA may outlive the workgroup's LDS allocation
 }

@@ -68,7 +68,9 @@ __global__ __launch_bounds__(256) void embed_ln_kernel(const int32_t* __restrict
                                                        const float* __restrict__ pemb, const float* __restrict__ temb,
                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
                                                        float eps, float* __restrict__ x32, half_t* __restrict__ x16,
-                                                       float* __restrict__ stats, half_t* __restrict__ xlo, uint8_t* __restrict__ x8) {
+                                                       float* __restrict__ stats, half_t* __restrict__ xlo, uint8_t* __restrict__ x8,
+                                                       unsigned int* __restrict__ x8_sat) {
+  int sat = 0;
   const int lane = threadIdx.x & 63;
   const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (t >= n_tok) return;
@@ -109,22 +111,23 @@ __global__ __launch_bounds__(256) void embed_ln_kernel(const int32_t* __restrict
       half4_t h;
       h[0] = (half_t)x[i].x; h[1] = (half_t)x[i].y; h[2] = (half_t)x[i].z; h[3] = (half_t)x[i].w;
       *(half4_t*)(x16 + (size_t)t * MV_HIDDEN + c) = h;
-      if (xlo) {  // two-plane raw stream (gemm_pp PP_RESLN3): lo = fp16(x - hi) instead of the fp32 row
+      if (x8) {  // MV_F16X8: the stream is hi fp16 + the lo8 plane of its [lo8 | hi8] planes (the A8 operand of the QKV GEMM, gemm_pp.h)
+        uint32_t h8, l8;
+        x8_planes4(x[i].x, x[i].y, x[i].z, x[i].w, h8, l8, sat);
+        *(uint32_t*)(x8 + (size_t)t * (2 * MV_HIDDEN) + c) = l8;
+        *(uint32_t*)(x8 + (size_t)t * (2 * MV_HIDDEN) + MV_HIDDEN + c) = h8;
+      } else if (xlo) {  // MV_F16: two-plane raw stream (gemm_pp PP_RESLN3): lo = fp16(x - hi) instead of the fp32 row
         half4_t l;
         l[0] = (half_t)(x[i].x - (float)h[0]); l[1] = (half_t)(x[i].y - (float)h[1]);
         l[2] = (half_t)(x[i].z - (float)h[2]); l[3] = (half_t)(x[i].w - (float)h[3]);
         *(half4_t*)(xlo + (size_t)t * MV_HIDDEN + c) = l;
-        if (x8) {  // MV_F16X8: [lo8 | hi8] planes of the raw stream (the A8 operand of the first QKV GEMM, gemm_pp.h)
-          uint32_t h8, l8;
-          x8_planes4(x[i].x, x[i].y, x[i].z, x[i].w, h8, l8);
-          *(uint32_t*)(x8 + (size_t)t * (2 * MV_HIDDEN) + c) = l8;
-          *(uint32_t*)(x8 + (size_t)t * (2 * MV_HIDDEN) + MV_HIDDEN + c) = h8;
-        }
       } else {
         *(float4*)(x32 + (size_t)t * MV_HIDDEN + c) = x[i];
       }
     }
+    x8_sat_flush(x8_sat, sat);
   } else {
+    (void)sat;
     ln_row_store<true>(x, gamma, beta, eps, lane, x32 + (size_t)t * MV_HIDDEN, x16 + (size_t)t * MV_HIDDEN, nullptr);
     // the embedding output IS the normalised stream: identity statistics for a PP_RESLN consumer (with gamma = 1, beta = 0)
     if (stats && lane == 0) {
@@ -152,14 +155,31 @@ __global__ __launch_bounds__(256) void ln_kernel(float* __restrict__ x32, half_t
   ln_row_store<W32>(x, gamma, beta, eps, lane, row, x16 + (size_t)t * MV_HIDDEN, W32 ? nullptr : stats + 2 * (size_t)t);
 }
 
+// four lo8 bytes (one dword of the stream's lo8 plane, MV_F16X8) -> the fp32 residuals they stand for
+__device__ __forceinline__ float4 x8_lo4(uint32_t l8) {
+  constexpr float SLO = 1.0f / (float)(2048 << MV_X8_ACT_SHIFT);
+  const float2_t a = __builtin_amdgcn_cvt_scalef32_pk_f32_fp8(l8, 1.0f, false), b = __builtin_amdgcn_cvt_scalef32_pk_f32_fp8(l8, 1.0f, true);
+  float4 y;
+  y.x = a.x * SLO; y.y = a.y * SLO; y.z = b.x * SLO; y.w = b.y * SLO;
+  return y;
+}
+
 // Two-plane raw stream -> fp32 rows (only the un-pruned last layer needs them: its final LayerNorm kernel reads fp32).
-__global__ __launch_bounds__(256) void hilo_to_f32_kernel(const half_t* __restrict__ hi, const half_t* __restrict__ lo, size_t n4,
-                                                          float* __restrict__ out) {
+// MV_F16: lo = the lo fp16 plane; MV_F16X8: x8 = the stream's [lo8 | hi8] planes (rows of 1536 bytes), lo = nullptr.
+__global__ __launch_bounds__(256) void hilo_to_f32_kernel(const half_t* __restrict__ hi, const half_t* __restrict__ lo,
+                                                          const uint8_t* __restrict__ x8, size_t n4, float* __restrict__ out) {
   const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= n4) return;
-  const half4_t h = *(const half4_t*)(hi + 4 * i), l = *(const half4_t*)(lo + 4 * i);
+  const half4_t h = *(const half4_t*)(hi + 4 * i);
   float4 y;
-  y.x = (float)h[0] + (float)l[0]; y.y = (float)h[1] + (float)l[1]; y.z = (float)h[2] + (float)l[2]; y.w = (float)h[3] + (float)l[3];
+  if (x8) {
+    const size_t t = (4 * i) / MV_HIDDEN, c = (4 * i) - t * MV_HIDDEN;
+    y = x8_lo4(*(const uint32_t*)(x8 + t * (2 * MV_HIDDEN) + c));
+    y.x += (float)h[0]; y.y += (float)h[1]; y.z += (float)h[2]; y.w += (float)h[3];
+  } else {
+    const half4_t l = *(const half4_t*)(lo + 4 * i);
+    y.x = (float)h[0] + (float)l[0]; y.y = (float)h[1] + (float)l[1]; y.z = (float)h[2] + (float)l[2]; y.w = (float)h[3] + (float)l[3];
+  }
   *(float4*)(out + 4 * i) = y;
 }
 
@@ -171,7 +191,8 @@ __global__ __launch_bounds__(256) void cls_gather_kernel(const float* __restrict
                                                          int B, const float* __restrict__ stats,
                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
                                                          float* __restrict__ c32, half_t* __restrict__ c16, int raw16,
-                                                         const half_t* __restrict__ xlo, int vstats, float eps) {
+                                                         const half_t* __restrict__ xlo, int vstats, float eps,
+                                                         const uint8_t* __restrict__ x8 = nullptr) {
 #pragma clang fp contract(off)
   const int lane = threadIdx.x & 63;
   const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -189,7 +210,11 @@ __global__ __launch_bounds__(256) void cls_gather_kernel(const float* __restrict
   for (int i = 0; i < 3; ++i) {
     const int c = 4 * lane + 256 * i;
     float4 y;
-    if (xlo) {  // two-plane raw stream: r = hi + lo
+    if (x8) {  // MV_F16X8: r = hi + the lo8 plane of the stream's fp8 planes
+      const half4_t hh = *(const half4_t*)(x16 + t * MV_HIDDEN + c);
+      y = x8_lo4(*(const uint32_t*)(x8 + t * (2 * MV_HIDDEN) + c));
+      y.x += (float)hh[0]; y.y += (float)hh[1]; y.z += (float)hh[2]; y.w += (float)hh[3];
+    } else if (xlo) {  // two-plane raw stream: r = hi + lo
       const half4_t hh = *(const half4_t*)(x16 + t * MV_HIDDEN + c), ll = *(const half4_t*)(xlo + t * MV_HIDDEN + c);
       y.x = (float)hh[0] + (float)ll[0]; y.y = (float)hh[1] + (float)ll[1];
       y.z = (float)hh[2] + (float)ll[2]; y.w = (float)hh[3] + (float)ll[3];

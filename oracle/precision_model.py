@@ -10,6 +10,9 @@ rounding function at exactly the tensors the engine rounds:
   ``p``                      softmax probabilities as the A operand of P·V
   ``ctx``                    attention context (A operand of the output projection)
   ``h``                      GELU output (A operand of FFN-2)
+  ``res``                    the raw residual stream AS STORED between the residual GEMMs (what the next residual add and its
+                             LayerNorm read back; the row statistics are taken from the fp32 accumulators before the store):
+                             "f16x2" = hi + lo fp16 planes (rounds 1-4), "f16x8" = hi fp16 + the lo8 plane of MV_F16X8 (round 5)
 
 Each knob is a per-layer list of formats: ``"f16"``, ``"f16x2"`` (hi + lo split, 22 bits), ``"bf16"``, ``"bf16x2"``,
 ``"bf16x3"``, ``"exact"``, ``"f16x8"`` (the MV_F16X8 planes; as an A-operand format ``"f16x8w"`` = only the weight-side term swept,
@@ -113,13 +116,14 @@ FORMATS = {
 # sweeps the A-side term in its Q block only (the weight-side term everywhere)
 X8_ENGINE = dict(w_qkv="f16x8", w_o="f16x8", w_1="f16x8", w_2="f16x8", a_qkv="f16x8q", a_ffn1="f16x8", ctx="f16x8", h="f16x8")
 
-KNOBS = ("w_qkv", "w_o", "w_1", "w_2", "a_qkv", "a_ffn1", "qkv", "p", "ctx", "h")
+KNOBS = ("w_qkv", "w_o", "w_1", "w_2", "a_qkv", "a_ffn1", "qkv", "p", "ctx", "h", "res")
 
 
 def engine_formats(layers: int, fmt: str = "f16", **override) -> Dict[str, List[str]]:
     """The engine's shipped rounding points (every knob ``fmt`` in every layer) with per-knob overrides: a format
     name (all layers) or a list of per-layer names."""
     cfg = {k: [fmt] * layers for k in KNOBS}
+    cfg["res"] = ["exact"] * layers  # (the two-plane fp16 stream is exact at this model's resolution: 2^-22)
     for k, v in override.items():
         cfg[k] = [v] * layers if isinstance(v, str) else list(v)
     return cfg
@@ -184,13 +188,13 @@ def encode(w, ids, mask, cfg: Optional[Dict[str, List[str]]], heads=12, eps=1e-1
         den = e.sum(-1, keepdims=True)
         ctx = ((R("p", l, e) @ vh) / den).transpose(0, 2, 1, 3).reshape(B, S, H)  # the engine normalises O after P·V
         mu, rstd = _ln_stats(r, eps)
-        x = (r - mu) * rstd * g + b
+        x = (R("res", l, r) - mu) * rstd * g + b  # the residual GEMM reads the STORED stream; its statistics come from the accumulators
         r1 = _mm(cfg["ctx"][l], cfg["w_o"][l], ctx, W(p + "attention.output.dense.weight")) + W(p + "attention.output.dense.bias") + x
         g1, b1 = W(p + "attention.output.LayerNorm.weight"), W(p + "attention.output.LayerNorm.bias")
         hpre = consumer(r1, g1, b1, W(p + "intermediate.dense.weight"), W(p + "intermediate.dense.bias"), "w_1", "a_ffn1", l)
         h = orc._gelu(hpre)
         mu, rstd = _ln_stats(r1, eps)
-        x1 = (r1 - mu) * rstd * g1 + b1
+        x1 = (R("res", l, r1) - mu) * rstd * g1 + b1
         r = _mm(cfg["h"][l], cfg["w_2"][l], h, W(p + "output.dense.weight")) + W(p + "output.dense.bias") + x1
         if cls_side and l >= cls_from_layer:
             mu, rstd = _ln_stats(rc, eps)

@@ -1,0 +1,55 @@
+"""Round 5 (VERDICT r4 next #1 "done" criterion): the trained-like logit error of the SHIPPED compute dtypes over >= 20 independent draws
+(weights, issue reports, anchors by seed; scripts/r05_make_refs.py holds the case definition and made the CPU references committed as
+tests/golden/r05_trained_like_refs.npz: oracle/hf_reference.py, fp32 torch).  GPU side only: build the seed's weights, run the engine, compare.
+Prints one row per seed and the distribution; also the saturation counter of the precise mode (mv_x8_saturation).
+Usage: python scripts/r05_error_distribution.py [--f16-seeds N] [--lib-tag TAG]"""
+import argparse
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "scripts"))
+from memvul_amd import synth  # noqa: E402
+from memvul_amd.binding import Engine  # noqa: E402
+import r05_make_refs as mk  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--f16-seeds", type=int, default=6, help="also run MV_F16 on the first N seeds")
+ap.add_argument("--seeds", type=int, default=len(mk.SEEDS))
+ap.add_argument("--json", default="")
+args = ap.parse_args()
+refs = np.load(mk.OUT)
+rows = []
+for n, seed in enumerate(mk.SEEDS[:args.seeds]):
+    key = f"seed_{seed}"
+    if key not in refs:
+        print("no reference for seed", seed, "(scripts/r05_make_refs.py)")
+        continue
+    lg = refs[key]
+    dims, ids, lens, aids, alens = mk.case_inputs(seed)
+    w = synth.make_weights(dims, seed=seed, qk_scale=2.0, match_scale=29.0, trained_like=True)
+    LA = int(alens.max())
+    errs, sat = {}, 0
+    for mode in (("precise", "f16") if n < args.f16_seeds else ("precise",)):
+        e = Engine(0, vocab_size=dims.vocab_size, layers=12, max_tokens=16 * 512, max_batch=16, max_anchors=16)
+        e.load_state_dict(w, mode)
+        e.anchor_append(aids[:, :LA], alens)
+        o = e.forward(ids, lens)
+        errs[mode] = float(np.abs(o["logits"] - lg).max())
+        if mode == "precise":
+            sat = e.x8_saturation()
+        e.close()
+    rows.append(dict(seed=seed, max_abs_logit=float(np.abs(lg).max()), precise=errs["precise"], f16=errs.get("f16"), x8_saturated=sat))
+    print("seed %d: max |logit| %.2f  precise %.2e  f16 %s  clamped %d" % (seed, rows[-1]["max_abs_logit"], errs["precise"],
+                                                                           "%.2e" % errs["f16"] if "f16" in errs else "-", sat), flush=True)
+pr = np.array([r["precise"] for r in rows])
+f = np.array([r["f16"] for r in rows if r["f16"] is not None])
+print("precise over %d draws: min %.2e  median %.2e  p90 %.2e  max %.2e" % (len(pr), pr.min(), np.median(pr), np.quantile(pr, 0.9), pr.max()))
+if len(f):
+    print("f16 over %d draws: min %.2e  median %.2e  max %.2e" % (len(f), f.min(), np.median(f), f.max()))
+if args.json:
+    json.dump(rows, open(args.json, "w"), indent=1)
