@@ -46,7 +46,6 @@ __global__ __launch_bounds__(NKB * 128) __attribute__((amdgpu_waves_per_eu(2, 2)
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int hi = lane >> 5, ql = lane & 31;
-  int x8_sat = 0;  // MV_F16X8: context elements beyond the fp8 planes' range (wave-uniform count: an SGPR)
 
   // ---- LDS-DMA geometry: wave w moves K pieces 4w..4w+3 and V^T pieces 4w..4w+3 of a chunk (1 KiB = 8 rows x 128 B)
   uint32_t srcK[2], srcV[2];  // per-lane byte offsets inside the chunk's K / V^T block for even / odd pieces
@@ -312,6 +311,7 @@ __global__ __launch_bounds__(NKB * 128) __attribute__((amdgpu_waves_per_eu(2, 2)
       if (j == NCH - 1) {
         const auto sw = __builtin_amdgcn_permlane32_swap(f2u(l_run), f2u(l_run), false, false);
         const float inv = 1.0f / (u2f(sw[0]) + u2f(sw[1]));
+        float vmax8 = 0.f;  // MV_F16X8: max |context value| of the unit (saturation accounting, common.h)
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
@@ -319,14 +319,27 @@ __global__ __launch_bounds__(NKB * 128) __attribute__((amdgpu_waves_per_eu(2, 2)
             const float x0 = o[dt][4 * rg + 0] * inv, x1 = o[dt][4 * rg + 1] * inv, x2 = o[dt][4 * rg + 2] * inv, x3 = o[dt][4 * rg + 3] * inv;
             opk[dt][rg][0] = pack_h2(x0, x1);
             opk[dt][rg][1] = pack_h2(x2, x3);
-            if constexpr (X8) x8_planes4(x0, x1, x2, x3, op8[dt][rg][1], op8[dt][rg][0], x8_sat);
+            if constexpr (X8) {
+              x8_planes4(x0, x1, x2, x3, op8[dt][rg][1], op8[dt][rg][0]);
+              vmax8 = x8_absmax4(vmax8, x0, x1, x2, x3);
+            }
           }
+        if constexpr (X8) {
+          if (x8_any_out_of_range(vmax8)) {  // rare: count exactly
+            int n = 0;
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+              for (int rg = 0; rg < 4; ++rg)
+                n += x8_count4(o[dt][4 * rg + 0] * inv, o[dt][4 * rg + 1] * inv, o[dt][4 * rg + 2] * inv, o[dt][4 * rg + 3] * inv);
+            x8_sat_add(a.x8_sat, n);
+          }
+        }
         prev = unit;
       }
     }
   }
   // ---- last unit's O: the K half of the slot no DMA was issued into (nothing reads it any more)
   flush_o(prev, smem + pb * BUF);
-  if constexpr (X8) x8_sat_flush(a.x8_sat, x8_sat);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // no LDS-DMA may outlive the workgroup's LDS allocation
 }

@@ -34,22 +34,32 @@ __device__ __forceinline__ uint32_t pack_fp8x4_scaled(float a, float b, float c,
 // four consecutive values -> (hi8 dword, lo8 dword).  ONE clamp per value (to +-448 / 2^shift = +-112) serves both planes: the
 // rounding residual of a clamped value c is at most 2^-5 (c below 128), i.e. 2^8 after the lo plane's 2^(11 + shift) — inside
 // e4m3's range — and a clamped-away value (exactly +-112, representable) has residual 0: it loses its correction term, nothing else.
-// `sat` (wave-uniform, lives in an SGPR: v_cmp -> s_bcnt1 -> s_add, no vector register) counts the elements the clamp changed: an
-// element beyond +-112 keeps fp16 accuracy but loses its correction term — silently, unless somebody counts (mv_x8_saturation).
-__device__ __forceinline__ void x8_planes4(float v0, float v1, float v2, float v3, uint32_t& hi8, uint32_t& lo8, int& sat) {
+__device__ __forceinline__ void x8_planes4(float v0, float v1, float v2, float v3, uint32_t& hi8, uint32_t& lo8) {
   constexpr float SH = 1.0f / (float)(1 << MV_X8_ACT_SHIFT), SL = 1.0f / (float)(2048 << MV_X8_ACT_SHIFT), BOUND = 448.f * SH;
-  sat += __builtin_popcountll(__builtin_amdgcn_ballot_w64(__builtin_fabsf(v0) > BOUND)) + __builtin_popcountll(__builtin_amdgcn_ballot_w64(__builtin_fabsf(v1) > BOUND)) +
-         __builtin_popcountll(__builtin_amdgcn_ballot_w64(__builtin_fabsf(v2) > BOUND)) + __builtin_popcountll(__builtin_amdgcn_ballot_w64(__builtin_fabsf(v3) > BOUND));
   v0 = __builtin_amdgcn_fmed3f(v0, -BOUND, BOUND); v1 = __builtin_amdgcn_fmed3f(v1, -BOUND, BOUND);
   v2 = __builtin_amdgcn_fmed3f(v2, -BOUND, BOUND); v3 = __builtin_amdgcn_fmed3f(v3, -BOUND, BOUND);
   hi8 = pack_fp8x4_scaled(v0, v1, v2, v3, SH);
   lo8 = pack_fp8x4_scaled(v0 - (float)(half_t)v0, v1 - (float)(half_t)v1, v2 - (float)(half_t)v2, v3 - (float)(half_t)v3, SL);
 }
-// a wave's share of the saturation count -> the handle's device counter (one atomic per wave that saw any; never in the common case)
-__device__ __forceinline__ void x8_sat_flush(unsigned int* counter, int sat) {
-  if (counter && sat) {
-    if ((threadIdx.x & 63) == 0) atomicAdd(counter, (unsigned int)sat);
-  }
+// Saturation accounting (mv_x8_saturation): an element beyond +-112 keeps fp16 accuracy but loses its correction term — silently,
+// unless somebody counts.  The producers fold |v| of everything they convert into ONE per-lane running maximum (two v_max3_f32 per
+// four values, no scalar state: a first form that counted with v_cmp + s_bcnt1 per value cost the FFN-1 epilogue 30 us in SGPR spills)
+// and test it once per block of values; only a block that holds an out-of-range element (never, on the models measured) is
+// re-counted exactly and added to the handle's device counter.
+#define MV_X8_ACT_BOUND (448.f / (float)(1 << MV_X8_ACT_SHIFT))
+__device__ __forceinline__ float x8_absmax4(float m, float v0, float v1, float v2, float v3) {
+  m = __builtin_fmaxf(__builtin_fmaxf(m, __builtin_fabsf(v0)), __builtin_fabsf(v1));
+  return __builtin_fmaxf(__builtin_fmaxf(m, __builtin_fabsf(v2)), __builtin_fabsf(v3));
+}
+__device__ __forceinline__ bool x8_any_out_of_range(float m) { return __builtin_amdgcn_ballot_w64(m > MV_X8_ACT_BOUND) != 0; }
+__device__ __forceinline__ int x8_count4(float v0, float v1, float v2, float v3) {  // wave-wide count (the rare path)
+  return __builtin_popcountll(__builtin_amdgcn_ballot_w64(__builtin_fabsf(v0) > MV_X8_ACT_BOUND)) +
+         __builtin_popcountll(__builtin_amdgcn_ballot_w64(__builtin_fabsf(v1) > MV_X8_ACT_BOUND)) +
+         __builtin_popcountll(__builtin_amdgcn_ballot_w64(__builtin_fabsf(v2) > MV_X8_ACT_BOUND)) +
+         __builtin_popcountll(__builtin_amdgcn_ballot_w64(__builtin_fabsf(v3) > MV_X8_ACT_BOUND));
+}
+__device__ __forceinline__ void x8_sat_add(unsigned int* counter, int n) {
+  if (counter && n && (threadIdx.x & 63) == 0) atomicAdd(counter, (unsigned int)n);
 }
 
 // Sum / max over the 64 lanes of a wave (all lanes receive the result).

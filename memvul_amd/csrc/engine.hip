@@ -184,6 +184,8 @@ struct mv_handle {
   bool cls_prune = true;   // env MEMVUL_CLS_PRUNE=0 disables
   int pp_gn_max = 4;       // raster group width cap of the persistent GEMM (env MEMVUL_GN_MAX: the A/B of profiles/r04_*)
   int pp_raster = 0;       // env MEMVUL_RASTER=1: the A-stationary raster where it applies (FFN-1, QKV at full-size grids)
+  bool stream_lo8 = false; // MV_F16X8, env MEMVUL_STREAM_LO8=1: the raw residual stream as hi fp16 + the lo8 plane of its fp8 planes (no lo fp16 plane;
+                           // gemm_pp.h X8 = 2): +1.5 % issue reports/s at 1.2x the trained-like logit error (profiles/r05_a_*) — opt-in
   int qkv_aside_mask = 1;  // MV_F16X8: which of the Q / K / V blocks of the QKV projection sweep the A-side correction term too (bit 0 / 1 / 2;
                            // gemm_pp.h x8_aside_mask).  Default: Q only.  env MEMVUL_QKV_ASIDE = a subset of "qkv" ("" / "none" = weight-side
                            // term only everywhere, "qkv" = round 3's form): the A/B switch of profiles/r04_d_*
@@ -363,6 +365,12 @@ int launch_pp(mv_handle* h, int cls, GemmArgs a) {
   ProfScope ps(h, cls);
   if (a.A8) {
     if (!a.W8 || (PPEPI != PP_QK && !a.out8)) return fail(h, MV_ERR_STATE, "internal: MV_F16X8 GEMM without its fp8 planes");
+    if constexpr (PPEPI == PP_RESLN3) {
+      if (!a.out16b) {  // the lo8 stream: no lo fp16 plane, the residual's low part is out8's lo8 plane
+        hipLaunchKernelGGL((gemm_pp_kernel<PPEPI, RAW, 2>), dim3(grid), dim3(512), lds, h->w->stream, a);
+        return launch_check(h, "gemm_pp");
+      }
+    }
     hipLaunchKernelGGL((gemm_pp_kernel<PPEPI, RAW, 1>), dim3(grid), dim3(512), lds, h->w->stream, a);
   } else {
     hipLaunchKernelGGL((gemm_pp_kernel<PPEPI, RAW, 0>), dim3(grid), dim3(512), lds, h->w->stream, a);
@@ -452,14 +460,15 @@ int encode_dev(mv_handle* h, const int32_t* d_ids, const int32_t* d_lens, int B,
   h->dbg_Sp = Sp;
   const bool big = pp_selected(h, Mpad);  // persistent GEMMs, raw two-plane stream (x16 = hi, xlo = lo), virtual LayerNorm
   const bool x8 = h->precise;             // MV_F16X8: + fp8 correction sweeps (forces the persistent path, pp_selected)
+  const bool lo8s = x8 && h->stream_lo8;  // the stream's low part is the lo8 plane of x8 (no xlo plane)
   const bool prune = !full && h->cls_prune && u_out && n_layers == c.layers && n_layers > 0;
   const unsigned ln_grid = (unsigned)((M + 3) / 4);
   {
     ProfScope ps(h, KC_EMBED_LN);
     if (big)
       hipLaunchKernelGGL(embed_ln_kernel<true>, dim3(ln_grid), dim3(256), 0, h->w->stream, d_ids, pitch, S_in, Sp, (int)M, c.vocab_size,
-                         h->wemb, h->pemb, h->temb, h->embg, h->embb, c.ln_eps, h->w->xres, h->w->x16, h->w->lnstats, h->w->xlo,
-                         x8 ? h->w->x8 : (uint8_t*)nullptr, h->x8_sat);
+                         h->wemb, h->pemb, h->temb, h->embg, h->embb, c.ln_eps, h->w->xres, h->w->x16, h->w->lnstats,
+                         lo8s ? (half_t*)nullptr : h->w->xlo, x8 ? h->w->x8 : (uint8_t*)nullptr, h->x8_sat);
     else
       hipLaunchKernelGGL(embed_ln_kernel<false>, dim3(ln_grid), dim3(256), 0, h->w->stream, d_ids, pitch, S_in, Sp, (int)M, c.vocab_size,
                          h->wemb, h->pemb, h->temb, h->embg, h->embb, c.ln_eps, h->w->xres, h->w->x16, (float*)nullptr,
@@ -476,8 +485,8 @@ int encode_dev(mv_handle* h, const int32_t* d_ids, const int32_t* d_lens, int B,
   };
   auto final_ln = [&](const float* g, const float* b) -> int {  // two-plane raw stream -> normalised fp32 rows (pooler / debug taps)
     const size_t n4 = (size_t)M * MV_HIDDEN / 4;
-    hipLaunchKernelGGL(hilo_to_f32_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, h->w->stream, h->w->x16, x8 ? (const half_t*)nullptr : h->w->xlo,
-                       x8 ? (const uint8_t*)h->w->x8 : (const uint8_t*)nullptr, n4, h->w->xres);
+    hipLaunchKernelGGL(hilo_to_f32_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, h->w->stream, h->w->x16, lo8s ? (const half_t*)nullptr : h->w->xlo,
+                       lo8s ? (const uint8_t*)h->w->x8 : (const uint8_t*)nullptr, n4, h->w->xres);
     if (int rc = launch_check(h, "hilo_to_f32")) return rc;
     return run_ln(h->w->xres, h->w->x16, (int)M, g, b);
   };
@@ -509,7 +518,7 @@ int encode_dev(mv_handle* h, const int32_t* d_ids, const int32_t* d_lens, int B,
       auto tail_rc = [&]() -> int {
         hipLaunchKernelGGL(cls_gather_kernel, dim3((B + 3) / 4), dim3(256), 0, h->w->stream, h->w->xres, h->w->x16, Sp, B,
                            big ? st_in : (const float*)nullptr, pend_g, pend_b, h->w->c32, h->w->c16, big ? 1 : 0,
-                           big ? h->w->xlo : (const half_t*)nullptr, big ? 1 : 0, c.ln_eps, x8 ? (const uint8_t*)h->w->x8 : (const uint8_t*)nullptr);
+                           big ? h->w->xlo : (const half_t*)nullptr, big ? 1 : 0, c.ln_eps, lo8s ? (const uint8_t*)h->w->x8 : (const uint8_t*)nullptr);
         if (int rc = launch_check(h, "cls_gather")) return rc;
         if (x8) {
           // MV_F16X8: the B [CLS] rows in full fp32 on the fp32-input matrix cores (their operand rounding would reach the
@@ -564,7 +573,7 @@ int encode_dev(mv_handle* h, const int32_t* d_ids, const int32_t* d_lens, int B,
       if (int rc = launch_attention(h, d_lens, B, Sp, x8)) return rc;
       // K4: attention output projection + bias + LayerNorm(residual), in place on the raw stream; + vstats of the new rows
       g.A = h->w->ctx; g.W = w.wo; g.bias = w.bo; g.N = MV_HIDDEN; g.K = MV_HIDDEN;
-      g.lnstats = st_in; g.lng = pend_g; g.lnb = pend_b; g.lnpart = st_mid; g.out16 = h->w->x16; g.out16b = h->w->xlo;
+      g.lnstats = st_in; g.lng = pend_g; g.lnb = pend_b; g.lnpart = st_mid; g.out16 = h->w->x16; g.out16b = lo8s ? (half_t*)nullptr : h->w->xlo;
       if (x8) { g.A8 = h->w->ctx8; g.W8 = w.wo8; g.x8_scale = w.sc_o; g.out8 = h->w->x8; g.x8_terms = 2; }
       if (int rc = launch_pp<PP_RESLN3>(h, KC_GEMM_OUT, g)) return rc;
       pend_g = w.ln1g; pend_b = w.ln1b;
@@ -575,7 +584,7 @@ int encode_dev(mv_handle* h, const int32_t* d_ids, const int32_t* d_lens, int B,
       if (int rc = launch_pp<PP_GELU>(h, KC_GEMM_FFN1, g)) return rc;
       // K6: FFN-2 + bias + LayerNorm(residual)
       g.A = h->w->h16; g.W = w.w2; g.bias = w.b2; g.N = MV_HIDDEN; g.K = MV_INTER;
-      g.lnstats = st_mid; g.lng = pend_g; g.lnb = pend_b; g.lnpart = st_in; g.out16 = h->w->x16; g.out16b = h->w->xlo;
+      g.lnstats = st_mid; g.lng = pend_g; g.lnb = pend_b; g.lnpart = st_in; g.out16 = h->w->x16; g.out16b = lo8s ? (half_t*)nullptr : h->w->xlo;
       if (x8) { g.A8 = h->w->h8; g.W8 = w.w28; g.x8_scale = w.sc_2; g.out8 = h->w->x8; g.x8_terms = 2; }  // (the lo8 plane is the stream's own lo since round 5: always written)
       if (int rc = launch_pp<PP_RESLN3>(h, KC_GEMM_FFN2, g)) return rc;
       pend_g = w.ln2g; pend_b = w.ln2b;
@@ -841,6 +850,7 @@ int mv_create(int device, const mv_config* cfg, mv_handle** out) try {
   hipFuncSetAttribute((const void*)gemm_pp_kernel<PP_QK, 1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS_BYTES_RAW);
   hipFuncSetAttribute((const void*)gemm_pp_kernel<PP_GELU, 1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS_BYTES_RAW);
   hipFuncSetAttribute((const void*)gemm_pp_kernel<PP_RESLN3, 0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS_BYTES);
+  hipFuncSetAttribute((const void*)gemm_pp_kernel<PP_RESLN3, 0, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS_BYTES);
 #define MV_ATT_ATTR(NKB, NCH)                                                                                                     \
   hipFuncSetAttribute((const void*)attention_v2_kernel<NKB, NCH, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT2_LDS_BYTES(NKB)); \
   hipFuncSetAttribute((const void*)attention_v2_kernel<NKB, NCH, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT2_LDS_BYTES(NKB))
@@ -862,6 +872,7 @@ int mv_create(int device, const mv_config* cfg, mv_handle** out) try {
       }
     }
   }
+  if (const char* e = getenv("MEMVUL_STREAM_LO8")) h->stream_lo8 = atoi(e) == 1;
   if (const char* e = getenv("MEMVUL_GN_MAX")) { const int v = atoi(e); if (v >= 1 && v <= 12) h->pp_gn_max = v; }
   if (const char* e = getenv("MEMVUL_RASTER")) h->pp_raster = atoi(e) == 1 ? 1 : 0;
   {

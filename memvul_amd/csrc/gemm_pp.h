@@ -236,6 +236,9 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmArgs a) {
   static_assert(EPI == PP_QK || EPI == PP_GELU || EPI == PP_RESLN3, "kernel kinds of the encoder layer");
   static_assert(RAW == (EPI != PP_RESLN3), "PP_QK / PP_GELU consume the raw stream (virtual LayerNorm), PP_RESLN3 produces it");
   constexpr bool IS_RES = (EPI == PP_RESLN3);
+  // X8 == 2 (PP_RESLN3 only; MEMVUL_STREAM_LO8=1): the raw stream is hi fp16 + the lo8 plane of its fp8 planes instead of hi + lo fp16
+  static_assert(X8 < 2 || IS_RES, "X8 = 2 selects the lo8 residual stream of the residual GEMMs");
+  constexpr bool LO8S = (X8 == 2);
   constexpr int WAITN = 2 * PP_F;
   constexpr int LDS_SCR = RAW ? PP_LDS_SCR_RAW : PP_LDS_SCR;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -259,7 +262,6 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmArgs a) {
     const int which = (tn * 256 + a.col0) / MV_HIDDEN;  // 0 = Q, 1 = K, 2 = V
     return (a.x8_aside_mask >> which) & 1;
   };
-  int x8_sat = 0;              // elements of this wave's outputs beyond the fp8 planes' range (common.h x8_planes4; wave-uniform -> an SGPR)
   int i_nk8 = X8 ? nk0 : 0;    // of the tile being STAGED (issue cursor)
   size_t i_off8 = 0;
   const int tm_count = a.M >> 8, tn_count = a.N >> 8;
@@ -402,10 +404,12 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmArgs a) {
   // the two fp16 planes of the 32 x 32 block i (token rows) x j (columns) of the residual tile at (mw0, nw0) by full-line loads
   // (16 rows x 64 B per instruction), parked in the four accumulators of that block: acc[2 i + pl][2 j + x] = plane pl (hi, lo),
   // rows crow + 16 x — the accumulator init transposes them into the C/D layout
-  // MV_F16X8 (round 5): the stream is hi fp16 + the lo8 plane of its fp8 planes (out8: rows [lo8 (768) | hi8 (768)]) — the SAME bytes the
-  // next consumer's correction sweep reads as A_lo8, so the stream has no lo fp16 plane of its own: r ~= hi + lo8 2^-(11 + shift)
-  // (2^-15 of the element instead of 2^-22; oracle/precision_model.py knob "res": +1.2e-4 on trained-like logits on its own, lost in
-  // the 3e-4 of the fp16 Q / K / V / P storage).  The lo8 lines (16 rows x 32 B per instruction) park in registers 0, 1 of the lo slot.
+  // LO8S (X8 = 2; round 5, opt-in MEMVUL_STREAM_LO8=1): the stream is hi fp16 + the lo8 plane of its fp8 planes (out8: rows
+  // [lo8 (768) | hi8 (768)]) — the SAME bytes the next consumer's correction sweep reads as A_lo8, so the stream has no lo fp16 plane of
+  // its own: r ~= hi + lo8 2^-(11 + shift), 2^-15 of the element instead of 2^-22.  Measured (profiles/r05_a_*): output projection
+  // 231 -> 219 us, FFN-2 563 -> 549 us, embedding 97 -> 77 us (+1.5 % issue reports/s) for trained-like logit errors 2.4 .. 6.3e-4 over 24
+  // draws against 2.3 .. 4.8e-4 (median 3.5 against 3.0e-4): not the default.  The lo8 lines (16 rows x 32 B per instruction) park in
+  // registers 0, 1 of the lo slot.
   auto park_residual = [&](int i, int mw0, int nw0) {
     const int crow = lane >> 2, cchunk = lane & 3;
 #pragma unroll
@@ -415,7 +419,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmArgs a) {
 #pragma unroll
         for (int x = 0; x < 2; ++x) {
           const size_t row = (size_t)(mw0 + i * 32 + x * 16 + crow);
-          if constexpr (X8) {
+          if constexpr (LO8S) {
             if (pl) {
               const float2 t = *(const float2*)(a.out8 + row * (2 * MV_HIDDEN) + nw0 + j * 32 + 8 * cchunk);
               acc[2 * i + 1][2 * j + x][0] = t.x; acc[2 * i + 1][2 * j + x][1] = t.y;
@@ -605,7 +609,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmArgs a) {
               for (int e = 0; e < 4; ++e) p[qq][e] = f2u(acc[2 * i + (qq >> 1)][2 * j + (qq & 1)][e]);
             u32x2 oh[4], ol[4];  // unit k = 2 tbl + cbl
             uint32_t ol8[4];     // MV_F16X8: the unit's four lo8 bytes
-            if constexpr (X8) {
+            if constexpr (LO8S) {
               const u32x2 l0 = {p[2][0], p[2][1]}, l1 = {p[3][0], p[3][1]};
               scr_f16_lo8_rev(scr_c, p[0], p[1], l0, l1, u00, u01, u00 + 1024u, u01 + 1024u, scr + (uint32_t)lane * 8u,
                               scr + (uint32_t)m16 * 32u + (uint32_t)q4 * 4u, oh, ol8);
@@ -618,7 +622,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmArgs a) {
               float4 bi, ga, be;
               lds_read_bgb1(baddr + (2 * j + cbl) * 64, bi, ga, be);
               float2_t lf01, lf23;  // MV_F16X8: e4m3 -> fp32 of the four lo8 bytes (the plane's 2^(11 + shift) pre-scale is undone in the add)
-              if constexpr (X8) {
+              if constexpr (LO8S) {
                 lf01 = __builtin_amdgcn_cvt_scalef32_pk_f32_fp8(ol8[k], 1.0f, false);
                 lf23 = __builtin_amdgcn_cvt_scalef32_pk_f32_fp8(ol8[k], 1.0f, true);
               }
@@ -627,7 +631,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmArgs a) {
                 const uint32_t wh = oh[k][e >> 1];  // scalar copies before the bit casts (see f2u)
                 const half2_t h2 = __builtin_bit_cast(half2_t, wh);
                 float r;
-                if constexpr (X8) {
+                if constexpr (LO8S) {
                   constexpr float SLO = 1.0f / (float)(2048 << MV_X8_ACT_SHIFT);
                   const float lo = (e == 0) ? lf01.x : (e == 1) ? lf01.y : (e == 2) ? lf23.x : lf23.y;
                   r = (float)h2[e & 1] + lo * SLO;  // (the product is exact: a power-of-two scale)
@@ -846,7 +850,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmArgs a) {
               *(u32x4*)(op + 16 * rstride) = o[2 * j + 1];
             }
           }
-          if constexpr (IS_RES && !X8) {  // second plane: lo = fp16(r - hi), same addresses in the lo buffer (MV_F16X8: the lo8 plane below IS the stream's lo)
+          if constexpr (IS_RES && !LO8S) {  // second plane: lo = fp16(r - hi), same addresses in the lo buffer (LO8S: the lo8 plane below IS the stream's lo)
 #pragma unroll
             for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -869,6 +873,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmArgs a) {
             // MV_F16X8: the [lo8 | hi8] planes of this output (the A8 operand of the next GEMM's correction sweep): rows of
             // 2 N bytes, lo8 of column n at byte n, hi8 at byte N + n; one 16-B store per lane, plane and 16-row half
             uint32_t dl[8], dh[8];  // [4 tbl + 2 j + cbl]: the dword of token 16 tbl + m16, columns 32 j + 16 cbl + 4 q4 .. + 3
+            float vmax8 = 0.f;      // max |value| of the block (saturation accounting, common.h)
             const uint32_t w8 = ub8 + (sf << 4);
             uint8_t* o8 = a.out8 + (size_t)(mb + crow) * (2 * a.N) + nw + 16 * cchunk;
 #pragma unroll
@@ -878,8 +883,17 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmArgs a) {
 #pragma unroll
                 for (int cbl = 0; cbl < 2; ++cbl) {
                   const int tb = 2 * i + tbl, cb = 2 * j + cbl;
-                  x8_planes4(acc[tb][cb][0], acc[tb][cb][1], acc[tb][cb][2], acc[tb][cb][3], dh[4 * tbl + 2 * j + cbl], dl[4 * tbl + 2 * j + cbl], x8_sat);
+                  x8_planes4(acc[tb][cb][0], acc[tb][cb][1], acc[tb][cb][2], acc[tb][cb][3], dh[4 * tbl + 2 * j + cbl], dl[4 * tbl + 2 * j + cbl]);
+                  vmax8 = x8_absmax4(vmax8, acc[tb][cb][0], acc[tb][cb][1], acc[tb][cb][2], acc[tb][cb][3]);
                 }
+            if (x8_any_out_of_range(vmax8)) {  // rare (never on the models measured): count this block's out-of-range elements exactly
+              int n = 0;
+#pragma unroll
+              for (int tbl = 0; tbl < 2; ++tbl)
+#pragma unroll
+                for (int cb = 0; cb < 4; ++cb) n += x8_count4(acc[2 * i + tbl][cb][0], acc[2 * i + tbl][cb][1], acc[2 * i + tbl][cb][2], acc[2 * i + tbl][cb][3]);
+              x8_sat_add(a.x8_sat, n);
+            }
             scr_f8x2(w8, w8 ^ 16u, w8 ^ 32u, w8 ^ 48u, dl, dh, scr_c, o);
             *(u32x4*)o8 = o[0];
             *(u32x4*)(o8 + (size_t)16 * (2 * a.N)) = o[1];
@@ -897,6 +911,5 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmArgs a) {
   if (wr == 0) run_tiles(std::integral_constant<int, 0>{});
   else run_tiles(std::integral_constant<int, 1>{});
 
-  if constexpr (X8 && EPI != PP_QK) x8_sat_flush(a.x8_sat, x8_sat);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // no LDS-DMA may outlive the workgroup's LDS allocation
 }

@@ -70,7 +70,7 @@ __global__ __launch_bounds__(256) void embed_ln_kernel(const int32_t* __restrict
                                                        float eps, float* __restrict__ x32, half_t* __restrict__ x16,
                                                        float* __restrict__ stats, half_t* __restrict__ xlo, uint8_t* __restrict__ x8,
                                                        unsigned int* __restrict__ x8_sat) {
-  int sat = 0;
+  float vmax8 = 0.f;  // MV_F16X8: max |stream value| of the row's share (saturation accounting, common.h)
   const int lane = threadIdx.x & 63;
   const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (t >= n_tok) return;
@@ -111,23 +111,30 @@ __global__ __launch_bounds__(256) void embed_ln_kernel(const int32_t* __restrict
       half4_t h;
       h[0] = (half_t)x[i].x; h[1] = (half_t)x[i].y; h[2] = (half_t)x[i].z; h[3] = (half_t)x[i].w;
       *(half4_t*)(x16 + (size_t)t * MV_HIDDEN + c) = h;
-      if (x8) {  // MV_F16X8: the stream is hi fp16 + the lo8 plane of its [lo8 | hi8] planes (the A8 operand of the QKV GEMM, gemm_pp.h)
+      if (x8) {  // MV_F16X8: [lo8 | hi8] planes of the raw stream (the A8 operand of the first QKV GEMM, gemm_pp.h)
         uint32_t h8, l8;
-        x8_planes4(x[i].x, x[i].y, x[i].z, x[i].w, h8, l8, sat);
+        x8_planes4(x[i].x, x[i].y, x[i].z, x[i].w, h8, l8);
+        vmax8 = x8_absmax4(vmax8, x[i].x, x[i].y, x[i].z, x[i].w);
         *(uint32_t*)(x8 + (size_t)t * (2 * MV_HIDDEN) + c) = l8;
         *(uint32_t*)(x8 + (size_t)t * (2 * MV_HIDDEN) + MV_HIDDEN + c) = h8;
-      } else if (xlo) {  // MV_F16: two-plane raw stream (gemm_pp PP_RESLN3): lo = fp16(x - hi) instead of the fp32 row
+      }
+      if (xlo) {  // two-plane raw stream (gemm_pp PP_RESLN3): lo = fp16(x - hi) instead of the fp32 row (nullptr with x8: the lo8 stream)
         half4_t l;
         l[0] = (half_t)(x[i].x - (float)h[0]); l[1] = (half_t)(x[i].y - (float)h[1]);
         l[2] = (half_t)(x[i].z - (float)h[2]); l[3] = (half_t)(x[i].w - (float)h[3]);
         *(half4_t*)(xlo + (size_t)t * MV_HIDDEN + c) = l;
-      } else {
+      } else if (!x8) {
         *(float4*)(x32 + (size_t)t * MV_HIDDEN + c) = x[i];
       }
     }
-    x8_sat_flush(x8_sat, sat);
+    if (x8 && x8_any_out_of_range(vmax8)) {  // rare: count exactly
+      int n = 0;
+#pragma unroll
+      for (int i = 0; i < 3; ++i) n += x8_count4(x[i].x, x[i].y, x[i].z, x[i].w);
+      x8_sat_add(x8_sat, n);
+    }
   } else {
-    (void)sat;
+    (void)vmax8;
     ln_row_store<true>(x, gamma, beta, eps, lane, x32 + (size_t)t * MV_HIDDEN, x16 + (size_t)t * MV_HIDDEN, nullptr);
     // the embedding output IS the normalised stream: identity statistics for a PP_RESLN consumer (with gamma = 1, beta = 0)
     if (stats && lane == 0) {
