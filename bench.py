@@ -298,6 +298,8 @@ def main():
         "e2e_mfma_frac": round(value / world * fpi_exec / 1e12 / MFMA_PEAK_TFLOPS, 4),
         "gflop_per_ir": {"algorithmic": round(fpi / 1e9, 3), "executed": round(fpi_exec / 1e9, 3), "last_layer_cls_pruning": pruned},
         "batches_in_flight": args.streams,
+        # MV_F16X8: activation elements beyond the +-112 range of the fp8 correction planes over everything this engine ran (mv_x8_saturation)
+        "x8_saturated_elements": (eng.x8_saturation() if (mode == "precise" and hasattr(eng, "x8_saturation")) else None),
         "stats_allgather_ms": round(gather_ms, 3),
         "stats_table_sum": int(table.sum()),
     }
@@ -357,6 +359,8 @@ def main():
         eng.close()
         other = "f16" if mode == "precise" else "precise"
         out["fast" if other == "f16" else "precise"] = second_mode_leg(args, other, dims, weights, aids, alens, ids, lens, contract)
+        # the opt-in lo8 residual stream of the precise mode (MEMVUL_STREAM_LO8=1, gemm_pp.h X8 = 2): rate and trained-like error of THIS run
+        out["precise_lo8_stream"] = lo8_stream_leg(args, dims, weights, aids, alens, ids, lens, S)
     print(json.dumps(out), flush=True)
     mvdist.shutdown()
 
@@ -418,6 +422,52 @@ def self_launch(n: int) -> int:
             if p.poll() is None:
                 p.kill()
     return rc
+
+
+def lo8_stream_leg(args, dims, weights, aids, alens, ids, lens, S):
+    """MV_F16X8 with MEMVUL_STREAM_LO8=1 (the raw residual stream as hi fp16 + the lo8 plane of its fp8 planes instead of hi + lo fp16
+    planes): the same K steps on the same workload, and its trained-like logit error against the CPU leg measured here (the same
+    sample as `contract`).  Not the default: ~+2.4 % for ~1.2x the error."""
+    old = os.environ.get("MEMVUL_STREAM_LO8")
+    os.environ["MEMVUL_STREAM_LO8"] = "1"
+    try:
+        B, G, K, W = args.batch, args.anchors, args.steps, args.warmup
+        res = {"switch": "MEMVUL_STREAM_LO8=1"}
+        if args.cpu_sample > 0:
+            res["logit_max_abs_err_trained_like"] = trained_like_errors(dims, S, modes=("precise",))["logit_max_abs_err_trained_like"]["precise"]
+            res["meets_contract"] = bool(res["logit_max_abs_err_trained_like"] <= LOGIT_TOL)
+        eng = Engine(0, vocab_size=dims.vocab_size, layers=dims.layers, max_tokens=max(B * S, 128 * 512), max_batch=max(B, 256), max_anchors=max(G, 1024))
+        eng.load_state_dict(weights, "precise")
+        eng.set_streams(args.streams)
+        for s0 in range(0, G, 128):
+            LA = int(alens[s0:s0 + 128].max())
+            eng.anchor_append(aids[s0:s0 + 128, :LA], alens[s0:s0 + 128])
+        eng.corpus_upload(ids, lens)
+        nb = len(lens) // B
+
+        def step(i):
+            eng.corpus_run((i % nb) * B, B, B, keep_probs=False)
+
+        for i in range(W):
+            step(i)
+        eng.sync()
+        t0 = time.perf_counter()
+        for i in range(K):
+            step(W + i)
+        eng.corpus_results(0, nb * B)
+        dt = time.perf_counter() - t0
+        res.update(value=round(K * B / dt, 2), unit="issue-reports/s", ms_per_step=round(dt / K * 1e3, 4))
+        if not args.no_profile:
+            res["kernels_avg_us"], _ = mode_profile(eng, step, K, B * S, S, G, dims.layers)
+            eng.set_streams(args.streams)
+        res["x8_saturated_elements"] = eng.x8_saturation()
+        eng.close()
+        return res
+    finally:
+        if old is None:
+            os.environ.pop("MEMVUL_STREAM_LO8", None)
+        else:
+            os.environ["MEMVUL_STREAM_LO8"] = old
 
 
 def sustained_leg(eng, step, B, seconds):
@@ -582,6 +632,7 @@ def cpu_baseline(weights, dims, eng, ids, lens, S, n, aids, alens):
         if best_dt is None or d < best_dt:
             best_t, best_dt = t, d
     torch.set_num_threads(best_t)
+    bs_cal, bs = bs, 64  # the CPU leg runs at batch 64; the thread count was chosen on batches of 16 (bounded time)
     ta0 = time.perf_counter()
     vs = []
     for s0 in range(0, G, 128):
@@ -613,7 +664,8 @@ def cpu_baseline(weights, dims, eng, ids, lens, S, n, aids, alens):
     gpu = eng.forward(ids[:n], lens[:n])
     err = float(np.abs(gpu["logits"] - logits).max())
     return ({"value": round(n / t_graph, 3), "with_host_loop": round(n / (t_graph + t_host), 3), "unit": "issue-reports/s", "cores": best_t,
-             "host_cores": cores, "kind": "port", "thread_calibration_irs_per_s": calib,
+             "host_cores": cores, "kind": "port", "thread_calibration_irs_per_s": calib, "thread_calibration_batch": bs_cal,
+             "host_limits": host_limits(),
              "host_work_ms_per_ir": round(t_host / n * 1e3, 3), "anchor_bank_build_s": round(anchor_s, 2),
              "sample": f"{n} synthetic IRs x {S} tokens, batch {bs}, fp32 torch-CPU ({best_t} threads): HF BertModel (eager attention) + tanh "
                        f"pooler + ReLU header + bias-free matcher = the reference's CPU graph (AllenNLP itself is not installable here; "
@@ -623,7 +675,28 @@ def cpu_baseline(weights, dims, eng, ids, lens, S, n, aids, alens):
             err, anchor_err)
 
 
-def trained_like_errors(dims, S, nt=16, gt=8):
+def host_limits():
+    """What bounds the CPU leg's parallelism on this box besides os.cpu_count(): the scheduler affinity of this process and the
+    container's cgroup CPU quota (cpu.max: "<quota us> <period us>" or "max") — why a thread count far below the hardware thread
+    count can be the fastest (threads beyond the quota only add contention)."""
+    out = {}
+    try:
+        out["sched_affinity_cpus"] = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            out["cgroup_" + os.path.basename(path)] = open(path).read().strip()
+        except Exception:
+            pass
+    try:
+        out["loadavg_1m"] = os.getloadavg()[0]
+    except Exception:
+        pass
+    return out
+
+
+def trained_like_errors(dims, S, nt=16, gt=8, modes=("f16", "precise")):
     """max |logit error| of BOTH compute dtypes against the CPU leg (oracle/hf_reference.py, fp32) on the trained-like weights of
     SURVEY.md §8d (synth.make_weights(trained_like=True, match_scale=29): LayerNorm outlier dims, peaked attention, |logit| ~ 3):
     the measurement that decides which mode may carry `value` and that the line reports next to it."""
@@ -639,7 +712,7 @@ def trained_like_errors(dims, S, nt=16, gt=8):
     v = ref.instance_forward(ta[:, :LA].astype(np.int64), synth.mask_from_lens(tl, LA))
     u, lg, p, best, idx = ref.predict(ids.astype(np.int64), np.ones((nt, S), bool), v)
     errs = {}
-    for mode in ("f16", "precise"):
+    for mode in modes:
         e2 = Engine(0, vocab_size=dims.vocab_size, layers=dims.layers, max_tokens=16 * 512, max_batch=16, max_anchors=16)
         e2.load_state_dict(wt, mode)
         e2.anchor_append(ta[:, :LA], tl)

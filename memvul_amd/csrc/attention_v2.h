@@ -320,18 +320,21 @@ __global__ __launch_bounds__(NKB * 128) __attribute__((amdgpu_waves_per_eu(2, 2)
             opk[dt][rg][0] = pack_h2(x0, x1);
             opk[dt][rg][1] = pack_h2(x2, x3);
             if constexpr (X8) {
-              x8_planes4(x0, x1, x2, x3, op8[dt][rg][1], op8[dt][rg][0]);
+              x8_planes4_in_range_packed(x0, x1, x2, x3, opk[dt][rg][0], opk[dt][rg][1], op8[dt][rg][1], op8[dt][rg][0]);
               vmax8 = x8_absmax4(vmax8, x0, x1, x2, x3);
             }
           }
         if constexpr (X8) {
-          if (x8_any_out_of_range(vmax8)) {  // rare: count exactly
+          if (x8_any_out_of_range(vmax8)) {  // rare: redo the unit's planes with the clamps, count exactly
             int n = 0;
 #pragma unroll
             for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
-              for (int rg = 0; rg < 4; ++rg)
-                n += x8_count4(o[dt][4 * rg + 0] * inv, o[dt][4 * rg + 1] * inv, o[dt][4 * rg + 2] * inv, o[dt][4 * rg + 3] * inv);
+              for (int rg = 0; rg < 4; ++rg) {
+                const float x0 = o[dt][4 * rg + 0] * inv, x1 = o[dt][4 * rg + 1] * inv, x2 = o[dt][4 * rg + 2] * inv, x3 = o[dt][4 * rg + 3] * inv;
+                x8_planes4(x0, x1, x2, x3, op8[dt][rg][1], op8[dt][rg][0]);
+                n += x8_count4(x0, x1, x2, x3);
+              }
             x8_sat_add(a.x8_sat, n);
           }
         }

@@ -41,6 +41,38 @@ __device__ __forceinline__ void x8_planes4(float v0, float v1, float v2, float v
   hi8 = pack_fp8x4_scaled(v0, v1, v2, v3, SH);
   lo8 = pack_fp8x4_scaled(v0 - (float)(half_t)v0, v1 - (float)(half_t)v1, v2 - (float)(half_t)v2, v3 - (float)(half_t)v3, SL);
 }
+// The common path: every value inside the range (|v| <= 112, checked per block by the caller through x8_absmax4 / x8_any_out_of_range, which
+// falls back to x8_planes4 for a block that is not): no clamps — and without them the fp16 rounding below is the SAME expression as the one the
+// producer's fp16 output store needs, so hipcc computes it once (v_cvt_pk_f16_f32 + v_cvt_f32_f16 instead of a second v_cvt_f16_f32 per value).
+// In range the two functions give identical bits.
+__device__ __forceinline__ void x8_planes4_in_range(float v0, float v1, float v2, float v3, uint32_t& hi8, uint32_t& lo8) {
+  constexpr float SH = 1.0f / (float)(1 << MV_X8_ACT_SHIFT), SL = 1.0f / (float)(2048 << MV_X8_ACT_SHIFT);
+  hi8 = pack_fp8x4_scaled(v0, v1, v2, v3, SH);
+  lo8 = pack_fp8x4_scaled(v0 - (float)(half_t)v0, v1 - (float)(half_t)v1, v2 - (float)(half_t)v2, v3 - (float)(half_t)v3, SL);
+}
+
+// The same with the fp16 roundings taken from the PACKED fp16 words the producer has already formed for its fp16 output (p01 = fp16(v0) | fp16(v1) << 16,
+// p23 likewise): hipcc turns {(half)a, (half)b} into one vector fptrunc (v_cvt_pk_f16_f32) that it does not unify with the scalar roundings above, so
+// FFN-1's VALU-bound epilogue would convert every value twice.  Identical bits.
+__device__ __forceinline__ void x8_planes4_in_range_packed(float v0, float v1, float v2, float v3, uint32_t p01, uint32_t p23, uint32_t& hi8, uint32_t& lo8) {
+  constexpr float SH = 1.0f / (float)(1 << MV_X8_ACT_SHIFT), SL = 1.0f / (float)(2048 << MV_X8_ACT_SHIFT);
+  // residual = v - fp16(v) as ONE v_fma_mix_f32 per value (fp16 half of the packed word x (-1) + v: exact, the same bits as convert + subtract); the
+  // asm also keeps the packed words opaque (instcombine would fold an extraction back into fpext(fptrunc(v)) and round every value twice again)
+  float l0, l1, l2, l3;
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm("v_fma_mix_f32 %0, %4, -1.0, %6 op_sel_hi:[1,0,0]\n\t"
+      "v_fma_mix_f32 %1, %4, -1.0, %7 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+      "v_fma_mix_f32 %2, %5, -1.0, %8 op_sel_hi:[1,0,0]\n\t"
+      "v_fma_mix_f32 %3, %5, -1.0, %9 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
+      : "=&v"(l0), "=&v"(l1), "=&v"(l2), "=&v"(l3)
+      : "v"(p01), "v"(p23), "v"(v0), "v"(v1), "v"(v2), "v"(v3));
+#else
+  l0 = l1 = l2 = l3 = 0.f;
+#endif
+  hi8 = pack_fp8x4_scaled(v0, v1, v2, v3, SH);
+  lo8 = pack_fp8x4_scaled(l0, l1, l2, l3, SL);
+}
+
 // Saturation accounting (mv_x8_saturation): an element beyond +-112 keeps fp16 accuracy but loses its correction term — silently,
 // unless somebody counts.  The producers fold |v| of everything they convert into ONE per-lane running maximum (two v_max3_f32 per
 // four values, no scalar state: a first form that counted with v_cmp + s_bcnt1 per value cost the FFN-1 epilogue 30 us in SGPR spills)

@@ -883,15 +883,26 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmArgs a) {
 #pragma unroll
                 for (int cbl = 0; cbl < 2; ++cbl) {
                   const int tb = 2 * i + tbl, cb = 2 * j + cbl;
-                  x8_planes4(acc[tb][cb][0], acc[tb][cb][1], acc[tb][cb][2], acc[tb][cb][3], dh[4 * tbl + 2 * j + cbl], dl[4 * tbl + 2 * j + cbl]);
+                  if constexpr (EPI == PP_GELU) {  // d[j][2 tbl + cbl] still holds this unit's packed fp16 output words
+                    const uint32_t p01 = d[j][2 * tbl + cbl][0], p23 = d[j][2 * tbl + cbl][1];
+                    x8_planes4_in_range_packed(acc[tb][cb][0], acc[tb][cb][1], acc[tb][cb][2], acc[tb][cb][3], p01, p23, dh[4 * tbl + 2 * j + cbl], dl[4 * tbl + 2 * j + cbl]);
+                  } else {
+                    x8_planes4_in_range(acc[tb][cb][0], acc[tb][cb][1], acc[tb][cb][2], acc[tb][cb][3], dh[4 * tbl + 2 * j + cbl], dl[4 * tbl + 2 * j + cbl]);
+                  }
                   vmax8 = x8_absmax4(vmax8, acc[tb][cb][0], acc[tb][cb][1], acc[tb][cb][2], acc[tb][cb][3]);
                 }
-            if (x8_any_out_of_range(vmax8)) {  // rare (never on the models measured): count this block's out-of-range elements exactly
+            if (x8_any_out_of_range(vmax8)) {  // rare (never on the models measured): redo this block with the clamps and count its out-of-range elements
               int n = 0;
 #pragma unroll
               for (int tbl = 0; tbl < 2; ++tbl)
 #pragma unroll
-                for (int cb = 0; cb < 4; ++cb) n += x8_count4(acc[2 * i + tbl][cb][0], acc[2 * i + tbl][cb][1], acc[2 * i + tbl][cb][2], acc[2 * i + tbl][cb][3]);
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                  for (int cbl = 0; cbl < 2; ++cbl) {
+                    const int tb = 2 * i + tbl, cb = 2 * j + cbl;
+                    x8_planes4(acc[tb][cb][0], acc[tb][cb][1], acc[tb][cb][2], acc[tb][cb][3], dh[4 * tbl + 2 * j + cbl], dl[4 * tbl + 2 * j + cbl]);
+                    n += x8_count4(acc[tb][cb][0], acc[tb][cb][1], acc[tb][cb][2], acc[tb][cb][3]);
+                  }
               x8_sat_add(a.x8_sat, n);
             }
             scr_f8x2(w8, w8 ^ 16u, w8 ^ 32u, w8 ^ 48u, dl, dh, scr_c, o);
