@@ -6,7 +6,9 @@ Cases (weights, issue reports, anchors all by seed; every one 12 layers, trained
   seed_<s>          s = 3001 .. 3024: 8 issue reports x 256 tokens (every second seed ragged) against 6 anchors of up to 512 tokens
                     (3001 .. 3006 are round 4's six draws)                                     -> logits [8, 6, 2]
   outlier_<k>       k = 1, 3, 10: the same model family with the outlier offsets x k (seed 4001) -> u [8, 512], v [6, 512], logits
-Usage: python scripts/r05_make_refs.py [first_seed last_seed]"""
+  len_<L>           L = 8, 16, 32, 64, 128, 256, 512: 16 full-length sequences of L tokens on the envelope model (seed 4001, outliers x1)
+                    -> embeddings [16, 512]: the sequence-length axis of the envelope (short sequences average less in attention)
+Usage: python scripts/r05_make_refs.py"""
 import os
 import sys
 
@@ -61,5 +63,30 @@ def main():
         np.savez_compressed(OUT, **have)
 
 
+LENGTHS = (8, 16, 32, 64, 128, 256, 512)
+
+
+def length_inputs(L):
+    dims = synth.BertDims(layers=12)
+    ids, lens = synth.make_ids(16, L, dims.vocab_size, seed=ENV_SEED + 100 + L)
+    return dims, ids, lens
+
+
+def main_lengths():
+    have = dict(np.load(OUT))
+    w = None
+    for L in LENGTHS:
+        if f"len_{L}" in have:
+            continue
+        dims, ids, lens = length_inputs(L)
+        if w is None:
+            w = synth.make_weights(dims, seed=ENV_SEED, qk_scale=2.0, match_scale=29.0, trained_like=True)
+            ref = HFReference(w, dims.as_dict(), threads=min(os.cpu_count() or 1, 16))
+        have[f"len_{L}"] = np.asarray(ref.instance_forward(ids.astype(np.int64), synth.mask_from_lens(lens, L)), np.float32)
+        print("length %d: max |v| %.2f" % (L, float(np.abs(have[f"len_{L}"]).max())), flush=True)
+        np.savez_compressed(OUT, **have)
+
+
 if __name__ == "__main__":
     main()
+    main_lengths()
