@@ -19,6 +19,8 @@ struct AttnArgs {
   int B;
   uint8_t* ctx8;        // MV_F16X8 (attention_v2_kernel<.., X8 = 1>): [B*S][1536] = [lo8 (768) | hi8 (768)] planes of ctx (gemm_pp.h)
   unsigned int* x8_sat; // MV_F16X8: device counter of context elements beyond the fp8 planes' range (common.h x8_planes4)
+  const half_t* vt_lo;  // attention_v2_kernel<.., VLO = 1> (MV_F16X8, padded length <= 128): V^T's second fp16 plane, fp16(V - fp16(V)), same layout as vt
+  const half_t *q_lo, *k_lo;  // the same for Q and K
 };
 
 // Last encoder layer: only the [CLS] query (token 0) of each issue report is consumed downstream

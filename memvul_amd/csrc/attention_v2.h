@@ -30,17 +30,24 @@
 
 #define ATT2_BUF_BYTES(NKB) ((NKB) * 16384)
 #define ATT2_LDS_BYTES(NKB) (2 * ATT2_BUF_BYTES(NKB))
+#define ATT2_LDS_BYTES_VLO(NKB) (2 * (NKB) * 32768)  // VLO: + the V^T and K lo planes in every ring slot
 
 // X8 1 (MV_F16X8, gemm_pp.h): the context is also written as fp8 planes [lo8 (768) | hi8 (768)] per token row to
 // AttnArgs::ctx8 — e4m3 of (O - fp16(O)) 2^(11 + s) and of O 2^s, the A8 operand of the output projection's correction sweep
 // (16 more registers across the unit boundary, a second pass through the O image); a separate instantiation.
 // (The timing ablations of rounds 1-2 — no Q loads / O stores / DMA / exp / MFMA / fragment reads — were retired: git history before round 5.)
-template <int NKB, int NCH = 1, int X8 = 0>  // chunk = 64 NKB keys = 2 NKB waves x 32 queries; padded length S = 64 NKB NCH
+// VLO 1 (MV_F16X8, padded length <= 128: NKB <= 2, NCH = 1): Q, K, V and P as hi + lo fp16 — S^T += K_lo Q_hi + K_hi Q_lo, O^T += V_lo P_hi + V_hi P_lo on top
+// of the hi x hi products.  What is left of the precise mode's error is the fp16 storage of Q, K, V and P, averaged by attention over the keys:
+// ~ 1 / sqrt(keys), so short sequences feel it most (profiles/r05_f_length_envelope.txt: 9.4e-4 on the logits at 8 tokens against 2.3e-4 at 256) — and
+// there the second planes are nearly free: the lo planes of K and V^T (written by the QKV projection's epilogue, GemmArgs::k_lo / vt_lo) ride through the
+// ring next to K and V^T, Q's lo fragments are prefetched with Q's, P_lo = fp16(p - fp16(p)) is formed with the packing.
+template <int NKB, int NCH = 1, int X8 = 0, int VLO = 0>  // chunk = 64 NKB keys = 2 NKB waves x 32 queries; padded length S = 64 NKB NCH
 __global__ __launch_bounds__(NKB * 128) __attribute__((amdgpu_waves_per_eu(2, 2))) void attention_v2_kernel(AttnArgs a, int nunits) {
+  static_assert(!VLO || (X8 && NCH == 1 && NKB <= 2), "the two-plane V / P path serves the precise mode's short passes");
   constexpr int S = NKB * 64;        // keys per chunk = queries per unit
   constexpr int ST = S * NCH;        // padded sequence length (row pitch of V^T, rows per head of Q / K)
   constexpr int NT = 2 * NKB;        // 32-key score fragments per chunk
-  constexpr int BUF = ATT2_BUF_BYTES(NKB), VOFF = NKB * 8192;
+  constexpr int BUF = VLO ? NKB * 32768 : ATT2_BUF_BYTES(NKB), VOFF = NKB * 8192, VLOFF = NKB * 16384, KLOFF = NKB * 24576;
   constexpr float LOG2E = 1.44269504088896340736f;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -89,10 +96,30 @@ __global__ __launch_bounds__(NKB * 128) __attribute__((amdgpu_waves_per_eu(2, 2)
       const int p = 4 * wave + x;  // 64-key block p >> 3, head dims 8 (p & 7) ..+7
       glds16((const half_t*)(vg + (size_t)(8 * (p & 7)) * (2 * ST) + (p >> 3) * 128 + srcV[x & 1]), kb + VOFF + p * 1024);
     }
+    if constexpr (VLO) {
+      const char* vlg = (const char*)(a.vt_lo + (size_t)bh * MV_HEAD_DIM * ST + (size_t)j * S);
+#pragma unroll
+      for (int x = 0; x < 4; ++x) {
+        const int p = 4 * wave + x;
+        glds16((const half_t*)(vlg + (size_t)(8 * (p & 7)) * (2 * ST) + (p >> 3) * 128 + srcV[x & 1]), kb + VLOFF + p * 1024);
+      }
+      const char* klg = (const char*)(a.k_lo + ((size_t)bh * ST + (size_t)j * S) * MV_HEAD_DIM);
+#pragma unroll
+      for (int x = 0; x < 4; ++x) {
+        const int p = 4 * wave + x;
+        glds16((const half_t*)(klg + p * 1024 + srcK[x & 1]), kb + KLOFF + p * 1024);
+      }
+    }
   };
   auto load_q = [&](int u, half8_t (&qf)[4]) {  // B operand of S^T = K Q^T: lane holds Q[qb S + 32 wave + ql][16 kk + 8 hi ..+7]
     const int bh = unit_bh(u), qb = unit_qb(u);
     const half_t* gq = a.q + ((size_t)bh * ST + qb * S + 32 * wave + ql) * MV_HEAD_DIM + hi * 8;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) qf[kk] = *(const half8_t*)(gq + kk * 16);
+  };
+  auto load_q_lo = [&](int u, half8_t (&qf)[4]) {  // VLO: the same fragments of Q's lo plane
+    const int bh = unit_bh(u), qb = unit_qb(u);
+    const half_t* gq = a.q_lo + ((size_t)bh * ST + qb * S + 32 * wave + ql) * MV_HEAD_DIM + hi * 8;
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) qf[kk] = *(const half8_t*)(gq + kk * 16);
   };
@@ -112,8 +139,10 @@ __global__ __launch_bounds__(NKB * 128) __attribute__((amdgpu_waves_per_eu(2, 2)
   const int first = blockIdx.x, stride = gridDim.x;
   if (first >= nunits) return;
   half8_t qf[4], qn[4];
+  half8_t qfl[VLO ? 4 : 1], qnl[VLO ? 4 : 1];  // VLO: Q's lo fragments, prefetched like Q's
   issue_chunk(first, 0, 0);
   load_q(first, qn);
+  if constexpr (VLO) load_q_lo(first, qnl);
   int len_n = a.lens[unit_bh(first) / MV_HEADS];  // prefetched like Q: a VGPR-destination load must never be waited for mid-unit
 
   uint32_t opk[2][4][2];  // normalised O^T of the previous unit, fp16 pairs: [dt][rg] = dims 32 dt + 8 rg + 4 hi ..+3
@@ -188,6 +217,7 @@ __global__ __launch_bounds__(NKB * 128) __attribute__((amdgpu_waves_per_eu(2, 2)
         // of their first use, i.e. after the next chunk's DMA has been issued, and drain it)
 #if defined(__HIP_DEVICE_COMPILE__)
         asm volatile("" : "+v"(qn[0]), "+v"(qn[1]), "+v"(qn[2]), "+v"(qn[3]), "+v"(len_n));
+        if constexpr (VLO) asm volatile("" : "+v"(qnl[0]), "+v"(qnl[1]), "+v"(qnl[2]), "+v"(qnl[3]));
 #endif
         len = __builtin_amdgcn_readfirstlane(len_n);
         // previous unit's O through the K half of the OTHER ring slot: rows 32 wave .. + 31 are exactly the rows this
@@ -198,6 +228,10 @@ __global__ __launch_bounds__(NKB * 128) __attribute__((amdgpu_waves_per_eu(2, 2)
         }
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) qf[kk] = qn[kk];
+        if constexpr (VLO) {
+#pragma unroll
+          for (int kk = 0; kk < 4; ++kk) qfl[kk] = qnl[kk];
+        }
       }
       if (j + 1 < NCH) issue_chunk(unit, j + 1, pb ^ 1);
       else if (nxt < nunits) issue_chunk(nxt, 0, pb ^ 1);
@@ -222,6 +256,15 @@ __global__ __launch_bounds__(NKB * 128) __attribute__((amdgpu_waves_per_eu(2, 2)
           for (int r = 0; r < 16; ++r) st[t][r] = 0.f;
 #pragma unroll
           for (int kk = 0; kk < 4; ++kk) st[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[t & 1][kk], qf[kk], st[t], 0, 0, 0);
+          if constexpr (VLO) {  // + K_hi Q_lo + K_lo Q_hi (the small terms after the large one; K's lo fragments read here: the short passes are not LDS-latency-bound)
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) st[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[t & 1][kk], qfl[kk], st[t], 0, 0, 0);
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+              const half8_t kl = *(const half8_t*)(kb + KLOFF + t * 4096 + koff[kk]);
+              st[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl, qf[kk], st[t], 0, 0, 0);
+            }
+          }
         }
         __builtin_amdgcn_sched_barrier(0);
       }
@@ -255,6 +298,7 @@ __global__ __launch_bounds__(NKB * 128) __attribute__((amdgpu_waves_per_eu(2, 2)
       const float nm = -mx * LOG2E;
       float ps4[4] = {0.f, 0.f, 0.f, 0.f};  // four independent partial sums (a single chain is 128 dependent adds)
       half8_t pf[NT][2];
+      half8_t pfl[VLO ? NT : 1][2];  // VLO: P's second fp16 plane
 #pragma unroll
       for (int t = 0; t < NT; ++t)
 #pragma unroll
@@ -262,7 +306,9 @@ __global__ __launch_bounds__(NKB * 128) __attribute__((amdgpu_waves_per_eu(2, 2)
           const float e = __builtin_fmaf(st[t][r], LOG2E, nm);
           const float p = __builtin_amdgcn_exp2f(e);
           ps4[r & 3] += p;
-          pf[t][r >> 3][r & 7] = (half_t)p;
+          const half_t ph = (half_t)p;
+          pf[t][r >> 3][r & 7] = ph;
+          if constexpr (VLO) pfl[t][r >> 3][r & 7] = (half_t)(p - (float)ph);
         }
       {
         const float psum = (ps4[0] + ps4[1]) + (ps4[2] + ps4[3]);
@@ -270,6 +316,7 @@ __global__ __launch_bounds__(NKB * 128) __attribute__((amdgpu_waves_per_eu(2, 2)
       }
       // next unit's Q fragments: issued in the unit's last chunk (the score registers are dead), they land under its PV phase
       if (j == NCH - 1 && nxt < nunits) {
+        if constexpr (VLO) load_q_lo(nxt, qnl);
         load_q(nxt, qn);
         len_n = a.lens[unit_bh(nxt) / MV_HEADS];
       }
@@ -299,12 +346,25 @@ __global__ __launch_bounds__(NKB * 128) __attribute__((amdgpu_waves_per_eu(2, 2)
         for (int t = 0; t < NT; ++t) {
           __builtin_amdgcn_sched_barrier(0);
           if (t + 1 < NT) read_v(t + 1, vf[(t + 1) & 1]);
+          half8_t vl[VLO ? 4 : 1];  // VLO: the lo plane's fragments of key block t
+          if constexpr (VLO) {
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+              for (int u = 0; u < 2; ++u)
+                vl[2 * dt + u] = *(const half8_t*)(kb + VLOFF + (t >> 1) * 8192 + dt * 4096 + voff[2 * (t & 1) + u]);
+          }
           __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
           for (int u = 0; u < 2; ++u)
 #pragma unroll
-            for (int dt = 0; dt < 2; ++dt)
+            for (int dt = 0; dt < 2; ++dt) {
               o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[t & 1][2 * dt + u], pf[t][u], o[dt], 0, 0, 0);
+              if constexpr (VLO) {
+                o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl[2 * dt + u], pf[t][u], o[dt], 0, 0, 0);
+                o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[t & 1][2 * dt + u], pfl[t][u], o[dt], 0, 0, 0);
+              }
+            }
         }
         __builtin_amdgcn_sched_barrier(0);
       }

@@ -120,6 +120,7 @@ struct Work {
   int32_t *d_ids = nullptr, *d_lens = nullptr;  // host-path inputs
   float* xres = nullptr;                        // residual stream fp32 [T][768]
   half_t *x16 = nullptr, *q = nullptr, *k = nullptr, *vt = nullptr, *ctx = nullptr, *h16 = nullptr;
+  half_t *vt_lo = nullptr, *q_lo = nullptr, *k_lo = nullptr;  // MV_F16X8, passes of padded length <= 128: second fp16 planes of V^T, Q, K (attention_v2.h VLO)
   float *u = nullptr, *pooled = nullptr;
   float *logits = nullptr, *probs = nullptr, *psame = nullptr, *best = nullptr;
   int32_t* best_idx = nullptr;
@@ -184,6 +185,8 @@ struct mv_handle {
   bool cls_prune = true;   // env MEMVUL_CLS_PRUNE=0 disables
   int pp_gn_max = 4;       // raster group width cap of the persistent GEMM (env MEMVUL_GN_MAX: the A/B of profiles/r04_*)
   int pp_raster = 0;       // env MEMVUL_RASTER=1: the A-stationary raster where it applies (FFN-1, QKV at full-size grids)
+  bool short_vlo = true;   // MV_F16X8, env MEMVUL_SHORT_VLO=0 disables: passes of padded length <= 128 carry V and P as hi + lo fp16 planes through attention
+                           // (attention_v2.h VLO): the fp16 storage of V and P is what is left of the precise mode's error and short sequences average it least
   bool stream_lo8 = false; // MV_F16X8, env MEMVUL_STREAM_LO8=1: the raw residual stream as hi fp16 + the lo8 plane of its fp8 planes (no lo fp16 plane;
                            // gemm_pp.h X8 = 2): +1.5 % issue reports/s at 1.2x the trained-like logit error (profiles/r05_a_*) — opt-in
   int qkv_aside_mask = 1;  // MV_F16X8: which of the Q / K / V blocks of the QKV projection sweep the A-side correction term too (bit 0 / 1 / 2;
@@ -409,9 +412,17 @@ int pool_head(mv_handle* h, const float* x, size_t row_stride, int B, float* u_o
 inline int padded_len(int S_in) { return (int)round_up(S_in, S_in <= 256 ? 64 : 128); }
 
 int launch_attention(mv_handle* h, const int32_t* d_lens, int B, int Sp, bool x8) {
-  AttnArgs a{h->w->q, h->w->k, h->w->vt, d_lens, h->w->ctx, Sp, B, x8 ? h->w->ctx8 : nullptr, h->x8_sat};
+  const bool vlo = x8 && h->short_vlo && Sp <= 128;  // the QKV projection of this pass wrote V^T's lo plane (encode_dev: the same predicate)
+  AttnArgs a{h->w->q, h->w->k, h->w->vt, d_lens, h->w->ctx, Sp, B, x8 ? h->w->ctx8 : nullptr, h->x8_sat, vlo ? h->w->vt_lo : nullptr,
+             vlo ? h->w->q_lo : nullptr, vlo ? h->w->k_lo : nullptr};
   ProfScope ps(h, KC_ATTENTION);
-  if (Sp <= 256) {
+  if (vlo) {
+    const int nkb = Sp / 64, items = B * MV_HEADS;
+    const int slots = h->num_cu * (nkb == 1 ? 2 : 1);  // resident workgroups by LDS: 64 / 128 KiB each
+    const int grid = items < slots ? items : slots;
+    if (nkb == 1) hipLaunchKernelGGL((attention_v2_kernel<1, 1, 1, 1>), dim3(grid), dim3(128), ATT2_LDS_BYTES_VLO(1), h->w->stream, a, items);
+    else hipLaunchKernelGGL((attention_v2_kernel<2, 1, 1, 1>), dim3(grid), dim3(256), ATT2_LDS_BYTES_VLO(2), h->w->stream, a, items);
+  } else if (Sp <= 256) {
     const int nkb = Sp / 64, items = B * MV_HEADS;
     const int slots = h->num_cu * (nkb == 1 ? 4 : nkb == 2 ? 2 : 1);  // resident workgroups: 8 waves and <= 128 KiB LDS per CU
     const int grid = items < slots ? items : slots;
@@ -568,6 +579,8 @@ int encode_dev(mv_handle* h, const int32_t* d_ids, const int32_t* d_lens, int B,
       // K2: Q, K, V^T projection of the raw stream (LayerNorm folded into W'' / b')
       g.A = h->w->x16; g.W = wqkv; g.bias = bqkv; g.N = 3 * MV_HIDDEN; g.K = MV_HIDDEN; g.lnstats = st_in;
       if (x8) { g.A8 = h->w->x8; g.W8 = w.wqkv_f8; g.x8_scale = w.sc_qkv; g.x8_terms = 3; g.x8_aside_mask = h->qkv_aside_mask; }
+      g.vt_lo = (x8 && h->short_vlo && Sp <= 128) ? h->w->vt_lo : nullptr;  // short passes: Q, K, V^T as hi + lo planes (launch_attention: the same predicate)
+      g.q_lo = h->w->q_lo; g.k_lo = h->w->k_lo;
       if (int rc = launch_pp<PP_QK>(h, KC_GEMM_QKV, g)) return rc;
       // K3: attention
       if (int rc = launch_attention(h, d_lens, B, Sp, x8)) return rc;
@@ -856,6 +869,8 @@ int mv_create(int device, const mv_config* cfg, mv_handle** out) try {
   hipFuncSetAttribute((const void*)attention_v2_kernel<NKB, NCH, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT2_LDS_BYTES(NKB))
   MV_ATT_ATTR(1, 1); MV_ATT_ATTR(2, 1); MV_ATT_ATTR(3, 1); MV_ATT_ATTR(4, 1); MV_ATT_ATTR(2, 3); MV_ATT_ATTR(2, 4);
 #undef MV_ATT_ATTR
+  hipFuncSetAttribute((const void*)attention_v2_kernel<1, 1, 1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT2_LDS_BYTES_VLO(1));
+  hipFuncSetAttribute((const void*)attention_v2_kernel<2, 1, 1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT2_LDS_BYTES_VLO(2));
   (void)hipGetLastError();
   if (const char* e = getenv("MEMVUL_GEMM_TILE")) h->gemm_tile = atoi(e);
   if (const char* e = getenv("MEMVUL_CLS_PRUNE")) h->cls_prune = atoi(e) != 0;
@@ -873,6 +888,7 @@ int mv_create(int device, const mv_config* cfg, mv_handle** out) try {
     }
   }
   if (const char* e = getenv("MEMVUL_STREAM_LO8")) h->stream_lo8 = atoi(e) == 1;
+  if (const char* e = getenv("MEMVUL_SHORT_VLO")) h->short_vlo = atoi(e) != 0;
   if (const char* e = getenv("MEMVUL_GN_MAX")) { const int v = atoi(e); if (v >= 1 && v <= 12) h->pp_gn_max = v; }
   if (const char* e = getenv("MEMVUL_RASTER")) h->pp_raster = atoi(e) == 1 ? 1 : 0;
   {
@@ -897,6 +913,9 @@ int mv_create(int device, const mv_config* cfg, mv_handle** out) try {
     A(dev_alloc(h, &h->w->q, T * MV_HIDDEN));
     A(dev_alloc(h, &h->w->k, T * MV_HIDDEN));
     A(dev_alloc(h, &h->w->vt, T * MV_HIDDEN));
+    A(dev_alloc(h, &h->w->vt_lo, T * MV_HIDDEN));
+    A(dev_alloc(h, &h->w->q_lo, T * MV_HIDDEN));
+    A(dev_alloc(h, &h->w->k_lo, T * MV_HIDDEN));
     A(dev_alloc(h, &h->w->ctx, T * MV_HIDDEN));
     A(dev_alloc(h, &h->w->h16, T * MV_INTER));
     A(dev_alloc(h, &h->w->lnstats, T * 6));

@@ -58,6 +58,8 @@ struct GemmArgs {
   int x8_terms;          // 0 / 2: both first-order terms; 1: only A_hi8 W_lo8 (the second halves of the rows: K bytes, K / 128 K-tiles);
                          // 3 (PP_QK): per Q / K / V block by x8_aside_mask
   int x8_aside_mask;     // x8_terms == 3: bit 0 / 1 / 2 set = the Q / K / V block sweeps both terms, clear = the weight-side term only
+  half_t* vt_lo;         // PP_QK X8, short passes (padded length <= 128): second fp16 plane of V^T, fp16(V - fp16(V)), same layout as vt (attention_v2.h VLO);
+  half_t *q_lo, *k_lo;   // the same for Q and K (set together with vt_lo)
   unsigned int* x8_sat;  // MV_F16X8 producers: device counter of activation elements the fp8 planes' +-112 clamp changed (common.h x8_planes4)
   int raster_mode;       // gemm_pp: 0 = column group > tile_m > tile_n; 1 = "A-stationary": consecutive persistent iterations of a workgroup
                          // keep its tile_m and walk the column groups (the XCD's A panels stay in its L2 across the whole N sweep)

@@ -765,6 +765,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmArgs a) {
         size_t jstride;   // elements between j blocks
         bool live = true;
         bool vtile = false;  // PP_QK: this tile belongs to the V block and is stored as V^T
+        ptrdiff_t lo_delta = 0;  // PP_QK X8, short passes: elements from this tile's output buffer to its second (lo) plane
         // V^T image: rows = head dims 16 cbl + 4 q4 + e, columns = tokens 16 tbl + m16 (2 bytes), 16-B chunk (token >> 3) ^ q4
         const uint32_t tb0 = scr + q4 * 256 + (m16 & 7) * 2;
         const uint32_t tt0 = tb0 + ((((uint32_t)(m16 >> 3)) ^ (uint32_t)q4) << 4), tt1 = tb0 + (((2u + (uint32_t)(m16 >> 3)) ^ (uint32_t)q4) << 4);
@@ -780,9 +781,11 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmArgs a) {
           if (vtile) {  // image rows = head dims, image columns = tokens (scr_f16x2_t)
             obase = a.vt + ((size_t)head * MV_HEAD_DIM + crow) * a.S + 8 * cchunk;
             rstride = a.S; istride = 0; jstride = (size_t)32 * a.S;
+            lo_delta = a.vt_lo - a.vt;
           } else {
             obase = (which ? a.k : a.q) + (size_t)head * a.S * MV_HEAD_DIM + (size_t)crow * MV_HEAD_DIM + 8 * cchunk;
             rstride = MV_HEAD_DIM; istride = 0; jstride = 32;  // the batch-row part is added per i below
+            lo_delta = which ? a.k_lo - a.k : a.q_lo - a.q;
           }
         }
         // RAW: bias' of this lane's columns (per-tile LDS image: one float4 per column block) and rstd of its eight token rows
@@ -848,6 +851,35 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmArgs a) {
               half_t* op = ob + j * jstride;
               *(u32x4*)op = o[2 * j];
               *(u32x4*)(op + 16 * rstride) = o[2 * j + 1];
+            }
+          }
+          if constexpr (EPI == PP_QK && X8) {
+            // short passes (a.vt_lo set: padded length <= 128): Q, K and V^T as TWO fp16 planes each — what is left of the precise mode's error is the
+            // fp16 storage of Q, K, V and P, which attention averages over the keys, so short sequences feel it most (profiles/r05_f_length_envelope.txt);
+            // the attention kernel of these passes adds the first-order terms K_lo Q_hi + K_hi Q_lo and V_lo P_hi + V_hi P_lo (attention_v2.h VLO).
+            // Same values as the first pass, recomputed.
+            if (a.vt_lo) {
+#pragma unroll
+              for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                  const int tb = 2 * i + (k >> 1), cb = 2 * j + (k & 1);
+                  const float v0 = __builtin_fmaf(rrs[tb], acc[tb][cb][0], rbv[cb].x), v1 = __builtin_fmaf(rrs[tb], acc[tb][cb][1], rbv[cb].y);
+                  const float v2 = __builtin_fmaf(rrs[tb], acc[tb][cb][2], rbv[cb].z), v3 = __builtin_fmaf(rrs[tb], acc[tb][cb][3], rbv[cb].w);
+                  d[j][k][0] = pack_h2(v0 - (float)(half_t)v0, v1 - (float)(half_t)v1);
+                  d[j][k][1] = pack_h2(v2 - (float)(half_t)v2, v3 - (float)(half_t)v3);
+                }
+              if (vtile) scr_f16x2_t(tt0, tt1, d[0], d[1], scr_c, o);
+              else scr_f16x2(u00, u01, u00 + 1024u, u01 + 1024u, d[0], d[1], scr_c, o);
+              if (live) {
+                half_t* ol = ob + lo_delta;
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                  half_t* op = ol + j * jstride;
+                  *(u32x4*)op = o[2 * j];
+                  *(u32x4*)(op + 16 * rstride) = o[2 * j + 1];
+                }
+              }
             }
           }
           if constexpr (IS_RES && !LO8S) {  // second plane: lo = fp16(r - hi), same addresses in the lo buffer (LO8S: the lo8 plane below IS the stream's lo)

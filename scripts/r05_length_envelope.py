@@ -23,8 +23,9 @@ dims = synth.BertDims(layers=12)
 w = synth.make_weights(dims, seed=mk.ENV_SEED, qk_scale=2.0, match_scale=29.0, trained_like=True)
 u_ref = refs["outlier_1_u"]
 out = []
-for mode, env in (("precise", {}), ("precise+lo8", {"MEMVUL_STREAM_LO8": "1"}), ("f16", {})):
+for mode, env in (("precise", {}), ("precise, one V/P plane (MEMVUL_SHORT_VLO=0)", {"MEMVUL_SHORT_VLO": "0"}), ("precise+lo8", {"MEMVUL_STREAM_LO8": "1"}), ("f16", {})):
     os.environ.pop("MEMVUL_STREAM_LO8", None)
+    os.environ.pop("MEMVUL_SHORT_VLO", None)
     os.environ.update(env)
     e = Engine(0, vocab_size=dims.vocab_size, layers=12, max_tokens=16 * 512, max_batch=16, max_anchors=16)
     e.load_state_dict(w, "f16" if mode == "f16" else "precise")
@@ -41,6 +42,6 @@ for mode, env in (("precise", {}), ("precise+lo8", {"MEMVUL_STREAM_LO8": "1"}), 
                                    logit_err=float(np.abs(lg_g - lg_r).max()))
     e.close()
     out.append(row)
-    print("%-12s " % mode + "  ".join("L=%d: embed %.1e logit %.2e" % (L, d["embed_err"], d["logit_err"]) for L, d in row["by_length"].items()), flush=True)
+    print("%-46s " % mode + "  ".join("L=%d: embed %.1e logit %.2e" % (L, d["embed_err"], d["logit_err"]) for L, d in row["by_length"].items()), flush=True)
 if len(sys.argv) > 1:
     json.dump(out, open(sys.argv[1], "w"), indent=1)

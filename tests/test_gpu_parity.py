@@ -147,6 +147,35 @@ def test_lo8_residual_stream_option(gu, golden_dir, name):
     eng.anchor_reset(); ref.anchor_reset()
 
 
+def test_short_sequences_carry_v_and_p_as_two_planes(gu, golden_dir):
+    """Round 5: what is left of the precise mode's error is the fp16 storage of V and P, which attention averages over the keys — short sequences
+    average it least (profiles/r05_f_length_envelope.txt: a 8-token sequence's embedding error alone cost 9.4e-4 on the logits at the trained-like matcher
+    norm).  Passes of padded length <= 128 therefore carry V and P as hi + lo fp16 planes through attention (attention_v2.h VLO, GemmArgs::vt_lo;
+    MEMVUL_SHORT_VLO=0 is the A/B switch).  16 sequences of 8 / 16 / 32 / 64 tokens on the envelope model against the CPU reference's embeddings
+    (tests/golden/r05_trained_like_refs.npz); logit error = what that embedding's error costs against 8 fixed issue-report embeddings."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts"))
+    import r05_make_refs as mk
+
+    refs = np.load(os.path.join(golden_dir, "r05_trained_like_refs.npz"))
+    dk, wk = dict(layers=12), dict(seed=mk.ENV_SEED, qk_scale=2.0, match_scale=29.0, trained_like=True)
+    dims, w = gu.weights_for(dk, wk)
+    u_ref = refs["outlier_1_u"]
+    errs = {}
+    for tag, env in (("two_planes", {}), ("one_plane", {"MEMVUL_SHORT_VLO": "0"})):
+        eng = gu.engine_for(dk, wk, compute_dtype="precise", env=env)
+        for L in (8, 16, 32, 64):
+            _, ids, lens = mk.length_inputs(L)
+            v = eng.encode(ids, lens)
+            lg_g = orc.match(u_ref, v, w[synth.KEY_MATCH_W])[0]
+            lg_r = orc.match(u_ref, refs[f"len_{L}"], w[synth.KEY_MATCH_W])[0]
+            errs[(tag, L)] = float(np.abs(lg_g - lg_r).max())
+    gu.record("short_sequences", **{f"{t}_{L}": e for (t, L), e in errs.items()})
+    for L in (8, 16, 32, 64):
+        assert errs[("two_planes", L)] <= 6e-4, errs          # with margin inside the 1e-3 contract (one plane: up to 9.4e-4)
+    assert sum(errs[("two_planes", L)] for L in (8, 16, 32)) < 0.8 * sum(errs[("one_plane", L)] for L in (8, 16, 32)), errs
+
+
 def test_small_pass_kernels_exclude_the_default_compute_dtype(gu):
     """the product default is MV_F16X8, which only exists on the persistent GEMM path — MEMVUL_GEMM_TILE=128 (the small-pass
     kernels forced) must fail at mv_finalize_weights with a message that names the switch, not compute something else."""
