@@ -311,7 +311,9 @@ def test_full_batch_trained_like_rows_against_the_oracle(gu, compute):
     gu.record("full_batch_trained_like", compute=compute, logits_err=e, logit_scale=float(np.abs(lg).max()),
               u_err=float(np.abs(out["embed"][rows] - u_ref).max()), v_err=float(np.abs(eng.anchor_get()[ga] - v_ref).max()))
     assert float(np.abs(lg).max()) > 1.5
-    assert e <= (LOGIT_TOL if compute == "precise" else TRAINED_LIKE_LOGIT_BOUND), e
+    # precise: 7.7e-4 with one plane of Q / K / V / P (anchors of 8 - 64 tokens average their fp16 storage over few keys), 5.3e-4 since the
+    # short passes carry two (attention_v2.h VLO): the bound guards that gain, the contract is LOGIT_TOL
+    assert e <= (7e-4 if compute == "precise" else TRAINED_LIKE_LOGIT_BOUND), e
     if compute == "precise":
         assert eng.x8_saturation() == 0  # nothing in this regime leaves the fp8 planes' range
     eng.anchor_reset()
