@@ -55,6 +55,8 @@
 // sweep's and the staging code is shared; an fp8 K-tile covers 128 products per row pair in the matrix-pipe time the fp16
 // tile needs for 64.  Cost: 2x the main loop (a three-sweep fp16 split: 3x); error: operand rounding 2^-12 -> ~2^-15.5
 // (oracle/precision_model.py "f16x8").  The producers (PP_GELU, PP_RESLN3; embedding, attention) write the [lo8 | hi8] planes.
+// X8 = 2 (PP_RESLN3, MEMVUL_STREAM_LO8=1): the same, with the raw stream's low part taken from / left in the lo8 plane (no lo fp16 plane).
+// PP_QK X8 with GemmArgs::vt_lo set (passes of padded length <= 128): second fp16 planes of Q, K and V^T for the two-plane attention (attention_v2.h VLO).
 #pragma once
 #include "common.h"
 #include <type_traits>
