@@ -100,3 +100,39 @@ def test_host_e4m3_encoder_matches_the_rounding_model():
     vals = e4m3_decode(codes)
     back = e4m3_bits(vals)
     assert np.array_equal(back[vals != 0], codes[vals != 0])
+
+
+def test_short_sequences_feel_the_qkvp_storage_floor():
+    """Round 5: what is left of the precise mode's error is the fp16 storage of Q, K, V and P, which attention averages over the keys — so it grows as
+    sequences shorten (GPU: profiles/r05_f_length_envelope.txt, 9.4e-4 at 8 tokens against 2.3e-4 at 256), and carrying the four tensors as hi + lo
+    planes through the attention of short passes (attention_v2.h VLO; model: formats "f16x2") takes it away.  Model, 16-token sequences on both sides."""
+    dims = synth.BertDims(layers=12)
+    w = synth.make_weights(dims, qk_scale=2.0, match_scale=29.0, trained_like=True)
+    B, S = 4, 16
+    ids, lens = synth.make_ids(B, S, dims.vocab_size, seed=41)
+    aids, alens = synth.make_ids(4, S, dims.vocab_size, seed=42)
+    mask, amask = synth.mask_from_lens(lens, S), synth.mask_from_lens(alens, S)
+    ref, _, _ = pm.logits(w, ids, mask, aids, amask, None)
+
+    def err(cfg):
+        lg, _, _ = pm.logits(w, ids, mask, aids, amask, cfg)
+        return float(np.sqrt(((lg - ref) ** 2).mean()))
+
+    g8 = dict(pm.X8_ENGINE)
+    one_plane = err(pm.engine_formats(12, "f16", **g8))
+    two_planes = err(pm.engine_formats(12, "f16", **dict(g8, qkv="f16x2", p="f16x2")))
+    print("\n16-token sequences, rms logit error: one plane of Q/K/V/P %.2e, two planes %.2e" % (one_plane, two_planes))
+    assert two_planes < 0.7 * one_plane
+
+
+def test_lo8_residual_stream_is_priced_by_the_model(case):
+    """The opt-in MEMVUL_STREAM_LO8=1 (the stored residual stream = hi fp16 + the lo8 plane, knob `res`): small in the model (the GPU's 24 draws say more:
+    +1.9e-4 in quadrature), nowhere near what an fp16-only stream would cost."""
+    L = 12
+    g8 = dict(pm.X8_ENGINE)
+    base = case(pm.engine_formats(L, "f16", **g8))
+    lo8 = case(pm.engine_formats(L, "f16", **dict(g8, res="f16x8")))
+    f16 = case(pm.engine_formats(L, "f16", **dict(g8, res="f16")))
+    print("\nstored residual stream: two fp16 planes %.2e | hi + lo8 %.2e | fp16 only %.2e" % (base, lo8, f16))
+    assert lo8 < 1e-3 and lo8 < base + 3e-4
+    assert f16 > 3 * lo8
