@@ -947,8 +947,7 @@ int mv_create(int device, const mv_config* cfg, mv_handle** out) try {
   }
   h->w = &h->work[0];
   A(dev_alloc(h, &h->anchors, (int64_t)cfg->max_anchors * h->P));
-  A(dev_alloc(h, &h->x8_sat, 4));
-  if (rc == MV_OK && hipMemset(h->x8_sat, 0, 4 * sizeof(unsigned int)) != hipSuccess) rc = fail(h, MV_ERR_HIP, "hipMemset(x8_sat)");
+  A(dev_alloc(h, &h->x8_sat, 4));  // (zeroed by dev_alloc)
   if (rc == MV_OK && hipStreamSynchronize(h->w->stream) != hipSuccess) rc = MV_ERR_HIP;
   if (rc != MV_OK) {
     g_create_error = h->err.empty() ? "workspace allocation failed" : h->err;
