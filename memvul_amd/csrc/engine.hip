@@ -137,6 +137,8 @@ struct Work {
   half_t* xlo = nullptr;                        // lo plane of the two-plane raw stream (PP_RESLN3)
   uint8_t *x8 = nullptr, *ctx8 = nullptr, *h8 = nullptr;  // MV_F16X8: [lo8 | hi8] planes of the raw stream [T][1536], the attention
                                                           // context [T][1536] and the GELU output [T][6144]
+  half_t* cls_lo = nullptr;   // MV_F16X8, cls_aside: 2^11 x the low parts of the [CLS] rows of a GEMM's A operand [Bp][3072] (cls_lo_gather_kernel)
+  float* cls_corr = nullptr;  // ... and 2^11 x their A-side correction term A_lo W_hi^T [Bp][3072] (GemmArgs::cls_corr)
 };
 
 struct mv_handle {
@@ -189,6 +191,9 @@ struct mv_handle {
                            // (attention_v2.h VLO): the fp16 storage of V and P is what is left of the precise mode's error and short sequences average it least
   bool stream_lo8 = false; // MV_F16X8, env MEMVUL_STREAM_LO8=1: the raw residual stream as hi fp16 + the lo8 plane of its fp8 planes (no lo fp16 plane;
                            // gemm_pp.h X8 = 2): +1.5 % issue reports/s at 1.2x the trained-like logit error (profiles/r05_a_*) — opt-in
+  bool cls_aside = false;  // MV_F16X8, env MEMVUL_CLS_ASIDE=1: passes of padded length >= 256 sweep the weight-side correction term only in EVERY GEMM and
+                           // add the A-side term for the [CLS] row of each sequence alone (a skinny fp16 GEMM over those B rows in front of each launch,
+                           // GemmArgs::cls_corr): the pooler reads only that row, every other row's A-side rounding reaches it averaged over the keys
   int qkv_aside_mask = 1;  // MV_F16X8: which of the Q / K / V blocks of the QKV projection sweep the A-side correction term too (bit 0 / 1 / 2;
                            // gemm_pp.h x8_aside_mask).  Default: Q only.  env MEMVUL_QKV_ASIDE = a subset of "qkv" ("" / "none" = weight-side
                            // term only everywhere, "qkv" = round 3's form): the A/B switch of profiles/r04_d_*
@@ -473,6 +478,22 @@ int encode_dev(mv_handle* h, const int32_t* d_ids, const int32_t* d_lens, int B,
   const bool x8 = h->precise;             // MV_F16X8: + fp8 correction sweeps (forces the persistent path, pp_selected)
   const bool lo8s = x8 && h->stream_lo8;  // the stream's low part is the lo8 plane of x8 (no xlo plane)
   const bool prune = !full && h->cls_prune && u_out && n_layers == c.layers && n_layers > 0;
+  // [CLS]-row A-side term (MEMVUL_CLS_ASIDE=1): every persistent GEMM of this pass sweeps the weight-side correction term only (x8_terms = 1) and the
+  // A-side term A_lo W_hi^T is formed for the B [CLS] rows alone: their low parts (2^11 x, fp16) gathered from the operand's lo plane (raw stream) or
+  // lo8 plane (context, GELU output), one skinny fp16 GEMM [B x K] x [K x N], and the launch adds the result to those rows' accumulators
+  // (gemm_pp.h GemmArgs::cls_corr).  Long passes only: short sequences average the other rows' roundings over too few keys.
+  const bool cls_as = big && x8 && h->cls_aside && !lo8s && Sp >= 256;
+  auto cls_fix = [&](const half_t* lo16, const uint8_t* lo8p, const half_t* W, int N, int K) -> int {
+    ProfScope ps(h, KC_OTHER);
+    const size_t n4 = (size_t)B * K / 4;
+    hipLaunchKernelGGL(cls_lo_gather_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, h->w->stream, lo16, lo8p, K, Sp, B, h->w->cls_lo);
+    if (int rc = launch_check(h, "cls_lo_gather")) return rc;
+    GemmArgs t{};
+    t.M = (int)round_up(B, 64); t.Mreal = B; t.S = 64; t.A = h->w->cls_lo; t.W = W; t.N = N; t.K = K; t.outf = h->w->cls_corr;
+    t.GN = choose_gn(N / 64, 8);
+    hipLaunchKernelGGL((gemm_ring_kernel<EPI_F32, 1, 1, 2, 2, 64, 4, 2>), dim3((unsigned)((t.M / 64) * (N / 64))), dim3(256), RING64_LDS, h->w->stream, t);
+    return launch_check(h, "cls_corr gemm_ring");
+  };
   const unsigned ln_grid = (unsigned)((M + 3) / 4);
   {
     ProfScope ps(h, KC_EMBED_LN);
@@ -521,6 +542,10 @@ int encode_dev(mv_handle* h, const int32_t* d_ids, const int32_t* d_lens, int B,
       if (big) {
         g.lnstats = st_in;
         if (x8) { g.A8 = h->w->x8; g.W8 = w.wqkv_f8 + (size_t)MV_HIDDEN * 2 * MV_HIDDEN; g.x8_scale = w.sc_qkv; g.x8_terms = 3; g.x8_aside_mask = h->qkv_aside_mask; }
+        if (cls_as) {
+          if (int rc = cls_fix(h->w->xlo, nullptr, g.W, g.N, g.K)) return rc;
+          g.cls_corr = h->w->cls_corr;
+        }
         if (int rc = launch_pp<PP_QK>(h, KC_GEMM_KV_LAST, g)) return rc;
       } else if (int rc = launch_small<EPI_QKV>(h, KC_GEMM_KV_LAST, g)) return rc;
       ProfScope tail(h, KC_CLS_TAIL);
@@ -581,6 +606,10 @@ int encode_dev(mv_handle* h, const int32_t* d_ids, const int32_t* d_lens, int B,
       if (x8) { g.A8 = h->w->x8; g.W8 = w.wqkv_f8; g.x8_scale = w.sc_qkv; g.x8_terms = 3; g.x8_aside_mask = h->qkv_aside_mask; }
       g.vt_lo = (x8 && h->short_vlo && Sp <= 128) ? h->w->vt_lo : nullptr;  // short passes: Q, K, V^T as hi + lo planes (launch_attention: the same predicate)
       g.q_lo = h->w->q_lo; g.k_lo = h->w->k_lo;
+      if (cls_as) {  // (x8_terms stays 3: a block of x8_aside_mask — Q by default — keeps its A-side term for EVERY row and takes nothing from cls_corr)
+        if (int rc = cls_fix(h->w->xlo, nullptr, g.W, g.N, g.K)) return rc;
+        g.cls_corr = h->w->cls_corr;
+      }
       if (int rc = launch_pp<PP_QK>(h, KC_GEMM_QKV, g)) return rc;
       // K3: attention
       if (int rc = launch_attention(h, d_lens, B, Sp, x8)) return rc;
@@ -588,17 +617,29 @@ int encode_dev(mv_handle* h, const int32_t* d_ids, const int32_t* d_lens, int B,
       g.A = h->w->ctx; g.W = w.wo; g.bias = w.bo; g.N = MV_HIDDEN; g.K = MV_HIDDEN;
       g.lnstats = st_in; g.lng = pend_g; g.lnb = pend_b; g.lnpart = st_mid; g.out16 = h->w->x16; g.out16b = lo8s ? (half_t*)nullptr : h->w->xlo;
       if (x8) { g.A8 = h->w->ctx8; g.W8 = w.wo8; g.x8_scale = w.sc_o; g.out8 = h->w->x8; g.x8_terms = 2; }
+      if (cls_as) {
+        if (int rc = cls_fix(nullptr, h->w->ctx8, g.W, g.N, g.K)) return rc;
+        g.x8_terms = 1;  // (g.cls_corr stays set for the rest of the layer: every GEMM's term goes through the same buffer)
+      }
       if (int rc = launch_pp<PP_RESLN3>(h, KC_GEMM_OUT, g)) return rc;
       pend_g = w.ln1g; pend_b = w.ln1b;
       // K5: FFN-1 + exact-erf GELU
       g.A = h->w->x16; g.W = w.w1_f; g.bias = w.b1_f; g.N = MV_INTER; g.K = MV_HIDDEN; g.lnstats = st_mid; g.out16 = h->w->h16;
       g.out16b = nullptr; g.lnpart = nullptr;
       if (x8) { g.A8 = h->w->x8; g.W8 = w.w1_f8; g.x8_scale = w.sc_1; g.out8 = h->w->h8; g.x8_terms = 2; }
+      if (cls_as) {
+        if (int rc = cls_fix(h->w->xlo, nullptr, g.W, g.N, g.K)) return rc;
+        g.x8_terms = 1;
+      }
       if (int rc = launch_pp<PP_GELU>(h, KC_GEMM_FFN1, g)) return rc;
       // K6: FFN-2 + bias + LayerNorm(residual)
       g.A = h->w->h16; g.W = w.w2; g.bias = w.b2; g.N = MV_HIDDEN; g.K = MV_INTER;
       g.lnstats = st_mid; g.lng = pend_g; g.lnb = pend_b; g.lnpart = st_in; g.out16 = h->w->x16; g.out16b = lo8s ? (half_t*)nullptr : h->w->xlo;
       if (x8) { g.A8 = h->w->h8; g.W8 = w.w28; g.x8_scale = w.sc_2; g.out8 = h->w->x8; g.x8_terms = 2; }  // (the lo8 plane is the stream's own lo since round 5: always written)
+      if (cls_as) {
+        if (int rc = cls_fix(nullptr, h->w->h8, g.W, g.N, g.K)) return rc;
+        g.x8_terms = 1;
+      }
       if (int rc = launch_pp<PP_RESLN3>(h, KC_GEMM_FFN2, g)) return rc;
       pend_g = w.ln2g; pend_b = w.ln2b;
       if (last) { if (int rc = final_ln(w.ln2g, w.ln2b)) return rc; }  // the pooler reads a normalised stream
@@ -889,6 +930,7 @@ int mv_create(int device, const mv_config* cfg, mv_handle** out) try {
   }
   if (const char* e = getenv("MEMVUL_STREAM_LO8")) h->stream_lo8 = atoi(e) == 1;
   if (const char* e = getenv("MEMVUL_SHORT_VLO")) h->short_vlo = atoi(e) != 0;
+  if (const char* e = getenv("MEMVUL_CLS_ASIDE")) h->cls_aside = atoi(e) == 1;
   if (const char* e = getenv("MEMVUL_GN_MAX")) { const int v = atoi(e); if (v >= 1 && v <= 12) h->pp_gn_max = v; }
   if (const char* e = getenv("MEMVUL_RASTER")) h->pp_raster = atoi(e) == 1 ? 1 : 0;
   {
@@ -1150,6 +1192,8 @@ int mv_finalize_weights(mv_handle* h, int compute_dtype) try {
       if (rc == MV_OK) rc = dev_alloc(h, &h->work[wi].ctx8, h->cap_tokens * 2 * MV_HIDDEN);
       if (rc == MV_OK) rc = dev_alloc(h, &h->work[wi].h8, h->cap_tokens * 2 * MV_INTER);
       if (rc == MV_OK) rc = dev_alloc(h, &h->work[wi].ch32, (int64_t)round_up(h->cfg.max_batch, 256) * MV_INTER);
+      if (rc == MV_OK) rc = dev_alloc(h, &h->work[wi].cls_lo, (int64_t)round_up(h->cfg.max_batch, 256) * MV_INTER);
+      if (rc == MV_OK) rc = dev_alloc(h, &h->work[wi].cls_corr, (int64_t)round_up(h->cfg.max_batch, 256) * MV_INTER);
       if (rc == MV_OK && hipStreamSynchronize(h->w->stream) != hipSuccess) rc = MV_ERR_HIP;
       h->w = keep;
       if (rc != MV_OK) return rc;

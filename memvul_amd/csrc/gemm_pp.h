@@ -702,6 +702,34 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmArgs a) {
       const uint32_t sf = (uint32_t)((m16 >> 2) & 3);
       const uint32_t scr_c = scr + (lane >> 2) * 64 + ((((uint32_t)lane & 3) ^ (((uint32_t)lane >> 4) & 3)) << 4);
       const int crow = lane >> 2, cchunk = lane & 3;  // coalesced layout: row (+16 for the second read), 16-B chunk
+      if constexpr (X8 == 1) {
+        // [CLS]-row A-side term (GemmArgs::cls_corr; engine.hip cls_aside): the sweep above carried the weight-side correction term only; the
+        // A-side term A_lo W_hi^T is added here for the ONE row per sequence whose rounding reaches the pooler un-averaged — the [CLS] row b S —
+        // from a skinny fp16 GEMM over those rows (2^11 x the term, so that its operands stay normal fp16 numbers).  S % 64 == 0 and
+        // mw % 128 == 0: of this wave's 128 rows only mw and mw + 64 can be such a row = token blocks 0 and 4, lanes m16 == 0.
+        if (a.cls_corr && !both_terms(tile_n)) {  // (a tile whose sweep carried both terms — the Q block of the QKV projection by default — has it already)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            const int row = mw + 64 * j;  // wave-uniform
+            if (row < a.Mreal && row % a.S == 0 && m16 == 0) {
+              const float* cp = a.cls_corr + (size_t)(row / a.S) * a.N + nw + 4 * q4;
+              floatx4 c[4];  // all four loads in flight before the first use: ONE exposed memory latency per tile that holds such a row
+#pragma unroll
+              for (int cb = 0; cb < 4; ++cb) c[cb] = *(const floatx4*)(cp + 16 * cb);
+#if defined(__HIP_DEVICE_COMPILE__)
+              asm volatile("" : "+v"(c[0]), "+v"(c[1]), "+v"(c[2]), "+v"(c[3]));
+#endif
+#pragma unroll
+              for (int cb = 0; cb < 4; ++cb) {
+                acc[4 * j][cb][0] = __builtin_fmaf(c[cb][0], 1.0f / 2048.0f, acc[4 * j][cb][0]);
+                acc[4 * j][cb][1] = __builtin_fmaf(c[cb][1], 1.0f / 2048.0f, acc[4 * j][cb][1]);
+                acc[4 * j][cb][2] = __builtin_fmaf(c[cb][2], 1.0f / 2048.0f, acc[4 * j][cb][2]);
+                acc[4 * j][cb][3] = __builtin_fmaf(c[cb][3], 1.0f / 2048.0f, acc[4 * j][cb][3]);
+              }
+            }
+          }
+        }
+      }
       if constexpr (IS_RES) {
         // vstats of the new raw rows: (sum, sum of squares) over this TILE's 256 columns.  Each wave reduces its 64 columns (a token
         // row's 64 values sit in the four lanes m16 + 16 q4), parks the 128 pairs in its own scratch, and after a workgroup barrier

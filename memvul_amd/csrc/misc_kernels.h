@@ -247,6 +247,30 @@ __global__ __launch_bounds__(256) void cls_gather_kernel(const float* __restrict
   }
 }
 
+// [CLS]-row A-side term (engine.hip cls_aside): the LOW parts of the [CLS] rows (stream row b Sp) of a persistent GEMM's A operand as a
+// compact fp16 matrix [B][K], scaled by 2^11 (x - fp16(x) is 2^-11 of x: the scaled values are normal fp16 numbers of the operand's own
+// magnitude; exact in both forms) — the A operand of the skinny GEMM that forms that row's A-side correction term A_lo W_hi^T.
+// lo16: the operand's lo fp16 plane, rows of K halves (the raw stream's xlo); lo8: its [lo8 | hi8] planes, rows of 2 K bytes (context, GELU
+// output): lo8 = e4m3((x - hi) 2^(11 + shift)).  Four values per thread.
+__global__ __launch_bounds__(256) void cls_lo_gather_kernel(const half_t* __restrict__ lo16, const uint8_t* __restrict__ lo8, int K, int Sp,
+                                                            int B, half_t* __restrict__ out) {
+  const size_t i4 = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (i4 >= (size_t)B * K) return;
+  const size_t b = i4 / K, k = i4 - b * K, t = b * Sp;
+  half4_t y;
+  if (lo8) {
+    constexpr float SC = 1.0f / (float)(1 << MV_X8_ACT_SHIFT);
+    const uint32_t l8 = *(const uint32_t*)(lo8 + t * (2 * (size_t)K) + k);
+    const float2_t p = __builtin_amdgcn_cvt_scalef32_pk_f32_fp8(l8, 1.0f, false), q = __builtin_amdgcn_cvt_scalef32_pk_f32_fp8(l8, 1.0f, true);
+    y[0] = (half_t)(p.x * SC); y[1] = (half_t)(p.y * SC); y[2] = (half_t)(q.x * SC); y[3] = (half_t)(q.y * SC);
+  } else {
+    const half4_t l = *(const half4_t*)(lo16 + t * K + k);
+    y[0] = (half_t)((float)l[0] * 2048.0f); y[1] = (half_t)((float)l[1] * 2048.0f);
+    y[2] = (half_t)((float)l[2] * 2048.0f); y[3] = (half_t)((float)l[3] * 2048.0f);
+  }
+  *(half4_t*)(out + i4) = y;
+}
+
 // K7, K8 (model_memory.py:99-102): u = relu(W_h tanh(W_p h[:,0] + b_p) + b_h), all fp32, as two launches of one
 // dense kernel: out[b][n] = act(sum_k x[b][k] W^T[k][n] + bias[n]), K = 768, on the fp32-input matrix cores
 // (v_mfma_f32_32x32x2_f32: exact fp32 products and sums, MI355X_MICROARCH.md "f32-input MFMA").  A workgroup owns

@@ -71,19 +71,32 @@ def _w_shift(w):
     return int(np.floor(np.log2(448.0 / m))) if m > 0 else 0
 
 
-def _mm(afmt, wfmt, A, W):
+def _mm(afmt, wfmt, A, W, cls_lo=None):
     """A @ W^T as the engine forms it.  Both operands "f16x8" (MV_F16X8): ONE fp16 sweep + two fp8 (e4m3) correction sweeps
-    into the same fp32 accumulators,  A_hi W_hi + A_lo8 W_hi8 + A_hi8 W_lo8;  otherwise each operand is rounded on its own."""
+    into the same fp32 accumulators,  A_hi W_hi + A_lo8 W_hi8 + A_hi8 W_lo8;  otherwise each operand is rounded on its own.
+    ``cls_lo`` (MEMVUL_CLS_ASIDE=1, engine.hip cls_aside; A is [B, S, K]): wherever the sweep carried the weight-side term only, row 0 of
+    every sequence — its [CLS] token — gets the A-side term from a skinny fp16 GEMM  fp16(2^11 A_lo) fp16(W)^T 2^-11  with A_lo taken from
+    the operand's lo fp16 plane ("lo16": the raw stream) or its lo8 plane ("lo8": context, GELU output)."""
     if afmt in ("f16x8", "f16x8w", "f16x8q", "f16x8k", "f16x8v") and wfmt == "f16x8":
         ah, ah8, al8 = _x8_planes(A, X8_ACT_SHIFT)
         wh, wh8, wl8 = _x8_planes(W, _w_shift(W))
         out = ah @ wh.T + ah8 @ wl8.T
+
+        def cls_term(cols):
+            if cls_lo and A.ndim == 3:
+                lo = _f16(A[:, 0] - ah[:, 0]) if cls_lo == "lo16" else al8[:, 0]
+                out[:, 0, cols] += (_f16(lo * 2048.0) @ wh[cols].T) / 2048.0
+
         if afmt == "f16x8w":  # the weight-side term only (gemm_pp.h x8_terms = 1)
+            cls_term(slice(None))
             return out
         if afmt != "f16x8":   # packed QKV weight [3 H][K]: the A-side term only in the Q / K / V block (gemm_pp.h x8_aside_mask)
             Hb = W.shape[0] // 3
             b = "qkv".index(afmt[-1])
             out[..., b * Hb:(b + 1) * Hb] += al8 @ wh8[b * Hb:(b + 1) * Hb].T
+            for o in range(3):
+                if o != b:
+                    cls_term(slice(o * Hb, (o + 1) * Hb))
             return out
         return out + al8 @ wh8.T
     return FORMATS[afmt](A) @ FORMATS[wfmt](W).T
@@ -116,6 +129,10 @@ FORMATS = {
 # sweeps the A-side term in its Q block only (the weight-side term everywhere)
 X8_ENGINE = dict(w_qkv="f16x8", w_o="f16x8", w_1="f16x8", w_2="f16x8", a_qkv="f16x8q", a_ffn1="f16x8", ctx="f16x8", h="f16x8")
 
+# ... and of its MEMVUL_CLS_ASIDE=1 form (round 5; pass ``cls_fix=True`` to encode / logits with it): the weight-side term everywhere, the A-side term
+# in the Q block of the QKV projection (all rows) and, through the skinny GEMMs, in the [CLS] row of every sequence
+X8_ENGINE_CLS = dict(w_qkv="f16x8", w_o="f16x8", w_1="f16x8", w_2="f16x8", a_qkv="f16x8q", a_ffn1="f16x8w", ctx="f16x8w", h="f16x8w")
+
 KNOBS = ("w_qkv", "w_o", "w_1", "w_2", "a_qkv", "a_ffn1", "qkv", "p", "ctx", "h", "res")
 
 
@@ -136,10 +153,11 @@ def _ln_stats(x, eps):
 
 
 def encode(w, ids, mask, cfg: Optional[Dict[str, List[str]]], heads=12, eps=1e-12, fold_ln=True, cls_side=None, cls_raw_kv=False,
-           cls_from_layer=0):
+           cls_from_layer=0, cls_fix=False):
     """float64 BERT forward with the engine's rounding points (``cfg`` None = exact).  ``fold_ln``: the QKV / FFN-1
     weights are rounded AFTER the preceding LayerNorm is folded in (W'' = W gamma - rowmean, gemm_pp.h) and the A operand
-    is the raw (pre-LayerNorm) stream, as on the engine's persistent-GEMM path."""
+    is the raw (pre-LayerNorm) stream, as on the engine's persistent-GEMM path.  ``cls_fix``: the [CLS]-row A-side term of MEMVUL_CLS_ASIDE=1
+    (see _mm) in every GEMM whose A format sweeps the weight-side term only."""
     W = lambda k: w[PFX + k].astype(np.float64)  # noqa: E731
     L = orc.n_layers(w)
     if cfg is None:
@@ -166,9 +184,9 @@ def encode(w, ids, mask, cfg: Optional[Dict[str, List[str]]], heads=12, eps=1e-1
         if fold_ln:
             Wg = Wm * g[None, :]
             bf = bias + Wm @ b
-            return rstd * _mm(cfg[aknob][l], cfg[wknob][l], r_raw, Wg - Wg.mean(-1, keepdims=True)) + bf
+            return rstd * _mm(cfg[aknob][l], cfg[wknob][l], r_raw, Wg - Wg.mean(-1, keepdims=True), "lo16" if cls_fix else None) + bf
         x = (r_raw - mu) * rstd * g + b
-        return _mm(cfg[aknob][l], cfg[wknob][l], x, Wm) + bias
+        return _mm(cfg[aknob][l], cfg[wknob][l], x, Wm, "lo16" if cls_fix else None) + bias
 
     for l in range(L):
         p = f"encoder.layer.{l}."
@@ -189,13 +207,13 @@ def encode(w, ids, mask, cfg: Optional[Dict[str, List[str]]], heads=12, eps=1e-1
         ctx = ((R("p", l, e) @ vh) / den).transpose(0, 2, 1, 3).reshape(B, S, H)  # the engine normalises O after P·V
         mu, rstd = _ln_stats(r, eps)
         x = (R("res", l, r) - mu) * rstd * g + b  # the residual GEMM reads the STORED stream; its statistics come from the accumulators
-        r1 = _mm(cfg["ctx"][l], cfg["w_o"][l], ctx, W(p + "attention.output.dense.weight")) + W(p + "attention.output.dense.bias") + x
+        r1 = _mm(cfg["ctx"][l], cfg["w_o"][l], ctx, W(p + "attention.output.dense.weight"), "lo8" if cls_fix else None) + W(p + "attention.output.dense.bias") + x
         g1, b1 = W(p + "attention.output.LayerNorm.weight"), W(p + "attention.output.LayerNorm.bias")
         hpre = consumer(r1, g1, b1, W(p + "intermediate.dense.weight"), W(p + "intermediate.dense.bias"), "w_1", "a_ffn1", l)
         h = orc._gelu(hpre)
         mu, rstd = _ln_stats(r1, eps)
         x1 = (R("res", l, r1) - mu) * rstd * g1 + b1
-        r = _mm(cfg["h"][l], cfg["w_2"][l], h, W(p + "output.dense.weight")) + W(p + "output.dense.bias") + x1
+        r = _mm(cfg["h"][l], cfg["w_2"][l], h, W(p + "output.dense.weight"), "lo8" if cls_fix else None) + W(p + "output.dense.bias") + x1
         if cls_side and l >= cls_from_layer:
             mu, rstd = _ln_stats(rc, eps)
             xc = (rc - mu) * rstd * gc + bc

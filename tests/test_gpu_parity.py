@@ -147,6 +147,55 @@ def test_lo8_residual_stream_option(gu, golden_dir, name):
     eng.anchor_reset(); ref.anchor_reset()
 
 
+@pytest.mark.parametrize("qkv_aside", ["q", "none"])
+@pytest.mark.parametrize("name", ["l12_trained_s256", "l12_trained_ragged"])
+def test_cls_row_aside_option(gu, golden_dir, name, qkv_aside):
+    """MEMVUL_CLS_ASIDE=1 (round 5): passes of padded length >= 256 sweep the weight-side correction term only and add the A-side term
+    A_lo W_hi^T for the [CLS] row of each sequence alone — cls_lo_gather_kernel + a skinny fp16 GEMM over the B rows in front of every persistent
+    GEMM, added to those rows' accumulators (gemm_pp.h GemmArgs::cls_corr) — because only that row reaches the pooler un-averaged
+    (oracle/precision_model.py knob `cls_fix`; tests/test_precision_model.py::test_cls_row_aside_is_priced_by_the_model).  With the term missing or
+    misplaced the logits would sit at the weight-side-only level (2.7e-3, profiles/r04_a2_*): the contract bound below is the functional test.
+    `qkv_aside` = "q": the Q block of the QKV projection keeps its A-side term for every row (the default mask), "none": no block does."""
+    import make_golden
+
+    g = np.load(os.path.join(golden_dir, f"{name}.npz"))
+    dk, wk, B, S, ragged, G, SA = make_golden.CASES[name]
+    assert S >= 256  # the option only acts on passes of padded length >= 256
+    env = {"MEMVUL_CLS_ASIDE": "1", "MEMVUL_QKV_ASIDE": qkv_aside}
+    eng = gu.engine_for(dk, wk, compute_dtype="precise", env=env, max_tokens=16384, max_batch=64, max_anchors=64)
+    eng.anchor_reset()
+    LA = int(g["anchor_lens"].max())
+    eng.anchor_append(g["anchor_ids"][:, :LA], g["anchor_lens"])
+    out = eng.forward(g["ids"], g["lens"], want_embed=True)
+    errs = dict(u=float(np.abs(out["embed"] - g["u"]).max()), logits=float(np.abs(out["logits"] - g["logits"]).max()),
+                p=float(np.abs(out["probs"] - g["p"]).max()), logit_scale=float(np.abs(g["logits"]).max()))
+    gu.record("precise_mode_cls_aside", case=name, qkv_aside=qkv_aside, **errs)
+    assert errs["logits"] <= LOGIT_TOL and errs["p"] <= 2e-4, errs
+    assert eng.x8_saturation() == 0
+    # the same model with both terms everywhere: the two differ, by less than the contract
+    ref = gu.engine_for(dk, wk, compute_dtype="precise", max_tokens=16384, max_batch=64, max_anchors=64)
+    ref.anchor_reset()
+    ref.anchor_append(g["anchor_ids"][:, :LA], g["anchor_lens"])
+    o2 = ref.forward(g["ids"], g["lens"])
+    d = float(np.abs(o2["logits"] - out["logits"]).max())
+    assert 0 < d <= LOGIT_TOL, d
+    eng.anchor_reset(); ref.anchor_reset()
+
+
+def test_cls_row_aside_leaves_short_passes_alone(gu):
+    """The option acts on passes of padded length >= 256 only: a 64-token pass gives the same bits with and without the switch."""
+    dk, wk = dict(layers=2), dict(qk_scale=2.0, match_scale=29.0, trained_like=True)
+    dims, w = gu.weights_for(dk, wk)
+    ids, lens = synth.make_ids(8, 64, dims.vocab_size, seed=5)
+    a = gu.engine_for(dk, wk, compute_dtype="precise", env={"MEMVUL_CLS_ASIDE": "1"}).encode(ids, lens)
+    b = gu.engine_for(dk, wk, compute_dtype="precise").encode(ids, lens)
+    assert np.array_equal(a, b)
+    ids, lens = synth.make_ids(4, 256, dims.vocab_size, seed=6)
+    a = gu.engine_for(dk, wk, compute_dtype="precise", env={"MEMVUL_CLS_ASIDE": "1"}).encode(ids, lens)
+    b = gu.engine_for(dk, wk, compute_dtype="precise").encode(ids, lens)
+    assert not np.array_equal(a, b) and float(np.abs(a - b).max()) < 1e-3
+
+
 def test_short_sequences_carry_v_and_p_as_two_planes(gu, golden_dir):
     """Round 5: what is left of the precise mode's error is the fp16 storage of V and P, which attention averages over the keys — short sequences
     average it least (profiles/r05_f_length_envelope.txt: a 8-token sequence's embedding error alone cost 9.4e-4 on the logits at the trained-like matcher
