@@ -47,6 +47,7 @@ else:
 
 MFMA_PEAK_TFLOPS = 2500.0  # MI355X dense fp16/bf16 MFMA peak (MI355X_MICROARCH.md)
 LOGIT_TOL = 1e-3           # BASELINE.json north_star: logits within 1e-3 of the reference CPU path
+DEFAULT_CLS_ASIDE = "0"    # the library's default of MEMVUL_CLS_ASIDE (engine.hip mv_handle::cls_aside)
 AUTO_MARGIN = 0.5          # --compute auto hands `value` to MV_F16 only if its measured trained-like error is <= AUTO_MARGIN * LOGIT_TOL
 MODE_DTYPE = {"f16": "fp16 (MV_F16: fp16 MFMA operands, fp32 accumulate)",
               "precise": "fp16 + fp8 (MV_F16X8: fp16 MFMA sweep + one OCP-e4m3 MFMA correction sweep per GEMM, fp32 accumulate)"}
@@ -361,6 +362,9 @@ def main():
         out["fast" if other == "f16" else "precise"] = second_mode_leg(args, other, dims, weights, aids, alens, ids, lens, contract)
         # the opt-in lo8 residual stream of the precise mode (MEMVUL_STREAM_LO8=1, gemm_pp.h X8 = 2): rate and trained-like error of THIS run
         out["precise_lo8_stream"] = lo8_stream_leg(args, dims, weights, aids, alens, ids, lens, S)
+        # the [CLS]-row A-side form (MEMVUL_CLS_ASIDE, engine.hip cls_aside): whichever of the two forms is NOT the library's default in this run
+        other_cls = "0" if os.environ.get("MEMVUL_CLS_ASIDE", DEFAULT_CLS_ASIDE) == "1" else "1"
+        out["precise_cls_aside_" + ("off" if other_cls == "0" else "on")] = precise_option_leg(args, dims, weights, aids, alens, ids, lens, S, {"MEMVUL_CLS_ASIDE": other_cls})
     print(json.dumps(out), flush=True)
     mvdist.shutdown()
 
@@ -428,11 +432,17 @@ def lo8_stream_leg(args, dims, weights, aids, alens, ids, lens, S):
     """MV_F16X8 with MEMVUL_STREAM_LO8=1 (the raw residual stream as hi fp16 + the lo8 plane of its fp8 planes instead of hi + lo fp16
     planes): the same K steps on the same workload, and its trained-like logit error against the CPU leg measured here (the same
     sample as `contract`).  Not the default: ~+2.4 % for ~1.2x the error."""
-    old = os.environ.get("MEMVUL_STREAM_LO8")
-    os.environ["MEMVUL_STREAM_LO8"] = "1"
+    return precise_option_leg(args, dims, weights, aids, alens, ids, lens, S, {"MEMVUL_STREAM_LO8": "1"})
+
+
+def precise_option_leg(args, dims, weights, aids, alens, ids, lens, S, switches):
+    """MV_F16X8 under a set of library switches (read at mv_create): the same K steps on the same workload, and the trained-like logit error of
+    that form against the CPU leg measured here (the same sample as `contract`)."""
+    saved = {k: os.environ.get(k) for k in switches}
+    os.environ.update(switches)
     try:
         B, G, K, W = args.batch, args.anchors, args.steps, args.warmup
-        res = {"switch": "MEMVUL_STREAM_LO8=1"}
+        res = {"switch": " ".join("%s=%s" % kv for kv in sorted(switches.items()))}
         if args.cpu_sample > 0:
             res["logit_max_abs_err_trained_like"] = trained_like_errors(dims, S, modes=("precise",))["logit_max_abs_err_trained_like"]["precise"]
             res["meets_contract"] = bool(res["logit_max_abs_err_trained_like"] <= LOGIT_TOL)
@@ -464,10 +474,11 @@ def lo8_stream_leg(args, dims, weights, aids, alens, ids, lens, S):
         eng.close()
         return res
     finally:
-        if old is None:
-            os.environ.pop("MEMVUL_STREAM_LO8", None)
-        else:
-            os.environ["MEMVUL_STREAM_LO8"] = old
+        for k, v in saved.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
 
 
 def sustained_leg(eng, step, B, seconds):

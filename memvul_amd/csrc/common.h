@@ -41,6 +41,15 @@ __device__ __forceinline__ void x8_planes4(float v0, float v1, float v2, float v
   hi8 = pack_fp8x4_scaled(v0, v1, v2, v3, SH);
   lo8 = pack_fp8x4_scaled(v0 - (float)(half_t)v0, v1 - (float)(half_t)v1, v2 - (float)(half_t)v2, v3 - (float)(half_t)v3, SL);
 }
+// the hi8 plane alone (a consumer that sweeps only the weight-side term never reads lo8): clamped form and the common in-range form
+__device__ __forceinline__ uint32_t x8_hi4(float v0, float v1, float v2, float v3) {
+  constexpr float SH = 1.0f / (float)(1 << MV_X8_ACT_SHIFT), BOUND = 448.f * SH;
+  return pack_fp8x4_scaled(__builtin_amdgcn_fmed3f(v0, -BOUND, BOUND), __builtin_amdgcn_fmed3f(v1, -BOUND, BOUND),
+                           __builtin_amdgcn_fmed3f(v2, -BOUND, BOUND), __builtin_amdgcn_fmed3f(v3, -BOUND, BOUND), SH);
+}
+__device__ __forceinline__ uint32_t x8_hi4_in_range(float v0, float v1, float v2, float v3) {
+  return pack_fp8x4_scaled(v0, v1, v2, v3, 1.0f / (float)(1 << MV_X8_ACT_SHIFT));
+}
 // The common path: every value inside the range (|v| <= 112, checked per block by the caller through x8_absmax4 / x8_any_out_of_range, which
 // falls back to x8_planes4 for a block that is not): no clamps — and without them the fp16 rounding below is the SAME expression as the one the
 // producer's fp16 output store needs, so hipcc computes it once (v_cvt_pk_f16_f32 + v_cvt_f32_f16 instead of a second v_cvt_f16_f32 per value).

@@ -620,6 +620,7 @@ int encode_dev(mv_handle* h, const int32_t* d_ids, const int32_t* d_lens, int B,
       if (cls_as) {
         if (int rc = cls_fix(nullptr, h->w->ctx8, g.W, g.N, g.K)) return rc;
         g.x8_terms = 1;  // (g.cls_corr stays set for the rest of the layer: every GEMM's term goes through the same buffer)
+        g.out8_hi_only = 1;  // the stream planes this launch writes are FFN-1's A8: weight-side term only (its [CLS] rows' low parts come from xlo)
       }
       if (int rc = launch_pp<PP_RESLN3>(h, KC_GEMM_OUT, g)) return rc;
       pend_g = w.ln1g; pend_b = w.ln1b;
@@ -630,6 +631,7 @@ int encode_dev(mv_handle* h, const int32_t* d_ids, const int32_t* d_lens, int B,
       if (cls_as) {
         if (int rc = cls_fix(h->w->xlo, nullptr, g.W, g.N, g.K)) return rc;
         g.x8_terms = 1;
+        g.out8_hi_only = 1;  // h8 is FFN-2's A8: hi8 alone, + the lo8 rows of the blocks that hold a [CLS] row (cls_fix reads them)
       }
       if (int rc = launch_pp<PP_GELU>(h, KC_GEMM_FFN1, g)) return rc;
       // K6: FFN-2 + bias + LayerNorm(residual)
@@ -639,6 +641,7 @@ int encode_dev(mv_handle* h, const int32_t* d_ids, const int32_t* d_lens, int B,
       if (cls_as) {
         if (int rc = cls_fix(nullptr, h->w->h8, g.W, g.N, g.K)) return rc;
         g.x8_terms = 1;
+        g.out8_hi_only = h->qkv_aside_mask == 0;  // the next QKV projection reads the stream's lo8 plane only in a block that sweeps its A-side term
       }
       if (int rc = launch_pp<PP_RESLN3>(h, KC_GEMM_FFN2, g)) return rc;
       pend_g = w.ln2g; pend_b = w.ln2b;

@@ -63,6 +63,8 @@ struct GemmArgs {
   unsigned int* x8_sat;  // MV_F16X8 producers: device counter of activation elements the fp8 planes' +-112 clamp changed (common.h x8_planes4)
   int raster_mode;       // gemm_pp: 0 = column group > tile_m > tile_n; 1 = "A-stationary": consecutive persistent iterations of a workgroup
                          // keep its tile_m and walk the column groups (the XCD's A panels stay in its L2 across the whole N sweep)
+  int out8_hi_only;      // gemm_pp X8 producers (PP_GELU / PP_RESLN3), cls_aside: the consumer of out8 sweeps the weight-side term only — write the hi8
+                         // plane alone, except in 32-row blocks that hold a [CLS] row (their lo8 row feeds cls_lo_gather_kernel)
   const float* cls_corr; // gemm_pp X8, "[CLS]-row A-side term" (engine.hip cls_aside): [ceil(M / S)][N] fp32 = 2^11 x the A-side first-order term
                          // A_lo W_hi^T of the [CLS] row (row b S) of every sequence, computed by a skinny fp16 GEMM in front of this launch
                          // and added to that row's accumulators before the epilogue; the main sweep then carries the weight-side term only

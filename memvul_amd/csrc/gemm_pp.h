@@ -938,6 +938,39 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmArgs a) {
             float vmax8 = 0.f;      // max |value| of the block (saturation accounting, common.h)
             const uint32_t w8 = ub8 + (sf << 4);
             uint8_t* o8 = a.out8 + (size_t)(mb + crow) * (2 * a.N) + nw + 16 * cchunk;
+            // GemmArgs::out8_hi_only (engine.hip cls_aside: the consumer sweeps the weight-side term only): no lo8 plane — except for a 32-row block
+            // that holds the [CLS] row of a sequence (row b S: wave-uniform), whose lo8 row feeds that row's A-side term (cls_lo_gather_kernel)
+            bool hi_only = false;
+            if constexpr (X8 == 1) hi_only = a.out8_hi_only && (mb % a.S != 0);
+            if (hi_only) {
+#pragma unroll
+              for (int tbl = 0; tbl < 2; ++tbl)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                  for (int cbl = 0; cbl < 2; ++cbl) {
+                    const int tb = 2 * i + tbl, cb = 2 * j + cbl;
+                    dh[4 * tbl + 2 * j + cbl] = x8_hi4_in_range(acc[tb][cb][0], acc[tb][cb][1], acc[tb][cb][2], acc[tb][cb][3]);
+                    vmax8 = x8_absmax4(vmax8, acc[tb][cb][0], acc[tb][cb][1], acc[tb][cb][2], acc[tb][cb][3]);
+                  }
+              if (x8_any_out_of_range(vmax8)) {  // rare: redo with the clamps and count
+                int n = 0;
+#pragma unroll
+                for (int tbl = 0; tbl < 2; ++tbl)
+#pragma unroll
+                  for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int cbl = 0; cbl < 2; ++cbl) {
+                      const int tb = 2 * i + tbl, cb = 2 * j + cbl;
+                      dh[4 * tbl + 2 * j + cbl] = x8_hi4(acc[tb][cb][0], acc[tb][cb][1], acc[tb][cb][2], acc[tb][cb][3]);
+                      n += x8_count4(acc[tb][cb][0], acc[tb][cb][1], acc[tb][cb][2], acc[tb][cb][3]);
+                    }
+                x8_sat_add(a.x8_sat, n);
+              }
+              scr_f8x1(w8, w8 ^ 16u, w8 ^ 32u, w8 ^ 48u, dh, scr_c, o);
+              *(u32x4*)(o8 + a.N) = o[0];
+              *(u32x4*)(o8 + a.N + (size_t)16 * (2 * a.N)) = o[1];
+            } else {
 #pragma unroll
             for (int tbl = 0; tbl < 2; ++tbl)
 #pragma unroll
@@ -972,6 +1005,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmArgs a) {
             *(u32x4*)(o8 + (size_t)16 * (2 * a.N)) = o[1];
             *(u32x4*)(o8 + a.N) = o[2];
             *(u32x4*)(o8 + a.N + (size_t)16 * (2 * a.N)) = o[3];
+            }
           }
           if constexpr (IS_RES) {  // block row i is out: request block row i of the NEXT tile's residual into its registers
             if (has_next) park_residual(i, (next_m << 8) + wr * 128, (next_n << 8) + wc * 64);
