@@ -139,6 +139,7 @@ struct Work {
                                                           // context [T][1536] and the GELU output [T][6144]
   half_t* cls_lo = nullptr;   // MV_F16X8, cls_aside: 2^11 x the low parts of the [CLS] rows of a GEMM's A operand [Bp][3072] (cls_lo_gather_kernel)
   float* cls_corr = nullptr;  // ... and 2^11 x their A-side correction term A_lo W_hi^T [Bp][3072] (GemmArgs::cls_corr)
+  int32_t* tile_both = nullptr;  // cls_aside: per 256-row tile of the pass, non-zero = its sequence is shorter than cls_min_len (GemmArgs::tile_both)
 };
 
 struct mv_handle {
@@ -191,7 +192,10 @@ struct mv_handle {
                            // (attention_v2.h VLO): the fp16 storage of V and P is what is left of the precise mode's error and short sequences average it least
   bool stream_lo8 = false; // MV_F16X8, env MEMVUL_STREAM_LO8=1: the raw residual stream as hi fp16 + the lo8 plane of its fp8 planes (no lo fp16 plane;
                            // gemm_pp.h X8 = 2): +1.5 % issue reports/s at 1.2x the trained-like logit error (profiles/r05_a_*) — opt-in
-  bool cls_aside = false;  // MV_F16X8, env MEMVUL_CLS_ASIDE=1: passes of padded length >= 256 sweep the weight-side correction term only in EVERY GEMM and
+  int cls_min_len = 128;   // ... and, inside such a pass, only sequences of at least this many tokens (env MEMVUL_CLS_ASIDE_MIN_LEN): the other rows' A-side
+                           // rounding reaches the [CLS] row averaged over the keys, and a short sequence averages over few (model: 1.5 - 1.8x the error below
+                           // 128 tokens).  The row tiles of a shorter sequence run the default form bit for bit (GemmArgs::tile_both, cls_tile_flags_kernel)
+  bool cls_aside = false;  // MV_F16X8, env MEMVUL_CLS_ASIDE=1: passes of padded length 256 / 512 sweep the weight-side correction term only in EVERY GEMM and
                            // add the A-side term for the [CLS] row of each sequence alone (a skinny fp16 GEMM over those B rows in front of each launch,
                            // GemmArgs::cls_corr): the pooler reads only that row, every other row's A-side rounding reaches it averaged over the keys
   int qkv_aside_mask = 1;  // MV_F16X8: which of the Q / K / V blocks of the QKV projection sweep the A-side correction term too (bit 0 / 1 / 2;
@@ -482,7 +486,15 @@ int encode_dev(mv_handle* h, const int32_t* d_ids, const int32_t* d_lens, int B,
   // A-side term A_lo W_hi^T is formed for the B [CLS] rows alone: their low parts (2^11 x, fp16) gathered from the operand's lo plane (raw stream) or
   // lo8 plane (context, GELU output), one skinny fp16 GEMM [B x K] x [K x N], and the launch adds the result to those rows' accumulators
   // (gemm_pp.h GemmArgs::cls_corr).  Long passes only: short sequences average the other rows' roundings over too few keys.
-  const bool cls_as = big && x8 && h->cls_aside && !lo8s && Sp >= 256;
+  // Passes of padded length 256 / 512 (a 256-row tile then belongs to ONE sequence, so the form of a sequence depends on its own length alone and a
+  // row's result stays independent of the batch it travels in); sequences shorter than cls_min_len keep the default form, tile by tile.
+  const bool cls_as = big && x8 && h->cls_aside && !lo8s && (Sp == 256 || Sp == 512);
+  if (cls_as) {
+    const int ntile = (int)(Mpad / 256);
+    hipLaunchKernelGGL(cls_tile_flags_kernel, dim3((unsigned)((ntile + 255) / 256)), dim3(256), 0, h->w->stream, d_lens, B, Sp, h->cls_min_len, ntile,
+                       h->w->tile_both);
+    if (int rc = launch_check(h, "cls_tile_flags")) return rc;
+  }
   auto cls_fix = [&](const half_t* lo16, const uint8_t* lo8p, const half_t* W, int N, int K) -> int {
     ProfScope ps(h, KC_OTHER);
     const size_t n4 = (size_t)B * K / 4;
@@ -531,6 +543,7 @@ int encode_dev(mv_handle* h, const int32_t* d_ids, const int32_t* d_lens, int B,
     const bool last = (l == n_layers - 1);
     GemmArgs g{};
     g.M = (int)Mpad; g.Mreal = (int)M; g.S = Sp; g.ln_eps = c.ln_eps; g.x8_sat = h->x8_sat;
+    g.tile_both = cls_as ? h->w->tile_both : nullptr;
     g.q = h->w->q; g.k = h->w->k; g.vt = h->w->vt;
     const half_t* wqkv = big ? w.wqkv_f : w.wqkv;
     const float* bqkv = big ? w.bqkv_f : w.bqkv;
@@ -542,10 +555,7 @@ int encode_dev(mv_handle* h, const int32_t* d_ids, const int32_t* d_lens, int B,
       if (big) {
         g.lnstats = st_in;
         if (x8) { g.A8 = h->w->x8; g.W8 = w.wqkv_f8 + (size_t)MV_HIDDEN * 2 * MV_HIDDEN; g.x8_scale = w.sc_qkv; g.x8_terms = 3; g.x8_aside_mask = h->qkv_aside_mask; }
-        if (cls_as) {
-          if (int rc = cls_fix(h->w->xlo, nullptr, g.W, g.N, g.K)) return rc;
-          g.cls_corr = h->w->cls_corr;
-        }
+        // (cls_aside: no row term here — K and V of the [CLS] token are one key among S for every query; its Q row is computed in fp32 by the tail below)
         if (int rc = launch_pp<PP_QK>(h, KC_GEMM_KV_LAST, g)) return rc;
       } else if (int rc = launch_small<EPI_QKV>(h, KC_GEMM_KV_LAST, g)) return rc;
       ProfScope tail(h, KC_CLS_TAIL);
@@ -606,7 +616,10 @@ int encode_dev(mv_handle* h, const int32_t* d_ids, const int32_t* d_lens, int B,
       if (x8) { g.A8 = h->w->x8; g.W8 = w.wqkv_f8; g.x8_scale = w.sc_qkv; g.x8_terms = 3; g.x8_aside_mask = h->qkv_aside_mask; }
       g.vt_lo = (x8 && h->short_vlo && Sp <= 128) ? h->w->vt_lo : nullptr;  // short passes: Q, K, V^T as hi + lo planes (launch_attention: the same predicate)
       g.q_lo = h->w->q_lo; g.k_lo = h->w->k_lo;
-      if (cls_as) {  // (x8_terms stays 3: a block of x8_aside_mask — Q by default — keeps its A-side term for EVERY row and takes nothing from cls_corr)
+      // cls_aside: x8_terms stays 3 — a block of x8_aside_mask (Q by default) keeps its A-side term for EVERY row.  The [CLS] row's term matters in
+      // the Q block only (its K and V are one key among S for every query: model, four draws: no gain), so the row term is formed only when the Q
+      // block sweeps the weight-side term alone (MEMVUL_QKV_ASIDE without q); the launch skips it in blocks that swept both terms (gemm_pp.h)
+      if (cls_as && !(h->qkv_aside_mask & 1)) {
         if (int rc = cls_fix(h->w->xlo, nullptr, g.W, g.N, g.K)) return rc;
         g.cls_corr = h->w->cls_corr;
       }
@@ -619,7 +632,7 @@ int encode_dev(mv_handle* h, const int32_t* d_ids, const int32_t* d_lens, int B,
       if (x8) { g.A8 = h->w->ctx8; g.W8 = w.wo8; g.x8_scale = w.sc_o; g.out8 = h->w->x8; g.x8_terms = 2; }
       if (cls_as) {
         if (int rc = cls_fix(nullptr, h->w->ctx8, g.W, g.N, g.K)) return rc;
-        g.x8_terms = 1;  // (g.cls_corr stays set for the rest of the layer: every GEMM's term goes through the same buffer)
+        g.cls_corr = h->w->cls_corr; g.x8_terms = 1;  // (cls_corr stays set for the rest of the layer: every GEMM's term goes through the same buffer)
         g.out8_hi_only = 1;  // the stream planes this launch writes are FFN-1's A8: weight-side term only (its [CLS] rows' low parts come from xlo)
       }
       if (int rc = launch_pp<PP_RESLN3>(h, KC_GEMM_OUT, g)) return rc;
@@ -934,6 +947,7 @@ int mv_create(int device, const mv_config* cfg, mv_handle** out) try {
   if (const char* e = getenv("MEMVUL_STREAM_LO8")) h->stream_lo8 = atoi(e) == 1;
   if (const char* e = getenv("MEMVUL_SHORT_VLO")) h->short_vlo = atoi(e) != 0;
   if (const char* e = getenv("MEMVUL_CLS_ASIDE")) h->cls_aside = atoi(e) == 1;
+  if (const char* e = getenv("MEMVUL_CLS_ASIDE_MIN_LEN")) { const int v = atoi(e); if (v >= 1 && v <= 512) h->cls_min_len = v; }
   if (const char* e = getenv("MEMVUL_GN_MAX")) { const int v = atoi(e); if (v >= 1 && v <= 12) h->pp_gn_max = v; }
   if (const char* e = getenv("MEMVUL_RASTER")) h->pp_raster = atoi(e) == 1 ? 1 : 0;
   {
@@ -1197,6 +1211,7 @@ int mv_finalize_weights(mv_handle* h, int compute_dtype) try {
       if (rc == MV_OK) rc = dev_alloc(h, &h->work[wi].ch32, (int64_t)round_up(h->cfg.max_batch, 256) * MV_INTER);
       if (rc == MV_OK) rc = dev_alloc(h, &h->work[wi].cls_lo, (int64_t)round_up(h->cfg.max_batch, 256) * MV_INTER);
       if (rc == MV_OK) rc = dev_alloc(h, &h->work[wi].cls_corr, (int64_t)round_up(h->cfg.max_batch, 256) * MV_INTER);
+      if (rc == MV_OK) rc = dev_alloc(h, &h->work[wi].tile_both, h->cap_tokens / 256 + 1);
       if (rc == MV_OK && hipStreamSynchronize(h->w->stream) != hipSuccess) rc = MV_ERR_HIP;
       h->w = keep;
       if (rc != MV_OK) return rc;

@@ -65,6 +65,8 @@ struct GemmArgs {
                          // keep its tile_m and walk the column groups (the XCD's A panels stay in its L2 across the whole N sweep)
   int out8_hi_only;      // gemm_pp X8 producers (PP_GELU / PP_RESLN3), cls_aside: the consumer of out8 sweeps the weight-side term only — write the hi8
                          // plane alone, except in 32-row blocks that hold a [CLS] row (their lo8 row feeds cls_lo_gather_kernel)
+  const int* tile_both;  // gemm_pp X8, cls_aside: [M / 256] flags, non-zero = a sequence of that row tile is shorter than MEMVUL_CLS_ASIDE_MIN_LEN: the tile runs
+                         // the default form (both terms where x8_terms = 1, no cls_corr, full planes); cls_tile_flags_kernel writes them once per pass
   const float* cls_corr; // gemm_pp X8, "[CLS]-row A-side term" (engine.hip cls_aside): [ceil(M / S)][N] fp32 = 2^11 x the A-side first-order term
                          // A_lo W_hi^T of the [CLS] row (row b S) of every sequence, computed by a skinny fp16 GEMM in front of this launch
                          // and added to that row's accumulators before the epilogue; the main sweep then carries the weight-side term only

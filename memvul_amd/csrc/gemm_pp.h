@@ -259,8 +259,13 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmArgs a) {
   // over the goldens l12_trained_s256 / _ragged and the reference's own 12-layer run (profiles/r04_d_qkv_aside_errors.txt), max:
   // all three 3.8e-4, Q only 4.2e-4, K only 4.7e-4, V only 4.4e-4, none 8.1e-4; oracle/precision_model.py predicts the same on the
   // first case (7.6e-4 / 2.9e-4 / 3.8e-4 for none / Q / all).  QKV launch 388 -> 335 us (310 with none), +2.9 % issue reports/s.
-  auto both_terms = [&](int tn) -> bool {
-    if (a.x8_terms != 3) return a.x8_terms != 1;
+  // a.tile_both (engine.hip cls_aside): per 256-row tile, non-zero = a sequence in it is too short for the [CLS]-row form (the other rows' A-side
+  // rounding reaches the [CLS] row averaged over the keys): such a tile sweeps BOTH terms where x8_terms asks for the weight-side one only, takes
+  // nothing from cls_corr and keeps its lo8 planes — i.e. it runs the default form bit for bit, whatever the rest of the pass does.
+  auto short_tile = [&](int tm) -> bool { return a.tile_both && a.tile_both[tm] != 0; };
+  auto both_terms = [&](int tm, int tn) -> bool {
+    if (a.x8_terms == 1) return short_tile(tm);
+    if (a.x8_terms != 3) return true;
     const int which = (tn * 256 + a.col0) / MV_HIDDEN;  // 0 = Q, 1 = K, 2 = V
     return (a.x8_aside_mask >> which) & 1;
   };
@@ -309,7 +314,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmArgs a) {
       if constexpr (X8) {
         tA = (size_t)tm * 256 * K * 2;
         tW = (size_t)tn * 256 * K * 2;
-        const bool both = both_terms(tn);
+        const bool both = both_terms(tm, tn);
         i_nk8 = both ? nk0 : nk0 >> 1;
         i_off8 = both ? 0 : (size_t)K;
       } else {
@@ -692,7 +697,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmArgs a) {
       two_ktiles(std::false_type{}, !X8 && kt + 2 >= nk0);
     }
     if constexpr (X8) {  // the correction sweep: the same intervals on the fp8 matrix path
-      const int nk = nk0 + (both_terms(tile_n) ? nk0 : nk0 >> 1);  // K-tiles of THIS output tile
+      const int nk = nk0 + (both_terms(tile_m, tile_n) ? nk0 : nk0 >> 1);  // K-tiles of THIS output tile
       for (int kt = nk0; kt < nk; kt += 2) two_ktiles(std::true_type{}, kt + 2 >= nk);
     }
 
@@ -707,7 +712,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmArgs a) {
         // A-side term A_lo W_hi^T is added here for the ONE row per sequence whose rounding reaches the pooler un-averaged — the [CLS] row b S —
         // from a skinny fp16 GEMM over those rows (2^11 x the term, so that its operands stay normal fp16 numbers).  S % 64 == 0 and
         // mw % 128 == 0: of this wave's 128 rows only mw and mw + 64 can be such a row = token blocks 0 and 4, lanes m16 == 0.
-        if (a.cls_corr && !both_terms(tile_n)) {  // (a tile whose sweep carried both terms — the Q block of the QKV projection by default — has it already)
+        if (a.cls_corr && !both_terms(tile_m, tile_n) && !short_tile(tile_m)) {  // (a tile whose sweep carried both terms has it already)
 #pragma unroll
           for (int j = 0; j < 2; ++j) {
             const int row = mw + 64 * j;  // wave-uniform
@@ -941,7 +946,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmArgs a) {
             // GemmArgs::out8_hi_only (engine.hip cls_aside: the consumer sweeps the weight-side term only): no lo8 plane — except for a 32-row block
             // that holds the [CLS] row of a sequence (row b S: wave-uniform), whose lo8 row feeds that row's A-side term (cls_lo_gather_kernel)
             bool hi_only = false;
-            if constexpr (X8 == 1) hi_only = a.out8_hi_only && (mb % a.S != 0);
+            if constexpr (X8 == 1) hi_only = a.out8_hi_only && (mb % a.S != 0) && !short_tile(tile_m);
             if (hi_only) {
 #pragma unroll
               for (int tbl = 0; tbl < 2; ++tbl)

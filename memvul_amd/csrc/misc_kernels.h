@@ -271,6 +271,18 @@ __global__ __launch_bounds__(256) void cls_lo_gather_kernel(const half_t* __rest
   *(half4_t*)(out + i4) = y;
 }
 
+// cls_aside: which 256-row tiles of a pass keep the default form — flags[tm] = 1 when a sequence that owns rows of tile tm has fewer than
+// min_len tokens (rows past the last sequence belong to nobody).  Once per pass (the lengths do not change between the layers).
+__global__ __launch_bounds__(256) void cls_tile_flags_kernel(const int32_t* __restrict__ lens, int B, int Sp, int min_len, int ntile,
+                                                             int32_t* __restrict__ flags) {
+  const int tm = blockIdx.x * 256 + threadIdx.x;
+  if (tm >= ntile) return;
+  const int b0 = (tm * 256) / Sp, b1 = (tm * 256 + 255) / Sp;
+  int f = 0;
+  for (int b = b0; b <= b1 && b < B; ++b) f |= lens[b] < min_len;
+  flags[tm] = f;
+}
+
 // K7, K8 (model_memory.py:99-102): u = relu(W_h tanh(W_p h[:,0] + b_p) + b_h), all fp32, as two launches of one
 // dense kernel: out[b][n] = act(sum_k x[b][k] W^T[k][n] + bias[n]), K = 768, on the fp32-input matrix cores
 // (v_mfma_f32_32x32x2_f32: exact fp32 products and sums, MI355X_MICROARCH.md "f32-input MFMA").  A workgroup owns

@@ -94,9 +94,10 @@ def _mm(afmt, wfmt, A, W, cls_lo=None):
             Hb = W.shape[0] // 3
             b = "qkv".index(afmt[-1])
             out[..., b * Hb:(b + 1) * Hb] += al8 @ wh8[b * Hb:(b + 1) * Hb].T
-            for o in range(3):
-                if o != b:
-                    cls_term(slice(o * Hb, (o + 1) * Hb))
+            if b != 0:  # the engine forms the [CLS] row's term of the QKV projection only when the Q block lacks the A-side term (engine.hip encode_dev:
+                for o in range(3):  # K and V of the [CLS] token are one key among S); the launch skips it in the block that swept both terms
+                    if o != b:
+                        cls_term(slice(o * Hb, (o + 1) * Hb))
             return out
         return out + al8 @ wh8.T
     return FORMATS[afmt](A) @ FORMATS[wfmt](W).T

@@ -47,7 +47,7 @@ def engine_for(dims_kw: dict, w_kw: dict, gemm_tile: int = 0, env: dict = None, 
         dims, w = weights_for(dims_kw, w_kw)
         kw = dict(max_tokens=16384, max_batch=64, max_anchors=64)
         kw.update(eng_kw)
-        switches = ("MEMVUL_GEMM_TILE", "MEMVUL_CLS_PRUNE", "MEMVUL_STREAMS", "MEMVUL_RASTER", "MEMVUL_GN_MAX", "MEMVUL_QKV_ASIDE", "MEMVUL_STREAM_LO8", "MEMVUL_SHORT_VLO", "MEMVUL_CLS_ASIDE")
+        switches = ("MEMVUL_GEMM_TILE", "MEMVUL_CLS_PRUNE", "MEMVUL_STREAMS", "MEMVUL_RASTER", "MEMVUL_GN_MAX", "MEMVUL_QKV_ASIDE", "MEMVUL_STREAM_LO8", "MEMVUL_SHORT_VLO", "MEMVUL_CLS_ASIDE", "MEMVUL_CLS_ASIDE_MIN_LEN")
         old = {k: os.environ.get(k) for k in switches}
         for k in switches:
             os.environ.pop(k, None)

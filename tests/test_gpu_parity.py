@@ -149,18 +149,18 @@ def test_lo8_residual_stream_option(gu, golden_dir, name):
 
 @pytest.mark.parametrize("qkv_aside", ["q", "none"])
 @pytest.mark.parametrize("name", ["l12_trained_s256", "l12_trained_ragged"])
-def test_cls_row_aside_option(gu, golden_dir, name, qkv_aside):
-    """MEMVUL_CLS_ASIDE=1 (round 5): passes of padded length >= 256 sweep the weight-side correction term only and add the A-side term
-    A_lo W_hi^T for the [CLS] row of each sequence alone — cls_lo_gather_kernel + a skinny fp16 GEMM over the B rows in front of every persistent
-    GEMM, added to those rows' accumulators (gemm_pp.h GemmArgs::cls_corr) — because only that row reaches the pooler un-averaged
+def test_cls_row_aside_form(gu, golden_dir, name, qkv_aside):
+    """MEMVUL_CLS_ASIDE (round 5): sequences of >= 128 tokens in passes of padded length 256 / 512 sweep the weight-side correction term only and get
+    the A-side term A_lo W_hi^T for their [CLS] row alone — cls_lo_gather_kernel + a skinny fp16 GEMM over the B rows in front of the persistent
+    GEMMs, added to those rows' accumulators (gemm_pp.h GemmArgs::cls_corr) — because only that row reaches the pooler un-averaged
     (oracle/precision_model.py knob `cls_fix`; tests/test_precision_model.py::test_cls_row_aside_is_priced_by_the_model).  With the term missing or
     misplaced the logits would sit at the weight-side-only level (2.7e-3, profiles/r04_a2_*): the contract bound below is the functional test.
-    `qkv_aside` = "q": the Q block of the QKV projection keeps its A-side term for every row (the default mask), "none": no block does."""
+    `qkv_aside` = "q": the Q block of the QKV projection keeps its A-side term for every row (the default mask), "none": no block does (then the
+    QKV projection takes a row term too)."""
     import make_golden
 
     g = np.load(os.path.join(golden_dir, f"{name}.npz"))
     dk, wk, B, S, ragged, G, SA = make_golden.CASES[name]
-    assert S >= 256  # the option only acts on passes of padded length >= 256
     env = {"MEMVUL_CLS_ASIDE": "1", "MEMVUL_QKV_ASIDE": qkv_aside}
     eng = gu.engine_for(dk, wk, compute_dtype="precise", env=env, max_tokens=16384, max_batch=64, max_anchors=64)
     eng.anchor_reset()
@@ -172,8 +172,8 @@ def test_cls_row_aside_option(gu, golden_dir, name, qkv_aside):
     gu.record("precise_mode_cls_aside", case=name, qkv_aside=qkv_aside, **errs)
     assert errs["logits"] <= LOGIT_TOL and errs["p"] <= 2e-4, errs
     assert eng.x8_saturation() == 0
-    # the same model with both terms everywhere: the two differ, by less than the contract
-    ref = gu.engine_for(dk, wk, compute_dtype="precise", max_tokens=16384, max_batch=64, max_anchors=64)
+    # the same model with both terms in every row: the two differ, by less than the contract
+    ref = gu.engine_for(dk, wk, compute_dtype="precise", env={"MEMVUL_CLS_ASIDE": "0"}, max_tokens=16384, max_batch=64, max_anchors=64)
     ref.anchor_reset()
     ref.anchor_append(g["anchor_ids"][:, :LA], g["anchor_lens"])
     o2 = ref.forward(g["ids"], g["lens"])
@@ -182,18 +182,43 @@ def test_cls_row_aside_option(gu, golden_dir, name, qkv_aside):
     eng.anchor_reset(); ref.anchor_reset()
 
 
-def test_cls_row_aside_leaves_short_passes_alone(gu):
-    """The option acts on passes of padded length >= 256 only: a 64-token pass gives the same bits with and without the switch."""
+def test_cls_row_aside_is_decided_per_sequence(gu, golden_dir):
+    """The other rows' A-side rounding reaches the [CLS] row averaged over the keys, so a sequence takes the form only if it has at least
+    MEMVUL_CLS_ASIDE_MIN_LEN (128) tokens — decided per 256-row tile from the sequence's own length (GemmArgs::tile_both), so that a row's result
+    still does not depend on the batch it travels in: short sequences give the both-terms form's bits, long ones the same bits alone or among
+    short batch-mates; with the rule lifted (MIN_LEN = 1) the short ones change too.  Passes of padded length 256 (issue reports) and 512 (anchors)."""
+    import make_golden
+
+    name = "l12_trained_ragged"
+    g = np.load(os.path.join(golden_dir, f"{name}.npz"))
+    dk, wk, B, S, ragged, G, SA = make_golden.CASES[name]
+    kw = dict(compute_dtype="precise", max_tokens=16384, max_batch=64, max_anchors=64)
+    for ids, lens in ((g["ids"], g["lens"]), (g["anchor_ids"], g["anchor_lens"])):
+        short = lens < 128
+        assert short.any() and (~short).any() and ids.shape[1] in (256, 512)
+        on = gu.engine_for(dk, wk, env={"MEMVUL_CLS_ASIDE": "1"}, **kw).encode(ids, lens)
+        alone = gu.engine_for(dk, wk, env={"MEMVUL_CLS_ASIDE": "1"}, **kw).encode(ids[~short], lens[~short])
+        off = gu.engine_for(dk, wk, env={"MEMVUL_CLS_ASIDE": "0"}, **kw).encode(ids, lens)
+        assert np.array_equal(on[short], off[short])                                   # short sequences: the both-terms form, bit for bit
+        assert all(not np.array_equal(on[i], off[i]) for i in np.flatnonzero(~short))  # long ones: the [CLS]-row form
+        assert np.array_equal(alone, on[~short])                                       # ... whatever travels with them
+        assert float(np.abs(on - off).max()) < 5e-4
+        lifted = gu.engine_for(dk, wk, env={"MEMVUL_CLS_ASIDE": "1", "MEMVUL_CLS_ASIDE_MIN_LEN": "1"}, **kw).encode(ids, lens)
+        assert all(not np.array_equal(lifted[i], off[i]) for i in np.flatnonzero(short))
+        assert np.array_equal(lifted[~short], on[~short])
+
+
+def test_cls_row_aside_leaves_other_pass_shapes_alone(gu):
+    """The form acts on passes of padded length 256 and 512 only (a 256-row tile then belongs to one sequence): 64- and 320-token passes (Sp = 64 / 384) give
+    the same bits with and without the switch, a 256-token one does not."""
     dk, wk = dict(layers=2), dict(qk_scale=2.0, match_scale=29.0, trained_like=True)
     dims, w = gu.weights_for(dk, wk)
-    ids, lens = synth.make_ids(8, 64, dims.vocab_size, seed=5)
-    a = gu.engine_for(dk, wk, compute_dtype="precise", env={"MEMVUL_CLS_ASIDE": "1"}).encode(ids, lens)
-    b = gu.engine_for(dk, wk, compute_dtype="precise").encode(ids, lens)
-    assert np.array_equal(a, b)
-    ids, lens = synth.make_ids(4, 256, dims.vocab_size, seed=6)
-    a = gu.engine_for(dk, wk, compute_dtype="precise", env={"MEMVUL_CLS_ASIDE": "1"}).encode(ids, lens)
-    b = gu.engine_for(dk, wk, compute_dtype="precise").encode(ids, lens)
-    assert not np.array_equal(a, b) and float(np.abs(a - b).max()) < 1e-3
+    for S, same in ((64, True), (320, True), (256, False)):
+        ids, lens = synth.make_ids(4, S, dims.vocab_size, seed=5 + S)
+        a = gu.engine_for(dk, wk, compute_dtype="precise", env={"MEMVUL_CLS_ASIDE": "1"}).encode(ids, lens)
+        b = gu.engine_for(dk, wk, compute_dtype="precise", env={"MEMVUL_CLS_ASIDE": "0"}).encode(ids, lens)
+        assert np.array_equal(a, b) == same, S
+        assert float(np.abs(a - b).max()) < 1e-3
 
 
 def test_short_sequences_carry_v_and_p_as_two_planes(gu, golden_dir):
