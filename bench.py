@@ -47,7 +47,7 @@ else:
 
 MFMA_PEAK_TFLOPS = 2500.0  # MI355X dense fp16/bf16 MFMA peak (MI355X_MICROARCH.md)
 LOGIT_TOL = 1e-3           # BASELINE.json north_star: logits within 1e-3 of the reference CPU path
-DEFAULT_CLS_ASIDE = "0"    # the library's default of MEMVUL_CLS_ASIDE (engine.hip mv_handle::cls_aside)
+DEFAULT_CLS_ASIDE = "1"    # the library's default of MEMVUL_CLS_ASIDE (engine.hip mv_handle::cls_aside)
 AUTO_MARGIN = 0.5          # --compute auto hands `value` to MV_F16 only if its measured trained-like error is <= AUTO_MARGIN * LOGIT_TOL
 MODE_DTYPE = {"f16": "fp16 (MV_F16: fp16 MFMA operands, fp32 accumulate)",
               "precise": "fp16 + fp8 (MV_F16X8: fp16 MFMA sweep + one OCP-e4m3 MFMA correction sweep per GEMM, fp32 accumulate)"}

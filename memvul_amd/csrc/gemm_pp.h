@@ -215,6 +215,17 @@ __device__ __forceinline__ void lds_read_bgb1(uint32_t addr, float4& bi, float4&
 #endif
 }
 
+// One dword at a wave-uniform address through the scalar cache.  hipcc reads such a value with global_load + v_readfirstlane (the kernel also
+// stores, so it cannot prove the location unclobbered) and waits for it with `s_waitcnt vmcnt(0)` — which here would drain the whole LDS-DMA
+// operand pipeline at every use (GemmArgs::tile_both read that way: FFN-1 +22 us); s_load_dword only waits on lgkmcnt.
+__device__ __forceinline__ int sload_i32(const int* p) {
+  int v = 0;
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm volatile("s_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(p) : "memory");
+#endif
+  return v;
+}
+
 // logical tile L of a persistent grid of G workgroups -> (tile_m, tile_n).  Mode 0: the grouped raster of gemm.h (all tile_m of a
 // column group, then the next group: an A panel is fetched once per group).  Mode 1 (host: only when tm_count * GN % G == 0): window
 // w = L / G of the sequence is (block b = w / ngroups of G consecutive (tile_m, tile_n-in-group) positions, column group g = w % ngroups),
@@ -262,7 +273,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmArgs a) {
   // a.tile_both (engine.hip cls_aside): per 256-row tile, non-zero = a sequence in it is too short for the [CLS]-row form (the other rows' A-side
   // rounding reaches the [CLS] row averaged over the keys): such a tile sweeps BOTH terms where x8_terms asks for the weight-side one only, takes
   // nothing from cls_corr and keeps its lo8 planes — i.e. it runs the default form bit for bit, whatever the rest of the pass does.
-  auto short_tile = [&](int tm) -> bool { return a.tile_both && a.tile_both[tm] != 0; };
+  auto short_tile = [&](int tm) -> bool { return a.tile_both && sload_i32(a.tile_both + tm) != 0; };
   auto both_terms = [&](int tm, int tn) -> bool {
     if (a.x8_terms == 1) return short_tile(tm);
     if (a.x8_terms != 3) return true;
@@ -574,6 +585,9 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmArgs a) {
     if (has_next) raster_pp(a, L + G, G, tm_count, tn_count, next_m, next_n);
     const int mw = (tile_m << 8) + wr * 128;  // first token row of this wave
     const int nw = (tile_n << 8) + wc * 64;   // first output column of this wave
+    bool tile_short = false;                  // cls_aside: this row tile's sequence keeps the default form (read once per tile)
+    if constexpr (X8 == 1) tile_short = short_tile(tile_m);
+    const bool tile_both_terms = X8 && (a.x8_terms == 1 ? tile_short : both_terms(tile_m, tile_n));
 
     // ---- accumulator init: zero (RAW) or bias + LayerNorm(residual).  The images are read with inline-asm ds_reads: hipcc would put
     // `s_waitcnt vmcnt(0)` in front of a compiler-visible LDS load here (LDS-DMA in flight) and drain the operand pipeline once per tile.
@@ -697,7 +711,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmArgs a) {
       two_ktiles(std::false_type{}, !X8 && kt + 2 >= nk0);
     }
     if constexpr (X8) {  // the correction sweep: the same intervals on the fp8 matrix path
-      const int nk = nk0 + (both_terms(tile_m, tile_n) ? nk0 : nk0 >> 1);  // K-tiles of THIS output tile
+      const int nk = nk0 + (tile_both_terms ? nk0 : nk0 >> 1);  // K-tiles of THIS output tile
       for (int kt = nk0; kt < nk; kt += 2) two_ktiles(std::true_type{}, kt + 2 >= nk);
     }
 
@@ -712,7 +726,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmArgs a) {
         // A-side term A_lo W_hi^T is added here for the ONE row per sequence whose rounding reaches the pooler un-averaged — the [CLS] row b S —
         // from a skinny fp16 GEMM over those rows (2^11 x the term, so that its operands stay normal fp16 numbers).  S % 64 == 0 and
         // mw % 128 == 0: of this wave's 128 rows only mw and mw + 64 can be such a row = token blocks 0 and 4, lanes m16 == 0.
-        if (a.cls_corr && !both_terms(tile_m, tile_n) && !short_tile(tile_m)) {  // (a tile whose sweep carried both terms has it already)
+        if (a.cls_corr && !tile_both_terms && !tile_short) {  // (a tile whose sweep carried both terms has it already)
 #pragma unroll
           for (int j = 0; j < 2; ++j) {
             const int row = mw + 64 * j;  // wave-uniform
@@ -946,7 +960,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmArgs a) {
             // GemmArgs::out8_hi_only (engine.hip cls_aside: the consumer sweeps the weight-side term only): no lo8 plane — except for a 32-row block
             // that holds the [CLS] row of a sequence (row b S: wave-uniform), whose lo8 row feeds that row's A-side term (cls_lo_gather_kernel)
             bool hi_only = false;
-            if constexpr (X8 == 1) hi_only = a.out8_hi_only && (mb % a.S != 0) && !short_tile(tile_m);
+            if constexpr (X8 == 1) hi_only = a.out8_hi_only && (mb % a.S != 0) && !tile_short;
             if (hi_only) {
 #pragma unroll
               for (int tbl = 0; tbl < 2; ++tbl)
