@@ -195,7 +195,6 @@ struct mv_handle {
   int cls_min_len = 128;   // ... and, inside such a pass, only sequences of at least this many tokens (env MEMVUL_CLS_ASIDE_MIN_LEN): the other rows' A-side
                            // rounding reaches the [CLS] row averaged over the keys, and a short sequence averages over few (model: 1.5 - 1.8x the error below
                            // 128 tokens).  The row tiles of a shorter sequence run the default form bit for bit (GemmArgs::tile_both, cls_tile_flags_kernel)
-  bool cls_fix_ring = false;  // (A/B switch MEMVUL_CLS_FIX=ring: the row term by cls_lo_gather_kernel + gemm_ring_kernel, two launches, instead of cls_corr_kernel)
   bool cls_aside = true;   // MV_F16X8 (default; env MEMVUL_CLS_ASIDE=0 = both terms in every row, the form of rounds 3-4): passes of padded length 256 / 512 sweep the weight-side correction term only in EVERY GEMM and
                            // add the A-side term for the [CLS] row of each sequence alone (a skinny fp16 GEMM over those B rows in front of each launch,
                            // GemmArgs::cls_corr): the pooler reads only that row, every other row's A-side rounding reaches it averaged over the keys
@@ -498,13 +497,6 @@ int encode_dev(mv_handle* h, const int32_t* d_ids, const int32_t* d_lens, int B,
   }
   auto cls_fix = [&](const half_t* lo16, const uint8_t* lo8p, const half_t* W, int N, int K) -> int {
     ProfScope ps(h, KC_OTHER);
-    if (!h->cls_fix_ring) {  // one launch: gather + skinny GEMM (misc_kernels.h cls_corr_kernel)
-      const dim3 grid((unsigned)((B + 31) / 32), (unsigned)(N / 32));
-      if (K == MV_HIDDEN) hipLaunchKernelGGL(cls_corr_kernel<MV_HIDDEN>, grid, dim3(512), 0, h->w->stream, lo16, lo8p, W, Sp, B, N, h->w->cls_corr);
-      else if (K == MV_INTER) hipLaunchKernelGGL(cls_corr_kernel<MV_INTER>, grid, dim3(512), 0, h->w->stream, lo16, lo8p, W, Sp, B, N, h->w->cls_corr);
-      else return fail(h, MV_ERR_INVALID, "internal: cls_corr at a contraction length other than 768 / 3072");
-      return launch_check(h, "cls_corr");
-    }
     const size_t n4 = (size_t)B * K / 4;
     hipLaunchKernelGGL(cls_lo_gather_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, h->w->stream, lo16, lo8p, K, Sp, B, h->w->cls_lo);
     if (int rc = launch_check(h, "cls_lo_gather")) return rc;
@@ -955,7 +947,6 @@ int mv_create(int device, const mv_config* cfg, mv_handle** out) try {
   if (const char* e = getenv("MEMVUL_STREAM_LO8")) h->stream_lo8 = atoi(e) == 1;
   if (const char* e = getenv("MEMVUL_SHORT_VLO")) h->short_vlo = atoi(e) != 0;
   if (const char* e = getenv("MEMVUL_CLS_ASIDE")) h->cls_aside = atoi(e) == 1;
-  if (const char* e = getenv("MEMVUL_CLS_FIX")) h->cls_fix_ring = strcmp(e, "ring") == 0;
   if (const char* e = getenv("MEMVUL_CLS_ASIDE_MIN_LEN")) { const int v = atoi(e); if (v >= 1 && v <= 512) h->cls_min_len = v; }
   if (const char* e = getenv("MEMVUL_GN_MAX")) { const int v = atoi(e); if (v >= 1 && v <= 12) h->pp_gn_max = v; }
   if (const char* e = getenv("MEMVUL_RASTER")) h->pp_raster = atoi(e) == 1 ? 1 : 0;

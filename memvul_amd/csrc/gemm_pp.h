@@ -721,17 +721,24 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmArgs a) {
       const uint32_t sf = (uint32_t)((m16 >> 2) & 3);
       const uint32_t scr_c = scr + (lane >> 2) * 64 + ((((uint32_t)lane & 3) ^ (((uint32_t)lane >> 4) & 3)) << 4);
       const int crow = lane >> 2, cchunk = lane & 3;  // coalesced layout: row (+16 for the second read), 16-B chunk
+      int cls_b[2] = {-1, -1};  // X8 = 1, cls_aside: the sequence whose [CLS] row is this wave's row mw + 64 j, or -1 (computed once per tile)
       if constexpr (X8 == 1) {
         // [CLS]-row A-side term (GemmArgs::cls_corr; engine.hip cls_aside): the sweep above carried the weight-side correction term only; the
         // A-side term A_lo W_hi^T is added here for the ONE row per sequence whose rounding reaches the pooler un-averaged — the [CLS] row b S —
         // from a skinny fp16 GEMM over those rows (2^11 x the term, so that its operands stay normal fp16 numbers).  S % 64 == 0 and
         // mw % 128 == 0: of this wave's 128 rows only mw and mw + 64 can be such a row = token blocks 0 and 4, lanes m16 == 0.
+        if (a.cls_corr || a.out8_hi_only) {
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            const int row = mw + 64 * j, b = row / a.S;  // wave-uniform
+            if (row < a.Mreal && b * a.S == row) cls_b[j] = b;
+          }
+        }
         if (a.cls_corr && !tile_both_terms && !tile_short) {  // (a tile whose sweep carried both terms has it already)
 #pragma unroll
           for (int j = 0; j < 2; ++j) {
-            const int row = mw + 64 * j;  // wave-uniform
-            if (row < a.Mreal && row % a.S == 0 && m16 == 0) {
-              const float* cp = a.cls_corr + (size_t)(row / a.S) * a.N + nw + 4 * q4;
+            if (cls_b[j] >= 0 && m16 == 0) {
+              const float* cp = a.cls_corr + (size_t)cls_b[j] * a.N + nw + 4 * q4;
               floatx4 c[4];  // all four loads in flight before the first use: ONE exposed memory latency per tile that holds such a row
 #pragma unroll
               for (int cb = 0; cb < 4; ++cb) c[cb] = *(const floatx4*)(cp + 16 * cb);
@@ -960,48 +967,21 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmArgs a) {
             // GemmArgs::out8_hi_only (engine.hip cls_aside: the consumer sweeps the weight-side term only): no lo8 plane — except for a 32-row block
             // that holds the [CLS] row of a sequence (row b S: wave-uniform), whose lo8 row feeds that row's A-side term (cls_lo_gather_kernel)
             bool hi_only = false;
-            if constexpr (X8 == 1) hi_only = a.out8_hi_only && (mb % a.S != 0) && !tile_short;
-            if (hi_only) {
-#pragma unroll
-              for (int tbl = 0; tbl < 2; ++tbl)
-#pragma unroll
-                for (int j = 0; j < 2; ++j)
-#pragma unroll
-                  for (int cbl = 0; cbl < 2; ++cbl) {
-                    const int tb = 2 * i + tbl, cb = 2 * j + cbl;
-                    dh[4 * tbl + 2 * j + cbl] = x8_hi4_in_range(acc[tb][cb][0], acc[tb][cb][1], acc[tb][cb][2], acc[tb][cb][3]);
-                    vmax8 = x8_absmax4(vmax8, acc[tb][cb][0], acc[tb][cb][1], acc[tb][cb][2], acc[tb][cb][3]);
-                  }
-              if (x8_any_out_of_range(vmax8)) {  // rare: redo with the clamps and count
-                int n = 0;
-#pragma unroll
-                for (int tbl = 0; tbl < 2; ++tbl)
-#pragma unroll
-                  for (int j = 0; j < 2; ++j)
-#pragma unroll
-                    for (int cbl = 0; cbl < 2; ++cbl) {
-                      const int tb = 2 * i + tbl, cb = 2 * j + cbl;
-                      dh[4 * tbl + 2 * j + cbl] = x8_hi4(acc[tb][cb][0], acc[tb][cb][1], acc[tb][cb][2], acc[tb][cb][3]);
-                      n += x8_count4(acc[tb][cb][0], acc[tb][cb][1], acc[tb][cb][2], acc[tb][cb][3]);
-                    }
-                x8_sat_add(a.x8_sat, n);
-              }
-              scr_f8x1(w8, w8 ^ 16u, w8 ^ 32u, w8 ^ 48u, dh, scr_c, o);
-              *(u32x4*)(o8 + a.N) = o[0];
-              *(u32x4*)(o8 + a.N + (size_t)16 * (2 * a.N)) = o[1];
-            } else {
+            if constexpr (X8 == 1) hi_only = a.out8_hi_only && !tile_short && !((i & 1) == 0 && cls_b[i >> 1] >= 0);
 #pragma unroll
             for (int tbl = 0; tbl < 2; ++tbl)
 #pragma unroll
               for (int j = 0; j < 2; ++j)
 #pragma unroll
                 for (int cbl = 0; cbl < 2; ++cbl) {
-                  const int tb = 2 * i + tbl, cb = 2 * j + cbl;
-                  if constexpr (EPI == PP_GELU) {  // d[j][2 tbl + cbl] still holds this unit's packed fp16 output words
+                  const int tb = 2 * i + tbl, cb = 2 * j + cbl, u = 4 * tbl + 2 * j + cbl;
+                  if (hi_only) {
+                    dh[u] = x8_hi4_in_range(acc[tb][cb][0], acc[tb][cb][1], acc[tb][cb][2], acc[tb][cb][3]);
+                  } else if constexpr (EPI == PP_GELU) {  // d[j][2 tbl + cbl] still holds this unit's packed fp16 output words
                     const uint32_t p01 = d[j][2 * tbl + cbl][0], p23 = d[j][2 * tbl + cbl][1];
-                    x8_planes4_in_range_packed(acc[tb][cb][0], acc[tb][cb][1], acc[tb][cb][2], acc[tb][cb][3], p01, p23, dh[4 * tbl + 2 * j + cbl], dl[4 * tbl + 2 * j + cbl]);
+                    x8_planes4_in_range_packed(acc[tb][cb][0], acc[tb][cb][1], acc[tb][cb][2], acc[tb][cb][3], p01, p23, dh[u], dl[u]);
                   } else {
-                    x8_planes4_in_range(acc[tb][cb][0], acc[tb][cb][1], acc[tb][cb][2], acc[tb][cb][3], dh[4 * tbl + 2 * j + cbl], dl[4 * tbl + 2 * j + cbl]);
+                    x8_planes4_in_range(acc[tb][cb][0], acc[tb][cb][1], acc[tb][cb][2], acc[tb][cb][3], dh[u], dl[u]);
                   }
                   vmax8 = x8_absmax4(vmax8, acc[tb][cb][0], acc[tb][cb][1], acc[tb][cb][2], acc[tb][cb][3]);
                 }
@@ -1019,11 +999,16 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmArgs a) {
                   }
               x8_sat_add(a.x8_sat, n);
             }
-            scr_f8x2(w8, w8 ^ 16u, w8 ^ 32u, w8 ^ 48u, dl, dh, scr_c, o);
-            *(u32x4*)o8 = o[0];
-            *(u32x4*)(o8 + (size_t)16 * (2 * a.N)) = o[1];
-            *(u32x4*)(o8 + a.N) = o[2];
-            *(u32x4*)(o8 + a.N + (size_t)16 * (2 * a.N)) = o[3];
+            if (hi_only) {
+              scr_f8x1(w8, w8 ^ 16u, w8 ^ 32u, w8 ^ 48u, dh, scr_c, o);
+              *(u32x4*)(o8 + a.N) = o[0];
+              *(u32x4*)(o8 + a.N + (size_t)16 * (2 * a.N)) = o[1];
+            } else {
+              scr_f8x2(w8, w8 ^ 16u, w8 ^ 32u, w8 ^ 48u, dl, dh, scr_c, o);
+              *(u32x4*)o8 = o[0];
+              *(u32x4*)(o8 + (size_t)16 * (2 * a.N)) = o[1];
+              *(u32x4*)(o8 + a.N) = o[2];
+              *(u32x4*)(o8 + a.N + (size_t)16 * (2 * a.N)) = o[3];
             }
           }
           if constexpr (IS_RES) {  // block row i is out: request block row i of the NEXT tile's residual into its registers

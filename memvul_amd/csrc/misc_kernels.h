@@ -271,69 +271,6 @@ __global__ __launch_bounds__(256) void cls_lo_gather_kernel(const half_t* __rest
   *(half4_t*)(out + i4) = y;
 }
 
-// The same gather and the skinny GEMM behind it in ONE launch: corr[b][n] = sum_k (2^11 A_lo[b Sp][k]) W[n][k], fp32 (GemmArgs::cls_corr), W = the
-// launch's fp16 weights [N][KT].  A workgroup owns 32 [CLS] rows x 32 columns; its 8 waves split K (KT / 8 each, ascending k inside a wave, a
-// chunk's 12 operand loads issued up front: the kernel is latency-bound, like dense768_kernel below) on v_mfma_f32_32x32x16_f16 — lane (row or
-// column lane & 31, k group lane >> 5) holds 8 consecutive k of its row — and the eight partial tiles are added in wave order through LDS
-// (deterministic).  Grid = ceil(B / 32) x N / 32.
-template <int KT>
-__global__ __launch_bounds__(512) void cls_corr_kernel(const half_t* __restrict__ lo16, const uint8_t* __restrict__ lo8,
-                                                       const half_t* __restrict__ W, int Sp, int B, int N, float* __restrict__ out) {
-  constexpr int NW = 8, KW = KT / NW, CH = 96;  // waves, k per wave, k per chunk of loads (6 MFMA steps)
-  static_assert(KW % CH == 0, "a wave walks its K share in chunks of 96");
-  __shared__ float part[NW][16][64];
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int b0 = blockIdx.x * 32, n0 = blockIdx.y * 32;
-  const int hi = lane >> 5, l31 = lane & 31;
-  const int row = (b0 + l31 < B) ? b0 + l31 : B - 1;  // rows past B: computed on a valid row, never stored
-  const size_t t = (size_t)row * Sp;                  // the [CLS] token's row of the pass
-  const int kl = wave * KW + 8 * hi;                  // this lane's k within a 16-wide step: kl + 16 s + (0 .. 7)
-  const half_t* wr = W + (size_t)(n0 + l31) * KT + kl;
-  floatx16 acc;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-#pragma unroll 1
-  for (int c = 0; c < KW; c += CH) {
-    half8_t fa[CH / 16], fw[CH / 16];
-#pragma unroll
-    for (int s = 0; s < CH / 16; ++s) {
-      const int k = c + 16 * s;
-      fw[s] = *(const half8_t*)(wr + k);
-      if (lo8) {  // e4m3((x - hi) 2^(11 + shift)) -> 2^11 (x - hi)
-        constexpr float SC = 1.0f / (float)(1 << MV_X8_ACT_SHIFT);
-        const uint2 v = *(const uint2*)(lo8 + t * (2 * (size_t)KT) + kl + k);
-        const float2_t p0 = __builtin_amdgcn_cvt_scalef32_pk_f32_fp8(v.x, 1.0f, false), p1 = __builtin_amdgcn_cvt_scalef32_pk_f32_fp8(v.x, 1.0f, true);
-        const float2_t p2 = __builtin_amdgcn_cvt_scalef32_pk_f32_fp8(v.y, 1.0f, false), p3 = __builtin_amdgcn_cvt_scalef32_pk_f32_fp8(v.y, 1.0f, true);
-        half8_t y;
-        y[0] = (half_t)(p0.x * SC); y[1] = (half_t)(p0.y * SC); y[2] = (half_t)(p1.x * SC); y[3] = (half_t)(p1.y * SC);
-        y[4] = (half_t)(p2.x * SC); y[5] = (half_t)(p2.y * SC); y[6] = (half_t)(p3.x * SC); y[7] = (half_t)(p3.y * SC);
-        fa[s] = y;
-      } else {
-        const half8_t l = *(const half8_t*)(lo16 + t * KT + kl + k);
-        half8_t y;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) y[e] = (half_t)((float)l[e] * 2048.0f);
-        fa[s] = y;
-      }
-    }
-#pragma unroll
-    for (int s = 0; s < CH / 16; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[s], fw[s], acc, 0, 0, 0);
-  }
-#pragma unroll
-  for (int r = 0; r < 16; ++r) part[wave][r][lane] = acc[r];
-  __syncthreads();
-#pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int idx = tid + 512 * j, r = idx >> 6, ln = idx & 63;
-    float v = part[0][r][ln];
-#pragma unroll
-    for (int q = 1; q < NW; ++q) v += part[q][r][ln];
-    const int orow = b0 + (r & 3) + 8 * (r >> 2) + 4 * (ln >> 5), ocol = n0 + (ln & 31);
-    if (orow < B) out[(size_t)orow * N + ocol] = v;
-  }
-}
-
 // cls_aside: which 256-row tiles of a pass keep the default form — flags[tm] = 1 when a sequence that owns rows of tile tm has fewer than
 // min_len tokens (rows past the last sequence belong to nobody).  Once per pass (the lengths do not change between the layers).
 __global__ __launch_bounds__(256) void cls_tile_flags_kernel(const int32_t* __restrict__ lens, int B, int Sp, int min_len, int ntile,
