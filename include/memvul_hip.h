@@ -78,7 +78,9 @@ typedef struct mv_config {
 /* Environment switches read HERE (every one has a tested default; DESIGN.md section 8 lists them with their measurements): MEMVUL_STREAM_LO8=1 (MV_F16X8: the
  * residual stream keeps 8 low bits instead of 16: +2.4 % issue reports/s, ~1.2x the trained-like logit error), MEMVUL_SHORT_VLO=0 (MV_F16X8: passes of padded
  * length <= 128 stop carrying Q, K, V, P as two fp16 planes through attention), MEMVUL_QKV_ASIDE (a subset of "qkv" or "none"; anything else is MV_ERR_INVALID),
- * MEMVUL_CLS_PRUNE, MEMVUL_STREAMS, MEMVUL_GEMM_TILE, MEMVUL_NUM_CU, MEMVUL_RASTER, MEMVUL_GN_MAX. */
+ * MEMVUL_CLS_ASIDE=0 (MV_F16X8: both first-order correction terms in EVERY row, the form of rounds 3-4: -12 % issue reports/s at the same trained-like
+ * logit error; default 1 = sequences of >= MEMVUL_CLS_ASIDE_MIN_LEN (128) tokens in passes of padded length 256 / 512 sweep the weight-side term and
+ * take the A-side term for their [CLS] row alone), MEMVUL_CLS_PRUNE, MEMVUL_STREAMS, MEMVUL_GEMM_TILE, MEMVUL_NUM_CU, MEMVUL_RASTER, MEMVUL_GN_MAX. */
 int mv_create(int device, const mv_config* cfg, mv_handle** out);
 void mv_destroy(mv_handle* h);
 /* Last error message of this handle (or of a failed mv_create when h == NULL). */

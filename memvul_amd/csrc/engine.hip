@@ -192,12 +192,12 @@ struct mv_handle {
                            // (attention_v2.h VLO): the fp16 storage of V and P is what is left of the precise mode's error and short sequences average it least
   bool stream_lo8 = false; // MV_F16X8, env MEMVUL_STREAM_LO8=1: the raw residual stream as hi fp16 + the lo8 plane of its fp8 planes (no lo fp16 plane;
                            // gemm_pp.h X8 = 2): +1.5 % issue reports/s at 1.2x the trained-like logit error (profiles/r05_a_*) — opt-in
-  int cls_min_len = 128;   // ... and, inside such a pass, only sequences of at least this many tokens (env MEMVUL_CLS_ASIDE_MIN_LEN): the other rows' A-side
-                           // rounding reaches the [CLS] row averaged over the keys, and a short sequence averages over few (model: 1.5 - 1.8x the error below
-                           // 128 tokens).  The row tiles of a shorter sequence run the default form bit for bit (GemmArgs::tile_both, cls_tile_flags_kernel)
-  bool cls_aside = true;   // MV_F16X8 (default; env MEMVUL_CLS_ASIDE=0 = both terms in every row, the form of rounds 3-4): passes of padded length 256 / 512 sweep the weight-side correction term only in EVERY GEMM and
-                           // add the A-side term for the [CLS] row of each sequence alone (a skinny fp16 GEMM over those B rows in front of each launch,
-                           // GemmArgs::cls_corr): the pooler reads only that row, every other row's A-side rounding reaches it averaged over the keys
+  bool cls_aside = true;   // MV_F16X8, the [CLS]-row form (default; env MEMVUL_CLS_ASIDE=0 = both correction terms in every row, the form of rounds 3-4): passes of
+                           // padded length 256 / 512 sweep the weight-side term only in every GEMM (the Q block of the QKV projection keeps both) and add the A-side
+                           // term for the [CLS] row of each sequence alone (a skinny fp16 GEMM over those B rows in front of each launch, GemmArgs::cls_corr): the
+                           // pooler reads only that row, every other row's A-side rounding reaches it averaged over the keys.  +14 % at the same error (r05_j*, r05_k*)
+  int cls_min_len = 128;   // ... for sequences of at least this many tokens (env MEMVUL_CLS_ASIDE_MIN_LEN): a short sequence averages over few keys (model: 1.5 -
+                           // 1.8x the error below 128 tokens), so its row tiles run the both-terms form, bit for bit (GemmArgs::tile_both, cls_tile_flags_kernel)
   int qkv_aside_mask = 1;  // MV_F16X8: which of the Q / K / V blocks of the QKV projection sweep the A-side correction term too (bit 0 / 1 / 2;
                            // gemm_pp.h x8_aside_mask).  Default: Q only.  env MEMVUL_QKV_ASIDE = a subset of "qkv" ("" / "none" = weight-side
                            // term only everywhere, "qkv" = round 3's form): the A/B switch of profiles/r04_d_*
@@ -482,12 +482,12 @@ int encode_dev(mv_handle* h, const int32_t* d_ids, const int32_t* d_lens, int B,
   const bool x8 = h->precise;             // MV_F16X8: + fp8 correction sweeps (forces the persistent path, pp_selected)
   const bool lo8s = x8 && h->stream_lo8;  // the stream's low part is the lo8 plane of x8 (no xlo plane)
   const bool prune = !full && h->cls_prune && u_out && n_layers == c.layers && n_layers > 0;
-  // [CLS]-row A-side term (MEMVUL_CLS_ASIDE=1): every persistent GEMM of this pass sweeps the weight-side correction term only (x8_terms = 1) and the
+  // The [CLS]-row form (mv_handle::cls_aside): every persistent GEMM of this pass sweeps the weight-side correction term only (x8_terms = 1) and the
   // A-side term A_lo W_hi^T is formed for the B [CLS] rows alone: their low parts (2^11 x, fp16) gathered from the operand's lo plane (raw stream) or
   // lo8 plane (context, GELU output), one skinny fp16 GEMM [B x K] x [K x N], and the launch adds the result to those rows' accumulators
-  // (gemm_pp.h GemmArgs::cls_corr).  Long passes only: short sequences average the other rows' roundings over too few keys.
-  // Passes of padded length 256 / 512 (a 256-row tile then belongs to ONE sequence, so the form of a sequence depends on its own length alone and a
-  // row's result stays independent of the batch it travels in); sequences shorter than cls_min_len keep the default form, tile by tile.
+  // (gemm_pp.h GemmArgs::cls_corr).  Passes of padded length 256 / 512: a 256-row tile then belongs to ONE sequence, so the form of a sequence
+  // depends on its own length alone (cls_tile_flags_kernel: sequences shorter than cls_min_len keep the both-terms form, tile by tile) and a row's
+  // result stays independent of the batch it travels in.
   const bool cls_as = big && x8 && h->cls_aside && !lo8s && (Sp == 256 || Sp == 512);
   if (cls_as) {
     const int ntile = (int)(Mpad / 256);

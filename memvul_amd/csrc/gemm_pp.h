@@ -55,6 +55,12 @@
 // sweep's and the staging code is shared; an fp8 K-tile covers 128 products per row pair in the matrix-pipe time the fp16
 // tile needs for 64.  Cost: 2x the main loop (a three-sweep fp16 split: 3x); error: operand rounding 2^-12 -> ~2^-15.5
 // (oracle/precision_model.py "f16x8").  The producers (PP_GELU, PP_RESLN3; embedding, attention) write the [lo8 | hi8] planes.
+// [CLS]-row form (round 5, the default; engine.hip cls_aside): only token 0 of a sequence reaches the pooler (model_memory.py:99) and every other row's
+// A-operand rounding reaches it through attention, averaged over the keys — so every launch sweeps the weight-side term only (x8_terms = 1: K / 128 fp8
+// K-tiles; the Q block of the QKV projection keeps both), the A-side term A_lo W_hi^T of the [CLS] rows alone arrives through GemmArgs::cls_corr (a skinny fp16
+// GEMM over those B rows in front of the launch) and is added to those rows' accumulators at the start of the epilogue, and the producers write the hi8
+// plane alone (GemmArgs::out8_hi_only; a 32-row block that holds a [CLS] row keeps its lo8 row).  Row tiles of sequences too short for it (GemmArgs::tile_both)
+// run the both-terms form bit for bit.  +14 % issue reports/s at the both-terms form's trained-like logit error (profiles/r05_j*, r05_k*).
 // X8 = 2 (PP_RESLN3, MEMVUL_STREAM_LO8=1): the same, with the raw stream's low part taken from / left in the lo8 plane (no lo fp16 plane).
 // PP_QK X8 with GemmArgs::vt_lo set (passes of padded length <= 128): second fp16 planes of Q, K and V^T for the two-plane attention (attention_v2.h VLO).
 #pragma once
