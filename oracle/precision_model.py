@@ -74,7 +74,7 @@ def _w_shift(w):
 def _mm(afmt, wfmt, A, W, cls_lo=None):
     """A @ W^T as the engine forms it.  Both operands "f16x8" (MV_F16X8): ONE fp16 sweep + two fp8 (e4m3) correction sweeps
     into the same fp32 accumulators,  A_hi W_hi + A_lo8 W_hi8 + A_hi8 W_lo8;  otherwise each operand is rounded on its own.
-    ``cls_lo`` (MEMVUL_CLS_ASIDE=1, engine.hip cls_aside; A is [B, S, K]): wherever the sweep carried the weight-side term only, row 0 of
+    ``cls_lo`` (the [CLS]-row form, engine.hip cls_aside; A is [B, S, K]): wherever the sweep carried the weight-side term only, row 0 of
     every sequence — its [CLS] token — gets the A-side term from a skinny fp16 GEMM  fp16(2^11 A_lo) fp16(W)^T 2^-11  with A_lo taken from
     the operand's lo fp16 plane ("lo16": the raw stream) or its lo8 plane ("lo8": context, GELU output)."""
     if afmt in ("f16x8", "f16x8w", "f16x8q", "f16x8k", "f16x8v") and wfmt == "f16x8":
@@ -126,12 +126,12 @@ FORMATS = {
     "f16x8q": _f16, "f16x8k": _f16, "f16x8v": _f16,
 }
 
-# the knobs of the SHIPPED MV_F16X8 engine (round 4): every GEMM sweeps both first-order terms except the QKV projection, which
-# sweeps the A-side term in its Q block only (the weight-side term everywhere)
+# the knobs of the MV_F16X8 engine in its both-terms form (rounds 3-4; MEMVUL_CLS_ASIDE=0, and every sequence shorter than 128 tokens): every GEMM sweeps both
+# first-order terms except the QKV projection, which sweeps the A-side term in its Q block only (the weight-side term everywhere)
 X8_ENGINE = dict(w_qkv="f16x8", w_o="f16x8", w_1="f16x8", w_2="f16x8", a_qkv="f16x8q", a_ffn1="f16x8", ctx="f16x8", h="f16x8")
 
-# ... and of its MEMVUL_CLS_ASIDE=1 form (round 5; pass ``cls_fix=True`` to encode / logits with it): the weight-side term everywhere, the A-side term
-# in the Q block of the QKV projection (all rows) and, through the skinny GEMMs, in the [CLS] row of every sequence
+# ... and in the SHIPPED [CLS]-row form (round 5, the default; pass ``cls_fix=True`` to encode / logits with it): the weight-side term everywhere, the A-side
+# term in the Q block of the QKV projection (all rows) and, through the skinny GEMMs, in the [CLS] row of every sequence for the other three GEMMs
 X8_ENGINE_CLS = dict(w_qkv="f16x8", w_o="f16x8", w_1="f16x8", w_2="f16x8", a_qkv="f16x8q", a_ffn1="f16x8w", ctx="f16x8w", h="f16x8w")
 
 KNOBS = ("w_qkv", "w_o", "w_1", "w_2", "a_qkv", "a_ffn1", "qkv", "p", "ctx", "h", "res")
@@ -157,7 +157,7 @@ def encode(w, ids, mask, cfg: Optional[Dict[str, List[str]]], heads=12, eps=1e-1
            cls_from_layer=0, cls_fix=False):
     """float64 BERT forward with the engine's rounding points (``cfg`` None = exact).  ``fold_ln``: the QKV / FFN-1
     weights are rounded AFTER the preceding LayerNorm is folded in (W'' = W gamma - rowmean, gemm_pp.h) and the A operand
-    is the raw (pre-LayerNorm) stream, as on the engine's persistent-GEMM path.  ``cls_fix``: the [CLS]-row A-side term of MEMVUL_CLS_ASIDE=1
+    is the raw (pre-LayerNorm) stream, as on the engine's persistent-GEMM path.  ``cls_fix``: the [CLS]-row A-side term of the shipped form
     (see _mm) in every GEMM whose A format sweeps the weight-side term only."""
     W = lambda k: w[PFX + k].astype(np.float64)  # noqa: E731
     L = orc.n_layers(w)

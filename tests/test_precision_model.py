@@ -144,7 +144,7 @@ def test_lo8_residual_stream_is_priced_by_the_model(case):
 
 
 def test_cls_row_aside_is_priced_by_the_model(case):
-    """MEMVUL_CLS_ASIDE=1 (round 5): only the [CLS] row of a sequence reaches the pooler (model_memory.py:99) — every other row's A-operand rounding
+    """The [CLS]-row form (round 5, the default; MEMVUL_CLS_ASIDE=0 = both terms in every row): only the [CLS] row of a sequence reaches the pooler (model_memory.py:99) — every other row's A-operand rounding
     reaches it through attention, averaged over the keys.  So the sweeps carry the weight-side term only (half a sweep; the Q block of the QKV
     projection keeps both) and the A-side term is restored for the [CLS] rows alone (a skinny fp16 GEMM over B rows per launch).  Model: without the
     row term the weight-side-only engine sits at the fp16 level; with it, at the shipped level (four seeds: 3.4 - 4.6e-4 against 3.0 - 4.4e-4;
@@ -154,7 +154,7 @@ def test_cls_row_aside_is_priced_by_the_model(case):
     w_only = case(pm.engine_formats(L, "f16", **pm.X8_ENGINE_CLS))
     cls = case(pm.engine_formats(L, "f16", **pm.X8_ENGINE_CLS), cls_fix=True)
     cls_none = case(pm.engine_formats(L, "f16", **dict(pm.X8_ENGINE_CLS, a_qkv="f16x8w")), cls_fix=True)
-    print("\nboth terms (shipped) %.2e | weight-side term only %.2e | + the A-side term of the [CLS] rows %.2e (without the Q block's: %.2e)"
+    print("\nboth terms in every row %.2e | weight-side term only %.2e | + the A-side term of the [CLS] rows %.2e (without the Q block's: %.2e)"
           % (shipped, w_only, cls, cls_none))
     assert w_only > 1e-3                      # dropping every A-side term does not hold the contract ...
     assert cls < 6e-4 and cls < shipped + 2.5e-4   # ... restoring it in one row per sequence does
