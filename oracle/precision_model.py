@@ -49,9 +49,9 @@ def _e4m3(x):
     what ``v_cvt_pk_fp8_f32`` after a clamp to +-448 produces on gfx950."""
     x = np.asarray(x, np.float64)
     a = np.abs(x)
-    e = np.clip(np.floor(np.log2(np.maximum(a, 1e-300))), -6, 8)
-    q = 2.0 ** (e - 3)
-    return np.sign(x) * np.minimum(np.round(a / q) * q, 448.0)
+    e = np.clip(np.frexp(a)[1] - 1, -6, 8)  # a = m 2^e', m in [0.5, 1): binade floor(log2 a) = e' - 1 (zero: e' = 0, clipped like any tiny value)
+    q = np.ldexp(1.0, e - 3)
+    return np.copysign(np.minimum(np.rint(a / q) * q, 448.0), x)
 
 
 # static power-of-two pre-scales of the fp8 planes (engine: MV_F16X8; the E8M0 scale operands of the MX instruction undo them
@@ -71,6 +71,20 @@ def _w_shift(w):
     return int(np.floor(np.log2(448.0 / m))) if m > 0 else 0
 
 
+_W_PLANES = {}  # planes of WEIGHT operands: the same 48 matrices meet every evaluation of a test module (float32 holds them exactly)
+
+
+def _w_planes(W):
+    key = (W.shape, float(W[0, 0]), float(W[-1, -1]), float(W[W.shape[0] // 2, W.shape[1] // 3]), float(W.sum()))
+    hit = _W_PLANES.get(key)
+    if hit is None:
+        if len(_W_PLANES) >= 64:
+            _W_PLANES.clear()
+        hit = tuple(p.astype(np.float32) for p in _x8_planes(W, _w_shift(W)))
+        _W_PLANES[key] = hit
+    return tuple(p.astype(np.float64) for p in hit)
+
+
 def _mm(afmt, wfmt, A, W, cls_lo=None):
     """A @ W^T as the engine forms it.  Both operands "f16x8" (MV_F16X8): ONE fp16 sweep + two fp8 (e4m3) correction sweeps
     into the same fp32 accumulators,  A_hi W_hi + A_lo8 W_hi8 + A_hi8 W_lo8;  otherwise each operand is rounded on its own.
@@ -79,7 +93,7 @@ def _mm(afmt, wfmt, A, W, cls_lo=None):
     the operand's lo fp16 plane ("lo16": the raw stream) or its lo8 plane ("lo8": context, GELU output)."""
     if afmt in ("f16x8", "f16x8w", "f16x8q", "f16x8k", "f16x8v") and wfmt == "f16x8":
         ah, ah8, al8 = _x8_planes(A, X8_ACT_SHIFT)
-        wh, wh8, wl8 = _x8_planes(W, _w_shift(W))
+        wh, wh8, wl8 = _w_planes(W)
         out = ah @ wh.T + ah8 @ wl8.T
 
         def cls_term(cols):

@@ -46,7 +46,7 @@ def test_where_the_logit_budget_goes(case):
     L = 12
     e_all = case(pm.engine_formats(L, "f16"))
     e_bf16 = case(pm.engine_formats(L, "bf16"))
-    single = {k: case(pm.engine_formats(L, "exact", **{k: "f16"})) for k in ("w_qkv", "w_2", "a_ffn1", "ctx", "h", "qkv")}
+    single = {k: case(pm.engine_formats(L, "exact", **{k: "f16"})) for k in ("w_qkv", "a_ffn1", "ctx", "h", "qkv")}
     e_side = case(pm.engine_formats(L, "f16"), cls_side="exact")
     e_side_w = case(pm.engine_formats(L, "f16", w_qkv="f16x2", w_o="f16x2", w_1="f16x2", w_2="f16x2"), cls_side="exact", cls_raw_kv=True)
     print("\nmax |logit err| at |logit| ~ 3, 12 layers:  all fp16 %.2e | all bf16 %.2e | one point alone %s | + exact [CLS] rows %.2e"
