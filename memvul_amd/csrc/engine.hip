@@ -28,11 +28,11 @@ namespace {
 
 enum KernelClass {
   KC_EMBED_LN = 0, KC_GEMM_QKV, KC_ATTENTION, KC_GEMM_OUT, KC_LN, KC_GEMM_FFN1, KC_GEMM_FFN2,
-  KC_POOL_HEAD, KC_MATCH, KC_TOPK, KC_TEST_GEMM, KC_OTHER, KC_GEMM_KV_LAST, KC_CLS_TAIL
+  KC_POOL_HEAD, KC_MATCH, KC_TOPK, KC_TEST_GEMM, KC_CLS_ROW_TERM, KC_GEMM_KV_LAST, KC_CLS_TAIL
 };
 const char* kKernelClassNames[MV_NUM_KERNEL_CLASSES] = {
     "embed_ln", "gemm_qkv", "attention", "gemm_attn_out", "layernorm", "gemm_ffn1_gelu", "gemm_ffn2",
-    "pool_head", "match", "topk", "test_gemm", "other", "gemm_kv_last", "cls_tail"};
+    "pool_head", "match", "topk", "test_gemm", "cls_row_term", "gemm_kv_last", "cls_tail"};
 
 thread_local std::string g_create_error;
 
@@ -496,7 +496,7 @@ int encode_dev(mv_handle* h, const int32_t* d_ids, const int32_t* d_lens, int B,
     if (int rc = launch_check(h, "cls_tile_flags")) return rc;
   }
   auto cls_fix = [&](const half_t* lo16, const uint8_t* lo8p, const half_t* W, int N, int K) -> int {
-    ProfScope ps(h, KC_OTHER);
+    ProfScope ps(h, KC_CLS_ROW_TERM);
     const size_t n4 = (size_t)B * K / 4;
     hipLaunchKernelGGL(cls_lo_gather_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, h->w->stream, lo16, lo8p, K, Sp, B, h->w->cls_lo);
     if (int rc = launch_check(h, "cls_lo_gather")) return rc;
