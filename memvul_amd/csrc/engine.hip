@@ -946,8 +946,21 @@ int mv_create(int device, const mv_config* cfg, mv_handle** out) try {
   }
   if (const char* e = getenv("MEMVUL_STREAM_LO8")) h->stream_lo8 = atoi(e) == 1;
   if (const char* e = getenv("MEMVUL_SHORT_VLO")) h->short_vlo = atoi(e) != 0;
-  if (const char* e = getenv("MEMVUL_CLS_ASIDE")) h->cls_aside = atoi(e) == 1;
-  if (const char* e = getenv("MEMVUL_CLS_ASIDE_MIN_LEN")) { const int v = atoi(e); if (v >= 1 && v <= 512) h->cls_min_len = v; }
+  if (const char* e = getenv("MEMVUL_CLS_ASIDE")) {  // (like MEMVUL_QKV_ASIDE: a typo must not silently change the numerics)
+    if (strcmp(e, "0") && strcmp(e, "1")) {
+      g_create_error = std::string("MEMVUL_CLS_ASIDE=\"") + e + "\": expected 0 or 1";
+      return MV_ERR_INVALID;  // the guard destroys the handle
+    }
+    h->cls_aside = e[0] == '1';
+  }
+  if (const char* e = getenv("MEMVUL_CLS_ASIDE_MIN_LEN")) {
+    const int v = atoi(e);
+    if (v < 1 || v > 512) {
+      g_create_error = std::string("MEMVUL_CLS_ASIDE_MIN_LEN=\"") + e + "\": expected 1 .. 512";
+      return MV_ERR_INVALID;
+    }
+    h->cls_min_len = v;
+  }
   if (const char* e = getenv("MEMVUL_GN_MAX")) { const int v = atoi(e); if (v >= 1 && v <= 12) h->pp_gn_max = v; }
   if (const char* e = getenv("MEMVUL_RASTER")) h->pp_raster = atoi(e) == 1 ? 1 : 0;
   {

@@ -260,9 +260,13 @@ def test_small_pass_kernels_exclude_the_default_compute_dtype(gu):
 
 
 def test_unknown_qkv_aside_characters_are_rejected(gu):
-    """a typo in MEMVUL_QKV_ASIDE must not silently change the numerics."""
+    """a typo in MEMVUL_QKV_ASIDE must not silently change the numerics (the same for MEMVUL_CLS_ASIDE and its length rule)."""
     with pytest.raises(RuntimeError, match="MEMVUL_QKV_ASIDE"):
         gu.engine_for(dict(layers=1), dict(), env={"MEMVUL_QKV_ASIDE": "qx"}, compute_dtype="precise")
+    with pytest.raises(RuntimeError, match="MEMVUL_CLS_ASIDE"):
+        gu.engine_for(dict(layers=1), dict(), env={"MEMVUL_CLS_ASIDE": "on"}, compute_dtype="precise")
+    with pytest.raises(RuntimeError, match="MEMVUL_CLS_ASIDE_MIN_LEN"):
+        gu.engine_for(dict(layers=1), dict(), env={"MEMVUL_CLS_ASIDE_MIN_LEN": "0"}, compute_dtype="precise")
 
 
 @pytest.mark.parametrize("compute", ["f16", "precise"])

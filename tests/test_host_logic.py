@@ -185,3 +185,19 @@ def test_default_compute_dtype_is_the_contract_holding_one(monkeypatch):
     from memvul_amd import model_memory, model_single
     for mod in (model_memory, model_single):  # neither names a default of its own: both defer to binding.default_compute()
         assert 'compute_dtype", None)' in inspect.getsource(mod)
+
+
+def test_documented_switch_defaults_match_the_library_source():
+    """bench.py and the docs name the library's default of MEMVUL_CLS_ASIDE / MEMVUL_CLS_ASIDE_MIN_LEN; the library source is the authority
+    (engine.hip mv_handle): a default flipped in one place only would make bench.py report the wrong form under `precise_cls_aside_*`."""
+    import re
+
+    import bench
+
+    src = open(os.path.join(ROOT, "memvul_amd", "csrc", "engine.hip")).read()
+    m = re.search(r"bool cls_aside = (true|false);", src)
+    assert m and bench.DEFAULT_CLS_ASIDE == ("1" if m.group(1) == "true" else "0")
+    n = re.search(r"int cls_min_len = (\d+);", src)
+    assert n and int(n.group(1)) == 128
+    hdr = open(os.path.join(ROOT, "include", "memvul_hip.h")).read()
+    assert "MEMVUL_CLS_ASIDE=0" in hdr and "MEMVUL_CLS_ASIDE_MIN_LEN (128)" in hdr
