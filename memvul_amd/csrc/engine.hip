@@ -196,8 +196,8 @@ struct mv_handle {
                            // padded length 256 / 512 sweep the weight-side term only in every GEMM (the Q block of the QKV projection keeps both) and add the A-side
                            // term for the [CLS] row of each sequence alone (a skinny fp16 GEMM over those B rows in front of each launch, GemmArgs::cls_corr): the
                            // pooler reads only that row, every other row's A-side rounding reaches it averaged over the keys.  +14 % at the same error (r05_j*, r05_k*)
-  int cls_min_len = 128;   // ... for sequences of at least this many tokens (env MEMVUL_CLS_ASIDE_MIN_LEN): a short sequence averages over few keys (model: 1.5 -
-                           // 1.8x the error below 128 tokens), so its row tiles run the both-terms form, bit for bit (GemmArgs::tile_both, cls_tile_flags_kernel)
+  int cls_min_len = 128;   // ... for sequences of at least this many tokens (env MEMVUL_CLS_ASIDE_MIN_LEN): a short sequence averages over few keys (model: 1.2 -
+                           // 1.6x the error at 16 - 128 tokens), so its row tiles run the both-terms form, bit for bit (GemmArgs::tile_both, cls_tile_flags_kernel)
   int qkv_aside_mask = 1;  // MV_F16X8: which of the Q / K / V blocks of the QKV projection sweep the A-side correction term too (bit 0 / 1 / 2;
                            // gemm_pp.h x8_aside_mask).  Default: Q only.  env MEMVUL_QKV_ASIDE = a subset of "qkv" ("" / "none" = weight-side
                            // term only everywhere, "qkv" = round 3's form): the A/B switch of profiles/r04_d_*

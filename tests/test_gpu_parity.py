@@ -184,7 +184,7 @@ def test_cls_row_aside_form(gu, golden_dir, name, qkv_aside):
 
 
 def test_cls_row_aside_is_decided_per_sequence(gu, golden_dir):
-    """The other rows' A-side rounding reaches the [CLS] row averaged over the keys, so a sequence takes the form only if it has at least
+    """The other rows' A-side rounding reaches the [CLS] row averaged over the keys (tests/test_precision_model.py::test_cls_row_form_needs_keys_to_average_over), so a sequence takes the form only if it has at least
     MEMVUL_CLS_ASIDE_MIN_LEN (128) tokens — decided per 256-row tile from the sequence's own length (GemmArgs::tile_both), so that a row's result
     still does not depend on the batch it travels in: short sequences give the both-terms form's bits, long ones the same bits alone or among
     short batch-mates; with the rule lifted (MIN_LEN = 1) the short ones change too.  Passes of padded length 256 (issue reports) and 512 (anchors)."""

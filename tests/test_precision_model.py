@@ -159,3 +159,27 @@ def test_cls_row_aside_is_priced_by_the_model(case):
     assert w_only > 1e-3                      # dropping every A-side term does not hold the contract ...
     assert cls < 6e-4 and cls < shipped + 2.5e-4   # ... restoring it in one row per sequence does
     assert cls_none < 8e-4
+
+
+def test_cls_row_form_needs_keys_to_average_over():
+    """Why the [CLS]-row form is decided per sequence (engine.hip cls_min_len = 128): the other rows' A-side rounding reaches the [CLS] row averaged over
+    the attention keys, and a short sequence has few.  Model, 32-token sequences on both sides (with the two-plane attention such passes run): the form
+    costs 1.6x the both-terms error there (rms 2.6e-4 against 1.6e-4, max 6.3e-4 against 4.2e-4; over 16 / 32 / 64 / 128 tokens the rms ratio reads
+    1.2 / 1.6 / 1.4 / 1.2 and the maxima 6.2 / 6.3 / 4.6 / 2.1e-4; at 256 tokens the GPU measures the same maxima for both forms over 24 draws)."""
+    dims = synth.BertDims(layers=12)
+    w = synth.make_weights(dims, qk_scale=2.0, match_scale=29.0, trained_like=True, seed=4001)
+    L = 32
+    ids, lens = synth.make_ids(6, L, dims.vocab_size, seed=41 + L)
+    aids, alens = synth.make_ids(6, L, dims.vocab_size, seed=42 + L)
+    mask, amask = synth.mask_from_lens(lens, L), synth.mask_from_lens(alens, L)
+    ref, _, _ = pm.logits(w, ids, mask, aids, amask, None)
+
+    def rms(cfg, **kw):
+        lg, _, _ = pm.logits(w, ids, mask, aids, amask, cfg, **kw)
+        return float(np.sqrt(((lg - ref) ** 2).mean()))
+
+    two = dict(qkv="f16x2", p="f16x2")
+    both = rms(pm.engine_formats(12, "f16", **dict(pm.X8_ENGINE, **two)))
+    cls = rms(pm.engine_formats(12, "f16", **dict(pm.X8_ENGINE_CLS, **two)), cls_fix=True)
+    print("\n32-token sequences, rms logit error: both terms in every row %.2e, [CLS]-row form %.2e" % (both, cls))
+    assert cls > 1.25 * both
