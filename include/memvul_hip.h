@@ -75,12 +75,18 @@ typedef struct mv_config {
 
 /* Replaces Model.from_params + model.to(cuda_device) (predict_memory.py:62-70): binds `device`,
  * creates the stream and reserves all workspaces. */
-/* Environment switches read HERE (every one has a tested default; DESIGN.md section 8 lists them with their measurements): MEMVUL_STREAM_LO8=1 (MV_F16X8: the
- * residual stream keeps 8 low bits instead of 16: +2.4 % issue reports/s, ~1.2x the trained-like logit error), MEMVUL_SHORT_VLO=0 (MV_F16X8: passes of padded
- * length <= 128 stop carrying Q, K, V, P as two fp16 planes through attention), MEMVUL_QKV_ASIDE (a subset of "qkv" or "none"; anything else is MV_ERR_INVALID),
- * MEMVUL_CLS_ASIDE=0 (MV_F16X8: both first-order correction terms in EVERY row, the form of rounds 3-4: -12 % issue reports/s at the same trained-like
- * logit error; default 1 = sequences of >= MEMVUL_CLS_ASIDE_MIN_LEN (128) tokens in passes of padded length 256 / 512 sweep the weight-side term and
- * take the A-side term for their [CLS] row alone), MEMVUL_CLS_PRUNE, MEMVUL_STREAMS, MEMVUL_GEMM_TILE, MEMVUL_NUM_CU, MEMVUL_RASTER, MEMVUL_GN_MAX. */
+/* Environment switches read HERE — five, each with a tested default, each parsed strictly (a value the library does not understand fails mv_create with a
+ * message; a typo never selects other numerics silently):
+ *   MEMVUL_CLS_ASIDE          1 (default) | 0.  MV_F16X8: 1 = the [CLS]-row form (every GEMM sweeps the weight-side correction term, the A-side term is
+ *                             restored for the [CLS] row of each sequence alone: only that row reaches the pooler, model_memory.py:99); 0 = both first-order
+ *                             terms in every row (rounds 3-4: -12 % issue reports/s, same trained-like logit error on diffuse attention).
+ *   MEMVUL_CLS_ASIDE_MIN_LEN  1 .. 512 (default 128): sequences shorter than this keep the both-terms form (few keys to average over).
+ *   MEMVUL_QKV_ASIDE          a subset of "qkv", "" or "none" (default "q"): the blocks of the QKV projection that sweep the A-side term for every row.
+ *   MEMVUL_CLS_PRUNE          1 (default) | 0: after the last layer's K / V projection only the [CLS] rows are processed.
+ *   MEMVUL_STREAMS            2 (default) | 1: batches of the resident sweep in flight (mv_set_streams changes it later).
+ * (The sixth switch of the product, MEMVUL_COMPUTE = precise | f16, is read by the Python surface: memvul_amd/binding.py default_compute.)
+ * Development A/B knobs (kernel path forced at test sizes, raster, grid share, one-plane short passes) exist only in the -DMEMVUL_DEV_SWITCHES build
+ * (libmemvul_hip_dev.so: memvul_amd/build.py, loaded by the GPU tests and A/B scripts that need them); this library does not read them. */
 int mv_create(int device, const mv_config* cfg, mv_handle** out);
 void mv_destroy(mv_handle* h);
 /* Last error message of this handle (or of a failed mv_create when h == NULL). */
@@ -161,9 +167,10 @@ int mv_corpus_results(mv_handle* h, int64_t first, int64_t count, float* best, i
 /* MV_F16X8 only (always 0 in MV_F16).  The fp8 planes of the activations (raw residual stream, attention context, GELU output) use ONE
  * static scale: |x| <= 112 is representable; an element beyond it keeps its fp16 accuracy but loses its correction term (the precision of
  * MV_F16 for that element) — the computation never fails over it.  *clamped = the number of such elements since the handle was created
- * (or since the last call with reset != 0), saturating at 2^32 - 1; synchronises.  A non-zero count on a real checkpoint means the 1e-3
+ * (or since the last call with reset != 0; a 64-bit device counter: it does not wrap); synchronises.  A non-zero count on a real checkpoint means the 1e-3
  * logit contract of model_memory.py:141 is no longer backed by the measurements in DESIGN.md section 2 for that model: the Python
- * wrapper warns once (binding.Engine).  No reference counterpart (the reference computes in fp32). */
+ * wrapper warns once (binding.Engine).  NaN activations are not counted (the range test is a floating-point maximum, which skips them): they
+ * propagate to the outputs as NaN, where they are visible.  No reference counterpart (the reference computes in fp32). */
 int mv_x8_saturation(mv_handle* h, int64_t* clamped, int reset);
 
 /* ---- multi-GPU exchange (the reference is single-process, predict_memory.py:103) --------------------

@@ -14,6 +14,8 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libmemvul_hip.so")
+LIB_PATH_DEV = os.path.join(_HERE, "lib", "libmemvul_hip_dev.so")  # the -DMEMVUL_DEV_SWITCHES build (memvul_amd/build.py): tests and A/B scripts only
+DEV_SWITCHES = ("MEMVUL_GEMM_TILE", "MEMVUL_SHORT_VLO", "MEMVUL_RASTER", "MEMVUL_GN_MAX", "MEMVUL_NUM_CU")  # read by that build alone
 
 MV_F32, MV_F16, MV_BF16, MV_I32, MV_I64 = 0, 1, 2, 3, 4
 MV_F16X8 = 6  # compute dtype only ("precise"): fp16 MFMA sweep + one fp8 (e4m3) correction sweep per GEMM (include/memvul_hip.h)
@@ -65,23 +67,23 @@ class MvConfig(C.Structure):
     ]
 
 
-_lib = None
+_libs = {}
 
 
-def load_library(path: Optional[str] = None):
+def load_library(path: Optional[str] = None, dev: bool = False):
     """dlopen the HIP library and declare the prototypes.  Raises RuntimeError if it is missing —
-    there is deliberately no other implementation to fall back to."""
-    global _lib
-    if _lib is not None:
-        return _lib
-    path = path or os.environ.get("MEMVUL_HIP_LIB") or LIB_PATH
+    there is deliberately no other implementation to fall back to.  dev: the development build (the same kernels, plus the
+    A/B knobs of DEV_SWITCHES at mv_create); the product never asks for it."""
+    path = path or (LIB_PATH_DEV if dev else (os.environ.get("MEMVUL_HIP_LIB") or LIB_PATH))
+    if path in _libs:
+        return _libs[path]
     if not os.path.exists(path):
         raise RuntimeError(
             f"libmemvul_hip.so not found at {path}: build it with `python -m memvul_amd.build` "
             "(hipcc --offload-arch=gfx950); the MemVul hot path has no CPU fallback"
         )
     try:
-        lib = C.CDLL(path, mode=C.RTLD_GLOBAL)
+        lib = C.CDLL(path, mode=C.RTLD_LOCAL)  # (two builds of the same symbols may live in one test process)
     except OSError as e:  # pragma: no cover
         raise RuntimeError(f"cannot load {path}: {e}") from e
     vp, i32p, f32p = C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_float)
@@ -129,7 +131,7 @@ def load_library(path: Optional[str] = None):
         fn = getattr(lib, name)  # AttributeError if the .so does not export a declared symbol
         fn.restype = res
         fn.argtypes = args
-    _lib = lib
+    _libs[path] = lib
     return lib
 
 
@@ -146,10 +148,11 @@ class Engine:
 
     def __init__(self, device: int = 0, *, vocab_size: int = 30522, layers: int = 12, max_pos: int = 512,
                  type_vocab: int = 2, ln_eps: float = 1e-12, max_tokens: int = 65536, max_batch: int = 512,
-                 max_anchors: int = 1024, same_idx: int = 0, proj_dim: int = 512):
+                 max_anchors: int = 1024, same_idx: int = 0, proj_dim: int = 512, dev: bool = False):
         """proj_dim: width of the embedding the matcher runs on — 512 (the header output: use_header=True, every reference
-        config) or 768 (use_header=False: the pooler output, no ``_projector_single`` in the state dict)."""
-        self._lib = load_library()
+        config) or 768 (use_header=False: the pooler output, no ``_projector_single`` in the state dict).  dev: load the development
+        build (tests / A/B scripts: the only one that reads DEV_SWITCHES)."""
+        self._lib = load_library(dev=dev)
         self.P = int(proj_dim)
         self.cfg = MvConfig(vocab_size, 768, layers, 12, 3072, max_pos, type_vocab, self.P, ln_eps, max_tokens,
                             max_batch, max_anchors, same_idx)
@@ -397,10 +400,10 @@ class Engine:
         ids, lens = _as(ids, np.int32), _as(lens, np.int32)
         self._check(self._lib.mv_debug_encode(self._h, _ptr(ids), _ptr(lens), ids.shape[0], ids.shape[1], n_layers), "mv_debug_encode")
         S = ids.shape[1]
-        self._dbg = (ids.shape[0], (S + 63) // 64 * 64 if S <= 256 else (S + 127) // 128 * 128)  # engine.hip padded_len
+        self._dbg = (ids.shape[0], (S + 63) // 64 * 64 if S <= 256 else (S + 127) // 128 * 128, lens.copy())  # engine.hip padded_len
 
     def debug_read(self, buffer: int) -> np.ndarray:
-        B, Sp = self._dbg
+        B, Sp, lens = self._dbg
         shapes = {
             0: ((B, Sp, 768), np.float32), 1: ((B, Sp, 768), np.float16), 2: ((B, 12, Sp, 64), np.float16),
             3: ((B, 12, Sp, 64), np.float16), 4: ((B, 12, 64, Sp), np.float16), 5: ((B, Sp, 768), np.float16),
@@ -409,7 +412,23 @@ class Engine:
         shape, dt = shapes[buffer]
         out = np.empty(shape, dt)
         self._check(self._lib.mv_debug_read(self._h, buffer, _ptr(out), out.nbytes), "mv_debug_read")
+        if getattr(self, "_precise", False) and buffer in self._TOKEN_AXIS:
+            # MV_F16X8 keeps the LAST token of every sequence in row 1 and token 1 in the last token's row (the "special rows" of
+            # misc_kernels.h embed_ln_kernel; only the [CLS] row's result leaves the encoder): hand the taps back in token order
+            ax = self._TOKEN_AXIS[buffer]
+            for b in range(B):
+                n = int(lens[b])
+                if n >= 3:
+                    idx = [slice(None)] * out.ndim
+                    idx[0] = b
+                    i1, i2 = list(idx), list(idx)
+                    i1[ax], i2[ax] = 1, n - 1
+                    t = out[tuple(i1)].copy()
+                    out[tuple(i1)] = out[tuple(i2)]
+                    out[tuple(i2)] = t
         return out
+
+    _TOKEN_AXIS = {0: 1, 1: 1, 2: 2, 3: 2, 4: 3, 5: 1, 6: 1}  # debug buffer -> its token axis
 
     def test_gemm(self, A16: np.ndarray, W16: np.ndarray, bias: Optional[np.ndarray], variant: int = 0, iters: int = 1):
         A16, W16 = _as(A16, np.float16), _as(W16, np.float16)

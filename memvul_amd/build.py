@@ -12,6 +12,10 @@ ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIB_DIR = os.path.join(HERE, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libmemvul_hip.so")
+# the same sources with -DMEMVUL_DEV_SWITCHES: the development A/B knobs (MEMVUL_GEMM_TILE, MEMVUL_SHORT_VLO, MEMVUL_RASTER, MEMVUL_GN_MAX,
+# MEMVUL_NUM_CU; engine.hip mv_create) exist only in this build — GPU tests that force a kernel path at test sizes and the A/B scripts load it
+LIB_PATH_DEV = os.path.join(LIB_DIR, "libmemvul_hip_dev.so")
+DEV_FLAGS = ("-DMEMVUL_DEV_SWITCHES",)
 SOURCES = ["engine.hip"]
 HEADERS = ["common.h", "gemm.h", "gemm_pp.h", "attention.h", "attention_v2.h", "misc_kernels.h", "match_topk.h", os.path.join(ROOT, "include", "memvul_hip.h")]
 ARCH = "gfx950"
@@ -25,6 +29,11 @@ def hipcc_path() -> str:
 
 
 STAMP_PATH = LIB_PATH + ".stamp"
+
+
+def _paths(dev: bool):
+    lib = LIB_PATH_DEV if dev else LIB_PATH
+    return lib, lib + ".stamp"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", "-shared", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function", "-Wno-unused-value"]
 
 
@@ -96,19 +105,22 @@ def device_code_fingerprint(lib_path: str = None) -> str:
     return h.hexdigest()
 
 
-def read_stamp() -> dict:
+def read_stamp(dev: bool = False) -> dict:
     """The stamp next to the library as a dict: src / cc (what it was built from) and dev (the device code it contains)."""
-    with open(STAMP_PATH) as f:
+    with open(_paths(dev)[1]) as f:
         return dict(line.split(" ", 1) for line in f.read().strip().splitlines() if " " in line)
 
 
-def is_stale(extra_flags=()) -> bool:
+def is_stale(extra_flags=(), dev: bool = False) -> bool:
     """True when the library must be rebuilt: no binary / stamp, other sources or flags, or — where a compiler exists to
     compare with — another compiler.  On a box WITHOUT hipcc only the source line is compared (the binary that travelled with
     the tree is then the one to use; ADVICE r2: the old single-hash stamp could never match there)."""
-    if not os.path.exists(LIB_PATH) or not os.path.exists(STAMP_PATH):
+    lib_path, stamp_path = _paths(dev)
+    if dev:
+        extra_flags = tuple(extra_flags) + DEV_FLAGS
+    if not os.path.exists(lib_path) or not os.path.exists(stamp_path):
         return True
-    with open(STAMP_PATH) as f:
+    with open(stamp_path) as f:
         have = dict(line.split(" ", 1) for line in f.read().strip().splitlines() if " " in line)
     want = dict(line.split(" ", 1) for line in build_fingerprint(extra_flags).splitlines())
     if have.get("src") != want["src"]:
@@ -116,16 +128,19 @@ def is_stale(extra_flags=()) -> bool:
     return want["cc"] != "unknown" and have.get("cc") != want["cc"]
 
 
-def build(force: bool = False, verbose: bool = True, extra_flags=()) -> str:
-    """Compile the HIP library for gfx950; returns the .so path."""
-    if not force and not is_stale(extra_flags):
-        return LIB_PATH
+def build(force: bool = False, verbose: bool = True, extra_flags=(), dev: bool = False) -> str:
+    """Compile the HIP library for gfx950; returns the .so path.  dev: the -DMEMVUL_DEV_SWITCHES build (libmemvul_hip_dev.so)."""
+    if not force and not is_stale(extra_flags, dev):
+        return _paths(dev)[0]
+    lib_path, stamp_path = _paths(dev)
+    if dev:
+        extra_flags = tuple(extra_flags) + DEV_FLAGS
     os.makedirs(LIB_DIR, exist_ok=True)
     cmd = [
         hipcc_path(), f"--offload-arch={ARCH}", *FLAGS,  # -Wno-unused-value: hipError_t of calls checked by launch_check
         *extra_flags,
         *[os.path.join(CSRC, s) for s in SOURCES],
-        "-o", LIB_PATH + ".tmp",
+        "-o", lib_path + ".tmp",
     ]
     if verbose:
         print("[memvul_amd.build]", " ".join(cmd), flush=True)
@@ -134,18 +149,26 @@ def build(force: bool = False, verbose: bool = True, extra_flags=()) -> str:
     # not understand (compressed bundle, no gfx950 entry) yields `dev unknown` — bench.load_pmc then compares whole stamps — instead
     # of a successful compile left without a stamp (and rebuilt, and failing again, on every load)
     try:
-        dev = device_code_fingerprint(LIB_PATH + ".tmp")
+        code = device_code_fingerprint(lib_path + ".tmp")
     except (RuntimeError, OSError, ValueError, struct_error) as e:
-        dev = "unknown"
+        code = "unknown"
         if verbose:
             print(f"[memvul_amd.build] device-code fingerprint unavailable ({e}); stamp carries `dev unknown`", flush=True)
-    with open(STAMP_PATH + ".tmp", "w") as f:
-        f.write(build_fingerprint(extra_flags) + "\ndev " + dev + "\n")
-    os.replace(LIB_PATH + ".tmp", LIB_PATH)
-    os.replace(STAMP_PATH + ".tmp", STAMP_PATH)
-    return LIB_PATH
+    with open(stamp_path + ".tmp", "w") as f:
+        f.write(build_fingerprint(extra_flags) + "\ndev " + code + "\n")
+    os.replace(lib_path + ".tmp", lib_path)
+    os.replace(stamp_path + ".tmp", stamp_path)
+    return lib_path
+
+
+def build_all(force: bool = False, verbose: bool = True):
+    """Both builds, compiled side by side (two hipcc processes)."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    with ThreadPoolExecutor(2) as ex:
+        futs = [ex.submit(build, force, verbose, (), d) for d in (False, True)]
+        return [f.result() for f in futs]
 
 
 if __name__ == "__main__":
-    build(force="--force" in sys.argv)
-    print(LIB_PATH)
+    print("\n".join(build_all(force="--force" in sys.argv)))

@@ -18,9 +18,13 @@ struct AttnArgs {
   int S;                // padded length: 64, 128, 192, 256, 384 or 512
   int B;
   uint8_t* ctx8;        // MV_F16X8 (attention_v2_kernel<.., X8 = 1>): [B*S][1536] = [lo8 (768) | hi8 (768)] planes of ctx (gemm_pp.h)
-  unsigned int* x8_sat; // MV_F16X8: device counter of context elements beyond the fp8 planes' range (common.h x8_planes4)
+  unsigned long long* x8_sat; // MV_F16X8: device counter of context elements beyond the fp8 planes' range (common.h x8_planes4)
   const half_t* vt_lo;  // attention_v2_kernel<.., VLO = 1> (MV_F16X8, padded length <= 128): V^T's second fp16 plane, fp16(V - fp16(V)), same layout as vt
   const half_t *q_lo, *k_lo;  // the same for Q and K
+  // MV_F16X8, round 6 "special rows" (rows 0 and 1 of every sequence hold its [CLS] and [SEP] token: misc_kernels.h embed_ln_kernel):
+  const half_t* vlo_sp;  // 2^11 x the low parts of V of those two keys, [b 12 + head][64 dims][2] fp16 (gemm_pp.h GemmArgs::vlo_sp): O += p[:, 0..1] V_lo[0..1] —
+                         // with attention sinks the sink token's V reaches every row's context un-averaged, so its fp16 storage alone costs 1.2e-3 on the logits
+  half_t* sp_lo_out;     // 2^11 x the low parts of the CONTEXT of those two rows, compact [2 b + row][768] fp16: the A operand of the output projection's row term
 };
 
 // Last encoder layer: only the [CLS] query (token 0) of each issue report is consumed downstream
@@ -35,7 +39,8 @@ struct AttnArgs {
 // (or ctx32: the same rows in fp32).
 __global__ __launch_bounds__(256) void attention_cls_kernel(const float* __restrict__ q, const half_t* __restrict__ k,
                                                             const half_t* __restrict__ vt, const int32_t* __restrict__ lens,
-                                                            half_t* __restrict__ ctx, int S, int nbh, float* __restrict__ ctx32 = nullptr) {
+                                                            half_t* __restrict__ ctx, int S, int nbh, float* __restrict__ ctx32 = nullptr,
+                                                            const half_t* __restrict__ vlo_sp = nullptr) {
   __shared__ float ps[4][512];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int bh = blockIdx.x * 4 + wave;
@@ -100,6 +105,10 @@ __global__ __launch_bounds__(256) void attention_cls_kernel(const float* __restr
     t += __shfl_xor(t, 2, 64);
     t += __shfl_xor(t, 4, 64);
     out = (c == db) ? t : out;  // lane (sub, c) keeps dim 8 c + sub
+  }
+  if (vlo_sp) {  // + p[0] V_lo[0] + p[1] V_lo[1]: the special rows' V as hi + lo (AttnArgs::vlo_sp; the values are 2^11 x the low parts)
+    const half2_t l2 = *(const half2_t*)(vlo_sp + ((size_t)bh * MV_HEAD_DIM + 8 * c + sub) * 2);
+    out = __builtin_fmaf(__builtin_fmaf(pw[0], (float)l2[0], pw[1] * (float)l2[1]), 1.0f / 2048.0f, out);
   }
   if (ctx32) ctx32[(size_t)b * MV_HIDDEN + h * MV_HEAD_DIM + 8 * c + sub] = out * inv;  // the fp32 [CLS] tail of MV_F16X8
   else ctx[(size_t)b * MV_HIDDEN + h * MV_HEAD_DIM + 8 * c + sub] = (half_t)(out * inv);

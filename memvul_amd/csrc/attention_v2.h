@@ -117,6 +117,15 @@ __global__ __launch_bounds__(NKB * 128) __attribute__((amdgpu_waves_per_eu(2, 2)
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) qf[kk] = *(const half8_t*)(gq + kk * 16);
   };
+  // special rows (AttnArgs::vlo_sp): the A operand of ONE more MFMA per 32 head dims — lane (dim 32 dt + ql, hi = 0) holds {V_lo[key 0][dim], V_lo[key 1][dim], 0 x 6}
+  // (2^11 x), lanes hi = 1 (keys 8 .. 15 of the k-slot group) zeros — against the P^T fragment of keys 0 .. 15
+  constexpr bool SPV = X8 && !VLO;
+  auto load_vsp = [&](int u, uint32_t (&v)[2]) {
+    const uint32_t* g = (const uint32_t*)a.vlo_sp + (size_t)unit_bh(u) * MV_HEAD_DIM + ql;
+    const uint32_t v0 = g[0], v1 = g[32];
+    v[0] = hi ? 0u : v0;
+    v[1] = hi ? 0u : v1;
+  };
   auto load_q_lo = [&](int u, half8_t (&qf)[4]) {  // VLO: the same fragments of Q's lo plane
     const int bh = unit_bh(u), qb = unit_qb(u);
     const half_t* gq = a.q_lo + ((size_t)bh * ST + qb * S + 32 * wave + ql) * MV_HEAD_DIM + hi * 8;
@@ -140,8 +149,11 @@ __global__ __launch_bounds__(NKB * 128) __attribute__((amdgpu_waves_per_eu(2, 2)
   if (first >= nunits) return;
   half8_t qf[4], qn[4];
   half8_t qfl[VLO ? 4 : 1], qnl[VLO ? 4 : 1];  // VLO: Q's lo fragments, prefetched like Q's
+  uint32_t vs[2] = {0u, 0u}, vsn[2] = {0u, 0u};  // SPV: this unit's / the next unit's special-row V_lo operand, prefetched like Q
+  const bool spv = SPV && a.vlo_sp != nullptr;
   issue_chunk(first, 0, 0);
   load_q(first, qn);
+  if (spv) load_vsp(first, vsn);
   if constexpr (VLO) load_q_lo(first, qnl);
   int len_n = a.lens[unit_bh(first) / MV_HEADS];  // prefetched like Q: a VGPR-destination load must never be waited for mid-unit
 
@@ -218,6 +230,7 @@ __global__ __launch_bounds__(NKB * 128) __attribute__((amdgpu_waves_per_eu(2, 2)
 #if defined(__HIP_DEVICE_COMPILE__)
         asm volatile("" : "+v"(qn[0]), "+v"(qn[1]), "+v"(qn[2]), "+v"(qn[3]), "+v"(len_n));
         if constexpr (VLO) asm volatile("" : "+v"(qnl[0]), "+v"(qnl[1]), "+v"(qnl[2]), "+v"(qnl[3]));
+        if constexpr (SPV) asm volatile("" : "+v"(vsn[0]), "+v"(vsn[1]));
 #endif
         len = __builtin_amdgcn_readfirstlane(len_n);
         // previous unit's O through the K half of the OTHER ring slot: rows 32 wave .. + 31 are exactly the rows this
@@ -228,6 +241,7 @@ __global__ __launch_bounds__(NKB * 128) __attribute__((amdgpu_waves_per_eu(2, 2)
         }
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) qf[kk] = qn[kk];
+        vs[0] = vsn[0]; vs[1] = vsn[1];
         if constexpr (VLO) {
 #pragma unroll
           for (int kk = 0; kk < 4; ++kk) qfl[kk] = qnl[kk];
@@ -318,6 +332,7 @@ __global__ __launch_bounds__(NKB * 128) __attribute__((amdgpu_waves_per_eu(2, 2)
       if (j == NCH - 1 && nxt < nunits) {
         if constexpr (VLO) load_q_lo(nxt, qnl);
         load_q(nxt, qn);
+        if (spv) load_vsp(nxt, vsn);
         len_n = a.lens[unit_bh(nxt) / MV_HEADS];
       }
       // ---- O^T[d][q] (+)= V^T[d][keys] P^T[keys][q]
@@ -326,6 +341,20 @@ __global__ __launch_bounds__(NKB * 128) __attribute__((amdgpu_waves_per_eu(2, 2)
         for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
           for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
+        if constexpr (SPV) {
+          // special rows: O^T starts from V_lo[keys 0, 1]^T P^T[keys 0, 1] — keys 0 .. 15 are the first k-slot group of the first score fragment; the operand is
+          // 2^11 x the low parts, so the product is scaled back before the sum over all keys is added on top (as the accumulator's start value this costs no
+          // live range; added after the P V loop it cost the S = 256 instantiation 70 VGPRs and 320 B of scratch)
+          if (spv) {
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt) {
+              const u32x4 av = {vs[dt], 0u, 0u, 0u};
+              o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8_t, av), pf[0][0], o[dt], 0, 0, 0);
+#pragma unroll
+              for (int r = 0; r < 16; ++r) o[dt][r] *= 1.0f / 2048.0f;
+            }
+          }
+        }
       } else {
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt)
@@ -385,6 +414,24 @@ __global__ __launch_bounds__(NKB * 128) __attribute__((amdgpu_waves_per_eu(2, 2)
             }
           }
         if constexpr (X8) {
+          // special rows: the low parts of the context rows of queries 0 and 1 of the sequence (lanes ql < 2 of wave 0 in query block 0), compact
+          // (AttnArgs::sp_lo_out).  A block of its own behind a wave-uniform branch: inside the loop above it cost the kernel 100 VGPRs of live range.
+          if (a.sp_lo_out && wave == 0 && unit_qb(unit) == 0) {
+            const int bh = unit_bh(unit), b = bh / MV_HEADS, h = bh - b * MV_HEADS;
+            half_t* sp = a.sp_lo_out + (size_t)(2 * b + (ql & 1)) * MV_HIDDEN + h * MV_HEAD_DIM + 4 * hi;
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+              for (int rg = 0; rg < 4; ++rg) {
+                half4_t l;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                  const float x = o[dt][4 * rg + e] * inv;
+                  l[e] = (half_t)((x - (float)(half_t)x) * 2048.0f);
+                }
+                if (ql < 2) *(half4_t*)(sp + 32 * dt + 8 * rg) = l;
+              }
+          }
           if (x8_any_out_of_range(vmax8)) {  // rare: redo the unit's planes with the clamps, count exactly
             int n = 0;
 #pragma unroll

@@ -99,8 +99,8 @@ __device__ __forceinline__ int x8_count4(float v0, float v1, float v2, float v3)
          __builtin_popcountll(__builtin_amdgcn_ballot_w64(__builtin_fabsf(v2) > MV_X8_ACT_BOUND)) +
          __builtin_popcountll(__builtin_amdgcn_ballot_w64(__builtin_fabsf(v3) > MV_X8_ACT_BOUND));
 }
-__device__ __forceinline__ void x8_sat_add(unsigned int* counter, int n) {
-  if (counter && n && (threadIdx.x & 63) == 0) atomicAdd(counter, (unsigned int)n);
+__device__ __forceinline__ void x8_sat_add(unsigned long long* counter, int n) {  // 64-bit: one element per token and layer cannot wrap it
+  if (counter && n && (threadIdx.x & 63) == 0) atomicAdd(counter, (unsigned long long)n);
 }
 
 // Sum / max over the 64 lanes of a wave (all lanes receive the result).

@@ -137,8 +137,10 @@ struct Work {
   half_t* xlo = nullptr;                        // lo plane of the two-plane raw stream (PP_RESLN3)
   uint8_t *x8 = nullptr, *ctx8 = nullptr, *h8 = nullptr;  // MV_F16X8: [lo8 | hi8] planes of the raw stream [T][1536], the attention
                                                           // context [T][1536] and the GELU output [T][6144]
-  half_t* cls_lo = nullptr;   // MV_F16X8, cls_aside: 2^11 x the low parts of the [CLS] rows of a GEMM's A operand [Bp][3072] (cls_lo_gather_kernel)
-  float* cls_corr = nullptr;  // ... and 2^11 x their A-side correction term A_lo W_hi^T [Bp][3072] (GemmArgs::cls_corr)
+  half_t* cls_lo = nullptr;   // MV_F16X8, special rows (rows 0, 1 of every sequence: its [CLS] and [SEP] token): 2^11 x the low parts of those rows of the NEXT GEMM's A operand,
+                              // compact [2 Bp][3072] fp16, written by the producing kernel's epilogue (GemmArgs::sp_lo_out / AttnArgs::sp_lo_out / embed_ln_kernel)
+  float* cls_corr = nullptr;  // ... and 2^11 x their A-side correction term A_lo W_hi^T [2 Bp][3072] (GemmArgs::cls_corr)
+  half_t* vlo_sp = nullptr;   // 2^11 x the low parts of V of the special rows [B 12][64][2] (GemmArgs::vlo_sp -> AttnArgs::vlo_sp)
   int32_t* tile_both = nullptr;  // cls_aside: per 256-row tile of the pass, non-zero = its sequence is shorter than cls_min_len (GemmArgs::tile_both)
 };
 
@@ -172,7 +174,7 @@ struct mv_handle {
   int rr = 0;                 // workspace set of the next resident-sweep batch
   float* anchors = nullptr;
   int n_anchors = 0;
-  unsigned int* x8_sat = nullptr;  // MV_F16X8: device counter of activation elements beyond the fp8 planes' range (mv_x8_saturation)
+  unsigned long long* x8_sat = nullptr;  // MV_F16X8: device counter (64-bit: it cannot wrap within a run) of activation elements beyond the fp8 planes' range (mv_x8_saturation)
 
   // resident corpus
   int32_t *c_ids = nullptr, *c_lens = nullptr;
@@ -190,8 +192,6 @@ struct mv_handle {
   int pp_raster = 0;       // env MEMVUL_RASTER=1: the A-stationary raster where it applies (FFN-1, QKV at full-size grids)
   bool short_vlo = true;   // MV_F16X8, env MEMVUL_SHORT_VLO=0 disables: passes of padded length <= 128 carry V and P as hi + lo fp16 planes through attention
                            // (attention_v2.h VLO): the fp16 storage of V and P is what is left of the precise mode's error and short sequences average it least
-  bool stream_lo8 = false; // MV_F16X8, env MEMVUL_STREAM_LO8=1: the raw residual stream as hi fp16 + the lo8 plane of its fp8 planes (no lo fp16 plane;
-                           // gemm_pp.h X8 = 2): +1.5 % issue reports/s at 1.2x the trained-like logit error (profiles/r05_a_*) — opt-in
   bool cls_aside = true;   // MV_F16X8, the [CLS]-row form (default; env MEMVUL_CLS_ASIDE=0 = both correction terms in every row, the form of rounds 3-4): passes of
                            // padded length 256 / 512 sweep the weight-side term only in every GEMM (the Q block of the QKV projection keeps both) and add the A-side
                            // term for the [CLS] row of each sequence alone (a skinny fp16 GEMM over those B rows in front of each launch, GemmArgs::cls_corr): the
@@ -377,12 +377,6 @@ int launch_pp(mv_handle* h, int cls, GemmArgs a) {
   ProfScope ps(h, cls);
   if (a.A8) {
     if (!a.W8 || (PPEPI != PP_QK && !a.out8)) return fail(h, MV_ERR_STATE, "internal: MV_F16X8 GEMM without its fp8 planes");
-    if constexpr (PPEPI == PP_RESLN3) {
-      if (!a.out16b) {  // the lo8 stream: no lo fp16 plane, the residual's low part is out8's lo8 plane
-        hipLaunchKernelGGL((gemm_pp_kernel<PPEPI, RAW, 2>), dim3(grid), dim3(512), lds, h->w->stream, a);
-        return launch_check(h, "gemm_pp");
-      }
-    }
     hipLaunchKernelGGL((gemm_pp_kernel<PPEPI, RAW, 1>), dim3(grid), dim3(512), lds, h->w->stream, a);
   } else {
     hipLaunchKernelGGL((gemm_pp_kernel<PPEPI, RAW, 0>), dim3(grid), dim3(512), lds, h->w->stream, a);
@@ -420,10 +414,12 @@ int pool_head(mv_handle* h, const float* x, size_t row_stride, int B, float* u_o
 // padded sequence length of a pass: attention_v2 runs 64-key blocks up to 256 and 128-key chunks above
 inline int padded_len(int S_in) { return (int)round_up(S_in, S_in <= 256 ? 64 : 128); }
 
-int launch_attention(mv_handle* h, const int32_t* d_lens, int B, int Sp, bool x8) {
+int launch_attention(mv_handle* h, const int32_t* d_lens, int B, int Sp, bool x8, bool sp_out = false) {
   const bool vlo = x8 && h->short_vlo && Sp <= 128;  // the QKV projection of this pass wrote V^T's lo plane (encode_dev: the same predicate)
   AttnArgs a{h->w->q, h->w->k, h->w->vt, d_lens, h->w->ctx, Sp, B, x8 ? h->w->ctx8 : nullptr, h->x8_sat, vlo ? h->w->vt_lo : nullptr,
-             vlo ? h->w->q_lo : nullptr, vlo ? h->w->k_lo : nullptr};
+             vlo ? h->w->q_lo : nullptr, vlo ? h->w->k_lo : nullptr,
+             (x8 && !vlo) ? h->w->vlo_sp : nullptr,     // special rows: V of keys 0, 1 as hi + lo (the two-plane short passes carry every key's lo plane)
+             sp_out ? h->w->cls_lo : nullptr};
   ProfScope ps(h, KC_ATTENTION);
   if (vlo) {
     const int nkb = Sp / 64, items = B * MV_HEADS;
@@ -480,7 +476,6 @@ int encode_dev(mv_handle* h, const int32_t* d_ids, const int32_t* d_lens, int B,
   h->dbg_Sp = Sp;
   const bool big = pp_selected(h, Mpad);  // persistent GEMMs, raw two-plane stream (x16 = hi, xlo = lo), virtual LayerNorm
   const bool x8 = h->precise;             // MV_F16X8: + fp8 correction sweeps (forces the persistent path, pp_selected)
-  const bool lo8s = x8 && h->stream_lo8;  // the stream's low part is the lo8 plane of x8 (no xlo plane)
   const bool prune = !full && h->cls_prune && u_out && n_layers == c.layers && n_layers > 0;
   // The [CLS]-row form (mv_handle::cls_aside): every persistent GEMM of this pass sweeps the weight-side correction term only (x8_terms = 1) and the
   // A-side term A_lo W_hi^T is formed for the B [CLS] rows alone: their low parts (2^11 x, fp16) gathered from the operand's lo plane (raw stream) or
@@ -488,23 +483,26 @@ int encode_dev(mv_handle* h, const int32_t* d_ids, const int32_t* d_lens, int B,
   // (gemm_pp.h GemmArgs::cls_corr).  Passes of padded length 256 / 512: a 256-row tile then belongs to ONE sequence, so the form of a sequence
   // depends on its own length alone (cls_tile_flags_kernel: sequences shorter than cls_min_len keep the both-terms form, tile by tile) and a row's
   // result stays independent of the batch it travels in.
-  const bool cls_as = big && x8 && h->cls_aside && !lo8s && (Sp == 256 || Sp == 512);
+  const bool cls_as = big && x8 && h->cls_aside && (Sp == 256 || Sp == 512);
   if (cls_as) {
     const int ntile = (int)(Mpad / 256);
     hipLaunchKernelGGL(cls_tile_flags_kernel, dim3((unsigned)((ntile + 255) / 256)), dim3(256), 0, h->w->stream, d_lens, B, Sp, h->cls_min_len, ntile,
                        h->w->tile_both);
     if (int rc = launch_check(h, "cls_tile_flags")) return rc;
   }
-  auto cls_fix = [&](const half_t* lo16, const uint8_t* lo8p, const half_t* W, int N, int K) -> int {
+  // Special rows (round 6): rows 0 and 1 of every sequence hold its [CLS] and its [SEP] token (embed_ln_kernel swaps the last token into row 1) — the token the
+  // pooler reads and the two tokens trained BERT heads use as attention sinks, i.e. the rows whose roundings can reach the pooler un-averaged.  For them every
+  // GEMM whose sweep carried the weight-side term only gets the A-side term from a skinny GEMM over the 2 B compact rows the PRODUCER's epilogue left in cls_lo
+  // (no gather launch), and attention adds p[:, 0..1] V_lo[0..1].  The K and V blocks of the QKV projection take it in every pass of this compute dtype (they
+  // never sweep the A-side term for all rows by default), the other three GEMMs where the [CLS]-row form is in force.
+  const bool special = big && x8;
+  auto row_term = [&](const half_t* W, int N, int K) -> int {  // cls_corr [2 B][N] = cls_lo [2 B][K] W^T (both 2^11 x)
     ProfScope ps(h, KC_CLS_ROW_TERM);
-    const size_t n4 = (size_t)B * K / 4;
-    hipLaunchKernelGGL(cls_lo_gather_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, h->w->stream, lo16, lo8p, K, Sp, B, h->w->cls_lo);
-    if (int rc = launch_check(h, "cls_lo_gather")) return rc;
     GemmArgs t{};
-    t.M = (int)round_up(B, 64); t.Mreal = B; t.S = 64; t.A = h->w->cls_lo; t.W = W; t.N = N; t.K = K; t.outf = h->w->cls_corr;
+    t.M = (int)round_up(2 * B, 64); t.Mreal = 2 * B; t.S = 64; t.A = h->w->cls_lo; t.W = W; t.N = N; t.K = K; t.outf = h->w->cls_corr;
     t.GN = choose_gn(N / 64, 8);
     hipLaunchKernelGGL((gemm_ring_kernel<EPI_F32, 1, 1, 2, 2, 64, 4, 2>), dim3((unsigned)((t.M / 64) * (N / 64))), dim3(256), RING64_LDS, h->w->stream, t);
-    return launch_check(h, "cls_corr gemm_ring");
+    return launch_check(h, "row term gemm_ring");
   };
   const unsigned ln_grid = (unsigned)((M + 3) / 4);
   {
@@ -512,11 +510,12 @@ int encode_dev(mv_handle* h, const int32_t* d_ids, const int32_t* d_lens, int B,
     if (big)
       hipLaunchKernelGGL(embed_ln_kernel<true>, dim3(ln_grid), dim3(256), 0, h->w->stream, d_ids, pitch, S_in, Sp, (int)M, c.vocab_size,
                          h->wemb, h->pemb, h->temb, h->embg, h->embb, c.ln_eps, h->w->xres, h->w->x16, h->w->lnstats,
-                         lo8s ? (half_t*)nullptr : h->w->xlo, x8 ? h->w->x8 : (uint8_t*)nullptr, h->x8_sat);
+                         h->w->xlo, x8 ? h->w->x8 : (uint8_t*)nullptr, h->x8_sat, special ? d_lens : (const int32_t*)nullptr,
+                         special ? h->w->cls_lo : (half_t*)nullptr);
     else
       hipLaunchKernelGGL(embed_ln_kernel<false>, dim3(ln_grid), dim3(256), 0, h->w->stream, d_ids, pitch, S_in, Sp, (int)M, c.vocab_size,
                          h->wemb, h->pemb, h->temb, h->embg, h->embb, c.ln_eps, h->w->xres, h->w->x16, (float*)nullptr,
-                         (half_t*)nullptr, (uint8_t*)nullptr, (unsigned int*)nullptr);
+                         (half_t*)nullptr, (uint8_t*)nullptr, (unsigned long long*)nullptr);
     if (int rc = launch_check(h, "embed_ln")) return rc;
   }
   // big: the LayerNorm whose statistics are pending in the vstats buffers — gamma / beta the next residual GEMM applies
@@ -529,8 +528,7 @@ int encode_dev(mv_handle* h, const int32_t* d_ids, const int32_t* d_lens, int B,
   };
   auto final_ln = [&](const float* g, const float* b) -> int {  // two-plane raw stream -> normalised fp32 rows (pooler / debug taps)
     const size_t n4 = (size_t)M * MV_HIDDEN / 4;
-    hipLaunchKernelGGL(hilo_to_f32_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, h->w->stream, h->w->x16, lo8s ? (const half_t*)nullptr : h->w->xlo,
-                       lo8s ? (const uint8_t*)h->w->x8 : (const uint8_t*)nullptr, n4, h->w->xres);
+    hipLaunchKernelGGL(hilo_to_f32_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, h->w->stream, h->w->x16, h->w->xlo, n4, h->w->xres);
     if (int rc = launch_check(h, "hilo_to_f32")) return rc;
     return run_ln(h->w->xres, h->w->x16, (int)M, g, b);
   };
@@ -555,7 +553,13 @@ int encode_dev(mv_handle* h, const int32_t* d_ids, const int32_t* d_lens, int B,
       if (big) {
         g.lnstats = st_in;
         if (x8) { g.A8 = h->w->x8; g.W8 = w.wqkv_f8 + (size_t)MV_HIDDEN * 2 * MV_HIDDEN; g.x8_scale = w.sc_qkv; g.x8_terms = 3; g.x8_aside_mask = h->qkv_aside_mask; }
-        // (cls_aside: no row term here — K and V of the [CLS] token are one key among S for every query; its Q row is computed in fp32 by the tail below)
+        if (special) {  // K and V of the special rows: row term wherever a block sweeps the weight-side term only; V also as hi + lo (the [CLS] query itself is fp32: the tail below)
+          if ((h->qkv_aside_mask & 6) != 6) {
+            if (int rc = row_term(g.W, g.N, g.K)) return rc;
+            g.cls_corr = h->w->cls_corr;
+          }
+          g.vlo_sp = (h->short_vlo && Sp <= 128) ? nullptr : h->w->vlo_sp;
+        }
         if (int rc = launch_pp<PP_QK>(h, KC_GEMM_KV_LAST, g)) return rc;
       } else if (int rc = launch_small<EPI_QKV>(h, KC_GEMM_KV_LAST, g)) return rc;
       ProfScope tail(h, KC_CLS_TAIL);
@@ -564,7 +568,7 @@ int encode_dev(mv_handle* h, const int32_t* d_ids, const int32_t* d_lens, int B,
       auto tail_rc = [&]() -> int {
         hipLaunchKernelGGL(cls_gather_kernel, dim3((B + 3) / 4), dim3(256), 0, h->w->stream, h->w->xres, h->w->x16, Sp, B,
                            big ? st_in : (const float*)nullptr, pend_g, pend_b, h->w->c32, h->w->c16, big ? 1 : 0,
-                           big ? h->w->xlo : (const half_t*)nullptr, big ? 1 : 0, c.ln_eps, lo8s ? (const uint8_t*)h->w->x8 : (const uint8_t*)nullptr);
+                           big ? h->w->xlo : (const half_t*)nullptr, big ? 1 : 0, c.ln_eps);
         if (int rc = launch_check(h, "cls_gather")) return rc;
         if (x8) {
           // MV_F16X8: the B [CLS] rows in full fp32 on the fp32-input matrix cores (their operand rounding would reach the
@@ -575,7 +579,7 @@ int encode_dev(mv_handle* h, const int32_t* d_ids, const int32_t* d_lens, int B,
                              (size_t)MV_HIDDEN, B, (const float*)w.wqT32, (const float*)w.bqkv, MV_HIDDEN, h->w->cq, (const float*)nullptr);
           if (int rc = launch_check(h, "cls q")) return rc;
           hipLaunchKernelGGL(attention_cls_kernel, dim3((B * MV_HEADS + 3) / 4), dim3(256), 0, h->w->stream, h->w->cq, h->w->k, h->w->vt,
-                             d_lens, h->w->cctx, Sp, B * MV_HEADS, h->w->pooled);
+                             d_lens, h->w->cctx, Sp, B * MV_HEADS, h->w->pooled, (const half_t*)g.vlo_sp);
           if (int rc = launch_check(h, "attention_cls")) return rc;
           hipLaunchKernelGGL((dense768_kernel<4, MV_HIDDEN>), dim3(gx, MV_HIDDEN / 32), dim3(512), 0, h->w->stream, (const float*)h->w->pooled,
                              (size_t)MV_HIDDEN, B, (const float*)w.woT32, (const float*)w.bo, MV_HIDDEN, h->w->c32, (const float*)h->w->c32);
@@ -616,24 +620,29 @@ int encode_dev(mv_handle* h, const int32_t* d_ids, const int32_t* d_lens, int B,
       if (x8) { g.A8 = h->w->x8; g.W8 = w.wqkv_f8; g.x8_scale = w.sc_qkv; g.x8_terms = 3; g.x8_aside_mask = h->qkv_aside_mask; }
       g.vt_lo = (x8 && h->short_vlo && Sp <= 128) ? h->w->vt_lo : nullptr;  // short passes: Q, K, V^T as hi + lo planes (launch_attention: the same predicate)
       g.q_lo = h->w->q_lo; g.k_lo = h->w->k_lo;
-      // cls_aside: x8_terms stays 3 — a block of x8_aside_mask (Q by default) keeps its A-side term for EVERY row.  The [CLS] row's term matters in
-      // the Q block only (its K and V are one key among S for every query: model, four draws: no gain), so the row term is formed only when the Q
-      // block sweeps the weight-side term alone (MEMVUL_QKV_ASIDE without q); the launch skips it in blocks that swept both terms (gemm_pp.h)
-      if (cls_as && !(h->qkv_aside_mask & 1)) {
-        if (int rc = cls_fix(h->w->xlo, nullptr, g.W, g.N, g.K)) return rc;
-        g.cls_corr = h->w->cls_corr;
+      // x8_terms stays 3 — a block of x8_aside_mask (Q by default) keeps its A-side term for EVERY row; the other blocks take it for the special rows from
+      // the row term (the launch skips it in blocks that swept both terms: gemm_pp.h).  With diffuse attention K and V of one token are one key among S for
+      // every query and the term buys nothing (round 5: model, four draws); with an attention sink on that token they reach every row un-averaged.
+      if (special) {
+        if (h->qkv_aside_mask != 7) {
+          if (int rc = row_term(g.W, g.N, g.K)) return rc;
+          g.cls_corr = h->w->cls_corr;
+        }
+        g.vlo_sp = g.vt_lo ? nullptr : h->w->vlo_sp;
       }
       if (int rc = launch_pp<PP_QK>(h, KC_GEMM_QKV, g)) return rc;
-      // K3: attention
-      if (int rc = launch_attention(h, d_lens, B, Sp, x8)) return rc;
+      g.cls_corr = nullptr; g.vlo_sp = nullptr;
+      // K3: attention (cls_as: + the context's special rows' low parts for the output projection's row term)
+      if (int rc = launch_attention(h, d_lens, B, Sp, x8, cls_as)) return rc;
       // K4: attention output projection + bias + LayerNorm(residual), in place on the raw stream; + vstats of the new rows
       g.A = h->w->ctx; g.W = w.wo; g.bias = w.bo; g.N = MV_HIDDEN; g.K = MV_HIDDEN;
-      g.lnstats = st_in; g.lng = pend_g; g.lnb = pend_b; g.lnpart = st_mid; g.out16 = h->w->x16; g.out16b = lo8s ? (half_t*)nullptr : h->w->xlo;
+      g.lnstats = st_in; g.lng = pend_g; g.lnb = pend_b; g.lnpart = st_mid; g.out16 = h->w->x16; g.out16b = h->w->xlo;
       if (x8) { g.A8 = h->w->ctx8; g.W8 = w.wo8; g.x8_scale = w.sc_o; g.out8 = h->w->x8; g.x8_terms = 2; }
       if (cls_as) {
-        if (int rc = cls_fix(nullptr, h->w->ctx8, g.W, g.N, g.K)) return rc;
+        if (int rc = row_term(g.W, g.N, g.K)) return rc;
         g.cls_corr = h->w->cls_corr; g.x8_terms = 1;  // (cls_corr stays set for the rest of the layer: every GEMM's term goes through the same buffer)
-        g.out8_hi_only = 1;  // the stream planes this launch writes are FFN-1's A8: weight-side term only (its [CLS] rows' low parts come from xlo)
+        g.out8_hi_only = 1;  // the stream planes this launch writes are FFN-1's A8: weight-side term only
+        g.sp_lo_out = h->w->cls_lo;  // the new stream rows' special low parts: FFN-1's row term
       }
       if (int rc = launch_pp<PP_RESLN3>(h, KC_GEMM_OUT, g)) return rc;
       pend_g = w.ln1g; pend_b = w.ln1b;
@@ -642,20 +651,23 @@ int encode_dev(mv_handle* h, const int32_t* d_ids, const int32_t* d_lens, int B,
       g.out16b = nullptr; g.lnpart = nullptr;
       if (x8) { g.A8 = h->w->x8; g.W8 = w.w1_f8; g.x8_scale = w.sc_1; g.out8 = h->w->h8; g.x8_terms = 2; }
       if (cls_as) {
-        if (int rc = cls_fix(h->w->xlo, nullptr, g.W, g.N, g.K)) return rc;
+        if (int rc = row_term(g.W, g.N, g.K)) return rc;
         g.x8_terms = 1;
-        g.out8_hi_only = 1;  // h8 is FFN-2's A8: hi8 alone, + the lo8 rows of the blocks that hold a [CLS] row (cls_fix reads them)
+        g.out8_hi_only = 1;  // h8 is FFN-2's A8: hi8 alone
       }
       if (int rc = launch_pp<PP_GELU>(h, KC_GEMM_FFN1, g)) return rc;
       // K6: FFN-2 + bias + LayerNorm(residual)
       g.A = h->w->h16; g.W = w.w2; g.bias = w.b2; g.N = MV_HIDDEN; g.K = MV_INTER;
-      g.lnstats = st_mid; g.lng = pend_g; g.lnb = pend_b; g.lnpart = st_in; g.out16 = h->w->x16; g.out16b = lo8s ? (half_t*)nullptr : h->w->xlo;
-      if (x8) { g.A8 = h->w->h8; g.W8 = w.w28; g.x8_scale = w.sc_2; g.out8 = h->w->x8; g.x8_terms = 2; }  // (the lo8 plane is the stream's own lo since round 5: always written)
+      g.lnstats = st_mid; g.lng = pend_g; g.lnb = pend_b; g.lnpart = st_in; g.out16 = h->w->x16; g.out16b = h->w->xlo;
+      if (x8) { g.A8 = h->w->h8; g.W8 = w.w28; g.x8_scale = w.sc_2; g.out8 = h->w->x8; g.x8_terms = 2; }
       if (cls_as) {
-        if (int rc = cls_fix(nullptr, h->w->h8, g.W, g.N, g.K)) return rc;
+        if (int rc = row_term(g.W, g.N, g.K)) return rc;
         g.x8_terms = 1;
         g.out8_hi_only = h->qkv_aside_mask == 0;  // the next QKV projection reads the stream's lo8 plane only in a block that sweeps its A-side term
+      } else {
+        g.cls_corr = nullptr;
       }
+      if (special) g.sp_lo_out = h->w->cls_lo;  // the next layer's QKV row term reads the new stream rows' special low parts in every pass of this compute dtype
       if (int rc = launch_pp<PP_RESLN3>(h, KC_GEMM_FFN2, g)) return rc;
       pend_g = w.ln2g; pend_b = w.ln2b;
       if (last) { if (int rc = final_ln(w.ln2g, w.ln2b)) return rc; }  // the pooler reads a normalised stream
@@ -901,7 +913,31 @@ int mv_create(int device, const mv_config* cfg, mv_handle** out) try {
   h->device = device;
   h->cfg = *cfg;
   h->P = cfg->proj_dim;
-  if (const char* ev = getenv("MEMVUL_STREAMS")) h->n_streams = h->n_alloc = (atoi(ev) == 1 ? 1 : 2);
+  // ---- environment switches (include/memvul_hip.h lists them).  Every one is parsed strictly: a value the library does not understand fails
+  // mv_create with a message — a typo must never silently select other numerics (or another stream count) than the one asked for.
+  auto env_int = [&](const char* name, int lo, int hi, int* out) -> bool {  // false = present and malformed (g_create_error set)
+    const char* e = getenv(name);
+    if (!e) return true;
+    char* end = nullptr;
+    const long v = strtol(e, &end, 10);
+    if (end == e || *end != '\0' || v < lo || v > hi) {
+      g_create_error = std::string(name) + "=\"" + e + "\": expected an integer in " + std::to_string(lo) + " .. " + std::to_string(hi);
+      return false;
+    }
+    *out = (int)v;
+    return true;
+  };
+  auto env_flag = [&](const char* name, bool* out) -> bool {
+    int v = *out ? 1 : 0;
+    if (!env_int(name, 0, 1, &v)) return false;
+    *out = v != 0;
+    return true;
+  };
+  {
+    int ns = h->n_streams;
+    if (!env_int("MEMVUL_STREAMS", 1, 2, &ns)) return MV_ERR_INVALID;  // (the guard destroys the handle)
+    h->n_streams = h->n_alloc = ns;
+  }
   for (int wi = 0; wi < h->n_alloc; ++wi) {
     e = hipStreamCreateWithFlags(&h->work[wi].stream, hipStreamNonBlocking);
     if (e != hipSuccess) {
@@ -920,7 +956,6 @@ int mv_create(int device, const mv_config* cfg, mv_handle** out) try {
   hipFuncSetAttribute((const void*)gemm_pp_kernel<PP_QK, 1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS_BYTES_RAW);
   hipFuncSetAttribute((const void*)gemm_pp_kernel<PP_GELU, 1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS_BYTES_RAW);
   hipFuncSetAttribute((const void*)gemm_pp_kernel<PP_RESLN3, 0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS_BYTES);
-  hipFuncSetAttribute((const void*)gemm_pp_kernel<PP_RESLN3, 0, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS_BYTES);
 #define MV_ATT_ATTR(NKB, NCH)                                                                                                     \
   hipFuncSetAttribute((const void*)attention_v2_kernel<NKB, NCH, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT2_LDS_BYTES(NKB)); \
   hipFuncSetAttribute((const void*)attention_v2_kernel<NKB, NCH, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT2_LDS_BYTES(NKB))
@@ -929,46 +964,43 @@ int mv_create(int device, const mv_config* cfg, mv_handle** out) try {
   hipFuncSetAttribute((const void*)attention_v2_kernel<1, 1, 1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT2_LDS_BYTES_VLO(1));
   hipFuncSetAttribute((const void*)attention_v2_kernel<2, 1, 1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT2_LDS_BYTES_VLO(2));
   (void)hipGetLastError();
-  if (const char* e = getenv("MEMVUL_GEMM_TILE")) h->gemm_tile = atoi(e);
-  if (const char* e = getenv("MEMVUL_CLS_PRUNE")) h->cls_prune = atoi(e) != 0;
+  if (!env_flag("MEMVUL_CLS_PRUNE", &h->cls_prune)) return MV_ERR_INVALID;
   if (const char* e = getenv("MEMVUL_QKV_ASIDE")) {
     h->qkv_aside_mask = 0;
     if (strcmp(e, "none")) {
       for (const char* c = e; *c; ++c) {
         const int bit = (*c == 'q' || *c == 'Q') ? 1 : (*c == 'k' || *c == 'K') ? 2 : (*c == 'v' || *c == 'V') ? 4 : 0;
-        if (!bit) {  // a typo must not silently change the numerics
+        if (!bit) {
           g_create_error = std::string("MEMVUL_QKV_ASIDE=\"") + e + "\": expected a subset of \"qkv\", \"\" or \"none\"";
-          return MV_ERR_INVALID;  // the guard destroys the handle
+          return MV_ERR_INVALID;
         }
         h->qkv_aside_mask |= bit;
       }
     }
   }
-  if (const char* e = getenv("MEMVUL_STREAM_LO8")) h->stream_lo8 = atoi(e) == 1;
-  if (const char* e = getenv("MEMVUL_SHORT_VLO")) h->short_vlo = atoi(e) != 0;
-  if (const char* e = getenv("MEMVUL_CLS_ASIDE")) {  // (like MEMVUL_QKV_ASIDE: a typo must not silently change the numerics)
-    if (strcmp(e, "0") && strcmp(e, "1")) {
-      g_create_error = std::string("MEMVUL_CLS_ASIDE=\"") + e + "\": expected 0 or 1";
-      return MV_ERR_INVALID;  // the guard destroys the handle
-    }
-    h->cls_aside = e[0] == '1';
-  }
-  if (const char* e = getenv("MEMVUL_CLS_ASIDE_MIN_LEN")) {
-    const int v = atoi(e);
-    if (v < 1 || v > 512) {
-      g_create_error = std::string("MEMVUL_CLS_ASIDE_MIN_LEN=\"") + e + "\": expected 1 .. 512";
-      return MV_ERR_INVALID;
-    }
-    h->cls_min_len = v;
-  }
-  if (const char* e = getenv("MEMVUL_GN_MAX")) { const int v = atoi(e); if (v >= 1 && v <= 12) h->pp_gn_max = v; }
-  if (const char* e = getenv("MEMVUL_RASTER")) h->pp_raster = atoi(e) == 1 ? 1 : 0;
+  if (!env_flag("MEMVUL_CLS_ASIDE", &h->cls_aside)) return MV_ERR_INVALID;
+  if (!env_int("MEMVUL_CLS_ASIDE_MIN_LEN", 1, 512, &h->cls_min_len)) return MV_ERR_INVALID;
   {
     int ncu = 0;
     if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && ncu > 0) h->num_cu = ncu;
-    // MEMVUL_NUM_CU: size the persistent grids for a share of the chip (two engines on two streams, scripts/dual_stream_probe.py)
-    if (const char* e = getenv("MEMVUL_NUM_CU")) { const int v = atoi(e); if (v > 0 && v <= h->num_cu) h->num_cu = v; }
   }
+#ifdef MEMVUL_DEV_SWITCHES
+  // Development A/B knobs: compiled only into libmemvul_hip_dev.so (memvul_amd/build.py dev=True; the GPU tests that force a kernel path at test
+  // sizes and the A/B scripts load that build) — the product library does not read them.
+  //   MEMVUL_GEMM_TILE  0 by pass size / 128 the small-pass kernels / 512 the persistent kernels forced
+  //   MEMVUL_SHORT_VLO  0: passes of padded length <= 128 carry Q, K, V, P as ONE fp16 plane through attention (the A/B of attention_v2.h VLO)
+  //   MEMVUL_NUM_CU     size the persistent grids for a share of the chip;  MEMVUL_RASTER 1: the A-stationary raster;  MEMVUL_GN_MAX 1 .. 12: raster group width cap
+  {
+    int gt = h->gemm_tile;
+    if (!env_int("MEMVUL_GEMM_TILE", 0, 512, &gt)) return MV_ERR_INVALID;
+    if (gt != 0 && gt != 128 && gt != 512) { g_create_error = "MEMVUL_GEMM_TILE: expected 0, 128 or 512"; return MV_ERR_INVALID; }
+    h->gemm_tile = gt;
+    if (!env_flag("MEMVUL_SHORT_VLO", &h->short_vlo)) return MV_ERR_INVALID;
+    if (!env_int("MEMVUL_GN_MAX", 1, 12, &h->pp_gn_max)) return MV_ERR_INVALID;
+    if (!env_int("MEMVUL_RASTER", 0, 1, &h->pp_raster)) return MV_ERR_INVALID;
+    if (!env_int("MEMVUL_NUM_CU", 1, h->num_cu, &h->num_cu)) return MV_ERR_INVALID;
+  }
+#endif
 
   h->cap_tokens = round_up(cfg->max_tokens, 256) + 256;
   const int64_t T = h->cap_tokens;
@@ -985,9 +1017,6 @@ int mv_create(int device, const mv_config* cfg, mv_handle** out) try {
     A(dev_alloc(h, &h->w->q, T * MV_HIDDEN));
     A(dev_alloc(h, &h->w->k, T * MV_HIDDEN));
     A(dev_alloc(h, &h->w->vt, T * MV_HIDDEN));
-    A(dev_alloc(h, &h->w->vt_lo, T * MV_HIDDEN));
-    A(dev_alloc(h, &h->w->q_lo, T * MV_HIDDEN));
-    A(dev_alloc(h, &h->w->k_lo, T * MV_HIDDEN));
     A(dev_alloc(h, &h->w->ctx, T * MV_HIDDEN));
     A(dev_alloc(h, &h->w->h16, T * MV_INTER));
     A(dev_alloc(h, &h->w->lnstats, T * 6));
@@ -1019,7 +1048,7 @@ int mv_create(int device, const mv_config* cfg, mv_handle** out) try {
   }
   h->w = &h->work[0];
   A(dev_alloc(h, &h->anchors, (int64_t)cfg->max_anchors * h->P));
-  A(dev_alloc(h, &h->x8_sat, 4));  // (zeroed by dev_alloc)
+  A(dev_alloc(h, &h->x8_sat, 1));  // (zeroed by dev_alloc)
   if (rc == MV_OK && hipStreamSynchronize(h->w->stream) != hipSuccess) rc = MV_ERR_HIP;
   if (rc != MV_OK) {
     g_create_error = h->err.empty() ? "workspace allocation failed" : h->err;
@@ -1222,9 +1251,15 @@ int mv_finalize_weights(mv_handle* h, int compute_dtype) try {
       if (rc == MV_OK) rc = dev_alloc(h, &h->work[wi].ctx8, h->cap_tokens * 2 * MV_HIDDEN);
       if (rc == MV_OK) rc = dev_alloc(h, &h->work[wi].h8, h->cap_tokens * 2 * MV_INTER);
       if (rc == MV_OK) rc = dev_alloc(h, &h->work[wi].ch32, (int64_t)round_up(h->cfg.max_batch, 256) * MV_INTER);
-      if (rc == MV_OK) rc = dev_alloc(h, &h->work[wi].cls_lo, (int64_t)round_up(h->cfg.max_batch, 256) * MV_INTER);
-      if (rc == MV_OK) rc = dev_alloc(h, &h->work[wi].cls_corr, (int64_t)round_up(h->cfg.max_batch, 256) * MV_INTER);
+      if (rc == MV_OK) rc = dev_alloc(h, &h->work[wi].cls_lo, 2 * (int64_t)round_up(h->cfg.max_batch, 256) * MV_INTER);
+      if (rc == MV_OK) rc = dev_alloc(h, &h->work[wi].cls_corr, 2 * (int64_t)round_up(h->cfg.max_batch, 256) * MV_INTER);
+      if (rc == MV_OK) rc = dev_alloc(h, &h->work[wi].vlo_sp, (int64_t)h->cfg.max_batch * MV_HEADS * MV_HEAD_DIM * 2);
       if (rc == MV_OK) rc = dev_alloc(h, &h->work[wi].tile_both, h->cap_tokens / 256 + 1);
+      if (h->short_vlo) {  // second fp16 planes of V^T, Q, K: read only by passes of padded length <= 128 in this compute dtype (attention_v2.h VLO)
+        if (rc == MV_OK) rc = dev_alloc(h, &h->work[wi].vt_lo, h->cap_tokens * MV_HIDDEN);
+        if (rc == MV_OK) rc = dev_alloc(h, &h->work[wi].q_lo, h->cap_tokens * MV_HIDDEN);
+        if (rc == MV_OK) rc = dev_alloc(h, &h->work[wi].k_lo, h->cap_tokens * MV_HIDDEN);
+      }
       if (rc == MV_OK && hipStreamSynchronize(h->w->stream) != hipSuccess) rc = MV_ERR_HIP;
       h->w = keep;
       if (rc != MV_OK) return rc;
@@ -1589,10 +1624,10 @@ int mv_x8_saturation(mv_handle* h, int64_t* clamped, int reset) try {
   if (!h || !clamped) return fail(h, MV_ERR_INVALID, "mv_x8_saturation: bad argument");
   HIPCHK(h, hipSetDevice(h->device));
   if (int rc = sync_all(h)) return rc;
-  unsigned int v = 0;
+  unsigned long long v = 0;
   HIPCHK(h, hipMemcpy(&v, h->x8_sat, sizeof(v), hipMemcpyDeviceToHost));
   if (reset) HIPCHK(h, hipMemset(h->x8_sat, 0, sizeof(v)));
-  *clamped = (int64_t)v;
+  *clamped = v > (unsigned long long)INT64_MAX ? INT64_MAX : (int64_t)v;
   return MV_OK;
 } catch (...) { return on_exception(h); }
 

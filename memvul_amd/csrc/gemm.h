@@ -60,16 +60,21 @@ struct GemmArgs {
   int x8_aside_mask;     // x8_terms == 3: bit 0 / 1 / 2 set = the Q / K / V block sweeps both terms, clear = the weight-side term only
   half_t* vt_lo;         // PP_QK X8, short passes (padded length <= 128): second fp16 plane of V^T, fp16(V - fp16(V)), same layout as vt (attention_v2.h VLO);
   half_t *q_lo, *k_lo;   // the same for Q and K (set together with vt_lo)
-  unsigned int* x8_sat;  // MV_F16X8 producers: device counter of activation elements the fp8 planes' +-112 clamp changed (common.h x8_planes4)
+  unsigned long long* x8_sat;  // MV_F16X8 producers: device counter of activation elements the fp8 planes' +-112 clamp changed (common.h x8_planes4)
   int raster_mode;       // gemm_pp: 0 = column group > tile_m > tile_n; 1 = "A-stationary": consecutive persistent iterations of a workgroup
                          // keep its tile_m and walk the column groups (the XCD's A panels stay in its L2 across the whole N sweep)
   int out8_hi_only;      // gemm_pp X8 producers (PP_GELU / PP_RESLN3), cls_aside: the consumer of out8 sweeps the weight-side term only — write the hi8
-                         // plane alone, except in 32-row blocks that hold a [CLS] row (their lo8 row feeds cls_lo_gather_kernel)
+                         // plane alone (the special rows' low parts travel through sp_lo_out)
   const int* tile_both;  // gemm_pp X8, cls_aside: [M / 256] flags, non-zero = a sequence of that row tile is shorter than MEMVUL_CLS_ASIDE_MIN_LEN: the tile runs
                          // the default form (both terms where x8_terms = 1, no cls_corr, full planes); cls_tile_flags_kernel writes them once per pass
-  const float* cls_corr; // gemm_pp X8, "[CLS]-row A-side term" (engine.hip cls_aside): [ceil(M / S)][N] fp32 = 2^11 x the A-side first-order term
-                         // A_lo W_hi^T of the [CLS] row (row b S) of every sequence, computed by a skinny fp16 GEMM in front of this launch
-                         // and added to that row's accumulators before the epilogue; the main sweep then carries the weight-side term only
+  const float* cls_corr; // gemm_pp X8, the row term of the SPECIAL ROWS (round 6; engine.hip): [2 ceil(M / S)][N] fp32 = 2^11 x the A-side first-order term
+                         // A_lo W_hi^T of rows b S ([CLS]) and b S + 1 ([SEP]: the embedding kernel computes the last token there) of every sequence, from a
+                         // skinny fp16 GEMM in front of this launch; added to those rows' accumulators before the epilogue in every tile whose sweep
+                         // carried the weight-side term only
+  half_t* sp_lo_out;     // gemm_pp X8 producers (PP_GELU / PP_RESLN3): 2^11 x the low parts (v - fp16(v)) of the special rows of THIS launch's output, compact
+                         // [2 b + row][N] fp16 — the A operand of the next GEMM's row term (no gather launch, no lo8 rows kept for it)
+  half_t* vlo_sp;        // PP_QK X8: 2^11 x the low parts of V of the special rows, [b 12 + head][64 dims][2 rows] fp16: attention adds p[:, 0..1] V_lo[0..1]
+                         // (attention_v2.h): with attention sinks V of the sink token reaches every row's context un-averaged
 };
 
 // logical tile index -> (tile_m, tile_n) under the grouped raster

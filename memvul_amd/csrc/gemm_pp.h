@@ -61,7 +61,6 @@
 // GEMM over those B rows in front of the launch) and is added to those rows' accumulators at the start of the epilogue, and the producers write the hi8
 // plane alone (GemmArgs::out8_hi_only; a 32-row block that holds a [CLS] row keeps its lo8 row).  Row tiles of sequences too short for it (GemmArgs::tile_both)
 // run the both-terms form bit for bit.  +14 % issue reports/s at the both-terms form's trained-like logit error (profiles/r05_j*, r05_k*).
-// X8 = 2 (PP_RESLN3, MEMVUL_STREAM_LO8=1): the same, with the raw stream's low part taken from / left in the lo8 plane (no lo fp16 plane).
 // PP_QK X8 with GemmArgs::vt_lo set (passes of padded length <= 128): second fp16 planes of Q, K and V^T for the two-plane attention (attention_v2.h VLO).
 #pragma once
 #include "common.h"
@@ -189,27 +188,6 @@ __device__ __forceinline__ void scr_f16_rev2(uint32_t wc, const u32x4& a0, const
 #endif
 }
 
-// MV_F16X8 form of the same: the residual block is the hi fp16 plane (a0, a1: rows lane >> 2 and + 16, 16-B chunk lane & 3) and the lo8
-// plane of the stream's fp8 planes (l0, l1: the same rows, the 8 bytes of columns 8 (lane & 3) .. + 7).  The lo8 image is [32 rows][32 B]
-// at the base of the wave's scratch (a lane writes its 8 bytes at lane * 8 [+ 512]: linear), written after the hi units have been read
-// (LDS executes a wave's instructions in order); unit (tbl, cbl) of the lane = the 4 bytes of token 16 tbl + m16, columns
-// 16 cbl + 4 q4 .. + 3 at rl + 512 tbl + 16 cbl.
-__device__ __forceinline__ void scr_f16_lo8_rev(uint32_t wc, const u32x4& a0, const u32x4& a1, const u32x2& l0, const u32x2& l1, uint32_t r0,
-                                                uint32_t r1, uint32_t r2, uint32_t r3, uint32_t wl, uint32_t rl, u32x2 (&oa)[4], uint32_t (&ol)[4]) {
-#if defined(__HIP_DEVICE_COMPILE__)
-  asm volatile(
-      "ds_write_b128 %8, %9\n\tds_write_b128 %8, %10 offset:1024\n\t"
-      "ds_read_b64 %0, %13\n\tds_read_b64 %1, %14\n\tds_read_b64 %2, %15\n\tds_read_b64 %3, %16\n\t"
-      "ds_write_b64 %17, %11\n\tds_write_b64 %17, %12 offset:512\n\t"
-      "ds_read_b32 %4, %18\n\tds_read_b32 %5, %18 offset:16\n\tds_read_b32 %6, %18 offset:512\n\tds_read_b32 %7, %18 offset:528\n\t"
-      "s_waitcnt lgkmcnt(0)"
-      : "=&v"(oa[0]), "=&v"(oa[1]), "=&v"(oa[2]), "=&v"(oa[3]), "=&v"(ol[0]), "=&v"(ol[1]), "=&v"(ol[2]), "=&v"(ol[3])
-      : "v"(wc), "v"(a0), "v"(a1), "v"(l0), "v"(l1), "v"(r0), "v"(r1), "v"(r2), "v"(r3), "v"(wl), "v"(rl)
-      : "memory");
-  __builtin_amdgcn_sched_barrier(0);
-#endif
-}
-
 // PP_RESLN3 accumulator init: one float4 of each of the bias, gamma and beta images (gamma at +3072 B, beta at +6144 B).
 __device__ __forceinline__ void lds_read_bgb1(uint32_t addr, float4& bi, float4& ga, float4& be) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -255,9 +233,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmArgs a) {
   static_assert(EPI == PP_QK || EPI == PP_GELU || EPI == PP_RESLN3, "kernel kinds of the encoder layer");
   static_assert(RAW == (EPI != PP_RESLN3), "PP_QK / PP_GELU consume the raw stream (virtual LayerNorm), PP_RESLN3 produces it");
   constexpr bool IS_RES = (EPI == PP_RESLN3);
-  // X8 == 2 (PP_RESLN3 only; MEMVUL_STREAM_LO8=1): the raw stream is hi fp16 + the lo8 plane of its fp8 planes instead of hi + lo fp16
-  static_assert(X8 < 2 || IS_RES, "X8 = 2 selects the lo8 residual stream of the residual GEMMs");
-  constexpr bool LO8S = (X8 == 2);
+  static_assert(X8 == 0 || X8 == 1, "X8 = 1: MV_F16X8 (the fp8 correction sweep)");
   constexpr int WAITN = 2 * PP_F;
   constexpr int LDS_SCR = RAW ? PP_LDS_SCR_RAW : PP_LDS_SCR;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -428,12 +404,6 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmArgs a) {
   // the two fp16 planes of the 32 x 32 block i (token rows) x j (columns) of the residual tile at (mw0, nw0) by full-line loads
   // (16 rows x 64 B per instruction), parked in the four accumulators of that block: acc[2 i + pl][2 j + x] = plane pl (hi, lo),
   // rows crow + 16 x — the accumulator init transposes them into the C/D layout
-  // LO8S (X8 = 2; round 5, opt-in MEMVUL_STREAM_LO8=1): the stream is hi fp16 + the lo8 plane of its fp8 planes (out8: rows
-  // [lo8 (768) | hi8 (768)]) — the SAME bytes the next consumer's correction sweep reads as A_lo8, so the stream has no lo fp16 plane of
-  // its own: r ~= hi + lo8 2^-(11 + shift), 2^-15 of the element instead of 2^-22.  Measured (profiles/r05_a_*): output projection
-  // 231 -> 219 us, FFN-2 563 -> 549 us, embedding 97 -> 77 us (+1.5 % issue reports/s) for trained-like logit errors 2.4 .. 6.3e-4 over 24
-  // draws against 2.3 .. 4.8e-4 (median 3.5 against 3.0e-4): not the default.  The lo8 lines (16 rows x 32 B per instruction) park in
-  // registers 0, 1 of the lo slot.
   auto park_residual = [&](int i, int mw0, int nw0) {
     const int crow = lane >> 2, cchunk = lane & 3;
 #pragma unroll
@@ -443,13 +413,6 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmArgs a) {
 #pragma unroll
         for (int x = 0; x < 2; ++x) {
           const size_t row = (size_t)(mw0 + i * 32 + x * 16 + crow);
-          if constexpr (LO8S) {
-            if (pl) {
-              const float2 t = *(const float2*)(a.out8 + row * (2 * MV_HIDDEN) + nw0 + j * 32 + 8 * cchunk);
-              acc[2 * i + 1][2 * j + x][0] = t.x; acc[2 * i + 1][2 * j + x][1] = t.y;
-              continue;
-            }
-          }
           const half_t* src = (pl ? a.out16b : a.out16) + row * MV_HIDDEN + nw0 + j * 32 + 8 * cchunk;
           const float4 t = *(const float4*)src;
           acc[2 * i + pl][2 * j + x][0] = t.x; acc[2 * i + pl][2 * j + x][1] = t.y;
@@ -592,7 +555,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmArgs a) {
     const int mw = (tile_m << 8) + wr * 128;  // first token row of this wave
     const int nw = (tile_n << 8) + wc * 64;   // first output column of this wave
     bool tile_short = false;                  // cls_aside: this row tile's sequence keeps the default form (read once per tile)
-    if constexpr (X8 == 1) tile_short = short_tile(tile_m);
+    if constexpr (X8) tile_short = short_tile(tile_m);
     const bool tile_both_terms = X8 && (a.x8_terms == 1 ? tile_short : both_terms(tile_m, tile_n));
 
     // ---- accumulator init: zero (RAW) or bias + LayerNorm(residual).  The images are read with inline-asm ds_reads: hipcc would put
@@ -635,38 +598,19 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmArgs a) {
 #pragma unroll
               for (int e = 0; e < 4; ++e) p[qq][e] = f2u(acc[2 * i + (qq >> 1)][2 * j + (qq & 1)][e]);
             u32x2 oh[4], ol[4];  // unit k = 2 tbl + cbl
-            uint32_t ol8[4];     // MV_F16X8: the unit's four lo8 bytes
-            if constexpr (LO8S) {
-              const u32x2 l0 = {p[2][0], p[2][1]}, l1 = {p[3][0], p[3][1]};
-              scr_f16_lo8_rev(scr_c, p[0], p[1], l0, l1, u00, u01, u00 + 1024u, u01 + 1024u, scr + (uint32_t)lane * 8u,
-                              scr + (uint32_t)m16 * 32u + (uint32_t)q4 * 4u, oh, ol8);
-            } else {
-              scr_f16_rev2(scr_c, p[0], p[1], p[2], p[3], u00, u01, u00 + 1024u, u01 + 1024u, oh, ol);
-            }
+            scr_f16_rev2(scr_c, p[0], p[1], p[2], p[3], u00, u01, u00 + 1024u, u01 + 1024u, oh, ol);
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
               const int tbl = k >> 1, cbl = k & 1;
               float4 bi, ga, be;
               lds_read_bgb1(baddr + (2 * j + cbl) * 64, bi, ga, be);
-              float2_t lf01, lf23;  // MV_F16X8: e4m3 -> fp32 of the four lo8 bytes (the plane's 2^(11 + shift) pre-scale is undone in the add)
-              if constexpr (LO8S) {
-                lf01 = __builtin_amdgcn_cvt_scalef32_pk_f32_fp8(ol8[k], 1.0f, false);
-                lf23 = __builtin_amdgcn_cvt_scalef32_pk_f32_fp8(ol8[k], 1.0f, true);
-              }
 #pragma unroll
               for (int e = 0; e < 4; ++e) {
                 const uint32_t wh = oh[k][e >> 1];  // scalar copies before the bit casts (see f2u)
                 const half2_t h2 = __builtin_bit_cast(half2_t, wh);
-                float r;
-                if constexpr (LO8S) {
-                  constexpr float SLO = 1.0f / (float)(2048 << MV_X8_ACT_SHIFT);
-                  const float lo = (e == 0) ? lf01.x : (e == 1) ? lf01.y : (e == 2) ? lf23.x : lf23.y;
-                  r = (float)h2[e & 1] + lo * SLO;  // (the product is exact: a power-of-two scale)
-                } else {
-                  const uint32_t wl = ol[k][e >> 1];
-                  const half2_t l2 = __builtin_bit_cast(half2_t, wl);
-                  r = (float)h2[e & 1] + (float)l2[e & 1];
-                }
+                const uint32_t wl = ol[k][e >> 1];
+                const half2_t l2 = __builtin_bit_cast(half2_t, wl);
+                const float r = (float)h2[e & 1] + (float)l2[e & 1];
                 const float t = (r - lnst[2 * i + tbl].x) * lnst[2 * i + tbl].y;
                 acc[2 * i + tbl][2 * j + cbl][e] = __builtin_fmaf(t, ((const float*)&ga)[e], ((const float*)&be)[e]) + ((const float*)&bi)[e];
               }
@@ -727,24 +671,25 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmArgs a) {
       const uint32_t sf = (uint32_t)((m16 >> 2) & 3);
       const uint32_t scr_c = scr + (lane >> 2) * 64 + ((((uint32_t)lane & 3) ^ (((uint32_t)lane >> 4) & 3)) << 4);
       const int crow = lane >> 2, cchunk = lane & 3;  // coalesced layout: row (+16 for the second read), 16-B chunk
-      int cls_b[2] = {-1, -1};  // X8 = 1, cls_aside: the sequence whose [CLS] row is this wave's row mw + 64 j, or -1 (computed once per tile)
-      if constexpr (X8 == 1) {
-        // [CLS]-row A-side term (GemmArgs::cls_corr; engine.hip cls_aside): the sweep above carried the weight-side correction term only; the
-        // A-side term A_lo W_hi^T is added here for the ONE row per sequence whose rounding reaches the pooler un-averaged — the [CLS] row b S —
-        // from a skinny fp16 GEMM over those rows (2^11 x the term, so that its operands stay normal fp16 numbers).  S % 64 == 0 and
-        // mw % 128 == 0: of this wave's 128 rows only mw and mw + 64 can be such a row = token blocks 0 and 4, lanes m16 == 0.
-        if (a.cls_corr || a.out8_hi_only) {
+      int cls_b[2] = {-1, -1};  // X8: the sequence whose rows 0, 1 are this wave's rows mw + 64 j, + 1, or -1 (computed once per tile)
+      if constexpr (X8) {
+        // Row term of the special rows (GemmArgs::cls_corr; engine.hip): where the sweep above carried the weight-side correction term only, the A-side
+        // term A_lo W_hi^T is added here for the TWO rows per sequence whose rounding can reach the pooler un-averaged — row b S, the [CLS] token, and
+        // row b S + 1, where the embedding kernel computes the [SEP] token (the attention sinks of trained BERT heads) — from a skinny fp16 GEMM over
+        // those rows (2^11 x the term, so that its operands stay normal fp16 numbers).  S % 64 == 0 and mw % 128 == 0: of this wave's 128 rows only
+        // mw (+ 1) and mw + 64 (+ 1) can be such rows = token blocks 0 and 4, lanes m16 < 2.
+        if (a.cls_corr || a.sp_lo_out || a.vlo_sp) {
 #pragma unroll
           for (int j = 0; j < 2; ++j) {
             const int row = mw + 64 * j, b = row / a.S;  // wave-uniform
             if (row < a.Mreal && b * a.S == row) cls_b[j] = b;
           }
         }
-        if (a.cls_corr && !tile_both_terms && !tile_short) {  // (a tile whose sweep carried both terms has it already)
+        if (a.cls_corr && !tile_both_terms) {  // (a tile whose sweep carried both terms has it already)
 #pragma unroll
           for (int j = 0; j < 2; ++j) {
-            if (cls_b[j] >= 0 && m16 == 0) {
-              const float* cp = a.cls_corr + (size_t)cls_b[j] * a.N + nw + 4 * q4;
+            if (cls_b[j] >= 0 && m16 < 2) {
+              const float* cp = a.cls_corr + (size_t)(2 * cls_b[j] + m16) * a.N + nw + 4 * q4;
               floatx4 c[4];  // all four loads in flight before the first use: ONE exposed memory latency per tile that holds such a row
 #pragma unroll
               for (int cb = 0; cb < 4; ++cb) c[cb] = *(const floatx4*)(cp + 16 * cb);
@@ -843,11 +788,11 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmArgs a) {
           if (vtile) {  // image rows = head dims, image columns = tokens (scr_f16x2_t)
             obase = a.vt + ((size_t)head * MV_HEAD_DIM + crow) * a.S + 8 * cchunk;
             rstride = a.S; istride = 0; jstride = (size_t)32 * a.S;
-            lo_delta = a.vt_lo - a.vt;
+            if (a.vt_lo) lo_delta = a.vt_lo - a.vt;
           } else {
             obase = (which ? a.k : a.q) + (size_t)head * a.S * MV_HEAD_DIM + (size_t)crow * MV_HEAD_DIM + 8 * cchunk;
             rstride = MV_HEAD_DIM; istride = 0; jstride = 32;  // the batch-row part is added per i below
-            lo_delta = which ? a.k_lo - a.k : a.q_lo - a.q;
+            if (a.vt_lo) lo_delta = which ? a.k_lo - a.k : a.q_lo - a.q;
           }
         }
         // RAW: bias' of this lane's columns (per-tile LDS image: one float4 per column block) and rstd of its eight token rows
@@ -916,6 +861,18 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmArgs a) {
             }
           }
           if constexpr (EPI == PP_QK && X8) {
+            // V of the special rows as hi + lo (GemmArgs::vlo_sp): lane = token 16 tb + m16 (tb = 2 i), registers = head dims 16 cb + 4 q4 + e of this wave's head
+            if (a.vlo_sp && vtile && (i & 1) == 0 && cls_b[i >> 1] >= 0 && m16 < 2) {
+              const int head = (nw + a.col0 - 2 * MV_HIDDEN) >> 6;
+              half_t* vp = a.vlo_sp + ((size_t)(cls_b[i >> 1] * MV_HEADS + head) * MV_HEAD_DIM + 4 * q4) * 2 + m16;
+#pragma unroll
+              for (int cb = 0; cb < 4; ++cb) {
+                const float vv[4] = {__builtin_fmaf(rrs[2 * i], acc[2 * i][cb][0], rbv[cb].x), __builtin_fmaf(rrs[2 * i], acc[2 * i][cb][1], rbv[cb].y),
+                                     __builtin_fmaf(rrs[2 * i], acc[2 * i][cb][2], rbv[cb].z), __builtin_fmaf(rrs[2 * i], acc[2 * i][cb][3], rbv[cb].w)};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) vp[(16 * cb + e) * 2] = (half_t)((vv[e] - (float)(half_t)vv[e]) * 2048.0f);
+              }
+            }
             // short passes (a.vt_lo set: padded length <= 128): Q, K and V^T as TWO fp16 planes each — what is left of the precise mode's error is the
             // fp16 storage of Q, K, V and P, which attention averages over the keys, so short sequences feel it most (profiles/r05_f_length_envelope.txt);
             // the attention kernel of these passes adds the first-order terms K_lo Q_hi + K_hi Q_lo and V_lo P_hi + V_hi P_lo (attention_v2.h VLO).
@@ -944,7 +901,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmArgs a) {
               }
             }
           }
-          if constexpr (IS_RES && !LO8S) {  // second plane: lo = fp16(r - hi), same addresses in the lo buffer (LO8S: the lo8 plane below IS the stream's lo)
+          if constexpr (IS_RES) {  // second plane: lo = fp16(r - hi), same addresses in the lo buffer
 #pragma unroll
             for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -970,10 +927,23 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmArgs a) {
             float vmax8 = 0.f;      // max |value| of the block (saturation accounting, common.h)
             const uint32_t w8 = ub8 + (sf << 4);
             uint8_t* o8 = a.out8 + (size_t)(mb + crow) * (2 * a.N) + nw + 16 * cchunk;
-            // GemmArgs::out8_hi_only (engine.hip cls_aside: the consumer sweeps the weight-side term only): no lo8 plane — except for a 32-row block
-            // that holds the [CLS] row of a sequence (row b S: wave-uniform), whose lo8 row feeds that row's A-side term (cls_lo_gather_kernel)
+            // GemmArgs::out8_hi_only (engine.hip cls_aside: the consumer sweeps the weight-side term only): no lo8 plane
             bool hi_only = false;
-            if constexpr (X8 == 1) hi_only = a.out8_hi_only && !tile_short && !((i & 1) == 0 && cls_b[i >> 1] >= 0);
+            if constexpr (X8) hi_only = a.out8_hi_only && !tile_short;
+            // the special rows' low parts, compact (GemmArgs::sp_lo_out): token block 2 i of an even block row holds rows mw + 32 i + m16
+            if (a.sp_lo_out && (i & 1) == 0 && cls_b[i >> 1] >= 0 && m16 < 2) {
+              half_t* sp = a.sp_lo_out + (size_t)(2 * cls_b[i >> 1] + m16) * a.N + nw + 4 * q4;
+#pragma unroll
+              for (int cb = 0; cb < 4; ++cb) {
+                half4_t l;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                  const float v = acc[2 * i][cb][e];
+                  l[e] = (half_t)((v - (float)(half_t)v) * 2048.0f);
+                }
+                *(half4_t*)(sp + 16 * cb) = l;
+              }
+            }
 #pragma unroll
             for (int tbl = 0; tbl < 2; ++tbl)
 #pragma unroll

@@ -62,6 +62,11 @@ __device__ __forceinline__ void ln_row_store(const float4 (&x)[3], const float* 
 // (the exact two-pass mean and variance, expressed as one (sum, sum of squares) pair); xlo: the stream as two fp16 planes
 // (gemm_pp PP_RESLN3), x8: + its fp8 planes (MV_F16X8).
 // `pitch` = ints between the rows of ids (>= S_in: a length-bucketed sweep reads only the first S_in columns of wider rows).
+// lens != nullptr (MV_F16X8, round 6 "special rows"): the LAST token of every sequence ([SEP]) is computed in row 1 and token 1 in the last token's row —
+// everything downstream is per-row or attention (a sum over the keys, whatever their order), positions enter through the position embedding added HERE
+// and the mask only asks "row < len", so only the [CLS] row's result matters and it does not change — which puts the two tokens trained BERT heads use
+// as attention sinks at the FIXED rows 0 and 1 of each sequence: the rows whose roundings can reach the pooler un-averaged (gemm_pp.h "special rows").
+// sp_lo: 2^11 x the low parts (x - fp16(x)) of those two rows, compact [2 b + row][768] fp16: the A operand of the first QKV projection's row term.
 template <bool RAWOUT>
 __global__ __launch_bounds__(256) void embed_ln_kernel(const int32_t* __restrict__ ids, int pitch, int S_in, int Sp, int n_tok,
                                                        int vocab, const float* __restrict__ wemb,
@@ -69,16 +74,22 @@ __global__ __launch_bounds__(256) void embed_ln_kernel(const int32_t* __restrict
                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
                                                        float eps, float* __restrict__ x32, half_t* __restrict__ x16,
                                                        float* __restrict__ stats, half_t* __restrict__ xlo, uint8_t* __restrict__ x8,
-                                                       unsigned int* __restrict__ x8_sat) {
+                                                       unsigned long long* __restrict__ x8_sat, const int32_t* __restrict__ lens = nullptr,
+                                                       half_t* __restrict__ sp_lo = nullptr) {
   float vmax8 = 0.f;  // MV_F16X8: max |stream value| of the row's share (saturation accounting, common.h)
   const int lane = threadIdx.x & 63;
   const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (t >= n_tok) return;
   const int b = t / Sp, s = t - b * Sp;
-  int id = (s < S_in) ? ids[(size_t)b * pitch + s] : 0;
+  int ss = s;  // the token position this row holds
+  if (lens) {
+    const int len = lens[b];
+    if (len >= 3) ss = (s == 1) ? len - 1 : (s == len - 1) ? 1 : s;
+  }
+  int id = (ss < S_in) ? ids[(size_t)b * pitch + ss] : 0;
   id = (id < 0 || id >= vocab) ? 0 : id;
   const float* w = wemb + (size_t)id * MV_HIDDEN;
-  const float* p = pemb + (size_t)(s < S_in ? s : 0) * MV_HIDDEN;  // columns >= S_in are engine padding (always masked)
+  const float* p = pemb + (size_t)(ss < S_in ? ss : 0) * MV_HIDDEN;  // columns >= S_in are engine padding (always masked)
   float4 x[3];
 #pragma unroll
   for (int i = 0; i < 3; ++i) {
@@ -118,7 +129,13 @@ __global__ __launch_bounds__(256) void embed_ln_kernel(const int32_t* __restrict
         *(uint32_t*)(x8 + (size_t)t * (2 * MV_HIDDEN) + c) = l8;
         *(uint32_t*)(x8 + (size_t)t * (2 * MV_HIDDEN) + MV_HIDDEN + c) = h8;
       }
-      if (xlo) {  // two-plane raw stream (gemm_pp PP_RESLN3): lo = fp16(x - hi) instead of the fp32 row (nullptr with x8: the lo8 stream)
+      if (sp_lo && s < 2) {
+        half4_t l;
+        l[0] = (half_t)((x[i].x - (float)h[0]) * 2048.0f); l[1] = (half_t)((x[i].y - (float)h[1]) * 2048.0f);
+        l[2] = (half_t)((x[i].z - (float)h[2]) * 2048.0f); l[3] = (half_t)((x[i].w - (float)h[3]) * 2048.0f);
+        *(half4_t*)(sp_lo + (size_t)(2 * b + s) * MV_HIDDEN + c) = l;
+      }
+      if (xlo) {  // two-plane raw stream (gemm_pp PP_RESLN3): lo = fp16(x - hi) instead of the fp32 row
         half4_t l;
         l[0] = (half_t)(x[i].x - (float)h[0]); l[1] = (half_t)(x[i].y - (float)h[1]);
         l[2] = (half_t)(x[i].z - (float)h[2]); l[3] = (half_t)(x[i].w - (float)h[3]);
@@ -162,31 +179,13 @@ __global__ __launch_bounds__(256) void ln_kernel(float* __restrict__ x32, half_t
   ln_row_store<W32>(x, gamma, beta, eps, lane, row, x16 + (size_t)t * MV_HIDDEN, W32 ? nullptr : stats + 2 * (size_t)t);
 }
 
-// four lo8 bytes (one dword of the stream's lo8 plane, MV_F16X8) -> the fp32 residuals they stand for
-__device__ __forceinline__ float4 x8_lo4(uint32_t l8) {
-  constexpr float SLO = 1.0f / (float)(2048 << MV_X8_ACT_SHIFT);
-  const float2_t a = __builtin_amdgcn_cvt_scalef32_pk_f32_fp8(l8, 1.0f, false), b = __builtin_amdgcn_cvt_scalef32_pk_f32_fp8(l8, 1.0f, true);
-  float4 y;
-  y.x = a.x * SLO; y.y = a.y * SLO; y.z = b.x * SLO; y.w = b.y * SLO;
-  return y;
-}
-
 // Two-plane raw stream -> fp32 rows (only the un-pruned last layer needs them: its final LayerNorm kernel reads fp32).
-// MV_F16: lo = the lo fp16 plane; MV_F16X8: x8 = the stream's [lo8 | hi8] planes (rows of 1536 bytes), lo = nullptr.
-__global__ __launch_bounds__(256) void hilo_to_f32_kernel(const half_t* __restrict__ hi, const half_t* __restrict__ lo,
-                                                          const uint8_t* __restrict__ x8, size_t n4, float* __restrict__ out) {
+__global__ __launch_bounds__(256) void hilo_to_f32_kernel(const half_t* __restrict__ hi, const half_t* __restrict__ lo, size_t n4, float* __restrict__ out) {
   const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= n4) return;
-  const half4_t h = *(const half4_t*)(hi + 4 * i);
+  const half4_t h = *(const half4_t*)(hi + 4 * i), l = *(const half4_t*)(lo + 4 * i);
   float4 y;
-  if (x8) {
-    const size_t t = (4 * i) / MV_HIDDEN, c = (4 * i) - t * MV_HIDDEN;
-    y = x8_lo4(*(const uint32_t*)(x8 + t * (2 * MV_HIDDEN) + c));
-    y.x += (float)h[0]; y.y += (float)h[1]; y.z += (float)h[2]; y.w += (float)h[3];
-  } else {
-    const half4_t l = *(const half4_t*)(lo + 4 * i);
-    y.x = (float)h[0] + (float)l[0]; y.y = (float)h[1] + (float)l[1]; y.z = (float)h[2] + (float)l[2]; y.w = (float)h[3] + (float)l[3];
-  }
+  y.x = (float)h[0] + (float)l[0]; y.y = (float)h[1] + (float)l[1]; y.z = (float)h[2] + (float)l[2]; y.w = (float)h[3] + (float)l[3];
   *(float4*)(out + 4 * i) = y;
 }
 
@@ -198,8 +197,7 @@ __global__ __launch_bounds__(256) void cls_gather_kernel(const float* __restrict
                                                          int B, const float* __restrict__ stats,
                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
                                                          float* __restrict__ c32, half_t* __restrict__ c16, int raw16,
-                                                         const half_t* __restrict__ xlo, int vstats, float eps,
-                                                         const uint8_t* __restrict__ x8 = nullptr) {
+                                                         const half_t* __restrict__ xlo, int vstats, float eps) {
 #pragma clang fp contract(off)
   const int lane = threadIdx.x & 63;
   const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -217,11 +215,7 @@ __global__ __launch_bounds__(256) void cls_gather_kernel(const float* __restrict
   for (int i = 0; i < 3; ++i) {
     const int c = 4 * lane + 256 * i;
     float4 y;
-    if (x8) {  // MV_F16X8: r = hi + the lo8 plane of the stream's fp8 planes
-      const half4_t hh = *(const half4_t*)(x16 + t * MV_HIDDEN + c);
-      y = x8_lo4(*(const uint32_t*)(x8 + t * (2 * MV_HIDDEN) + c));
-      y.x += (float)hh[0]; y.y += (float)hh[1]; y.z += (float)hh[2]; y.w += (float)hh[3];
-    } else if (xlo) {  // two-plane raw stream: r = hi + lo
+    if (xlo) {  // two-plane raw stream: r = hi + lo
       const half4_t hh = *(const half4_t*)(x16 + t * MV_HIDDEN + c), ll = *(const half4_t*)(xlo + t * MV_HIDDEN + c);
       y.x = (float)hh[0] + (float)ll[0]; y.y = (float)hh[1] + (float)ll[1];
       y.z = (float)hh[2] + (float)ll[2]; y.w = (float)hh[3] + (float)ll[3];
@@ -245,30 +239,6 @@ __global__ __launch_bounds__(256) void cls_gather_kernel(const float* __restrict
       *(half4_t*)(c16 + (size_t)b * MV_HIDDEN + c) = *(const half4_t*)(x16 + t * MV_HIDDEN + c);
     }
   }
-}
-
-// [CLS]-row A-side term (engine.hip cls_aside): the LOW parts of the [CLS] rows (stream row b Sp) of a persistent GEMM's A operand as a
-// compact fp16 matrix [B][K], scaled by 2^11 (x - fp16(x) is 2^-11 of x: the scaled values are normal fp16 numbers of the operand's own
-// magnitude; exact in both forms) — the A operand of the skinny GEMM that forms that row's A-side correction term A_lo W_hi^T.
-// lo16: the operand's lo fp16 plane, rows of K halves (the raw stream's xlo); lo8: its [lo8 | hi8] planes, rows of 2 K bytes (context, GELU
-// output): lo8 = e4m3((x - hi) 2^(11 + shift)).  Four values per thread.
-__global__ __launch_bounds__(256) void cls_lo_gather_kernel(const half_t* __restrict__ lo16, const uint8_t* __restrict__ lo8, int K, int Sp,
-                                                            int B, half_t* __restrict__ out) {
-  const size_t i4 = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
-  if (i4 >= (size_t)B * K) return;
-  const size_t b = i4 / K, k = i4 - b * K, t = b * Sp;
-  half4_t y;
-  if (lo8) {
-    constexpr float SC = 1.0f / (float)(1 << MV_X8_ACT_SHIFT);
-    const uint32_t l8 = *(const uint32_t*)(lo8 + t * (2 * (size_t)K) + k);
-    const float2_t p = __builtin_amdgcn_cvt_scalef32_pk_f32_fp8(l8, 1.0f, false), q = __builtin_amdgcn_cvt_scalef32_pk_f32_fp8(l8, 1.0f, true);
-    y[0] = (half_t)(p.x * SC); y[1] = (half_t)(p.y * SC); y[2] = (half_t)(q.x * SC); y[3] = (half_t)(q.y * SC);
-  } else {
-    const half4_t l = *(const half4_t*)(lo16 + t * K + k);
-    y[0] = (half_t)((float)l[0] * 2048.0f); y[1] = (half_t)((float)l[1] * 2048.0f);
-    y[2] = (half_t)((float)l[2] * 2048.0f); y[3] = (half_t)((float)l[3] * 2048.0f);
-  }
-  *(half4_t*)(out + i4) = y;
 }
 
 // cls_aside: which 256-row tiles of a pass keep the default form — flags[tm] = 1 when a sequence that owns rows of tile tm has fewer than

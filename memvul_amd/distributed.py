@@ -42,6 +42,11 @@ RENDEZVOUS_TIMEOUT_S = 180.0
 # early waits for the slowest one inside the barrier / all-gather; rank 0 concatenating part files between two barriers)
 HUB_IO_TIMEOUT_S = float(os.environ.get("MEMVUL_HUB_TIMEOUT_S", "900"))
 HUB_DATA_TIMEOUT_S = float(os.environ.get("MEMVUL_HUB_DATA_TIMEOUT_S", str(6 * 3600)))
+EXIT_PORT_IN_USE = 98  # exit code of a rank 0 whose hub port was taken by somebody else between the launcher's probe and its own bind (bench.self_launch retries)
+
+
+class HubPortInUse(RuntimeError):
+    """rank 0 could not bind MASTER_PORT + 1: another process holds it."""
 
 
 def shard_range(n: int, rank: int, world: int) -> Tuple[int, int]:
@@ -80,7 +85,15 @@ class _Hub:
         if rank == 0:
             srv = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
             srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
-            srv.bind((addr, port))
+            try:
+                srv.bind((addr, port))
+            except OSError as e:
+                import errno
+
+                srv.close()
+                if e.errno == errno.EADDRINUSE:
+                    raise HubPortInUse(f"rendezvous hub: {addr}:{port} (MASTER_PORT + 1) is in use by another process") from e
+                raise
             srv.listen(world + 8)
             deadline = time.time() + timeout_s
             by_rank = {}

@@ -60,6 +60,7 @@ def make_weights(
     trained_like: bool = False,
     use_header: bool = True,
     outlier_scale: float = 1.0,
+    sink: Optional[dict] = None,
 ) -> Dict[str, np.ndarray]:
     """Random-init weights of the reference architecture, fp32.
 
@@ -80,6 +81,10 @@ def make_weights(
     (1 = -4 / +3; the precision-envelope sweep of round 5 runs 1x, 3x, 10x: at 10x single hidden values pass 100 and reach the
     +-112 range of the MV_F16X8 fp8 planes, mv_x8_saturation).  ``use_header=False``: the state dict of a model built without the
     512-d header (no ``_projector_single``; ``_projector.weight`` is ``[2, 3 * 768]``).
+    ``sink`` (round 6: the attention-concentration axis of the precision envelope): ``dict(token="sep" | "cls", rows="cls" | "all", gains=[g_0 ..
+    g_{L-1}])`` makes every head of every layer put a chosen share of its attention mass on ONE token — the [SEP] or the [CLS] token of each
+    sequence, as trained BERT checkpoints do — for the [CLS] row alone or for every row; see ``apply_sink`` (the gains come from
+    ``calibrate_sink``, which measures the achieved mass on the CPU oracle).
     """
     rng = np.random.Generator(np.random.PCG64(seed))
     H, I, P = dims.hidden, dims.intermediate, dims.proj_dim
@@ -149,7 +154,167 @@ def make_weights(
             if k.endswith("LayerNorm.weight"):
                 w[k] = w[k].copy()
                 w[k][[H // 3 + 52, H // 2 - 3]] = [0.6, 0.8]
+    if sink:
+        apply_sink(w, dims, seed, **sink)
     return w
+
+
+# ---- attention sinks (round 6) -------------------------------------------------------------------------------------------------------
+# Trained BERT heads put most of their mass on [SEP] / [CLS] (1 - 4 effective keys of 256); the random-init family above spreads the [CLS] row over
+# 67 - 149 keys.  What matters for the engine's precision argument is exactly that: the [CLS]-row form of the correction sweeps and the one-plane
+# Q / K / V / P storage rest on "another row's rounding reaches the [CLS] row averaged over the keys".  Mechanism, in the weights only (the model
+# stays a plain BERT state dict): hidden dimension SINK_DIM is a FLAG of the sink token (its word embedding carries +SINK_FLAG there, the LayerNorms
+# keep the dimension alive with gamma = SINK_GAMMA, beta = 0), every head h of layer l gets a rank-1 key term  k_h += g_l x[SINK_DIM] dir_h  and
+# every query a component along dir_h — a constant for all rows (rows = "all":  b_q += 8 dir_h) or proportional to a second flag that only the
+# [CLS] token carries (rows = "cls":  W_q[:, CLSQ_DIM] += 8 dir_h / SINK_NOMINAL) — so the score of (query, sink key) is raised by ~ g_l x_sink.
+SINK_DIM, CLSQ_DIM = 71, 167
+SINK_FLAG, SINK_GAMMA, SINK_NOMINAL = 0.3, 1.1, 8.0
+CLS_ID, SEP_ID, MID_ID = 101, 102, 1012  # token = "mid": an ORDINARY token (bert-base-uncased's "."), placed in the middle of each sequence by mark_mid_token
+
+
+def sink_token_id(token: str) -> int:
+    return {"sep": SEP_ID, "cls": CLS_ID, "mid": MID_ID}[token]
+
+
+def sink_positions(lens, token: str) -> np.ndarray:
+    lens = np.asarray(lens)
+    return {"sep": lens - 1, "cls": np.zeros_like(lens), "mid": lens // 2}[token]
+
+
+def mark_mid_token(ids, lens):
+    """ids with MID_ID at position len // 2 of every row (the sink token of token = "mid"; rows of fewer than 4 tokens are left alone)."""
+    ids = np.array(ids, copy=True)
+    for b, n in enumerate(np.asarray(lens)):
+        if n >= 4:
+            ids[b, int(n) // 2] = MID_ID
+    return ids
+
+
+def _sink_dirs(dims: "BertDims", seed: int) -> np.ndarray:
+    """One unit direction per (layer, head) in the head's 64-d space, by seed: [L, heads, 64]."""
+    rng = np.random.Generator(np.random.PCG64(seed + 424243))
+    dirs = rng.standard_normal((dims.layers, dims.heads, dims.hidden // dims.heads)).astype(np.float32)
+    return dirs / np.linalg.norm(dirs, axis=-1, keepdims=True)
+
+
+def apply_sink(w, dims: "BertDims", seed: int, token: str = "sep", rows: str = "cls", gains=None):
+    """In place: the sink terms described above.  ``gains``: one g_l per layer (calibrate_sink); None = no key terms yet (what calibrate_sink starts from)."""
+    assert token in ("sep", "cls", "mid") and rows in ("cls", "all")
+    H = dims.hidden
+    dirs = _sink_dirs(dims, seed)
+    e = PFX_BERT + "embeddings."
+    we = w[e + "word_embeddings.weight"] = w[e + "word_embeddings.weight"].copy()
+    we[sink_token_id(token), SINK_DIM] += SINK_FLAG
+    if rows == "cls":
+        we[CLS_ID, CLSQ_DIM] += SINK_FLAG
+    for k in list(w):
+        if k.endswith("LayerNorm.weight"):
+            w[k] = w[k].copy()
+            w[k][[SINK_DIM, CLSQ_DIM]] = SINK_GAMMA
+        if k.endswith("LayerNorm.bias"):
+            w[k] = w[k].copy()
+            w[k][[SINK_DIM, CLSQ_DIM]] = 0.0
+    for l in range(dims.layers):
+        p = PFX_BERT + f"encoder.layer.{l}."
+        d = dirs[l].reshape(H)  # head-major: rows h * 64 .. of the projections
+        if rows == "all":
+            w[p + "attention.self.query.bias"] = (w[p + "attention.self.query.bias"] + 8.0 * d).astype(np.float32)
+        else:
+            wq = w[p + "attention.self.query.weight"] = w[p + "attention.self.query.weight"].copy()
+            wq[:, CLSQ_DIM] += np.float32(8.0 / SINK_NOMINAL) * d
+        if gains is not None:
+            wk = w[p + "attention.self.key.weight"] = w[p + "attention.self.key.weight"].copy()
+            wk[:, SINK_DIM] += np.float32(gains[l]) * d
+    return w
+
+
+def sink_report(w, dims: "BertDims", ids, lens, token: str = "sep", rows: str = "cls"):
+    """Per layer, on an fp32 numpy restatement of the forward (kept here so that calibrate_sink needs nothing outside this module): the mean share of
+    attention mass on the sink token — of the [CLS] row (rows = "cls") or of all valid rows (rows = "all") — and the [CLS] row's effective number of
+    keys 1 / sum p^2, both averaged over sequences and heads.  Returns (mass [L], eff_keys [L])."""
+    return _sink_forward(w, dims, ids, lens, token, rows, None, None)[:2]
+
+
+def calibrate_sink(dims: "BertDims", seed: int, target: float, token: str = "sep", rows: str = "cls", n: int = 4, seq_len: int = 256, **weight_kw):
+    """gains [L] such that the measured mass share (sink_report) is ``target`` in every layer, found layer by layer by bisection on the CPU (the
+    stream into layer l depends on the gains of the layers before it).  Calibration batch: n full-length sequences of seq_len tokens."""
+    ids, lens = make_ids(n, seq_len, dims.vocab_size, seed=seed + 31337)
+    if token == "mid":
+        ids = mark_mid_token(ids, lens)
+    w = make_weights(dims, seed=seed, sink=dict(token=token, rows=rows, gains=None), **weight_kw)
+    return _sink_forward(w, dims, ids, lens, token, rows, target, seed)[2]
+
+
+def _sink_forward(w, dims, ids, lens, token, rows, target, seed):
+    from scipy.special import erf as _erf
+
+    H, nh = dims.hidden, dims.heads
+    hd = H // nh
+    B, S = ids.shape
+    W = lambda k: w[PFX_BERT + k].astype(np.float32)  # noqa: E731
+    dirs = _sink_dirs(dims, seed) if target is not None else None
+
+    def ln(x, g, b):
+        mu = x.mean(-1, keepdims=True)
+        var = ((x - mu) ** 2).mean(-1, keepdims=True)
+        return (x - mu) / np.sqrt(var + np.float32(dims.ln_eps)) * g + b
+
+    def probs(scores):
+        e = np.exp(scores - scores.max(-1, keepdims=True))
+        return e / e.sum(-1, keepdims=True)
+
+    x = W("embeddings.word_embeddings.weight")[ids] + W("embeddings.position_embeddings.weight")[np.arange(S)][None] + W("embeddings.token_type_embeddings.weight")[0][None, None]
+    x = ln(x, W("embeddings.LayerNorm.weight"), W("embeddings.LayerNorm.bias"))
+    mask = mask_from_lens(lens, S)
+    addmask = ((1.0 - mask.astype(np.float32)) * np.float32(-10000.0))[:, None, None, :]
+    spos = sink_positions(lens, token)
+    bi = np.arange(B)
+
+    def measure(pr):
+        on_sink = pr[bi, :, :, spos]  # [B, nh, S(query)]
+        if rows == "cls":
+            mass = float(on_sink[:, :, 0].mean())
+        else:
+            mass = float((on_sink * mask[:, None, :]).sum() / (mask.sum() * nh))
+        return mass, float((1.0 / (pr[:, :, 0, :] ** 2).sum(-1)).mean())
+
+    masses, effs, gains = [], [], []
+    for l in range(dims.layers):
+        p = f"encoder.layer.{l}."
+        sp = lambda t: t.reshape(B, S, nh, hd).transpose(0, 2, 1, 3)  # noqa: E731
+        qh = sp(x @ W(p + "attention.self.query.weight").T + W(p + "attention.self.query.bias"))
+        kh = sp(x @ W(p + "attention.self.key.weight").T + W(p + "attention.self.key.bias"))
+        vh = sp(x @ W(p + "attention.self.value.weight").T + W(p + "attention.self.value.bias"))
+        sc = qh @ kh.transpose(0, 1, 3, 2) / np.float32(8.0) + addmask  # [B, nh, S, S]
+        if target is not None:
+            # the rank-1 key term  k_h += g x[SINK_DIM] dir_h  adds  g x_j[SINK_DIM] (q_i . dir_h) / 8  to score (i, j): bisect g on the measured mass
+            qd = (qh * dirs[l][None, :, None, :]).sum(-1) / np.float32(8.0)  # [B, nh, S]
+            extra = qd[:, :, :, None] * x[:, None, None, :, SINK_DIM]        # [B, nh, S, S]
+            lo, hi = 0.0, 64.0
+            for _ in range(18):
+                g = 0.5 * (lo + hi)
+                if measure(probs(sc + np.float32(g) * extra))[0] < target:
+                    lo = g
+                else:
+                    hi = g
+            g = float(np.float32(0.5 * (lo + hi)))
+            gains.append(g)
+            # continue on the weights as apply_sink will write them (the term lands in W_k in fp32)
+            wk = w[PFX_BERT + p + "attention.self.key.weight"] = w[PFX_BERT + p + "attention.self.key.weight"].copy()
+            wk[:, SINK_DIM] += np.float32(g) * dirs[l].reshape(H)
+            kh = sp(x @ wk.T + W(p + "attention.self.key.bias"))
+            sc = qh @ kh.transpose(0, 1, 3, 2) / np.float32(8.0) + addmask
+        pr = probs(sc)
+        mass, eff = measure(pr)
+        masses.append(mass)
+        effs.append(eff)
+        ctx = (pr @ vh).transpose(0, 2, 1, 3).reshape(B, S, H)
+        x1 = ln(ctx @ W(p + "attention.output.dense.weight").T + W(p + "attention.output.dense.bias") + x, W(p + "attention.output.LayerNorm.weight"),
+                W(p + "attention.output.LayerNorm.bias"))
+        hh = x1 @ W(p + "intermediate.dense.weight").T + W(p + "intermediate.dense.bias")
+        hh = (hh * np.float32(0.5) * (np.float32(1.0) + _erf(hh / np.float32(np.sqrt(2.0))))).astype(np.float32)
+        x = ln(hh @ W(p + "output.dense.weight").T + W(p + "output.dense.bias") + x1, W(p + "output.LayerNorm.weight"), W(p + "output.LayerNorm.bias"))
+    return np.array(masses), np.array(effs), gains
 
 
 def make_ids(

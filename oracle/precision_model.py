@@ -85,12 +85,13 @@ def _w_planes(W):
     return tuple(p.astype(np.float64) for p in hit)
 
 
-def _mm(afmt, wfmt, A, W, cls_lo=None):
+def _mm(afmt, wfmt, A, W, cls_lo=None, rows=None):
     """A @ W^T as the engine forms it.  Both operands "f16x8" (MV_F16X8): ONE fp16 sweep + two fp8 (e4m3) correction sweeps
     into the same fp32 accumulators,  A_hi W_hi + A_lo8 W_hi8 + A_hi8 W_lo8;  otherwise each operand is rounded on its own.
     ``cls_lo`` (the [CLS]-row form, engine.hip cls_aside; A is [B, S, K]): wherever the sweep carried the weight-side term only, row 0 of
     every sequence — its [CLS] token — gets the A-side term from a skinny fp16 GEMM  fp16(2^11 A_lo) fp16(W)^T 2^-11  with A_lo taken from
-    the operand's lo fp16 plane ("lo16": the raw stream) or its lo8 plane ("lo8": context, GELU output)."""
+    the operand's lo fp16 plane ("lo16": the raw stream) or its lo8 plane ("lo8": context, GELU output).  ``rows`` (int [B, R], round 6): the rows of
+    each sequence that get the term instead of row 0 alone (e.g. the [CLS] and the [SEP] token)."""
     if afmt in ("f16x8", "f16x8w", "f16x8q", "f16x8k", "f16x8v") and wfmt == "f16x8":
         ah, ah8, al8 = _x8_planes(A, X8_ACT_SHIFT)
         wh, wh8, wl8 = _w_planes(W)
@@ -98,8 +99,14 @@ def _mm(afmt, wfmt, A, W, cls_lo=None):
 
         def cls_term(cols):
             if cls_lo and A.ndim == 3:
-                lo = _f16(A[:, 0] - ah[:, 0]) if cls_lo == "lo16" else al8[:, 0]
-                out[:, 0, cols] += (_f16(lo * 2048.0) @ wh[cols].T) / 2048.0
+                rr = np.zeros((A.shape[0], 1), np.int64) if rows is None else rows
+                bi = np.arange(A.shape[0])
+                for j in range(rr.shape[1]):
+                    r = rr[:, j]
+                    if j and (r == rr[:, 0]).all():
+                        continue
+                    lo = _f16(A[bi, r] - ah[bi, r]) if cls_lo == "lo16" else al8[bi, r]
+                    out[bi, r, cols] += (_f16(lo * 2048.0) @ wh[cols].T) / 2048.0
 
         if afmt == "f16x8w":  # the weight-side term only (gemm_pp.h x8_terms = 1)
             cls_term(slice(None))
@@ -108,7 +115,7 @@ def _mm(afmt, wfmt, A, W, cls_lo=None):
             Hb = W.shape[0] // 3
             b = "qkv".index(afmt[-1])
             out[..., b * Hb:(b + 1) * Hb] += al8 @ wh8[b * Hb:(b + 1) * Hb].T
-            if b != 0:  # the engine forms the [CLS] row's term of the QKV projection only when the Q block lacks the A-side term (engine.hip encode_dev:
+            if b != 0 or rows is not None:  # the engine forms the [CLS] row's term of the QKV projection only when the Q block lacks the A-side term (engine.hip encode_dev:
                 for o in range(3):  # K and V of the [CLS] token are one key among S); the launch skips it in the block that swept both terms
                     if o != b:
                         cls_term(slice(o * Hb, (o + 1) * Hb))
@@ -148,7 +155,12 @@ X8_ENGINE = dict(w_qkv="f16x8", w_o="f16x8", w_1="f16x8", w_2="f16x8", a_qkv="f1
 # term in the Q block of the QKV projection (all rows) and, through the skinny GEMMs, in the [CLS] row of every sequence for the other three GEMMs
 X8_ENGINE_CLS = dict(w_qkv="f16x8", w_o="f16x8", w_1="f16x8", w_2="f16x8", a_qkv="f16x8q", a_ffn1="f16x8w", ctx="f16x8w", h="f16x8w")
 
+# Round 6, the special rows: the formats of X8_ENGINE_CLS with THESE keyword arguments of encode / logits are the shipped default — the row terms go to the
+# [CLS] AND the [SEP] row of every sequence (in the K / V blocks of the QKV projection too) and V of those two rows reaches attention as hi + lo
+SHIPPED_KW = dict(cls_fix=True, special="cls+sep", special_v="f16x2")
+
 KNOBS = ("w_qkv", "w_o", "w_1", "w_2", "a_qkv", "a_ffn1", "qkv", "p", "ctx", "h", "res")
+# (round 6) "q", "k", "v": the storage format of one of the three alone; each follows "qkv" unless given
 
 
 def engine_formats(layers: int, fmt: str = "f16", **override) -> Dict[str, List[str]]:
@@ -158,6 +170,8 @@ def engine_formats(layers: int, fmt: str = "f16", **override) -> Dict[str, List[
     cfg["res"] = ["exact"] * layers  # (the two-plane fp16 stream is exact at this model's resolution: 2^-22)
     for k, v in override.items():
         cfg[k] = [v] * layers if isinstance(v, str) else list(v)
+    for k in ("q", "k", "v"):
+        cfg.setdefault(k, cfg["qkv"])
     return cfg
 
 
@@ -168,17 +182,24 @@ def _ln_stats(x, eps):
 
 
 def encode(w, ids, mask, cfg: Optional[Dict[str, List[str]]], heads=12, eps=1e-12, fold_ln=True, cls_side=None, cls_raw_kv=False,
-           cls_from_layer=0, cls_fix=False):
+           cls_from_layer=0, cls_fix=False, special="cls", special_v=None, special_a_qkv=True):
     """float64 BERT forward with the engine's rounding points (``cfg`` None = exact).  ``fold_ln``: the QKV / FFN-1
     weights are rounded AFTER the preceding LayerNorm is folded in (W'' = W gamma - rowmean, gemm_pp.h) and the A operand
     is the raw (pre-LayerNorm) stream, as on the engine's persistent-GEMM path.  ``cls_fix``: the [CLS]-row A-side term of the shipped form
-    (see _mm) in every GEMM whose A format sweeps the weight-side term only."""
+    (see _mm) in every GEMM whose A format sweeps the weight-side term only; ``special`` = "cls" (row 0 of every sequence) or "cls+sep" (round 6:
+    also its last token: the two tokens trained BERT heads use as attention sinks).  ``special_v`` (a format name, e.g. "f16x2"): V of the special rows is
+    stored in that format instead of the ``v`` knob's (the attention kernel adds p[:, special] V_lo[special]: two rank-1 updates per head)."""
     W = lambda k: w[PFX + k].astype(np.float64)  # noqa: E731
     L = orc.n_layers(w)
     if cfg is None:
         cfg = engine_formats(L, "exact")
     R = lambda knob, l, x: FORMATS[cfg[knob][l]](x)  # noqa: E731
+    for k3 in ("q", "k", "v"):
+        cfg.setdefault(k3, cfg["qkv"])
     B, S = ids.shape
+    rows = None
+    if special == "cls+sep":
+        rows = np.stack([np.zeros(B, np.int64), mask.astype(np.int64).sum(1) - 1], 1)
     H = W("embeddings.word_embeddings.weight").shape[1]
     d = H // heads
     r = (W("embeddings.word_embeddings.weight")[ids] + W("embeddings.position_embeddings.weight")[np.arange(S)][None]
@@ -199,9 +220,9 @@ def encode(w, ids, mask, cfg: Optional[Dict[str, List[str]]], heads=12, eps=1e-1
         if fold_ln:
             Wg = Wm * g[None, :]
             bf = bias + Wm @ b
-            return rstd * _mm(cfg[aknob][l], cfg[wknob][l], r_raw, Wg - Wg.mean(-1, keepdims=True), "lo16" if cls_fix else None) + bf
+            return rstd * _mm(cfg[aknob][l], cfg[wknob][l], r_raw, Wg - Wg.mean(-1, keepdims=True), "lo16" if cls_fix else None, rows) + bf
         x = (r_raw - mu) * rstd * g + b
-        return _mm(cfg[aknob][l], cfg[wknob][l], x, Wm, "lo16" if cls_fix else None) + bias
+        return _mm(cfg[aknob][l], cfg[wknob][l], x, Wm, "lo16" if cls_fix else None, rows) + bias
 
     for l in range(L):
         p = f"encoder.layer.{l}."
@@ -212,7 +233,13 @@ def encode(w, ids, mask, cfg: Optional[Dict[str, List[str]]], heads=12, eps=1e-1
         r_in = r
         if cls_side and l == cls_from_layer and l > 0:
             rc, gc, bc = r[:, 0].copy(), g, b
-        qkv = R("qkv", l, consumer(r, g, b, Wqkv, bqkv, "w_qkv", "a_qkv", l))
+        qkv = consumer(r, g, b, Wqkv, bqkv, "w_qkv", "a_qkv", l)
+        vst = R("v", l, qkv[..., 2 * H:])
+        if special_v:
+            rr = np.zeros((B, 1), np.int64) if rows is None else rows
+            for j in range(rr.shape[1]):
+                vst[np.arange(B), rr[:, j]] = FORMATS[special_v](qkv[np.arange(B), rr[:, j], 2 * H:])
+        qkv = np.concatenate([R("q", l, qkv[..., :H]), R("k", l, qkv[..., H:2 * H]), vst], -1)
         sp = lambda t: t.reshape(B, S, heads, d).transpose(0, 2, 1, 3)  # noqa: E731
         qh, kh, vh = sp(qkv[..., :H]), sp(qkv[..., H:2 * H]), sp(qkv[..., 2 * H:])
         sc = qh @ kh.transpose(0, 1, 3, 2) + addmask  # 1/sqrt(d) folded into W_q (exact power of two)
@@ -222,13 +249,13 @@ def encode(w, ids, mask, cfg: Optional[Dict[str, List[str]]], heads=12, eps=1e-1
         ctx = ((R("p", l, e) @ vh) / den).transpose(0, 2, 1, 3).reshape(B, S, H)  # the engine normalises O after P·V
         mu, rstd = _ln_stats(r, eps)
         x = (R("res", l, r) - mu) * rstd * g + b  # the residual GEMM reads the STORED stream; its statistics come from the accumulators
-        r1 = _mm(cfg["ctx"][l], cfg["w_o"][l], ctx, W(p + "attention.output.dense.weight"), "lo8" if cls_fix else None) + W(p + "attention.output.dense.bias") + x
+        r1 = _mm(cfg["ctx"][l], cfg["w_o"][l], ctx, W(p + "attention.output.dense.weight"), "lo8" if cls_fix else None, rows) + W(p + "attention.output.dense.bias") + x
         g1, b1 = W(p + "attention.output.LayerNorm.weight"), W(p + "attention.output.LayerNorm.bias")
         hpre = consumer(r1, g1, b1, W(p + "intermediate.dense.weight"), W(p + "intermediate.dense.bias"), "w_1", "a_ffn1", l)
         h = orc._gelu(hpre)
         mu, rstd = _ln_stats(r1, eps)
         x1 = (R("res", l, r1) - mu) * rstd * g1 + b1
-        r = _mm(cfg["h"][l], cfg["w_2"][l], h, W(p + "output.dense.weight"), "lo8" if cls_fix else None) + W(p + "output.dense.bias") + x1
+        r = _mm(cfg["h"][l], cfg["w_2"][l], h, W(p + "output.dense.weight"), "lo8" if cls_fix else None, rows) + W(p + "output.dense.bias") + x1
         if cls_side and l >= cls_from_layer:
             mu, rstd = _ln_stats(rc, eps)
             xc = (rc - mu) * rstd * gc + bc

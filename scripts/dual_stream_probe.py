@@ -24,7 +24,7 @@ def make(ncu):
         os.environ["MEMVUL_NUM_CU"] = str(ncu)
     else:
         os.environ.pop("MEMVUL_NUM_CU", None)
-    e = Engine(0, vocab_size=dims.vocab_size, layers=dims.layers, max_tokens=B * S, max_batch=B, max_anchors=128)
+    e = Engine(0, vocab_size=dims.vocab_size, layers=dims.layers, max_tokens=B * S, max_batch=B, max_anchors=128, dev=True)  # MEMVUL_NUM_CU: a development switch
     e.load_state_dict(w)
     e.anchor_set(anchors)
     e.corpus_upload(ids, lens)

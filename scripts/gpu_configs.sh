@@ -1,5 +1,5 @@
 #!/bin/bash
-# Round 3: the other BASELINE configs and the precise mode as bench lines + rocprofv3 evidence (one GPU-box visit).
+# The other BASELINE configs and the precise mode as bench lines + rocprofv3 evidence (one GPU-box visit).
 #   cfg 3 (S = 512, B = 128), cfg 5 (1000 anchors), ragged corpus; kernel trace + SQ / GRBM counters of `--compute precise`.
 set -u
 O=gpurun_out
@@ -9,19 +9,19 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 note() { echo "== $* ($(date +%H:%M:%S))"; }
 python -m memvul_amd.build > /dev/null || exit 1   # no-op when the binary that travelled matches the sources; never profile a stale one
 Q="--cpu-sample 0 --sustain-s 0 --no-precise"
-: > $O/r03_f_bench_lines.jsonl
+: > $O/other_configs_bench_lines.jsonl
 note "cfg 3: S=512, B=128 (f16, precise)"
-timeout 300 python bench.py --seq-len 512 --batch 128 --matcher-anchors 0 $Q 2>> $O/cfg.err | tail -1 >> $O/r03_f_bench_lines.jsonl
-timeout 300 python bench.py --seq-len 512 --batch 128 --matcher-anchors 0 --compute precise $Q 2>> $O/cfg.err | tail -1 >> $O/r03_f_bench_lines.jsonl
+timeout 300 python bench.py --seq-len 512 --batch 128 --matcher-anchors 0 $Q 2>> $O/cfg.err | tail -1 >> $O/other_configs_bench_lines.jsonl
+timeout 300 python bench.py --seq-len 512 --batch 128 --matcher-anchors 0 --compute precise $Q 2>> $O/cfg.err | tail -1 >> $O/other_configs_bench_lines.jsonl
 note "cfg 5: 1000 anchors"
-timeout 300 python bench.py --anchors 1000 $Q 2>> $O/cfg.err | tail -1 >> $O/r03_f_bench_lines.jsonl
+timeout 300 python bench.py --anchors 1000 $Q 2>> $O/cfg.err | tail -1 >> $O/other_configs_bench_lines.jsonl
 note "ragged corpus"
-timeout 300 python bench.py --ragged --matcher-anchors 0 $Q 2>> $O/cfg.err | tail -1 >> $O/r03_f_bench_lines.jsonl
+timeout 300 python bench.py --ragged --matcher-anchors 0 $Q 2>> $O/cfg.err | tail -1 >> $O/other_configs_bench_lines.jsonl
 note "precise as the headline mode"
-timeout 300 python bench.py --compute precise --matcher-anchors 0 $Q 2>> $O/cfg.err | tail -1 >> $O/r03_f_bench_lines.jsonl
+timeout 300 python bench.py --compute precise --matcher-anchors 0 $Q 2>> $O/cfg.err | tail -1 >> $O/other_configs_bench_lines.jsonl
 python - <<'PY'
 import json
-for l in open("gpurun_out/r03_f_bench_lines.jsonl"):
+for l in open("gpurun_out/other_configs_bench_lines.jsonl"):
     try:
         d = json.loads(l)
         print(d["dtype"][:12], d["config"]["seq_len"], d["config"]["global_batch"], d["config"]["anchors"], "IR/s", d["value"], "frac", d.get("roofline", {}).get("frac"),

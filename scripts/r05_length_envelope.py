@@ -23,11 +23,11 @@ dims = synth.BertDims(layers=12)
 w = synth.make_weights(dims, seed=mk.ENV_SEED, qk_scale=2.0, match_scale=29.0, trained_like=True)
 u_ref = refs["outlier_1_u"]
 out = []
-for mode, env in (("precise", {}), ("precise, one V/P plane (MEMVUL_SHORT_VLO=0)", {"MEMVUL_SHORT_VLO": "0"}), ("precise+lo8", {"MEMVUL_STREAM_LO8": "1"}), ("f16", {})):
-    os.environ.pop("MEMVUL_STREAM_LO8", None)
+# (MEMVUL_SHORT_VLO is a development switch since round 6: only the -DMEMVUL_DEV_SWITCHES build reads it — Engine(dev=True))
+for mode, env in (("precise", {}), ("precise, one V/P plane (MEMVUL_SHORT_VLO=0, development build)", {"MEMVUL_SHORT_VLO": "0"}), ("f16", {})):
     os.environ.pop("MEMVUL_SHORT_VLO", None)
     os.environ.update(env)
-    e = Engine(0, vocab_size=dims.vocab_size, layers=12, max_tokens=16 * 512, max_batch=16, max_anchors=16)
+    e = Engine(0, vocab_size=dims.vocab_size, layers=12, max_tokens=16 * 512, max_batch=16, max_anchors=16, dev=bool(env))
     e.load_state_dict(w, "f16" if mode == "f16" else "precise")
     row = dict(mode=mode, by_length={})
     for L in mk.LENGTHS:

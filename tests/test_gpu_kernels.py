@@ -125,14 +125,16 @@ def _taps(gu, B, S, ragged):
     return dims, w, ids, lens, mask, taps, u
 
 
+@pytest.mark.parametrize("compute", ["precise", "f16"])
 @pytest.mark.parametrize("B,S,ragged", [(3, 64, False), (2, 128, True), (2, 100, True)])
-def test_embeddings_layernorm(gu, B, S, ragged):
+def test_embeddings_layernorm(gu, B, S, ragged, compute):
+    """(precise: the raw two-plane stream + vstats of the persistent path, normalised by the final LayerNorm kernel; f16 at this size: the fused embedding LayerNorm)"""
     dims, w, ids, lens, mask, taps, _ = _taps(gu, B, S, ragged)
-    eng = gu.engine_for(L2, WK)
+    eng = gu.engine_for(L2, WK, compute_dtype=compute)
     eng.debug_encode(ids, lens, 0)
     x = eng.debug_read(0)[:, :S]
     err = float(np.abs(x - taps["embed"]).max())
-    gu.record("embed_ln", B=B, S=S, max_err=err)
+    gu.record("embed_ln", B=B, S=S, compute=compute, max_err=err)
     assert err < 2e-5
     x16 = eng.debug_read(1)[:, :S].astype(np.float32)
     assert np.abs(x16 - taps["embed"]).max() < 4e-3

@@ -27,13 +27,17 @@ def gu():
     return gpu_util
 
 
-@pytest.mark.parametrize("gemm_tile", [0, 512])
+PATHS = [(0, "precise"), (0, "f16"), (512, "f16")]  # (MEMVUL_GEMM_TILE, compute dtype): the product default (always the persistent kernels), then the opt-in
+                                                     # MV_F16 on the path its pass size selects and with the bench-scale kernels forced at test sizes
+
+
+@pytest.mark.parametrize("gemm_tile,compute", PATHS)
 @pytest.mark.parametrize("name", ["l2_peaky_full", "l2_ragged", "l12_base_ragged", "l12_base_s256"])
-def test_golden_logits(gu, golden_dir, name, gemm_tile):
+def test_golden_logits(gu, golden_dir, name, gemm_tile, compute):
     import make_golden
     g = np.load(os.path.join(golden_dir, f"{name}.npz"))
     dk, wk, B, S, ragged, G, SA = make_golden.CASES[name]
-    eng = gu.engine_for(dk, wk, gemm_tile=gemm_tile)  # 512 = the bench-scale GEMM path forced at test sizes
+    eng = gu.engine_for(dk, wk, gemm_tile=gemm_tile, compute_dtype=compute)
     eng.anchor_reset()
     LA = int(g["anchor_lens"].max())
     eng.anchor_append(g["anchor_ids"][:, :LA], g["anchor_lens"])  # one chunk padded to its longest (predict_memory.py:81)
@@ -44,7 +48,7 @@ def test_golden_logits(gu, golden_dir, name, gemm_tile):
         logits=float(np.abs(out["logits"] - g["logits"]).max()), p=float(np.abs(out["probs"] - g["p"]).max()),
         logit_scale=float(np.abs(g["logits"]).max()),
     )
-    gu.record("golden", case=name, gemm_tile=gemm_tile, **errs)
+    gu.record("golden", case=name, gemm_tile=gemm_tile, compute=compute, **errs)
     assert errs["logits"] <= LOGIT_TOL, errs
     assert errs["p"] <= LOGIT_TOL, errs
     # decisions: best-anchor index agrees wherever the reference's top-2 margin exceeds the tolerance
@@ -67,7 +71,7 @@ def test_trained_like_logits(gu, golden_dir, name, gemm_tile):
     import make_golden
     g = np.load(os.path.join(golden_dir, f"{name}.npz"))
     dk, wk, B, S, ragged, G, SA = make_golden.CASES[name]
-    eng = gu.engine_for(dk, wk, gemm_tile=gemm_tile, max_tokens=16384, max_batch=64, max_anchors=64)
+    eng = gu.engine_for(dk, wk, gemm_tile=gemm_tile, compute_dtype="f16", max_tokens=16384, max_batch=64, max_anchors=64)  # the opt-in mode and its measured bound
     eng.anchor_reset()
     LA = int(g["anchor_lens"].max())
     eng.anchor_append(g["anchor_ids"][:, :LA], g["anchor_lens"])
@@ -117,35 +121,6 @@ def test_precise_mode_holds_1e3_in_the_trained_like_regime(gu, golden_dir, name)
     assert errs["logits"] <= (PRECISE_TRAINED_LIKE_REGRESSION_BOUND if "trained" in name else LOGIT_TOL), errs
     assert errs["p"] <= 1e-4, errs
     eng.anchor_reset()
-
-
-@pytest.mark.parametrize("name", ["l12_trained_s256", "l12_trained_ragged", "l2_ragged"])
-def test_lo8_residual_stream_option(gu, golden_dir, name):
-    """MEMVUL_STREAM_LO8=1 (round 5, opt-in): the precise mode's raw residual stream as hi fp16 + the lo8 plane of its fp8 planes — the
-    bytes the next GEMM's correction sweep reads anyway — instead of hi + lo fp16 planes (gemm_pp.h X8 = 2: its own kernel instantiation;
-    embed / cls_gather / hilo_to_f32 read the same plane).  +2.4 % issue reports/s for ~1.2x the trained-like logit error
-    (profiles/r05_a_*, r05_b_*: 24 draws 2.4 .. 6.3e-4 against 2.3 .. 4.8e-4): inside the 1e-3 contract, not the default."""
-    import make_golden
-
-    g = np.load(os.path.join(golden_dir, f"{name}.npz"))
-    dk, wk, B, S, ragged, G, SA = make_golden.CASES[name]
-    eng = gu.engine_for(dk, wk, compute_dtype="precise", env={"MEMVUL_STREAM_LO8": "1"}, max_tokens=16384, max_batch=64, max_anchors=64)
-    eng.anchor_reset()
-    LA = int(g["anchor_lens"].max())
-    eng.anchor_append(g["anchor_ids"][:, :LA], g["anchor_lens"])
-    out = eng.forward(g["ids"], g["lens"], want_embed=True)
-    errs = dict(u=float(np.abs(out["embed"] - g["u"]).max()), logits=float(np.abs(out["logits"] - g["logits"]).max()),
-                p=float(np.abs(out["probs"] - g["p"]).max()), logit_scale=float(np.abs(g["logits"]).max()))
-    gu.record("precise_mode_lo8_stream", case=name, **errs)
-    assert errs["logits"] <= LOGIT_TOL and errs["p"] <= 2e-4, errs
-    # same model on the default stream: the two differ, by less than the contract
-    ref = gu.engine_for(dk, wk, compute_dtype="precise", max_tokens=16384, max_batch=64, max_anchors=64)
-    ref.anchor_reset()
-    ref.anchor_append(g["anchor_ids"][:, :LA], g["anchor_lens"])
-    o2 = ref.forward(g["ids"], g["lens"])
-    d = float(np.abs(o2["logits"] - out["logits"]).max())
-    assert 0 < d <= LOGIT_TOL, d
-    eng.anchor_reset(); ref.anchor_reset()
 
 
 @pytest.mark.parametrize("qkv_aside", ["q", "none"])
@@ -487,10 +462,11 @@ def test_last_layer_pruning_matches_full_forward(gu, B, S, ragged, gemm_tile, co
     assert np.abs(u_cls - u_ref).max() < 2e-3
 
 
+@pytest.mark.parametrize("compute", ["precise", "f16"])
 @pytest.mark.parametrize("outliers", [False, True])
 @pytest.mark.parametrize("prune", ["0", "1"])
 @pytest.mark.parametrize("B,S", [(6, 128), (3, 256), (5, 200)])
-def test_virtual_layernorm_matches_explicit_layernorm(gu, B, S, prune, outliers):
+def test_virtual_layernorm_matches_explicit_layernorm(gu, B, S, prune, outliers, compute):
     """The persistent path has no LayerNorm kernel between the GEMMs — the consumer GEMMs read the raw stream (two fp16
     planes) with gamma / beta / the row mean folded into their weights and scale rows by rstd in the epilogue
     (W LN(r) + b = rstd (W'' r) + b'), the residual GEMMs emit the rows' partial sums — while the small-pass path
@@ -500,23 +476,26 @@ def test_virtual_layernorm_matches_explicit_layernorm(gu, B, S, prune, outliers)
     dk, wk = dict(layers=4, vocab_size=2048), dict(qk_scale=2.0, ln_outliers=outliers)
     dims, w = gu.weights_for(dk, wk)
     ids, lens = synth.make_ids(B, S, dims.vocab_size, ragged=True, min_len=9)
-    u_v = gu.engine_for(dk, wk, gemm_tile=512, env={"MEMVUL_CLS_PRUNE": prune}).encode(ids, lens)
-    u_e = gu.engine_for(dk, wk, gemm_tile=128, env={"MEMVUL_CLS_PRUNE": prune}).encode(ids, lens)
+    # the virtual side in both compute dtypes (the product default runs the persistent kernels at every size; MV_F16 has them forced here); the explicit
+    # side exists in MV_F16 only (the small-pass kernels)
+    u_v = gu.engine_for(dk, wk, gemm_tile=0 if compute == "precise" else 512, compute_dtype=compute, env={"MEMVUL_CLS_PRUNE": prune}).encode(ids, lens)
+    u_e = gu.engine_for(dk, wk, gemm_tile=128, compute_dtype="f16", env={"MEMVUL_CLS_PRUNE": prune}).encode(ids, lens)
     u_ref = orc.instance_forward(w, ids.astype(np.int64), synth.mask_from_lens(lens, S))
     ev, ee = float(np.abs(u_v - u_ref).max()), float(np.abs(u_e - u_ref).max())
-    gu.record("virtual_ln", B=B, S=S, prune=prune, outliers=outliers, virtual_vs_oracle=ev, explicit_vs_oracle=ee,
+    gu.record("virtual_ln", B=B, S=S, prune=prune, outliers=outliers, compute=compute, virtual_vs_oracle=ev, explicit_vs_oracle=ee,
               virtual_vs_explicit=float(np.abs(u_v - u_e).max()), u_scale=float(np.abs(u_ref).max()))
     assert ev < 2e-3 and ev < 3 * ee + 2e-4
 
 
-def test_length_bucketed_sweep_matches_padded_sweep(gu):
+@pytest.mark.parametrize("compute", ["precise", "f16"])
+def test_length_bucketed_sweep_matches_padded_sweep(gu, compute):
     """Engine.bucketed_sweep: rows sorted by length, every batch processed at its own longest member's length
     (mv_corpus_run_len) instead of the corpus-wide S, results returned in the original order.  Same per-row mathematics
     at a different padded length (different tiling / kernel instantiation): probabilities agree at the fp16-operand
     level and the decisions agree wherever the top-2 margin is clear."""
     dk, wk = dict(layers=3, vocab_size=2048), dict(qk_scale=2.0, match_scale=6.0)
     dims, w = gu.weights_for(dk, wk)
-    eng = gu.engine_for(dk, wk, max_tokens=64 * 256, max_batch=64, max_anchors=32)
+    eng = gu.engine_for(dk, wk, compute_dtype=compute, max_tokens=64 * 256, max_batch=64, max_anchors=32)
     ids, lens = synth.make_ids(150, 256, dims.vocab_size, ragged=True, min_len=5)
     eng.anchor_set(synth.make_anchor_bank(24))
     eng.corpus_upload(ids, lens)
@@ -524,7 +503,7 @@ def test_length_bucketed_sweep_matches_padded_sweep(gu):
     best0, idx0, ps0 = eng.corpus_results(0, 150, with_probs=True)
     best1, idx1, ps1 = eng.bucketed_sweep(ids, lens, 64, with_probs=True)
     d = float(np.abs(ps0 - ps1).max())
-    gu.record("bucketed_sweep", max_p_diff=d)
+    gu.record("bucketed_sweep", compute=compute, max_p_diff=d)
     assert d < 1e-3
     srt = np.sort(ps0, axis=1)
     clear = (srt[:, -1] - srt[:, -2]) > 4e-3
@@ -540,13 +519,13 @@ def test_length_bucketed_sweep_matches_padded_sweep(gu):
     eng.anchor_reset()
 
 
-@pytest.mark.parametrize("gemm_tile", [0, 512])
-def test_edge_shapes_against_the_oracle(gu, gemm_tile):
+@pytest.mark.parametrize("gemm_tile,compute", PATHS)
+def test_edge_shapes_against_the_oracle(gu, gemm_tile, compute):
     """The smallest and the largest inputs the path accepts: a one-token issue report, one anchor, a batch whose rows
     are 1 / 33 / 64 tokens long, and a 512-token row (max_pos) next to a 3-token one; errors for what it must reject."""
     dk, wk = dict(layers=2, vocab_size=2048), dict(qk_scale=3.0)
     dims, w = gu.weights_for(dk, wk)
-    eng = gu.engine_for(dk, wk, gemm_tile=gemm_tile, max_tokens=8 * 512, max_batch=8, max_anchors=4)
+    eng = gu.engine_for(dk, wk, gemm_tile=gemm_tile, compute_dtype=compute, max_tokens=8 * 512, max_batch=8, max_anchors=4)
 
     def check(ids, lens, G):
         S = ids.shape[1]
@@ -622,13 +601,14 @@ def test_use_header_false_matches_the_oracle(gu, compute):
     eng.anchor_reset()
 
 
-def test_sweeps_chunk_batches_larger_than_one_pass(gu):
+@pytest.mark.parametrize("compute", ["precise", "f16"])
+def test_sweeps_chunk_batches_larger_than_one_pass(gu, compute):
     """batch_size = 512 (the reference __main__ value, predict_memory.py:207) with issue reports longer than
     max_tokens / 512 used to fail with MV_ERR_CAPACITY on the resident sweeps.  mv_corpus_run_len now walks such a batch in
     passes of what fits (as mv_forward / mv_encode do) with bit-identical per-row results."""
     dk, wk = dict(layers=2, vocab_size=2048), dict(qk_scale=2.0, match_scale=6.0)
     dims, w = gu.weights_for(dk, wk)
-    eng = gu.engine_for(dk, wk, max_tokens=24 * 256, max_batch=512, max_anchors=32)  # 24 rows of 256 tokens per pass
+    eng = gu.engine_for(dk, wk, compute_dtype=compute, max_tokens=24 * 256, max_batch=512, max_anchors=32)  # 24 rows of 256 tokens per pass
     ids, lens = synth.make_ids(130, 256, dims.vocab_size, ragged=True, min_len=120)
     eng.anchor_set(synth.make_anchor_bank(9))
     best, idx, ps = eng.bucketed_sweep(ids, lens, 512, with_probs=True)       # one "batch" of 130 rows > 24 per pass

@@ -91,7 +91,7 @@ print("STUB_OK", probs.shape, float(probs[0, 0, 0]))
 @pytest.mark.gpu
 def test_stub_runs_as_written_and_equals_the_binding():
     env = dict(os.environ, LD_LIBRARY_PATH=os.path.join(ROOT, "memvul_amd", "lib") + ":" + os.environ.get("LD_LIBRARY_PATH", ""))
-    for k in ("MEMVUL_COMPUTE", "MEMVUL_STREAM_LO8", "MEMVUL_SHORT_VLO", "MEMVUL_QKV_ASIDE", "MEMVUL_CLS_ASIDE", "MEMVUL_CLS_ASIDE_MIN_LEN"):
+    for k in ("MEMVUL_COMPUTE", "MEMVUL_QKV_ASIDE", "MEMVUL_CLS_ASIDE", "MEMVUL_CLS_ASIDE_MIN_LEN"):
         env.pop(k, None)  # the stub names its compute dtype itself; the binding it is compared with must run on the library's defaults too
     code = "ROOT = %r\n" % ROOT + DRIVER
     r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
