@@ -83,7 +83,8 @@ def load_library(path: Optional[str] = None, dev: bool = False):
             "(hipcc --offload-arch=gfx950); the MemVul hot path has no CPU fallback"
         )
     try:
-        lib = C.CDLL(path, mode=C.RTLD_LOCAL)  # (two builds of the same symbols may live in one test process)
+        # the product library as always (RTLD_GLOBAL); the development build, which a test process may load NEXT TO it, privately
+        lib = C.CDLL(path, mode=C.RTLD_LOCAL if path == LIB_PATH_DEV else C.RTLD_GLOBAL)
     except OSError as e:  # pragma: no cover
         raise RuntimeError(f"cannot load {path}: {e}") from e
     vp, i32p, f32p = C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_float)

@@ -122,9 +122,8 @@ __global__ __launch_bounds__(NKB * 128) __attribute__((amdgpu_waves_per_eu(2, 2)
   constexpr bool SPV = X8 && !VLO;
   auto load_vsp = [&](int u, uint32_t (&v)[2]) {
     const uint32_t* g = (const uint32_t*)a.vlo_sp + (size_t)unit_bh(u) * MV_HEAD_DIM + ql;
-    const uint32_t v0 = g[0], v1 = g[32];
-    v[0] = hi ? 0u : v0;
-    v[1] = hi ? 0u : v1;
+    v[0] = g[0];  // (raw: the zeros of the hi = 1 lanes are selected where the operand is USED — any use here makes hipcc wait for the load, and for the
+    v[1] = g[32];  //  K / V^T / Q loads in flight before it, in the middle of the unit: +15 us per launch)
   };
   auto load_q_lo = [&](int u, half8_t (&qf)[4]) {  // VLO: the same fragments of Q's lo plane
     const int bh = unit_bh(u), qb = unit_qb(u);
@@ -150,10 +149,10 @@ __global__ __launch_bounds__(NKB * 128) __attribute__((amdgpu_waves_per_eu(2, 2)
   half8_t qf[4], qn[4];
   half8_t qfl[VLO ? 4 : 1], qnl[VLO ? 4 : 1];  // VLO: Q's lo fragments, prefetched like Q's
   uint32_t vs[2] = {0u, 0u}, vsn[2] = {0u, 0u};  // SPV: this unit's / the next unit's special-row V_lo operand, prefetched like Q
-  const bool spv = SPV && a.vlo_sp != nullptr;
+  constexpr bool spv = SPV;  // (the engine hands every X8 launch that is not a two-plane short pass the special rows' V_lo: no run-time test, no branch around the prefetch)
   issue_chunk(first, 0, 0);
   load_q(first, qn);
-  if (spv) load_vsp(first, vsn);
+  if constexpr (spv) load_vsp(first, vsn);
   if constexpr (VLO) load_q_lo(first, qnl);
   int len_n = a.lens[unit_bh(first) / MV_HEADS];  // prefetched like Q: a VGPR-destination load must never be waited for mid-unit
 
@@ -199,6 +198,18 @@ __global__ __launch_bounds__(NKB * 128) __attribute__((amdgpu_waves_per_eu(2, 2)
     for (int it = 0; it < 4; ++it) v[it] = *(const u32x4*)(kb + o_rd + it * 1024);
 #pragma unroll
     for (int it = 0; it < 4; ++it) *(u32x4*)(dst + (size_t)(8 * it) * (2 * MV_HIDDEN)) = v[it];
+    // special rows (AttnArgs::sp_lo_out): the low parts of the context rows of queries 0 and 1 of the sequence, compact, taken from the lo8 bytes this pass has
+    // just laid into the image (rows 0 and 1 of wave 0 in query block 0; 32 lanes x one dword): e4m3((x - fp16(x)) 2^(11 + shift)) -> fp16, 2^11 x the low part.
+    // (Formed from the fp32 context in the unit's last phase — by wave 0 alone, with every other wave waiting at the hand-over — it cost the launch 17 us.)
+    if (a.sp_lo_out && wave == 0 && qb == 0 && lane < 32) {
+      const int r = lane >> 4, w = lane & 15;
+      const uint32_t l8 = *(const uint32_t*)(kb + r * 128 + ((((uint32_t)(w >> 2)) ^ (uint32_t)r) << 4) + (w & 3) * 4);
+      constexpr float SC = 1.0f / (float)(1 << MV_X8_ACT_SHIFT);
+      const float2_t p = __builtin_amdgcn_cvt_scalef32_pk_f32_fp8(l8, 1.0f, false), q = __builtin_amdgcn_cvt_scalef32_pk_f32_fp8(l8, 1.0f, true);
+      half4_t y;
+      y[0] = (half_t)(p.x * SC); y[1] = (half_t)(p.y * SC); y[2] = (half_t)(q.x * SC); y[3] = (half_t)(q.y * SC);
+      *(half4_t*)(a.sp_lo_out + (size_t)(2 * b + r) * MV_HIDDEN + h * MV_HEAD_DIM + 4 * w) = y;
+    }
   };
   auto flush_o = [&](int u, char* kb) {
     flush_plane(u, kb, opk, a.ctx);
@@ -332,7 +343,7 @@ __global__ __launch_bounds__(NKB * 128) __attribute__((amdgpu_waves_per_eu(2, 2)
       if (j == NCH - 1 && nxt < nunits) {
         if constexpr (VLO) load_q_lo(nxt, qnl);
         load_q(nxt, qn);
-        if (spv) load_vsp(nxt, vsn);
+        if constexpr (spv) load_vsp(nxt, vsn);
         len_n = a.lens[unit_bh(nxt) / MV_HEADS];
       }
       // ---- O^T[d][q] (+)= V^T[d][keys] P^T[keys][q]
@@ -342,13 +353,15 @@ __global__ __launch_bounds__(NKB * 128) __attribute__((amdgpu_waves_per_eu(2, 2)
 #pragma unroll
           for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
         if constexpr (SPV) {
-          // special rows: O^T starts from V_lo[keys 0, 1]^T P^T[keys 0, 1] — keys 0 .. 15 are the first k-slot group of the first score fragment; the operand is
-          // 2^11 x the low parts, so the product is scaled back before the sum over all keys is added on top (as the accumulator's start value this costs no
-          // live range; added after the P V loop it cost the S = 256 instantiation 70 VGPRs and 320 B of scratch)
-          if (spv) {
+          // special rows: O^T starts from V_lo[keys 0, 1]^T P^T[keys 0, 1] — keys 0 .. 15 are the first k-slot group of the first score fragment.  The V_lo operand
+          // is 2^11 x the low parts (normal fp16 numbers); the product is scaled back in fp32 before the sum over all keys is added on top.  (Scaling the P
+          // fragment by 2^-11 in fp16 instead — four packed multiplies for 32 — turns probabilities below 2^-3 into subnormals: measured 6.3e-4 instead of
+          // 3.5e-4 on a golden, for 2 us.)  As the accumulator's START value the term costs no live range (added after the P V loop it cost the S = 256
+          // instantiation 70 VGPRs and 320 B of scratch); in all +3 .. 4 us per launch at S = 256 (profiles/r06_b_*).
+          if constexpr (spv) {
 #pragma unroll
             for (int dt = 0; dt < 2; ++dt) {
-              const u32x4 av = {vs[dt], 0u, 0u, 0u};
+              const u32x4 av = {hi ? 0u : vs[dt], 0u, 0u, 0u};
               o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8_t, av), pf[0][0], o[dt], 0, 0, 0);
 #pragma unroll
               for (int r = 0; r < 16; ++r) o[dt][r] *= 1.0f / 2048.0f;
@@ -414,24 +427,6 @@ __global__ __launch_bounds__(NKB * 128) __attribute__((amdgpu_waves_per_eu(2, 2)
             }
           }
         if constexpr (X8) {
-          // special rows: the low parts of the context rows of queries 0 and 1 of the sequence (lanes ql < 2 of wave 0 in query block 0), compact
-          // (AttnArgs::sp_lo_out).  A block of its own behind a wave-uniform branch: inside the loop above it cost the kernel 100 VGPRs of live range.
-          if (a.sp_lo_out && wave == 0 && unit_qb(unit) == 0) {
-            const int bh = unit_bh(unit), b = bh / MV_HEADS, h = bh - b * MV_HEADS;
-            half_t* sp = a.sp_lo_out + (size_t)(2 * b + (ql & 1)) * MV_HIDDEN + h * MV_HEAD_DIM + 4 * hi;
-#pragma unroll
-            for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-              for (int rg = 0; rg < 4; ++rg) {
-                half4_t l;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                  const float x = o[dt][4 * rg + e] * inv;
-                  l[e] = (half_t)((x - (float)(half_t)x) * 2048.0f);
-                }
-                if (ql < 2) *(half4_t*)(sp + 32 * dt + 8 * rg) = l;
-              }
-          }
           if (x8_any_out_of_range(vmax8)) {  // rare: redo the unit's planes with the clamps, count exactly
             int n = 0;
 #pragma unroll

@@ -72,8 +72,12 @@ def collate(instances: List[Instance], vocab=None) -> Dict[str, Any]:
             for b, ins in enumerate(instances):
                 toks = ins.fields[name].tokens
                 n = len(toks)
-                ids[b, :n] = [t.text_id for t in toks]
-                typ[b, :n] = [t.type_id or 0 for t in toks]
+                row = getattr(toks, "ids", None)
+                if row is not None:  # tokenizer.TokenRow: the id array itself (single-segment: type ids 0)
+                    ids[b, :n] = row
+                else:
+                    ids[b, :n] = [t.text_id for t in toks]
+                    typ[b, :n] = [t.type_id or 0 for t in toks]
                 mask[b, :n] = True
             out[name] = {"tokens": {"token_ids": ids, "mask": mask, "type_ids": typ}}
         elif isinstance(f0, LabelField):

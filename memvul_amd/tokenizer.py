@@ -35,6 +35,40 @@ def _find_vocab(model_name: str) -> Optional[str]:
     return None
 
 
+class TokenRow:
+    """The tokens of one text as a sequence over its id array: ``len``, iteration and indexing give ``Token`` objects (built when asked for: with
+    the WordPiece backend their ``text`` is looked up then), ``ids`` gives the int32 array the collation reads directly — a file of 40 k issue
+    reports is 8 M tokens, and one Python object per token costs more than the tokenisation itself."""
+
+    __slots__ = ("ids", "_hf")
+
+    def __init__(self, ids, hf=None):
+        self.ids, self._hf = ids, hf
+
+    def __len__(self):
+        return len(self.ids)
+
+    def _tok(self, i: int) -> Token:
+        return Token(self._hf.convert_ids_to_tokens(i) if self._hf is not None else str(i), i, 0)
+
+    def __getitem__(self, k):
+        if isinstance(k, slice):
+            return TokenRow(self.ids[k], self._hf)
+        return self._tok(int(self.ids[k]))
+
+    def __iter__(self):
+        if self._hf is not None:
+            ids = [int(i) for i in self.ids]
+            return (Token(t, i, 0) for t, i in zip(self._hf.convert_ids_to_tokens(ids), ids))
+        return (Token(str(int(i)), int(i), 0) for i in self.ids)
+
+    def __eq__(self, other):
+        try:
+            return len(self) == len(other) and all((a.text, a.text_id, a.type_id) == (b.text, b.text_id, b.type_id) for a, b in zip(self, other))
+        except (TypeError, AttributeError):
+            return NotImplemented
+
+
 @register_builtin(Tokenizer, "pretrained_transformer")
 class PretrainedTransformerTokenizer(Tokenizer):
     def __init__(self, model_name: str = "bert-base-uncased", add_special_tokens: bool = True, max_length: Optional[int] = None,
@@ -119,6 +153,11 @@ class PretrainedTransformerTokenizer(Tokenizer):
 
     def _hash_encode_many(self, texts: List[str]) -> List[List[int]]:
         return [self._hash_encode(t) for t in texts]
+
+    def batch_token_rows(self, texts: List[str]) -> List["TokenRow"]:
+        """``batch_tokenize`` without the Token objects: one TokenRow per text (same tokens, same ids, materialised on demand)."""
+        ids, lens = self.batch_ids(texts)
+        return [TokenRow(ids[i, :lens[i]], self._hf) for i in range(len(texts))]
 
     def batch_tokenize(self, texts: List[str]) -> List[List[Token]]:
         """``[tokenize(t) for t in texts]`` with ONE call into the tokenizer backend (same tokens, same ids)."""

@@ -200,4 +200,9 @@ def test_documented_switch_defaults_match_the_library_source():
     n = re.search(r"int cls_min_len = (\d+);", src)
     assert n and int(n.group(1)) == 128
     hdr = open(os.path.join(ROOT, "include", "memvul_hip.h")).read()
-    assert "MEMVUL_CLS_ASIDE=0" in hdr and "MEMVUL_CLS_ASIDE_MIN_LEN (128)" in hdr
+    assert "MEMVUL_CLS_ASIDE          1 (default) | 0" in hdr and "MEMVUL_CLS_ASIDE_MIN_LEN  1 .. 512 (default 128)" in hdr
+    # the development knobs are NOT product switches: the header names none of them as read by this library (engine.hip reads them under MEMVUL_DEV_SWITCHES only)
+    from memvul_amd import binding
+    block = src[src.index("#ifdef MEMVUL_DEV_SWITCHES"):src.index("#endif", src.index("#ifdef MEMVUL_DEV_SWITCHES"))]
+    for k in binding.DEV_SWITCHES:
+        assert src.count('"%s"' % k) == block.count('"%s"' % k) >= 1, k
