@@ -112,6 +112,19 @@ class DataLoader:
         return self._instances
 
     def __iter__(self) -> Iterator[Dict[str, Any]]:
+        if self._instances is None and self.reader is not None:
+            # first pass: batches are collated as the reader produces the Instances (ReaderMemory streams its tokenisation), the list is kept for later passes
+            acc, cur = [], []
+            for ins in self.reader.read(self.data_path):
+                acc.append(ins)
+                cur.append(ins)
+                if len(cur) == self.batch_size:
+                    yield collate(cur, self._vocab)
+                    cur = []
+            if cur:
+                yield collate(cur, self._vocab)
+            self._instances = acc
+            return
         ins = self.iter_instances()
         for s in range(0, len(ins), self.batch_size):
             yield collate(ins[s : s + self.batch_size], self._vocab)

@@ -70,7 +70,10 @@ class ReaderMemory(DatasetReader):
             for k, v in self._anchor.items():
                 self._anchor[k] = self._tokenizer.tokenize(v)
 
-    def read_dataset(self, file_path):
+    STREAM_CHUNK = 4096  # samples tokenised per batched call when the Instances are streamed (_read)
+
+    def read_dataset(self, file_path, defer_tokens: bool = False):
+        """``defer_tokens`` (the streaming form of _read): return the grouped samples WITHOUT their "description" tokens; _read tokenises them chunk by chunk."""
         if "golden" in file_path:
             dataset = dict()
             with open(file_path, "r", encoding="utf-8") as f:
@@ -85,6 +88,9 @@ class ReaderMemory(DatasetReader):
         dataset = self._grouped_samples(file_path)
         flat = [s for group in dataset.values() for s in group]
         rows_of = getattr(self._tokenizer, "batch_token_rows", None)
+        if defer_tokens and rows_of is not None and not HAVE_ALLENNLP:
+            self._dataset[file_path] = dataset
+            return dataset
         if rows_of is not None and not HAVE_ALLENNLP:
             # ONE batched call into the tokenizer backend for the whole file, tokens as id arrays (tokenizer.TokenRow: Token objects only when somebody
             # asks for them) — text by text with a list of Token objects per text this stage ran at 1.2 k issue reports/s (profiles/r06_*_e2e_dropin.txt)
@@ -158,8 +164,33 @@ class ReaderMemory(DatasetReader):
         return {"type": type_, "ids": ids, "lens": lens, "same": same, "labels": labels,
                 "urls": [s["Issue_Url"] for s in all_data], "n_total": n_total, "first": first}
 
+    def _stream(self, samples, type_):
+        """Instances of ``samples`` in order, tokenised STREAM_CHUNK texts per batched call with the NEXT chunk's call running on a helper thread (the
+        WordPiece backend releases the GIL) while this chunk's Instances are consumed — so that a consumer that scores batches as they arrive
+        (predict_memory.evaluate) overlaps the tokenisation of a 40 k-report file (2.4 s) with the GPU instead of waiting for it."""
+        from concurrent.futures import ThreadPoolExecutor
+
+        rows_of = self._tokenizer.batch_token_rows
+        chunks = [samples[i:i + self.STREAM_CHUNK] for i in range(0, len(samples), self.STREAM_CHUNK)]
+
+        def tok(chunk):
+            todo = [s for s in chunk if "description" not in s]
+            for s, row in zip(todo, rows_of([self._text_of(s) for s in todo])):
+                s["description"] = row
+            return chunk
+
+        with ThreadPoolExecutor(1) as ex:
+            fut = ex.submit(tok, chunks[0]) if chunks else None
+            for k in range(len(chunks)):
+                chunk = fut.result()
+                fut = ex.submit(tok, chunks[k + 1]) if k + 1 < len(chunks) else None
+                for sample in chunk:
+                    yield self.text_to_instance((sample, sample), type_=type_)
+
     def _read(self, file_path):
-        dataset = self.read_dataset(file_path)
+        streaming = (("test_" in file_path or "validation_" in file_path) and "golden" not in file_path
+                     and hasattr(self._tokenizer, "batch_token_rows") and not HAVE_ALLENNLP)
+        dataset = self.read_dataset(file_path, defer_tokens=streaming)
         all_data = list()
         for ll in list(dataset.values()):
             all_data.extend(ll)
@@ -173,13 +204,19 @@ class ReaderMemory(DatasetReader):
             logger.info(f"Num of golden instances is {len(all_data)}")
         elif "test_" in file_path:
             logger.info("Begin predict------")
-            for sample in reversed(all_data):  # positives first, then the negatives
-                yield self.text_to_instance((sample, sample), type_="unlabel")
+            if streaming:
+                yield from self._stream(all_data[::-1], "unlabel")
+            else:
+                for sample in reversed(all_data):  # positives first, then the negatives
+                    yield self.text_to_instance((sample, sample), type_="unlabel")
             logger.info(f"Predict sample num is {len(all_data)}")
         elif "validation_" in file_path:
             logger.info("Begin testing------")
-            for sample in reversed(all_data):
-                yield self.text_to_instance((sample, sample), type_="test")
+            if streaming:
+                yield from self._stream(all_data[::-1], "test")
+            else:
+                for sample in reversed(all_data):
+                    yield self.text_to_instance((sample, sample), type_="test")
             logger.info(f"Test sample num is {len(all_data)}")
         else:
             raise NotImplementedError(

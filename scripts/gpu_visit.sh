@@ -46,8 +46,8 @@ for step in "$@"; do
            else ( timeout 1500 python -m pytest tests -m gpu -q > $V/pytest_gpu.log 2>&1; echo "pytest rc=$?" >> $V/pytest_gpu.log ); fi
            grep -E "passed|failed|^FAILED|^ERROR|rc=" $V/pytest_gpu.log | tail -15 ;;
     smoke) timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $V/smoke.txt 2>&1; tail -2 $V/smoke.txt ;;
-    bench) ( /usr/bin/time -f "wall %e s" timeout 600 python bench.py > $V/bench_line.json 2> $V/bench_line.err; echo "rc=$?" >> $V/bench_line.err ); line $V/bench_line.json; grep wall $V/bench_line.err ;;
-    driver) ( /usr/bin/time -f "wall %e s" timeout 600 python bench.py --gpus 1 --steps 20 --warmup 5 > $V/bench_line_driver_form.json 2> $V/bench_line_driver_form.err; echo "rc=$?" >> $V/bench_line_driver_form.err ); line $V/bench_line_driver_form.json; grep wall $V/bench_line_driver_form.err ;;
+    bench) ( T0=$(date +%s); timeout 600 python bench.py > $V/bench_line.json 2> $V/bench_line.err; echo "rc=$? wall $(( $(date +%s) - T0 )) s" >> $V/bench_line.err ); line $V/bench_line.json; tail -1 $V/bench_line.err ;;
+    driver) ( T0=$(date +%s); timeout 600 python bench.py --gpus 1 --steps 20 --warmup 5 > $V/bench_line_driver_form.json 2> $V/bench_line_driver_form.err; echo "rc=$? wall $(( $(date +%s) - T0 )) s" >> $V/bench_line_driver_form.err ); line $V/bench_line_driver_form.json; tail -1 $V/bench_line_driver_form.err ;;
     quick) ( timeout 300 python bench.py --cpu-sample 0 --no-second --matcher-anchors 0 --sustain-s 0 $arg > $V/bench_quick.json 2> $V/bench_quick.err ); line $V/bench_quick.json ;;
     ab) ( timeout 900 python bench.py --ab > $V/bench_line_ab.json 2> $V/bench_line_ab.err ); line $V/bench_line_ab.json ;;
     pmc) m=${arg%%:*}; c=cfg2; [ "$arg" != "$m" ] && c=${arg#*:}; [ -z "$m" ] && m=precise
@@ -57,7 +57,7 @@ for step in "$@"; do
     lengths) timeout 500 python scripts/r05_length_envelope.py > $V/length_envelope.txt 2>&1; tail -12 $V/length_envelope.txt ;;
     sink) timeout 1500 python scripts/r06_sink_envelope.py --json $V/sink_envelope.json $arg > $V/sink_envelope.txt 2>&1; grep -v amdgpu.ids $V/sink_envelope.txt | tail -14 ;;
     configs) bash scripts/gpu_configs.sh > $V/other_configs.txt 2>&1; tail -12 $V/other_configs.txt ;;
-    e2e) timeout 1500 python scripts/e2e_dropin_probe.py $arg > $V/e2e_dropin.txt 2>&1; tail -20 $V/e2e_dropin.txt ;;
+    e2e) timeout 1500 python scripts/r06_e2e_dropin.py $arg > $V/e2e_dropin.txt 2>&1; tail -20 $V/e2e_dropin.txt ;;
     cmd) bash -c "$arg" ;;
     *) echo "unknown step $name" ;;
   esac

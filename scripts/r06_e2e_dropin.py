@@ -113,6 +113,8 @@ def main():
     print("N = %d issue reports, 124 anchors, batch 512, precise compute dtype (the default), host cores %d, real BertTokenizerFast over a synthetic %d-entry "
           "WordPiece vocabulary" % (n, os.cpu_count(), 30522), flush=True)
     results = {}
+    os.environ["MEMVUL_RECORD_WORKERS"] = sys.argv[2] if len(sys.argv) > 2 else "0"
+    print("MEMVUL_RECORD_WORKERS = %s (processes formatting the JSON records; 0 = in the driver process)" % os.environ["MEMVUL_RECORD_WORKERS"])
     for form, kw in (("arrays", dict(sweep="arrays")), ("sweep", dict(sweep=True)), ("instances", dict(sweep=False))):
         st = Stage()
         import memvul_amd.reader_memory as rm
