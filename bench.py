@@ -307,6 +307,9 @@ def main():
         "batches_in_flight": args.streams,
         # MV_F16X8: activation elements beyond the +-112 range of the fp8 correction planes over everything this engine ran (mv_x8_saturation)
         "x8_saturated_elements": (eng.x8_saturation() if (mode == "precise" and hasattr(eng, "x8_saturation")) else None),
+        # MV_F16X8: the concentration monitor (mv_attention_concentration): largest collision mass of a [CLS] row on ORDINARY keys / items above 0.25 over everything this engine ran
+        "attention_concentration": (dict(zip(("max_collision_on_ordinary_keys", "items_over_0.25", "items_total"), eng.attention_concentration()))
+                                    if (mode == "precise" and hasattr(eng, "attention_concentration")) else None),
         "stats_allgather_ms": round(gather_ms, 3),
         "stats_table_sum": int(table.sum()),
     }

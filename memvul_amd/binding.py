@@ -52,7 +52,7 @@ ABI_SYMBOLS = [
     "mv_create", "mv_destroy", "mv_last_error", "mv_sync", "mv_load_tensor", "mv_finalize_weights",
     "mv_anchor_reset", "mv_anchor_append", "mv_anchor_count", "mv_anchor_get", "mv_anchor_set",
     "mv_forward", "mv_encode", "mv_match", "mv_topk", "mv_corpus_upload", "mv_corpus_run", "mv_corpus_run_len",
-    "mv_corpus_results", "mv_x8_saturation", "mv_set_streams", "mv_profile_enable", "mv_profile_select", "mv_profile_read", "mv_kernel_class_name",
+    "mv_corpus_results", "mv_x8_saturation", "mv_attention_concentration", "mv_set_streams", "mv_profile_enable", "mv_profile_select", "mv_profile_read", "mv_kernel_class_name",
     "mv_debug_encode", "mv_debug_read", "mv_test_gemm", "mv_test_gemm_pp", "mv_test_e4m3", "mv_comm_prepare", "mv_comm_unique_id", "mv_comm_init", "mv_comm_allgather",
     "mv_comm_destroy", "mv_comm_info", "mv_device_count",
 ]
@@ -110,6 +110,7 @@ def load_library(path: Optional[str] = None, dev: bool = False):
         "mv_corpus_run_len": (C.c_int, [vp, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_int]),
         "mv_corpus_results": (C.c_int, [vp, C.c_int64, C.c_int64, vp, vp, vp]),
         "mv_x8_saturation": (C.c_int, [vp, C.POINTER(C.c_int64), C.c_int]),
+        "mv_attention_concentration": (C.c_int, [vp, C.POINTER(C.c_float), C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.c_int]),
         "mv_set_streams": (C.c_int, [vp, C.c_int]),
         "mv_profile_enable": (C.c_int, [vp, C.c_int]),
         "mv_profile_select": (C.c_int, [vp, C.c_uint32]),
@@ -217,8 +218,25 @@ class Engine:
         self._check(self._lib.mv_x8_saturation(self._h, C.byref(n), int(bool(reset))), "mv_x8_saturation")
         return int(n.value)
 
+    def attention_concentration(self, reset: bool = False):
+        """MV_F16X8: (max_collision, items_over, items_total) of mv_attention_concentration — the largest sum_{j >= 2} p[CLS row][j]^2 over every (sequence,
+        head, layer) processed so far, the number of them above 0.25 — more than half of a head's [CLS]-row attention on one token that is neither [CLS] nor
+        [SEP]: the regime outside the measured envelope of the default form (include/memvul_hip.h) — and the number looked at."""
+        m, n, t = C.c_float(0), C.c_int64(0), C.c_int64(0)
+        self._check(self._lib.mv_attention_concentration(self._h, C.byref(m), C.byref(n), C.byref(t), int(bool(reset))), "mv_attention_concentration")
+        return float(m.value), int(n.value), int(t.value)
+
     def _check_saturation(self):
         """Called after the host-synchronous entry points of the precise mode: warn ONCE when the fp8 planes clamped anything."""
+        if getattr(self, "_precise", False) and not getattr(self, "_conc_warned", False):
+            m, n, t = self.attention_concentration()
+            if t >= 100 and n > 0.02 * t:  # systematic, not the odd head of the odd sequence
+                self._conc_warned = True
+                warnings.warn(f"MV_F16X8: in {n} of {t} (sequence, head, layer) items the [CLS] row puts more than half of a head's attention on ONE ordinary token "
+                              f"(collision mass up to {m:.2f}): the 1e-3 logit tolerance of the default form is backed by measurement for diffuse attention and "
+                              "for attention sinks on [CLS] / [SEP] only (profiles/r06_c_sink_envelope.txt: 1.0 - 3.7e-3 for such a sink); "
+                              "MEMVUL_CLS_ASIDE=0 MEMVUL_QKV_ASIDE=qkv is the most conservative form (include/memvul_hip.h mv_attention_concentration)",
+                              RuntimeWarning, stacklevel=3)
         if getattr(self, "_precise", False) and not self._sat_warned:
             n = self.x8_saturation()
             if n:

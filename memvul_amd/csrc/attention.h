@@ -24,6 +24,12 @@ struct AttnArgs {
   // MV_F16X8, round 6 "special rows" (rows 0 and 1 of every sequence hold its [CLS] and [SEP] token: misc_kernels.h embed_ln_kernel):
   const half_t* vlo_sp;  // 2^11 x the low parts of V of those two keys, [b 12 + head][64 dims][2] fp16 (gemm_pp.h GemmArgs::vlo_sp): O += p[:, 0..1] V_lo[0..1] —
                          // with attention sinks the sink token's V reaches every row's context un-averaged, so its fp16 storage alone costs 1.2e-3 on the logits
+  unsigned long long* conc;  // X8, the concentration monitor (mv_attention_concentration): [0] = max over every (sequence, head, launch) of the [CLS] query row's collision
+                             // mass on ORDINARY keys, sum_{j >= 2} p[0][j]^2, as float bits (>= f^2 when one token that is neither [CLS] nor [SEP] holds the share f of that
+                             // row's attention), [1] = the number of (sequence, head, launch) items where it exceeds 0.25, [2] = the number of items looked at (sequences of >= 16 tokens).  The special rows cover sinks on the two
+                             // delimiter tokens; a sink on an ordinary token is outside the measured envelope of the default form (profiles/r06_*_sink_envelope.txt)
+  int lo8_min_len;       // X8: sequences of at least this many tokens get the hi8 plane of ctx8 alone (0: every sequence gets both planes): in the [CLS]-row form the
+                         // output projection sweeps the weight-side term only and never reads a long sequence's lo8 plane (50 MB of 201 MB the launch writes)
   half_t* sp_lo_out;     // 2^11 x the low parts of the CONTEXT of those two rows, compact [2 b + row][768] fp16: the A operand of the output projection's row term
 };
 

@@ -179,7 +179,7 @@ __global__ __launch_bounds__(NKB * 128) __attribute__((amdgpu_waves_per_eu(2, 2)
   };
   // X8: the fp8 planes through the same image: row q = [lo8 of dims 0..63 | hi8 of dims 0..63], i.e. 16-B slot
   // 2 dt + (rg >> 1) (+ 4 for hi8) at byte 8 (rg & 1) + 4 hi; read back as whole rows, stored as two 64-B segments per row
-  auto flush_x8 = [&](int u, char* kb) {
+  auto flush_x8 = [&](int u, char* kb, int len_u) {
     const uint32_t o_wr8 = (uint32_t)((32 * wave + ql) * 128 + 4 * hi);
 #pragma unroll
     for (int dt = 0; dt < 2; ++dt)
@@ -196,8 +196,11 @@ __global__ __launch_bounds__(NKB * 128) __attribute__((amdgpu_waves_per_eu(2, 2)
     u32x4 v[4];
 #pragma unroll
     for (int it = 0; it < 4; ++it) v[it] = *(const u32x4*)(kb + o_rd + it * 1024);
+    // (AttnArgs::lo8_min_len: a sequence long enough for the [CLS]-row form keeps no lo8 plane: lanes of slots 0 .. 3 — the lo8 half of the image rows — store nothing)
+    if (!(a.lo8_min_len > 0 && len_u >= a.lo8_min_len && slot < 4)) {
 #pragma unroll
-    for (int it = 0; it < 4; ++it) *(u32x4*)(dst + (size_t)(8 * it) * (2 * MV_HIDDEN)) = v[it];
+      for (int it = 0; it < 4; ++it) *(u32x4*)(dst + (size_t)(8 * it) * (2 * MV_HIDDEN)) = v[it];
+    }
     // special rows (AttnArgs::sp_lo_out): the low parts of the context rows of queries 0 and 1 of the sequence, compact, taken from the lo8 bytes this pass has
     // just laid into the image (rows 0 and 1 of wave 0 in query block 0; 32 lanes x one dword): e4m3((x - fp16(x)) 2^(11 + shift)) -> fp16, 2^11 x the low part.
     // (Formed from the fp32 context in the unit's last phase — by wave 0 alone, with every other wave waiting at the hand-over — it cost the launch 17 us.)
@@ -211,18 +214,19 @@ __global__ __launch_bounds__(NKB * 128) __attribute__((amdgpu_waves_per_eu(2, 2)
       *(half4_t*)(a.sp_lo_out + (size_t)(2 * b + r) * MV_HIDDEN + h * MV_HEAD_DIM + 4 * w) = y;
     }
   };
-  auto flush_o = [&](int u, char* kb) {
+  auto flush_o = [&](int u, char* kb, int len_u) {
     flush_plane(u, kb, opk, a.ctx);
     if constexpr (X8) {
       // the image rows are wave-private and LDS executes a wave's instructions in order: the second pass's writes may
       // follow the first plane's reads directly (hipcc waits for the read results before the global stores use them)
-      flush_x8(u, kb);
+      flush_x8(u, kb, len_u);
     }
   };
 
-  int pb = 0, prev = -1, len = 0;
+  int pb = 0, prev = -1, len = 0, len_prev = 0;
   floatx16 o[2];
   float m_run = 0.f, l_run = 0.f;  // NCH > 1: running row maximum / this lane's share of the running row sum
+  float c_run = 0.f, csp_run = 0.f;  // X8, wave 0: this lane's share of sum e^2 over the keys / over keys 0 and 1 (AttnArgs::conc)
   for (int unit = first; unit < nunits; unit += stride) {
     const int nxt = unit + stride;
 #pragma unroll 1  // one body for every chunk: unrolled, the two copies of a 200-register body spill
@@ -247,7 +251,7 @@ __global__ __launch_bounds__(NKB * 128) __attribute__((amdgpu_waves_per_eu(2, 2)
         // previous unit's O through the K half of the OTHER ring slot: rows 32 wave .. + 31 are exactly the rows this
         // wave's own K pieces of the next chunk will overwrite, so the only ordering needed is this wave's lgkmcnt(0)
         if (prev >= 0) {
-          flush_o(prev, smem + (pb ^ 1) * BUF);
+          flush_o(prev, smem + (pb ^ 1) * BUF, len_prev);
           asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         }
 #pragma unroll
@@ -339,6 +343,38 @@ __global__ __launch_bounds__(NKB * 128) __attribute__((amdgpu_waves_per_eu(2, 2)
         const float psum = (ps4[0] + ps4[1]) + (ps4[2] + ps4[3]);
         l_run = (j > 0) ? __builtin_fmaf(l_run, alpha, psum) : psum;
       }
+      if constexpr (X8) {
+        // concentration monitor (AttnArgs::conc): sum_j p[q][j]^2 of this lane's query over this chunk's keys, from the packed fp16 probabilities, by the first
+        // wave of the sequence's first query block alone (64 v_dot2_f32_f16: lanes 0 and 32 hold query 0 = the [CLS] row)
+        if (a.conc && wave == 0 && unit_qb(unit) == 0) {
+          float s2 = 0.f;
+#pragma unroll
+          for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                const half2_t h2 = {pf[t][u][2 * e], pf[t][u][2 * e + 1]};
+                s2 = __builtin_amdgcn_fdot2(h2, h2, s2, false);
+              }
+          const float e0 = (float)pf[0][0][0], e1 = (float)pf[0][0][1];  // keys 0 and 1 (lanes of hi = 0, first chunk)
+          const float sp = (j == 0 && hi == 0) ? __builtin_fmaf(e0, e0, e1 * e1) : 0.f;
+          if constexpr (NCH == 1) {  // the whole row is here: finish now (nothing of it lives across the P V phase: two more live values cost the S = 256 build 150 B of scratch)
+            const auto cs = __builtin_amdgcn_permlane32_swap(f2u(s2 - sp), f2u(s2 - sp), false, false);
+            const auto ls = __builtin_amdgcn_permlane32_swap(f2u(l_run), f2u(l_run), false, false);
+            const float linv = 1.0f / (u2f(ls[0]) + u2f(ls[1]));
+            const float coll = (u2f(cs[0]) + u2f(cs[1])) * linv * linv;
+            if (lane == 0 && len >= 16) {  // query 0 of the sequence (a sequence of a handful of tokens concentrates by construction: not what is looked for)
+              atomicMax(a.conc, (unsigned long long)f2u(fmaxf(coll, 0.f)));
+              if (coll > 0.25f) atomicAdd(a.conc + 1, 1ull);
+              atomicAdd(a.conc + 2, 1ull);
+            }
+          } else {
+            c_run = (j > 0) ? __builtin_fmaf(c_run, alpha * alpha, s2) : s2;
+            csp_run = (j > 0) ? __builtin_fmaf(csp_run, alpha * alpha, sp) : sp;
+          }
+        }
+      }
       // next unit's Q fragments: issued in the unit's last chunk (the score registers are dead), they land under its PV phase
       if (j == NCH - 1 && nxt < nunits) {
         if constexpr (VLO) load_q_lo(nxt, qnl);
@@ -413,6 +449,18 @@ __global__ __launch_bounds__(NKB * 128) __attribute__((amdgpu_waves_per_eu(2, 2)
       if (j == NCH - 1) {
         const auto sw = __builtin_amdgcn_permlane32_swap(f2u(l_run), f2u(l_run), false, false);
         const float inv = 1.0f / (u2f(sw[0]) + u2f(sw[1]));
+        if constexpr (X8 && NCH > 1) {
+          if (a.conc && wave == 0 && unit_qb(unit) == 0) {
+            const float own = c_run - csp_run;  // ordinary keys of this lane's half
+            const auto cs = __builtin_amdgcn_permlane32_swap(f2u(own), f2u(own), false, false);
+            const float coll = (u2f(cs[0]) + u2f(cs[1])) * inv * inv;
+            if (lane == 0 && len >= 16) {  // query 0 of the sequence (a sequence of a handful of tokens concentrates by construction: not what is looked for)
+              atomicMax(a.conc, (unsigned long long)f2u(fmaxf(coll, 0.f)));
+              if (coll > 0.25f) atomicAdd(a.conc + 1, 1ull);
+              atomicAdd(a.conc + 2, 1ull);
+            }
+          }
+        }
         float vmax8 = 0.f;  // MV_F16X8: max |context value| of the unit (saturation accounting, common.h)
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt)
@@ -441,10 +489,11 @@ __global__ __launch_bounds__(NKB * 128) __attribute__((amdgpu_waves_per_eu(2, 2)
           }
         }
         prev = unit;
+        len_prev = len;
       }
     }
   }
   // ---- last unit's O: the K half of the slot no DMA was issued into (nothing reads it any more)
-  flush_o(prev, smem + pb * BUF);
+  flush_o(prev, smem + pb * BUF, len_prev);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // no LDS-DMA may outlive the workgroup's LDS allocation
 }

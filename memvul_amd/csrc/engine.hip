@@ -174,6 +174,7 @@ struct mv_handle {
   int rr = 0;                 // workspace set of the next resident-sweep batch
   float* anchors = nullptr;
   int n_anchors = 0;
+  unsigned long long* attn_conc = nullptr;  // MV_F16X8: [0] max collision mass of the [CLS] row on ordinary keys (float bits), [1] items above 0.25 (AttnArgs::conc)
   unsigned long long* x8_sat = nullptr;  // MV_F16X8: device counter (64-bit: it cannot wrap within a run) of activation elements beyond the fp8 planes' range (mv_x8_saturation)
 
   // resident corpus
@@ -419,6 +420,8 @@ int launch_attention(mv_handle* h, const int32_t* d_lens, int B, int Sp, bool x8
   AttnArgs a{h->w->q, h->w->k, h->w->vt, d_lens, h->w->ctx, Sp, B, x8 ? h->w->ctx8 : nullptr, h->x8_sat, vlo ? h->w->vt_lo : nullptr,
              vlo ? h->w->q_lo : nullptr, vlo ? h->w->k_lo : nullptr,
              (x8 && !vlo) ? h->w->vlo_sp : nullptr,     // special rows: V of keys 0, 1 as hi + lo (the two-plane short passes carry every key's lo plane)
+             x8 ? h->attn_conc : nullptr,               // concentration monitor (mv_attention_concentration)
+             sp_out ? h->cls_min_len : 0,               // [CLS]-row form: no lo8 plane of the context for the sequences that take it
              sp_out ? h->w->cls_lo : nullptr};
   ProfScope ps(h, KC_ATTENTION);
   if (vlo) {
@@ -1049,6 +1052,7 @@ int mv_create(int device, const mv_config* cfg, mv_handle** out) try {
   h->w = &h->work[0];
   A(dev_alloc(h, &h->anchors, (int64_t)cfg->max_anchors * h->P));
   A(dev_alloc(h, &h->x8_sat, 1));  // (zeroed by dev_alloc)
+  A(dev_alloc(h, &h->attn_conc, 4));
   if (rc == MV_OK && hipStreamSynchronize(h->w->stream) != hipSuccess) rc = MV_ERR_HIP;
   if (rc != MV_OK) {
     g_create_error = h->err.empty() ? "workspace allocation failed" : h->err;
@@ -1628,6 +1632,20 @@ int mv_x8_saturation(mv_handle* h, int64_t* clamped, int reset) try {
   HIPCHK(h, hipMemcpy(&v, h->x8_sat, sizeof(v), hipMemcpyDeviceToHost));
   if (reset) HIPCHK(h, hipMemset(h->x8_sat, 0, sizeof(v)));
   *clamped = v > (unsigned long long)INT64_MAX ? INT64_MAX : (int64_t)v;
+  return MV_OK;
+} catch (...) { return on_exception(h); }
+
+int mv_attention_concentration(mv_handle* h, float* max_collision, int64_t* items_over, int64_t* items_total, int reset) try {
+  if (!h || !max_collision || !items_over || !items_total) return fail(h, MV_ERR_INVALID, "mv_attention_concentration: bad argument");
+  HIPCHK(h, hipSetDevice(h->device));
+  if (int rc = sync_all(h)) return rc;
+  unsigned long long v[4] = {0, 0, 0, 0};
+  HIPCHK(h, hipMemcpy(v, h->attn_conc, sizeof(v), hipMemcpyDeviceToHost));
+  if (reset) HIPCHK(h, hipMemset(h->attn_conc, 0, sizeof(v)));
+  const uint32_t bits = (uint32_t)v[0];
+  std::memcpy(max_collision, &bits, 4);
+  *items_over = v[1] > (unsigned long long)INT64_MAX ? INT64_MAX : (int64_t)v[1];
+  *items_total = v[2] > (unsigned long long)INT64_MAX ? INT64_MAX : (int64_t)v[2];
   return MV_OK;
 } catch (...) { return on_exception(h); }
 

@@ -85,6 +85,62 @@ def _w_planes(W):
     return tuple(p.astype(np.float64) for p in hit)
 
 
+# Round 6, model only: alternative forms of the WEIGHT-SIDE term A_hi8 W_lo8^T (the 300 us per layer every row still pays).
+#   None       e4m3 x e4m3, every K-tile (the engine)
+#   "fp4"      both operands as MX-fp4 (e2m1, one power-of-two scale per 32 K-elements): 4x the fp16 matrix rate, half the bytes
+#   "sparse"   W_lo8 pruned 2:4 along K (the two largest of every four kept): the sparse matrix path, half the W_lo8 bytes
+#   "tophalf"  the term only in the half of a matrix' 128-wide K-tiles with the largest ||W_lo[:, tile]||_F rms(A[.., tile]) (static per matrix)
+#   "none"     no weight-side term (for scale)
+# W_SIDE_ONLY: restrict the alternative form to these weight knobs (e.g. {"w_1"}); the others keep the engine's form.
+W_SIDE_MODE = None
+W_SIDE_ONLY = None
+_cur_wknob = None
+
+
+def _e2m1_mx(x, axis=-1, block=32):
+    """MX-fp4: e2m1 (values 0, .5, 1, 1.5, 2, 3, 4, 6 x sign) with one shared power-of-two scale per `block` consecutive elements along `axis` (scale = 2^(floor(log2 max) - 2))."""
+    x = np.moveaxis(np.asarray(x, np.float64), axis, -1)
+    sh = x.shape
+    pad = (-sh[-1]) % block
+    if pad:
+        x = np.concatenate([x, np.zeros(sh[:-1] + (pad,))], -1)
+    xb = x.reshape(x.shape[:-1] + (-1, block))
+    m = np.abs(xb).max(-1, keepdims=True)
+    e = np.where(m > 0, np.floor(np.log2(np.where(m > 0, m, 1.0))) - 2.0, 0.0)
+    y = xb / 2.0 ** e
+    grid = np.array([0.0, 0.5, 1.0, 1.5, 2.0, 3.0, 4.0, 6.0])
+    a = np.minimum(np.abs(y), 6.0)
+    idx = np.abs(a[..., None] - grid).argmin(-1)
+    q = np.copysign(grid[idx], y) * 2.0 ** e
+    q = q.reshape(x.shape)[..., :sh[-1]]
+    return np.moveaxis(q, -1, axis)
+
+
+def _wside_term(ah8, wl8, A):
+    mode = W_SIDE_MODE if (W_SIDE_ONLY is None or _cur_wknob in W_SIDE_ONLY) else None
+    if mode is None:
+        return ah8 @ wl8.T
+    if mode == "none":
+        return 0.0
+    if mode == "fp4":
+        return _e2m1_mx(ah8) @ _e2m1_mx(wl8).T
+    if mode == "sparse":
+        w4 = wl8.reshape(wl8.shape[0], -1, 4)
+        order = np.argsort(-np.abs(w4), -1)
+        keep = np.zeros_like(w4, bool)
+        np.put_along_axis(keep, order[..., :2], True, -1)
+        return ah8 @ (w4 * keep).reshape(wl8.shape).T
+    if mode == "tophalf":
+        K = wl8.shape[1]
+        nt = K // 128
+        score = np.array([np.linalg.norm(wl8[:, t * 128:(t + 1) * 128]) * np.sqrt((A[..., t * 128:(t + 1) * 128] ** 2).mean()) for t in range(nt)])
+        keep = np.zeros(K, bool)
+        for t in np.argsort(-score)[: (nt + 1) // 2]:
+            keep[t * 128:(t + 1) * 128] = True
+        return ah8[..., keep] @ wl8[:, keep].T
+    raise ValueError(mode)
+
+
 def _mm(afmt, wfmt, A, W, cls_lo=None, rows=None):
     """A @ W^T as the engine forms it.  Both operands "f16x8" (MV_F16X8): ONE fp16 sweep + two fp8 (e4m3) correction sweeps
     into the same fp32 accumulators,  A_hi W_hi + A_lo8 W_hi8 + A_hi8 W_lo8;  otherwise each operand is rounded on its own.
@@ -95,7 +151,7 @@ def _mm(afmt, wfmt, A, W, cls_lo=None, rows=None):
     if afmt in ("f16x8", "f16x8w", "f16x8q", "f16x8k", "f16x8v") and wfmt == "f16x8":
         ah, ah8, al8 = _x8_planes(A, X8_ACT_SHIFT)
         wh, wh8, wl8 = _w_planes(W)
-        out = ah @ wh.T + ah8 @ wl8.T
+        out = ah @ wh.T + _wside_term(ah8, wl8, A)
 
         def cls_term(cols):
             if cls_lo and A.ndim == 3:
@@ -216,6 +272,8 @@ def encode(w, ids, mask, cfg: Optional[Dict[str, List[str]]], heads=12, eps=1e-1
 
     def consumer(r_raw, g, b, Wm, bias, wknob, aknob, l):
         """rstd * (W'' · round(r)) + b'  ==  W · LN(r) + bias  up to the roundings"""
+        global _cur_wknob
+        _cur_wknob = wknob
         mu, rstd = _ln_stats(r_raw, eps)
         if fold_ln:
             Wg = Wm * g[None, :]
@@ -249,12 +307,15 @@ def encode(w, ids, mask, cfg: Optional[Dict[str, List[str]]], heads=12, eps=1e-1
         ctx = ((R("p", l, e) @ vh) / den).transpose(0, 2, 1, 3).reshape(B, S, H)  # the engine normalises O after P·V
         mu, rstd = _ln_stats(r, eps)
         x = (R("res", l, r) - mu) * rstd * g + b  # the residual GEMM reads the STORED stream; its statistics come from the accumulators
+        global _cur_wknob
+        _cur_wknob = "w_o"
         r1 = _mm(cfg["ctx"][l], cfg["w_o"][l], ctx, W(p + "attention.output.dense.weight"), "lo8" if cls_fix else None, rows) + W(p + "attention.output.dense.bias") + x
         g1, b1 = W(p + "attention.output.LayerNorm.weight"), W(p + "attention.output.LayerNorm.bias")
         hpre = consumer(r1, g1, b1, W(p + "intermediate.dense.weight"), W(p + "intermediate.dense.bias"), "w_1", "a_ffn1", l)
         h = orc._gelu(hpre)
         mu, rstd = _ln_stats(r1, eps)
         x1 = (R("res", l, r1) - mu) * rstd * g1 + b1
+        _cur_wknob = "w_2"
         r = _mm(cfg["h"][l], cfg["w_2"][l], h, W(p + "output.dense.weight"), "lo8" if cls_fix else None, rows) + W(p + "output.dense.bias") + x1
         if cls_side and l >= cls_from_layer:
             mu, rstd = _ln_stats(rc, eps)

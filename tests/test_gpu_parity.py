@@ -196,6 +196,50 @@ def test_attention_sinks_on_the_delimiter_tokens_hold_the_contract(gu, golden_di
         eng.close()
 
 
+def test_concentration_monitor_tells_ordinary_token_sinks_from_delimiter_sinks(gu, golden_dir):
+    """mv_attention_concentration (round 6): the special rows cover attention sinks on [CLS] / [SEP]; a head whose [CLS] row concentrates on an ORDINARY token is
+    outside the measured envelope of the default form (profiles/r06_c_sink_envelope.txt: 1.0 - 3.7e-3) — so the attention kernel keeps the largest collision mass
+    sum_{j >= 2} p[CLS row][j]^2 it has seen and counts the (sequence, head, layer) items above 0.25, and the Python wrapper warns once.  A [SEP] sink (80 % of
+    every row's mass) must NOT trip it, the same sink on a token in the middle of the sequence must, the diffuse model reads ~1 / (effective keys)."""
+    import sys
+    import warnings
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts"))
+    import r06_make_sink_refs as mk6
+    from memvul_amd.binding import Engine
+
+    refs = np.load(os.path.join(golden_dir, "r06_sink_refs.npz"))
+    seen = {}
+    for case in ("sep_all_80_3001", "mid_all_80_3001"):
+        token, rows, pct, seed = case.split("_")
+        dims, w, ids, lens, aids, alens, _ = mk6.case(token, rows, int(pct) / 100.0, int(seed), gains=refs[case + "_gains"])
+        eng = Engine(0, vocab_size=dims.vocab_size, layers=12, max_tokens=16 * 512, max_batch=16, max_anchors=16)
+        try:
+            eng.load_state_dict(w)
+            with warnings.catch_warnings(record=True) as rec:
+                warnings.simplefilter("always")
+                eng.encode(ids, lens)
+                eng.encode(ids, lens)
+            seen[case] = eng.attention_concentration() + (sum("ONE ordinary token" in str(r.message) for r in rec),)
+            assert eng.attention_concentration(reset=True)[1] == seen[case][1] and eng.attention_concentration() == (0.0, 0, 0)
+        finally:
+            eng.close()
+    gu.record("concentration_monitor", **{k: list(v) for k, v in seen.items()})
+    m_sep, n_sep, t_sep, warned_sep = seen["sep_all_80_3001"]
+    m_mid, n_mid, t_mid, warned_mid = seen["mid_all_80_3001"]
+    assert t_sep == t_mid == 2 * 8 * 12 * 12                               # two passes of 8 sequences x 12 heads x 12 layers looked at
+    assert n_sep <= 0.02 * t_sep and warned_sep == 0, seen                 # the sink sits on a special row: covered, silent
+    assert n_mid >= 0.5 * t_mid and m_mid > 0.4 and warned_mid == 1, seen  # 80 % on an ordinary token: most (sequence, head, layer) items, warned once
+    # the diffuse family of the other tests: far below the threshold
+    dk, wk = dict(layers=2), dict(qk_scale=2.0, match_scale=29.0, trained_like=True)
+    dims, w = gu.weights_for(dk, wk)
+    eng = gu.engine_for(dk, wk, compute_dtype="precise")
+    eng.attention_concentration(reset=True)
+    ids, lens = synth.make_ids(4, 256, dims.vocab_size, seed=9)
+    eng.encode(ids, lens)
+    m, n, t = eng.attention_concentration()
+    assert n == 0 and t == 4 * 12 and 0.0 < m < 0.1, (m, n, t)
+
+
 def test_cls_row_aside_is_decided_per_sequence(gu, golden_dir):
     """The other rows' A-side rounding reaches the [CLS] row averaged over the keys (tests/test_precision_model.py::test_cls_row_form_needs_keys_to_average_over), so a sequence takes the form only if it has at least
     MEMVUL_CLS_ASIDE_MIN_LEN (128) tokens — decided per 256-row tile from the sequence's own length (GemmArgs::tile_both), so that a row's result
