@@ -162,7 +162,9 @@ def evaluate_arrays(model, arrays: Dict[str, Any], batch_size: int = 512, output
     model.eval()
     if record_workers is None:
         record_workers = int(os.environ.get("MEMVUL_RECORD_WORKERS", "0"))
-    n = len(arrays["lens"])
+    # ``arrays``: the whole set as one dict (ReaderMemory.read_arrays) or a stream of such dicts (ReaderMemory.iter_arrays: each a multiple of batch_size
+    # samples but the last; the next one is being tokenised while this one is scored)
+    parts = [arrays] if isinstance(arrays, dict) else arrays
     step = max(1, chunk_batches) * batch_size
     q: "queue.Queue" = queue.Queue(maxsize=2)
     err: List[BaseException] = []
@@ -176,10 +178,10 @@ def evaluate_arrays(model, arrays: Dict[str, Any], batch_size: int = 512, output
                     item = q.get()
                     if item is None:
                         return
-                    s0, p_same = item
+                    part, s0, p_same = item
                     for b0 in range(0, len(p_same), batch_size):
                         a, b = s0 + b0, s0 + min(b0 + batch_size, len(p_same))
-                        rw.submit(arrays["urls"][a:b], arrays["labels"][a:b], p_same[b0:b0 + batch_size])
+                        rw.submit(part["urls"][a:b], part["labels"][a:b], p_same[b0:b0 + batch_size])
         except BaseException as e:  # surfaced on the caller's thread below
             err.append(e)
             while q.get() is not None:
@@ -190,10 +192,12 @@ def evaluate_arrays(model, arrays: Dict[str, Any], batch_size: int = 512, output
         th = threading.Thread(target=writer, name="memvul-records", daemon=True)
         th.start()
     try:
-        for s0 in range(0, n, step):
-            _, _, p_same = model.sweep_arrays(arrays, s0, min(n, s0 + step), batch_size, with_probs=th is not None)
-            if th is not None:
-                q.put((s0, p_same))
+        for part in parts:
+            n = len(part["lens"])
+            for s0 in range(0, n, step):
+                _, _, p_same = model.sweep_arrays(part, s0, min(n, s0 + step), batch_size, with_probs=th is not None)
+                if th is not None:
+                    q.put((part, s0, p_same))
     finally:
         if th is not None:
             q.put(None)
@@ -244,7 +248,11 @@ def test_siamese(archive_file, input_file, input_golden_file, test_config=None, 
     logger.info("Reading evaluation data from %s", input_file)
     if sweep == "arrays":
         bs = batch_size or int((config.get("validation_data_loader") or config.get("data_loader") or {}).get("batch_size", 512))
-        arrays = dataset_reader.read_arrays(input_file, workers=int(os.environ.get("MEMVUL_TOKENIZER_WORKERS", "0")))
+        tw = int(os.environ.get("MEMVUL_TOKENIZER_WORKERS", "0"))
+        if tw == 0 and hasattr(dataset_reader, "iter_arrays") and hasattr(getattr(dataset_reader, "_tokenizer", None), "batch_ids"):  # streamed: chunk k + 1 is tokenised while chunk k is scored
+            arrays = dataset_reader.iter_arrays(input_file, chunk=32 * bs)
+        else:
+            arrays = dataset_reader.read_arrays(input_file, workers=tw)
         metrics = evaluate_arrays(model, arrays, bs, output_file=output_file, predictions_output_file=predictions_output_file)
         logger.info("Finished evaluating.")
         return metrics

@@ -164,6 +164,37 @@ class ReaderMemory(DatasetReader):
         return {"type": type_, "ids": ids, "lens": lens, "same": same, "labels": labels,
                 "urls": [s["Issue_Url"] for s in all_data], "n_total": n_total, "first": first}
 
+    def iter_arrays(self, file_path, chunk: int = 16384):
+        """``read_arrays`` as a stream of array dicts of ``chunk`` consecutive samples each (same order, same keys; ``first`` = the chunk's offset in the
+        whole set), the NEXT chunk's batched tokenisation running on a helper thread while the caller scores this one (predict_memory.evaluate_arrays):
+        the whole-job rate of the array form is then bound by the slower of the two stages, not by their sum."""
+        from concurrent.futures import ThreadPoolExecutor
+
+        if "test_" in file_path:
+            type_ = "unlabel"
+        elif "validation_" in file_path and "golden" not in file_path:
+            type_ = "test"
+        else:
+            raise NotImplementedError("iter_arrays serves the 'test_' / 'validation_' branches (reader_memory.py:146-157)")
+        dataset = self._grouped_samples(file_path)
+        all_data = [s for group in dataset.values() for s in group]
+        all_data.reverse()
+        n_total = len(all_data)
+
+        def make(first):
+            part = all_data[first:first + chunk]
+            ids, lens = self._tokenizer.batch_ids([self._text_of(s) for s in part])
+            return {"type": type_, "ids": ids, "lens": lens, "same": np.fromiter((s[self._target] == "pos" for s in part), dtype=bool, count=len(part)),
+                    "labels": [s["CWE_ID"] if s[self._target] == "pos" else s[self._target] for s in part],
+                    "urls": [s["Issue_Url"] for s in part], "n_total": n_total, "first": first}
+
+        with ThreadPoolExecutor(1) as ex:
+            fut = ex.submit(make, 0) if n_total else None
+            for first in range(0, n_total, chunk):
+                cur = fut.result()
+                fut = ex.submit(make, first + chunk) if first + chunk < n_total else None
+                yield cur
+
     def _stream(self, samples, type_):
         """Instances of ``samples`` in order, tokenised STREAM_CHUNK texts per batched call with the NEXT chunk's call running on a helper thread (the
         WordPiece backend releases the GIL) while this chunk's Instances are consumed — so that a consumer that scores batches as they arrive

@@ -226,7 +226,7 @@ def test_concentration_monitor_tells_ordinary_token_sinks_from_delimiter_sinks(g
     gu.record("concentration_monitor", **{k: list(v) for k, v in seen.items()})
     m_sep, n_sep, t_sep, warned_sep = seen["sep_all_80_3001"]
     m_mid, n_mid, t_mid, warned_mid = seen["mid_all_80_3001"]
-    assert t_sep == t_mid == 2 * 8 * 12 * 12                               # two passes of 8 sequences x 12 heads x 12 layers looked at
+    assert t_sep == t_mid == 2 * 8 * 12 * 11                               # two passes of 8 sequences x 12 heads x 11 layers looked at (the pruned last layer runs the single-query tail)
     assert n_sep <= 0.02 * t_sep and warned_sep == 0, seen                 # the sink sits on a special row: covered, silent
     assert n_mid >= 0.5 * t_mid and m_mid > 0.4 and warned_mid == 1, seen  # 80 % on an ordinary token: most (sequence, head, layer) items, warned once
     # the diffuse family of the other tests: far below the threshold
