@@ -789,7 +789,7 @@ def mode_profile(eng, step, K, M, S, G, layers):
 def cfg3_leg(eng, dims, mode, K, W, streams, profile=True, B3=128, S3=512):
     """BASELINE.json configs[2] on the engine that carried `value` (same compute dtype): S = 512, B = 128 — rate, executed-FLOP
     fraction of the MFMA peak, the dominant GEMM class's roofline and the attention kernel's launch time (the S = 512 attention runs
-    the chunked online-softmax form of attention_v2.h).  rocprofv3 evidence: profiles/r04_cfg3_* (scripts/gpu_pmc.sh cfg3)."""
+    the chunked online-softmax form of attention_v2.h).  rocprofv3 evidence: profiles/r06_cfg3_precise_* (scripts/gpu_pmc.sh cfg3)."""
     nb = 8
     ids, lens = synth.make_ids(nb * B3, S3, dims.vocab_size, seed=synth.SEED + 303)
     eng.corpus_upload(ids, lens)
