@@ -238,18 +238,27 @@ def _ln_stats(x, eps):
 
 
 def encode(w, ids, mask, cfg: Optional[Dict[str, List[str]]], heads=12, eps=1e-12, fold_ln=True, cls_side=None, cls_raw_kv=False,
-           cls_from_layer=0, cls_fix=False, special="cls", special_v=None, special_a_qkv=True):
+           cls_from_layer=0, cls_fix=False, special="cls", special_v=None, special_a_qkv=True, res_special=None):
     """float64 BERT forward with the engine's rounding points (``cfg`` None = exact).  ``fold_ln``: the QKV / FFN-1
     weights are rounded AFTER the preceding LayerNorm is folded in (W'' = W gamma - rowmean, gemm_pp.h) and the A operand
     is the raw (pre-LayerNorm) stream, as on the engine's persistent-GEMM path.  ``cls_fix``: the [CLS]-row A-side term of the shipped form
     (see _mm) in every GEMM whose A format sweeps the weight-side term only; ``special`` = "cls" (row 0 of every sequence) or "cls+sep" (round 6:
     also its last token: the two tokens trained BERT heads use as attention sinks).  ``special_v`` (a format name, e.g. "f16x2"): V of the special rows is
-    stored in that format instead of the ``v`` knob's (the attention kernel adds p[:, special] V_lo[special]: two rank-1 updates per head)."""
+    stored in that format instead of the ``v`` knob's (the attention kernel adds p[:, special] V_lo[special]: two rank-1 updates per head).  ``res_special`` (a format
+    name): the special rows of the STORED residual stream keep that format while every other row follows the ``res`` knob (a model-side experiment of round 6: the stream
+    of the ordinary rows as its hi plane alone)."""
     W = lambda k: w[PFX + k].astype(np.float64)  # noqa: E731
     L = orc.n_layers(w)
     if cfg is None:
         cfg = engine_formats(L, "exact")
-    R = lambda knob, l, x: FORMATS[cfg[knob][l]](x)  # noqa: E731
+    def R(knob, l, x):
+        y = FORMATS[cfg[knob][l]](x)
+        if knob == "res" and res_special:
+            rr = np.zeros((x.shape[0], 1), np.int64) if rows is None else rows
+            for j in range(rr.shape[1]):
+                y[np.arange(x.shape[0]), rr[:, j]] = FORMATS[res_special](x[np.arange(x.shape[0]), rr[:, j]])
+        return y
+
     for k3 in ("q", "k", "v"):
         cfg.setdefault(k3, cfg["qkv"])
     B, S = ids.shape
