@@ -176,7 +176,7 @@ int mv_x8_saturation(mv_handle* h, int64_t* clamped, int reset);
 /* MV_F16X8 only (0 / 0 in MV_F16).  The concentration monitor: what the default form's 1e-3 is measured for is diffuse attention and attention sinks on the two
  * delimiter tokens — the [CLS] and the [SEP] token of a sequence sit in its rows 0 and 1 (the "special rows": A-side correction terms in every GEMM, V as hi + lo;
  * DESIGN.md section 2) — as trained BERT heads have them (custom_PTM_embedder.py:228 runs HF BertModel).  A head whose [CLS] row puts most of its mass on ONE
- * ORDINARY token is outside that envelope (measured 1.0 - 3.7e-3 with 50 - 80 % of the mass there, profiles/r06_c_sink_envelope.txt).  The attention kernel
+ * ORDINARY token is outside that envelope (measured 0.8 - 2.7e-3 with 50 - 80 % of the mass there, profiles/r06_k_sink_envelope.txt).  The attention kernel
  * therefore keeps, at no measurable cost, *max_collision = the maximum over every (sequence, head, layer) processed since the handle was created (or the last reset)
  * of sum_{j >= 2} p[CLS row][j]^2 (>= f^2 when one ordinary token holds the share f), *items_over = how many of them exceeded 0.25 (f > 0.5) and *items_total = how
  * many were looked at (sequences of at least 16 tokens); synchronises.  The Python wrapper warns once when more than 2 % of the items are over (binding.Engine).

@@ -134,11 +134,13 @@ struct Work {
   half_t *c16 = nullptr, *cctx = nullptr, *ch16 = nullptr;
   float *lnstats = nullptr, *lnpart = nullptr;  // the two vstats buffers [T][3][2] of the virtual LayerNorm (layer input / mid-layer;
                                                 // each residual GEMM reads one, writes the other)
-  half_t* xlo = nullptr;                        // lo plane of the two-plane raw stream (PP_RESLN3)
+  half_t* xlo = nullptr;                        // MV_F16: lo plane of the two-plane raw stream (PP_RESLN3).  MV_F16X8 does not touch it: the stream's low part is the lo8 plane of x8 (+ st_lo)
   uint8_t *x8 = nullptr, *ctx8 = nullptr, *h8 = nullptr;  // MV_F16X8: [lo8 | hi8] planes of the raw stream [T][1536], the attention
                                                           // context [T][1536] and the GELU output [T][6144]
   half_t* cls_lo = nullptr;   // MV_F16X8, special rows (rows 0, 1 of every sequence: its [CLS] and [SEP] token): 2^11 x the low parts of those rows of the NEXT GEMM's A operand,
                               // compact [2 Bp][3072] fp16, written by the producing kernel's epilogue (GemmArgs::sp_lo_out / AttnArgs::sp_lo_out / embed_ln_kernel)
+  half_t* st_lo = nullptr;    // ... 2^11 x the low parts of those rows of the RAW STREAM [2 Bp][768]: the A operand of the QKV / FFN-1 row terms, and — in the [CLS]-row form,
+                              // with the stream of every other row being hi + the lo8 plane of its fp8 planes (gemm.h GemmArgs::out16b) — what the residual GEMMs read back
   float* cls_corr = nullptr;  // ... and 2^11 x their A-side correction term A_lo W_hi^T [2 Bp][3072] (GemmArgs::cls_corr)
   half_t* vlo_sp = nullptr;   // 2^11 x the low parts of V of the special rows [B 12][64][2] (GemmArgs::vlo_sp -> AttnArgs::vlo_sp)
   int32_t* tile_both = nullptr;  // cls_aside: per 256-row tile of the pass, non-zero = its sequence is shorter than cls_min_len (GemmArgs::tile_both)
@@ -477,7 +479,7 @@ int encode_dev(mv_handle* h, const int32_t* d_ids, const int32_t* d_lens, int B,
   if (n_layers < 0 || n_layers > c.layers) n_layers = c.layers;
   h->dbg_B = B;
   h->dbg_Sp = Sp;
-  const bool big = pp_selected(h, Mpad);  // persistent GEMMs, raw two-plane stream (x16 = hi, xlo = lo), virtual LayerNorm
+  const bool big = pp_selected(h, Mpad);  // persistent GEMMs, raw stream as hi + a low part (x16 = hi; MV_F16: xlo, MV_F16X8: the lo8 plane of x8 + st_lo), virtual LayerNorm
   const bool x8 = h->precise;             // MV_F16X8: + fp8 correction sweeps (forces the persistent path, pp_selected)
   const bool prune = !full && h->cls_prune && u_out && n_layers == c.layers && n_layers > 0;
   // The [CLS]-row form (mv_handle::cls_aside): every persistent GEMM of this pass sweeps the weight-side correction term only (x8_terms = 1) and the
@@ -499,10 +501,10 @@ int encode_dev(mv_handle* h, const int32_t* d_ids, const int32_t* d_lens, int B,
   // (no gather launch), and attention adds p[:, 0..1] V_lo[0..1].  The K and V blocks of the QKV projection take it in every pass of this compute dtype (they
   // never sweep the A-side term for all rows by default), the other three GEMMs where the [CLS]-row form is in force.
   const bool special = big && x8;
-  auto row_term = [&](const half_t* W, int N, int K) -> int {  // cls_corr [2 B][N] = cls_lo [2 B][K] W^T (both 2^11 x)
+  auto row_term = [&](const half_t* A, const half_t* W, int N, int K) -> int {  // cls_corr [2 B][N] = A [2 B][K] W^T (both 2^11 x); A = st_lo (stream) or cls_lo (context, GELU output)
     ProfScope ps(h, KC_CLS_ROW_TERM);
     GemmArgs t{};
-    t.M = (int)round_up(2 * B, 64); t.Mreal = 2 * B; t.S = 64; t.A = h->w->cls_lo; t.W = W; t.N = N; t.K = K; t.outf = h->w->cls_corr;
+    t.M = (int)round_up(2 * B, 64); t.Mreal = 2 * B; t.S = 64; t.A = A; t.W = W; t.N = N; t.K = K; t.outf = h->w->cls_corr;
     t.GN = choose_gn(N / 64, 8);
     hipLaunchKernelGGL((gemm_ring_kernel<EPI_F32, 1, 1, 2, 2, 64, 4, 2>), dim3((unsigned)((t.M / 64) * (N / 64))), dim3(256), RING64_LDS, h->w->stream, t);
     return launch_check(h, "row term gemm_ring");
@@ -513,8 +515,8 @@ int encode_dev(mv_handle* h, const int32_t* d_ids, const int32_t* d_lens, int B,
     if (big)
       hipLaunchKernelGGL(embed_ln_kernel<true>, dim3(ln_grid), dim3(256), 0, h->w->stream, d_ids, pitch, S_in, Sp, (int)M, c.vocab_size,
                          h->wemb, h->pemb, h->temb, h->embg, h->embb, c.ln_eps, h->w->xres, h->w->x16, h->w->lnstats,
-                         h->w->xlo, x8 ? h->w->x8 : (uint8_t*)nullptr, h->x8_sat, special ? d_lens : (const int32_t*)nullptr,
-                         special ? h->w->cls_lo : (half_t*)nullptr);
+                         x8 ? (half_t*)nullptr : h->w->xlo, x8 ? h->w->x8 : (uint8_t*)nullptr, h->x8_sat, special ? d_lens : (const int32_t*)nullptr,
+                         special ? h->w->st_lo : (half_t*)nullptr);
     else
       hipLaunchKernelGGL(embed_ln_kernel<false>, dim3(ln_grid), dim3(256), 0, h->w->stream, d_ids, pitch, S_in, Sp, (int)M, c.vocab_size,
                          h->wemb, h->pemb, h->temb, h->embg, h->embb, c.ln_eps, h->w->xres, h->w->x16, (float*)nullptr,
@@ -531,7 +533,8 @@ int encode_dev(mv_handle* h, const int32_t* d_ids, const int32_t* d_lens, int B,
   };
   auto final_ln = [&](const float* g, const float* b) -> int {  // two-plane raw stream -> normalised fp32 rows (pooler / debug taps)
     const size_t n4 = (size_t)M * MV_HIDDEN / 4;
-    hipLaunchKernelGGL(hilo_to_f32_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, h->w->stream, h->w->x16, h->w->xlo, n4, h->w->xres);
+    hipLaunchKernelGGL(hilo_to_f32_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, h->w->stream, h->w->x16, h->w->xlo, n4, h->w->xres,
+                       special ? (const half_t*)h->w->st_lo : (const half_t*)nullptr, Sp, (const uint8_t*)h->w->x8);
     if (int rc = launch_check(h, "hilo_to_f32")) return rc;
     return run_ln(h->w->xres, h->w->x16, (int)M, g, b);
   };
@@ -558,7 +561,7 @@ int encode_dev(mv_handle* h, const int32_t* d_ids, const int32_t* d_lens, int B,
         if (x8) { g.A8 = h->w->x8; g.W8 = w.wqkv_f8 + (size_t)MV_HIDDEN * 2 * MV_HIDDEN; g.x8_scale = w.sc_qkv; g.x8_terms = 3; g.x8_aside_mask = h->qkv_aside_mask; }
         if (special) {  // K and V of the special rows: row term wherever a block sweeps the weight-side term only; V also as hi + lo (the [CLS] query itself is fp32: the tail below)
           if ((h->qkv_aside_mask & 6) != 6) {
-            if (int rc = row_term(g.W, g.N, g.K)) return rc;
+            if (int rc = row_term(h->w->st_lo, g.W, g.N, g.K)) return rc;
             g.cls_corr = h->w->cls_corr;
           }
           g.vlo_sp = (h->short_vlo && Sp <= 128) ? nullptr : h->w->vlo_sp;
@@ -571,7 +574,7 @@ int encode_dev(mv_handle* h, const int32_t* d_ids, const int32_t* d_lens, int B,
       auto tail_rc = [&]() -> int {
         hipLaunchKernelGGL(cls_gather_kernel, dim3((B + 3) / 4), dim3(256), 0, h->w->stream, h->w->xres, h->w->x16, Sp, B,
                            big ? st_in : (const float*)nullptr, pend_g, pend_b, h->w->c32, h->w->c16, big ? 1 : 0,
-                           big ? h->w->xlo : (const half_t*)nullptr, big ? 1 : 0, c.ln_eps);
+                           big ? h->w->xlo : (const half_t*)nullptr, big ? 1 : 0, c.ln_eps, special ? (const half_t*)h->w->st_lo : (const half_t*)nullptr);
         if (int rc = launch_check(h, "cls_gather")) return rc;
         if (x8) {
           // MV_F16X8: the B [CLS] rows in full fp32 on the fp32-input matrix cores (their operand rounding would reach the
@@ -628,7 +631,7 @@ int encode_dev(mv_handle* h, const int32_t* d_ids, const int32_t* d_lens, int B,
       // every query and the term buys nothing (round 5: model, four draws); with an attention sink on that token they reach every row un-averaged.
       if (special) {
         if (h->qkv_aside_mask != 7) {
-          if (int rc = row_term(g.W, g.N, g.K)) return rc;
+          if (int rc = row_term(h->w->st_lo, g.W, g.N, g.K)) return rc;
           g.cls_corr = h->w->cls_corr;
         }
         g.vlo_sp = g.vt_lo ? nullptr : h->w->vlo_sp;
@@ -642,21 +645,22 @@ int encode_dev(mv_handle* h, const int32_t* d_ids, const int32_t* d_lens, int B,
       g.lnstats = st_in; g.lng = pend_g; g.lnb = pend_b; g.lnpart = st_mid; g.out16 = h->w->x16; g.out16b = h->w->xlo;
       if (x8) { g.A8 = h->w->ctx8; g.W8 = w.wo8; g.x8_scale = w.sc_o; g.out8 = h->w->x8; g.x8_terms = 2; }
       if (cls_as) {
-        if (int rc = row_term(g.W, g.N, g.K)) return rc;
+        if (int rc = row_term(h->w->cls_lo, g.W, g.N, g.K)) return rc;  // (the context's special low parts: launch_attention)
         g.cls_corr = h->w->cls_corr; g.x8_terms = 1;  // (cls_corr stays set for the rest of the layer: every GEMM's term goes through the same buffer)
-        g.out8_hi_only = 1;  // the stream planes this launch writes are FFN-1's A8: weight-side term only
-        g.sp_lo_out = h->w->cls_lo;  // the new stream rows' special low parts: FFN-1's row term
+        g.out8_hi_only = 0;  // FFN-1 sweeps the weight-side term only (hi8), but the lo8 plane IS the stream's low part: FFN-2 reads it back (gemm.h GemmArgs::out16b)
       }
+      if (special) g.sp_lo_out = h->w->st_lo;  // the stream rows' special low parts, read back and rewritten in place: FFN-1's row term, and FFN-2's residual
       if (int rc = launch_pp<PP_RESLN3>(h, KC_GEMM_OUT, g)) return rc;
       pend_g = w.ln1g; pend_b = w.ln1b;
       // K5: FFN-1 + exact-erf GELU
       g.A = h->w->x16; g.W = w.w1_f; g.bias = w.b1_f; g.N = MV_INTER; g.K = MV_HIDDEN; g.lnstats = st_mid; g.out16 = h->w->h16;
-      g.out16b = nullptr; g.lnpart = nullptr;
+      g.out16b = nullptr; g.lnpart = nullptr; g.sp_lo_out = nullptr;
       if (x8) { g.A8 = h->w->x8; g.W8 = w.w1_f8; g.x8_scale = w.sc_1; g.out8 = h->w->h8; g.x8_terms = 2; }
       if (cls_as) {
-        if (int rc = row_term(g.W, g.N, g.K)) return rc;
+        if (int rc = row_term(h->w->st_lo, g.W, g.N, g.K)) return rc;
         g.x8_terms = 1;
         g.out8_hi_only = 1;  // h8 is FFN-2's A8: hi8 alone
+        g.sp_lo_out = h->w->cls_lo;  // the GELU output's special low parts: FFN-2's row term
       }
       if (int rc = launch_pp<PP_GELU>(h, KC_GEMM_FFN1, g)) return rc;
       // K6: FFN-2 + bias + LayerNorm(residual)
@@ -664,13 +668,13 @@ int encode_dev(mv_handle* h, const int32_t* d_ids, const int32_t* d_lens, int B,
       g.lnstats = st_mid; g.lng = pend_g; g.lnb = pend_b; g.lnpart = st_in; g.out16 = h->w->x16; g.out16b = h->w->xlo;
       if (x8) { g.A8 = h->w->h8; g.W8 = w.w28; g.x8_scale = w.sc_2; g.out8 = h->w->x8; g.x8_terms = 2; }
       if (cls_as) {
-        if (int rc = row_term(g.W, g.N, g.K)) return rc;
+        if (int rc = row_term(h->w->cls_lo, g.W, g.N, g.K)) return rc;
         g.x8_terms = 1;
-        g.out8_hi_only = h->qkv_aside_mask == 0;  // the next QKV projection reads the stream's lo8 plane only in a block that sweeps its A-side term
+        g.out8_hi_only = 0;  // the lo8 plane is the stream's low part as well as the A-side operand of the next QKV projection's Q block
       } else {
         g.cls_corr = nullptr;
       }
-      if (special) g.sp_lo_out = h->w->cls_lo;  // the next layer's QKV row term reads the new stream rows' special low parts in every pass of this compute dtype
+      if (special) g.sp_lo_out = h->w->st_lo;  // the next layer's QKV row term reads the new stream rows' special low parts in every pass of this compute dtype
       if (int rc = launch_pp<PP_RESLN3>(h, KC_GEMM_FFN2, g)) return rc;
       pend_g = w.ln2g; pend_b = w.ln2b;
       if (last) { if (int rc = final_ln(w.ln2g, w.ln2b)) return rc; }  // the pooler reads a normalised stream
@@ -1257,6 +1261,7 @@ int mv_finalize_weights(mv_handle* h, int compute_dtype) try {
       if (rc == MV_OK) rc = dev_alloc(h, &h->work[wi].ch32, (int64_t)round_up(h->cfg.max_batch, 256) * MV_INTER);
       if (rc == MV_OK) rc = dev_alloc(h, &h->work[wi].cls_lo, 2 * (int64_t)round_up(h->cfg.max_batch, 256) * MV_INTER);
       if (rc == MV_OK) rc = dev_alloc(h, &h->work[wi].cls_corr, 2 * (int64_t)round_up(h->cfg.max_batch, 256) * MV_INTER);
+      if (rc == MV_OK) rc = dev_alloc(h, &h->work[wi].st_lo, 2 * (int64_t)round_up(h->cfg.max_batch, 256) * MV_HIDDEN);
       if (rc == MV_OK) rc = dev_alloc(h, &h->work[wi].vlo_sp, (int64_t)h->cfg.max_batch * MV_HEADS * MV_HEAD_DIM * 2);
       if (rc == MV_OK) rc = dev_alloc(h, &h->work[wi].tile_both, h->cap_tokens / 256 + 1);
       if (h->short_vlo) {  // second fp16 planes of V^T, Q, K: read only by passes of padded length <= 128 in this compute dtype (attention_v2.h VLO)

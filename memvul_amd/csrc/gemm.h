@@ -37,7 +37,10 @@ struct GemmArgs {
   int GN;             // raster group width in tiles (divides N / tile)
   float* outf;        // EPI_F32: [M][N]
   half_t* out16;      // EPI_GELU: [M][N]; PP_RESLN3: the hi plane of the raw stream (the next consumer's fp16 operand)
-  half_t* out16b;     // PP_RESLN3: the lo plane, fp16(r - hi)
+  half_t* out16b;     // PP_RESLN3, MV_F16: the lo plane, fp16(r - hi).  MV_F16X8 (round 6) has no lo fp16 plane: the residual's low part is read back from the lo8 plane of
+                      // out8 (in place: r ~= hi + lo8 2^-(11 + shift), 2^-15 of the element), and the SPECIAL rows' — whose stream reaches the pooler un-averaged — from
+                      // sp_lo_out (hi + lo, compact): 5 of the 19 bytes per element the two residual GEMMs of a layer moved.  Round 5's lo8 stream applied to EVERY row
+                      // cost 3.0 -> 3.5e-4 on the median; model with the special rows kept as hi + lo (scripts/r06_stream_model.py): the two-plane stream's error
   float* xres;        // EPI_RES: [M][N] residual stream, updated in place
   half_t* q;          // EPI_QKV: [B][12][S][64]  (W_q, b_q pre-scaled by 1/8)
   half_t* k;          //          [B][12][S][64]

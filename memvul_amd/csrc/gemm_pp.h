@@ -44,7 +44,8 @@
 // producer (PP_RESLN3) normalises the residual tile it loads anyway while initialising the accumulators and writes the new raw
 // stream as TWO fp16 planes  hi = fp16(r)  (the operand of the RAW consumers),  lo = fp16(r - hi)  (r ~= hi + lo to 2^-22)
 // plus the rows' "vstats": per row and 256-column tile the (sum, sum of squares); every consumer turns the three pairs of a
-// row into (mean, rstd) itself (common.h ln_from_partials).
+// row into (mean, rstd) itself (common.h ln_from_partials).  (X8: no lo fp16 plane — the low part is the lo8 plane of the stream's fp8 planes, the special
+// rows' the compact sp_lo_out: park_residual, gemm.h GemmArgs::out16b.)
 //
 // X8 = 1 (compute dtype MV_F16X8, "precise"): every GEMM adds a SECOND sweep (x8_terms = 1: its weight-side half only) on the fp8 matrix path into the same fp32
 // accumulators:  A W ~= A_hi W_hi + 2^-s (A_lo8 W_hi8 + A_hi8 W_lo8),  A_hi = fp16(A), A_lo8 = e4m3((A - A_hi) 2^(11 + sa)),
@@ -187,6 +188,7 @@ __device__ __forceinline__ void scr_f16_rev2(uint32_t wc, const u32x4& a0, const
   __builtin_amdgcn_sched_barrier(0);
 #endif
 }
+
 
 // PP_RESLN3 accumulator init: one float4 of each of the bias, gamma and beta images (gamma at +3072 B, beta at +6144 B).
 __device__ __forceinline__ void lds_read_bgb1(uint32_t addr, float4& bi, float4& ga, float4& be) {
@@ -404,8 +406,21 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmArgs a) {
   // the two fp16 planes of the 32 x 32 block i (token rows) x j (columns) of the residual tile at (mw0, nw0) by full-line loads
   // (16 rows x 64 B per instruction), parked in the four accumulators of that block: acc[2 i + pl][2 j + x] = plane pl (hi, lo),
   // rows crow + 16 x — the accumulator init transposes them into the C/D layout
+  // X8 (MV_F16X8): the raw stream has NO lo fp16 plane.  The rows' low part is the lo8 plane of the stream's fp8 planes (out8, in place: rows [lo8 (768) | hi8 (768)];
+  // 16 rows x 32 B per instruction), parked in registers 0, 1 of the lo slot — except the SPECIAL rows' (rows 0, 1 of a sequence = lanes crow < 2 of block row 0 or 2),
+  // which take 2^11 x their low parts from the compact sp_lo_out (16 B; what the previous residual GEMM or the embedding kernel left there: a tile reads its
+  // entries before it writes them); the accumulator init turns both into what a lo fp16 plane would hold
   auto park_residual = [&](int i, int mw0, int nw0) {
     const int crow = lane >> 2, cchunk = lane & 3;
+    bool sp_c = false;  // this lane's row of block row i (x = 0) is a special row
+    size_t sp_off = 0;
+    if constexpr (X8) {
+      if ((i & 1) == 0) {
+        const int row0 = mw0 + 32 * i, b = row0 / a.S;
+        sp_c = row0 < a.Mreal && b * a.S == row0 && crow < 2;
+        sp_off = (size_t)(2 * b + crow) * MV_HIDDEN;
+      }
+    }
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -413,8 +428,20 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmArgs a) {
 #pragma unroll
         for (int x = 0; x < 2; ++x) {
           const size_t row = (size_t)(mw0 + i * 32 + x * 16 + crow);
-          const half_t* src = (pl ? a.out16b : a.out16) + row * MV_HIDDEN + nw0 + j * 32 + 8 * cchunk;
-          const float4 t = *(const float4*)src;
+          if constexpr (X8) {
+            if (pl == 1) {
+              float4 t;  // (every register written on both sides: with different register sets per side hipcc indexes the accumulator array dynamically = scratch)
+              if ((i & 1) == 0 && x == 0 && sp_c) {
+                t = *(const float4*)(a.sp_lo_out + sp_off + nw0 + j * 32 + 8 * cchunk);
+              } else {
+                const float2 u = *(const float2*)(a.out8 + row * (2 * MV_HIDDEN) + nw0 + j * 32 + 8 * cchunk);
+                t.x = u.x; t.y = u.y; t.z = 0.f; t.w = 0.f;
+              }
+              acc[2 * i + 1][2 * j + x][0] = t.x; acc[2 * i + 1][2 * j + x][1] = t.y; acc[2 * i + 1][2 * j + x][2] = t.z; acc[2 * i + 1][2 * j + x][3] = t.w;
+              continue;
+            }
+          }
+          const float4 t = *(const float4*)((pl ? a.out16b : a.out16) + row * MV_HIDDEN + nw0 + j * 32 + 8 * cchunk);
           acc[2 * i + pl][2 * j + x][0] = t.x; acc[2 * i + pl][2 * j + x][1] = t.y;
           acc[2 * i + pl][2 * j + x][2] = t.z; acc[2 * i + pl][2 * j + x][3] = t.w;
         }
@@ -584,6 +611,36 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmArgs a) {
         if (it == 0) {
 #pragma unroll
           for (int i = 0; i < 4; ++i) park_residual(i, mw, nw);
+        }
+        if constexpr (X8) {
+          // the parked lo8 bytes (two registers: 8 columns) / compact special-row parts (four registers, 2^11 x) -> the four registers of packed fp16 a lo plane
+          // would hold: e4m3 x 2^-(11 + shift) and fp16 x 2^-11 are exact in fp16 (subnormals included).  (The whole tile in front of the loop below: converting block
+          // row by block row inside it, in place or on the way into the transposition, costs 0.8 - 1 KB of scratch per lane with hipcc 7.2.)
+          const half2_t s8 = {(half_t)(1.0f / (float)(2048 << MV_X8_ACT_SHIFT)), (half_t)(1.0f / (float)(2048 << MV_X8_ACT_SHIFT))};
+          const half2_t s11 = {(half_t)(1.0f / 2048.0f), (half_t)(1.0f / 2048.0f)};
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            bool sp_c = false;
+            if ((i & 1) == 0) {
+              const int row0 = mw + 32 * i, sb0 = row0 / a.S;
+              sp_c = row0 < a.Mreal && sb0 * a.S == row0 && (lane >> 2) < 2;
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+              for (int x = 0; x < 2; ++x) {
+                floatx4& l = acc[2 * i + 1][2 * j + x];
+                const uint32_t w0 = f2u(l[0]), w1 = f2u(l[1]), w2 = f2u(l[2]), w3 = f2u(l[3]);
+                half2_t c0 = __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(w0, 1.0f, false) * s8, c1 = __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(w0, 1.0f, true) * s8;
+                half2_t c2 = __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(w1, 1.0f, false) * s8, c3 = __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(w1, 1.0f, true) * s8;
+                if ((i & 1) == 0 && x == 0 && sp_c) {
+                  c0 = __builtin_bit_cast(half2_t, w0) * s11; c1 = __builtin_bit_cast(half2_t, w1) * s11;
+                  c2 = __builtin_bit_cast(half2_t, w2) * s11; c3 = __builtin_bit_cast(half2_t, w3) * s11;
+                }
+                l[0] = u2f(__builtin_bit_cast(uint32_t, c0)); l[1] = u2f(__builtin_bit_cast(uint32_t, c1));
+                l[2] = u2f(__builtin_bit_cast(uint32_t, c2)); l[3] = u2f(__builtin_bit_cast(uint32_t, c3));
+              }
+          }
         }
 #pragma unroll
         for (int tb = 0; tb < 8; ++tb) lnst[tb] = ln_from_partials(lnp[tb][0], lnp[tb][1], lnp[tb][2], a.ln_eps);
@@ -901,7 +958,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmArgs a) {
               }
             }
           }
-          if constexpr (IS_RES) {  // second plane: lo = fp16(r - hi), same addresses in the lo buffer
+          if constexpr (IS_RES && !X8) {  // second plane: lo = fp16(r - hi), same addresses in the lo buffer (X8: the lo8 plane below is the stream's low part)
 #pragma unroll
             for (int j = 0; j < 2; ++j)
 #pragma unroll

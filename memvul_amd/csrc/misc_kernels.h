@@ -179,13 +179,32 @@ __global__ __launch_bounds__(256) void ln_kernel(float* __restrict__ x32, half_t
   ln_row_store<W32>(x, gamma, beta, eps, lane, row, x16 + (size_t)t * MV_HIDDEN, W32 ? nullptr : stats + 2 * (size_t)t);
 }
 
-// Two-plane raw stream -> fp32 rows (only the un-pruned last layer needs them: its final LayerNorm kernel reads fp32).
-__global__ __launch_bounds__(256) void hilo_to_f32_kernel(const half_t* __restrict__ hi, const half_t* __restrict__ lo, size_t n4, float* __restrict__ out) {
+// Raw stream -> fp32 rows (only the un-pruned last layer needs them: its final LayerNorm kernel reads fp32).  MV_F16: hi + lo fp16 planes.  MV_F16X8 (sp_lo != null;
+// gemm.h GemmArgs::out16b): a row's low part is the lo8 plane of x8 (rows [lo8 (768) | hi8 (768)]), a special row's (2^11 x) the compact sp_lo [2 b + row][768].
+__global__ __launch_bounds__(256) void hilo_to_f32_kernel(const half_t* __restrict__ hi, const half_t* __restrict__ lo, size_t n4, float* __restrict__ out,
+                                                          const half_t* __restrict__ sp_lo = nullptr, int Sp = 0, const uint8_t* __restrict__ x8 = nullptr) {
   const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= n4) return;
-  const half4_t h = *(const half4_t*)(hi + 4 * i), l = *(const half4_t*)(lo + 4 * i);
+  const half4_t h = *(const half4_t*)(hi + 4 * i);
+  float l[4];
+  if (!sp_lo) {
+    const half4_t t = *(const half4_t*)(lo + 4 * i);
+    l[0] = (float)t[0]; l[1] = (float)t[1]; l[2] = (float)t[2]; l[3] = (float)t[3];
+  } else {
+    const size_t row = (4 * i) / MV_HIDDEN, col = 4 * i - row * MV_HIDDEN;
+    const size_t b = row / Sp, s = row - b * Sp;
+    if (s < 2) {
+      const half4_t t = *(const half4_t*)(sp_lo + (2 * b + s) * MV_HIDDEN + col);
+      l[0] = (float)t[0] * (1.0f / 2048.0f); l[1] = (float)t[1] * (1.0f / 2048.0f); l[2] = (float)t[2] * (1.0f / 2048.0f); l[3] = (float)t[3] * (1.0f / 2048.0f);
+    } else {
+      constexpr float SLO = 1.0f / (float)(2048 << MV_X8_ACT_SHIFT);
+      const uint32_t w = *(const uint32_t*)(x8 + row * (2 * MV_HIDDEN) + col);
+      const float2_t p = __builtin_amdgcn_cvt_scalef32_pk_f32_fp8(w, 1.0f, false), q = __builtin_amdgcn_cvt_scalef32_pk_f32_fp8(w, 1.0f, true);
+      l[0] = p.x * SLO; l[1] = p.y * SLO; l[2] = q.x * SLO; l[3] = q.y * SLO;
+    }
+  }
   float4 y;
-  y.x = (float)h[0] + (float)l[0]; y.y = (float)h[1] + (float)l[1]; y.z = (float)h[2] + (float)l[2]; y.w = (float)h[3] + (float)l[3];
+  y.x = (float)h[0] + l[0]; y.y = (float)h[1] + l[1]; y.z = (float)h[2] + l[2]; y.w = (float)h[3] + l[3];
   *(float4*)(out + 4 * i) = y;
 }
 
@@ -197,12 +216,16 @@ __global__ __launch_bounds__(256) void cls_gather_kernel(const float* __restrict
                                                          int B, const float* __restrict__ stats,
                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
                                                          float* __restrict__ c32, half_t* __restrict__ c16, int raw16,
-                                                         const half_t* __restrict__ xlo, int vstats, float eps) {
+                                                         const half_t* __restrict__ xlo, int vstats, float eps,
+                                                         const half_t* __restrict__ sp_lo = nullptr) {
 #pragma clang fp contract(off)
   const int lane = threadIdx.x & 63;
   const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (b >= B) return;
   const size_t t = (size_t)b * Sp;
+  // MV_F16X8 (sp_lo != null): the stream has no lo fp16 plane; the [CLS] row's low part lives in the compact sp_lo (2^11 x), row 2 b
+  const half_t* lo_row = sp_lo ? sp_lo + (size_t)(2 * b) * MV_HIDDEN : xlo + t * MV_HIDDEN;
+  const float lo_scale = sp_lo ? 1.0f / 2048.0f : 1.0f;
   float mean = 0.f, rstd = 1.f;
   if (stats && vstats) {
     const float2* p = (const float2*)(stats + 6 * t);
@@ -216,9 +239,9 @@ __global__ __launch_bounds__(256) void cls_gather_kernel(const float* __restrict
     const int c = 4 * lane + 256 * i;
     float4 y;
     if (xlo) {  // two-plane raw stream: r = hi + lo
-      const half4_t hh = *(const half4_t*)(x16 + t * MV_HIDDEN + c), ll = *(const half4_t*)(xlo + t * MV_HIDDEN + c);
-      y.x = (float)hh[0] + (float)ll[0]; y.y = (float)hh[1] + (float)ll[1];
-      y.z = (float)hh[2] + (float)ll[2]; y.w = (float)hh[3] + (float)ll[3];
+      const half4_t hh = *(const half4_t*)(x16 + t * MV_HIDDEN + c), ll = *(const half4_t*)(lo_row + c);
+      y.x = __builtin_fmaf((float)ll[0], lo_scale, (float)hh[0]); y.y = __builtin_fmaf((float)ll[1], lo_scale, (float)hh[1]);
+      y.z = __builtin_fmaf((float)ll[2], lo_scale, (float)hh[2]); y.w = __builtin_fmaf((float)ll[3], lo_scale, (float)hh[3]);
     } else {
       y = *(const float4*)(x32 + t * MV_HIDDEN + c);
     }

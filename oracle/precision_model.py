@@ -213,7 +213,12 @@ X8_ENGINE_CLS = dict(w_qkv="f16x8", w_o="f16x8", w_1="f16x8", w_2="f16x8", a_qkv
 
 # Round 6, the special rows: the formats of X8_ENGINE_CLS with THESE keyword arguments of encode / logits are the shipped default — the row terms go to the
 # [CLS] AND the [SEP] row of every sequence (in the K / V blocks of the QKV projection too) and V of those two rows reaches attention as hi + lo
-SHIPPED_KW = dict(cls_fix=True, special="cls+sep", special_v="f16x2")
+SHIPPED_KW = dict(cls_fix=True, special="cls+sep", special_v="f16x2", res_special="exact")
+# ... and (round 6, second half) MV_F16X8 stores the residual stream of every OTHER row as hi fp16 + the lo8 plane of its fp8 planes (gemm.h GemmArgs::out16b): the knobs
+# of the shipped default are X8_ENGINE_SHIPPED with SHIPPED_KW (res_special: the special rows keep hi + lo; with the "exact" stream of X8_ENGINE_CLS it changes nothing).
+# scripts/r06_stream_model.py: this form models at the two-plane stream's error; the ordinary rows' stream as the hi plane ALONE (res="f16") at +14 % (GPU: +28 % on the
+# median of 24 draws for +4 % issue reports/s: not taken); the hi plane alone in EVERY row at 3 - 6e-3
+X8_ENGINE_SHIPPED = dict(X8_ENGINE_CLS, res="f16x8")
 
 KNOBS = ("w_qkv", "w_o", "w_1", "w_2", "a_qkv", "a_ffn1", "qkv", "p", "ctx", "h", "res")
 # (round 6) "q", "k", "v": the storage format of one of the three alone; each follows "qkv" unless given

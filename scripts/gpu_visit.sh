@@ -42,7 +42,7 @@ for step in "$@"; do
   name=${step%%:*}; arg=""; [ "$step" != "$name" ] && arg=${step#*:}
   echo "== $step ($(date +%H:%M:%S))"
   case $name in
-    suite) if [ -n "$arg" ]; then ( timeout 1500 python -m pytest tests -m gpu -q -x -k "$arg" > $V/pytest_gpu.log 2>&1; echo "pytest rc=$?" >> $V/pytest_gpu.log )
+    suite) if [ -n "$arg" ]; then ( timeout 1500 python -m pytest tests -m gpu -q -k "$arg" > $V/pytest_gpu.log 2>&1; echo "pytest rc=$?" >> $V/pytest_gpu.log )
            else ( timeout 1500 python -m pytest tests -m gpu -q > $V/pytest_gpu.log 2>&1; echo "pytest rc=$?" >> $V/pytest_gpu.log ); fi
            grep -E "passed|failed|^FAILED|^ERROR|rc=" $V/pytest_gpu.log | tail -15 ;;
     smoke) timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $V/smoke.txt 2>&1; tail -2 $V/smoke.txt ;;

@@ -51,7 +51,10 @@ def main():
     ap.add_argument("--max-draws", type=int, default=24)
     ap.add_argument("--json", default="")
     ap.add_argument("--only", default="", help="restrict to configurations whose tag starts with this (e.g. sep_all_80)")
+    ap.add_argument("--default-qkv", default="", help="run the 'default' column with MEMVUL_QKV_ASIDE set to this (an A/B of that switch over every draw)")
     args = ap.parse_args()
+    if args.default_qkv:
+        FORMS["default"] = {"MEMVUL_QKV_ASIDE": args.default_qkv}
     refs = np.load(mk6.OUT)
     cases = sorted(k[:-3] for k in refs.files if k.endswith("_lg"))
     rows = []

@@ -133,9 +133,18 @@ def test_embeddings_layernorm(gu, B, S, ragged, compute):
     eng = gu.engine_for(L2, WK, compute_dtype=compute)
     eng.debug_encode(ids, lens, 0)
     x = eng.debug_read(0)[:, :S]
-    err = float(np.abs(x - taps["embed"]).max())
+    e_row = np.abs(x - taps["embed"]).max(-1)
+    err = float(e_row.max())
     gu.record("embed_ln", B=B, S=S, compute=compute, max_err=err)
-    assert err < 2e-5
+    if compute == "precise":
+        # MV_F16X8 keeps the raw stream as hi fp16 + the lo8 plane of its fp8 planes (2^-15 of the element; gemm.h GemmArgs::out16b) — except the special rows (the [CLS]
+        # and the last token of every sequence), which keep hi + lo: their stream reaches the pooler un-averaged
+        sp = np.zeros(e_row.shape, bool)
+        for b_ in range(B):
+            sp[b_, 0] = sp[b_, lens[b_] - 1] = True
+        assert float(e_row[sp].max()) < 2e-5 and err < 1.5e-4, (float(e_row[sp].max()), err)  # measured 5.2 - 5.7e-5
+    else:
+        assert err < 2e-5
     x16 = eng.debug_read(1)[:, :S].astype(np.float32)
     assert np.abs(x16 - taps["embed"]).max() < 4e-3
 

@@ -198,7 +198,7 @@ def test_attention_sinks_on_the_delimiter_tokens_hold_the_contract(gu, golden_di
 
 def test_concentration_monitor_tells_ordinary_token_sinks_from_delimiter_sinks(gu, golden_dir):
     """mv_attention_concentration (round 6): the special rows cover attention sinks on [CLS] / [SEP]; a head whose [CLS] row concentrates on an ORDINARY token is
-    outside the measured envelope of the default form (profiles/r06_f_sink_envelope.txt: 1.0 - 3.7e-3) — so the attention kernel keeps the largest collision mass
+    outside the measured envelope of the default form (profiles/r06_k_sink_envelope.txt: 0.8 - 2.7e-3) — so the attention kernel keeps the largest collision mass
     sum_{j >= 2} p[CLS row][j]^2 it has seen and counts the (sequence, head, layer) items above 0.25, and the Python wrapper warns once.  A [SEP] sink (80 % of
     every row's mass) must NOT trip it, the same sink on a token in the middle of the sequence must, the diffuse model reads ~1 / (effective keys)."""
     import sys
