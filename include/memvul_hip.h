@@ -79,9 +79,10 @@ typedef struct mv_config {
  * message; a typo never selects other numerics silently):
  *   MEMVUL_CLS_ASIDE          1 (default) | 0.  MV_F16X8: 1 = the [CLS]-row form (every GEMM sweeps the weight-side correction term, the A-side term is
  *                             restored for the [CLS] row of each sequence alone: only that row reaches the pooler, model_memory.py:99); 0 = both first-order
- *                             terms in every row (rounds 3-4: -12 % issue reports/s, same trained-like logit error on diffuse attention).
+ *                             terms in every row (rounds 3-4: -13 % issue reports/s, same trained-like logit error on diffuse attention).
  *   MEMVUL_CLS_ASIDE_MIN_LEN  1 .. 512 (default 128): sequences shorter than this keep the both-terms form (few keys to average over).
- *   MEMVUL_QKV_ASIDE          a subset of "qkv", "" or "none" (default "q"): the blocks of the QKV projection that sweep the A-side term for every row.
+ *   MEMVUL_QKV_ASIDE          a subset of "qkv", "" or "none" (default "none"): the blocks of the QKV projection that sweep the A-side term for EVERY row (the special
+ *                             rows get it in every block either way; "q" = the default of rounds 4 - 6a: -2.7 % issue reports/s, 3 % less logit error).
  *   MEMVUL_CLS_PRUNE          1 (default) | 0: after the last layer's K / V projection only the [CLS] rows are processed.
  *   MEMVUL_STREAMS            2 (default) | 1: batches of the resident sweep in flight (mv_set_streams changes it later).
  * (The sixth switch of the product, MEMVUL_COMPUTE = precise | f16, is read by the Python surface: memvul_amd/binding.py default_compute.)
@@ -176,7 +177,7 @@ int mv_x8_saturation(mv_handle* h, int64_t* clamped, int reset);
 /* MV_F16X8 only (0 / 0 in MV_F16).  The concentration monitor: what the default form's 1e-3 is measured for is diffuse attention and attention sinks on the two
  * delimiter tokens — the [CLS] and the [SEP] token of a sequence sit in its rows 0 and 1 (the "special rows": A-side correction terms in every GEMM, V as hi + lo;
  * DESIGN.md section 2) — as trained BERT heads have them (custom_PTM_embedder.py:228 runs HF BertModel).  A head whose [CLS] row puts most of its mass on ONE
- * ORDINARY token is outside that envelope (measured 0.8 - 2.7e-3 with 50 - 80 % of the mass there, profiles/r06_k_sink_envelope.txt).  The attention kernel
+ * ORDINARY token is outside that envelope (measured 0.8 - 2.7e-3 with 50 - 80 % of the mass there, profiles/r06_n_sink_envelope.txt).  The attention kernel
  * therefore keeps, at no measurable cost, *max_collision = the maximum over every (sequence, head, layer) processed since the handle was created (or the last reset)
  * of sum_{j >= 2} p[CLS row][j]^2 (>= f^2 when one ordinary token holds the share f), *items_over = how many of them exceeded 0.25 (f > 0.5) and *items_total = how
  * many were looked at (sequences of at least 16 tokens); synchronises.  The Python wrapper warns once when more than 2 % of the items are over (binding.Engine).

@@ -234,7 +234,7 @@ class Engine:
                 self._conc_warned = True
                 warnings.warn(f"MV_F16X8: in {n} of {t} (sequence, head, layer) items the [CLS] row puts more than half of a head's attention on ONE ordinary token "
                               f"(collision mass up to {m:.2f}): the 1e-3 logit tolerance of the default form is backed by measurement for diffuse attention and "
-                              "for attention sinks on [CLS] / [SEP] only (profiles/r06_k_sink_envelope.txt: 0.8 - 2.7e-3 for such a sink); "
+                              "for attention sinks on [CLS] / [SEP] only (profiles/r06_n_sink_envelope.txt: 0.8 - 2.7e-3 for such a sink); "
                               "MEMVUL_CLS_ASIDE=0 MEMVUL_QKV_ASIDE=qkv is the most conservative form (include/memvul_hip.h mv_attention_concentration)",
                               RuntimeWarning, stacklevel=3)
         if getattr(self, "_precise", False) and not self._sat_warned:

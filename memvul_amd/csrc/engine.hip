@@ -201,9 +201,11 @@ struct mv_handle {
                            // pooler reads only that row, every other row's A-side rounding reaches it averaged over the keys.  +14 % at the same error (r05_j*, r05_k*)
   int cls_min_len = 128;   // ... for sequences of at least this many tokens (env MEMVUL_CLS_ASIDE_MIN_LEN): a short sequence averages over few keys (model: 1.2 -
                            // 1.6x the error at 16 - 128 tokens), so its row tiles run the both-terms form, bit for bit (GemmArgs::tile_both, cls_tile_flags_kernel)
-  int qkv_aside_mask = 1;  // MV_F16X8: which of the Q / K / V blocks of the QKV projection sweep the A-side correction term too (bit 0 / 1 / 2;
-                           // gemm_pp.h x8_aside_mask).  Default: Q only.  env MEMVUL_QKV_ASIDE = a subset of "qkv" ("" / "none" = weight-side
-                           // term only everywhere, "qkv" = round 3's form): the A/B switch of profiles/r04_d_*
+  int qkv_aside_mask = 0;  // MV_F16X8: which of the Q / K / V blocks of the QKV projection sweep the A-side correction term for EVERY row (bit 0 / 1 / 2;
+                           // gemm_pp.h x8_aside_mask).  Default (round 6, second half): none — the special rows get the term from their row term in every block, and an
+                           // ordinary row's Q rounding, like its K and V rounding, reaches the pooler only through attention, averaged over the keys (model: q / none / qkv
+                           // within 7 % of each other, scripts/r06_qkv_model.py; GPU, 60 draws: +3 % error for +2.7 % issue reports/s, profiles/r06_m_*).  Rounds 4 - 6a: Q ("q").
+                           // env MEMVUL_QKV_ASIDE = a subset of "qkv", "" or "none" ("qkv" = round 3's form)
 
   // profiling
   uint32_t prof_mask = 0xffffffffu;  // kernel classes that get HIP events while profiling is on

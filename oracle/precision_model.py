@@ -218,7 +218,9 @@ SHIPPED_KW = dict(cls_fix=True, special="cls+sep", special_v="f16x2", res_specia
 # of the shipped default are X8_ENGINE_SHIPPED with SHIPPED_KW (res_special: the special rows keep hi + lo; with the "exact" stream of X8_ENGINE_CLS it changes nothing).
 # scripts/r06_stream_model.py: this form models at the two-plane stream's error; the ordinary rows' stream as the hi plane ALONE (res="f16") at +14 % (GPU: +28 % on the
 # median of 24 draws for +4 % issue reports/s: not taken); the hi plane alone in EVERY row at 3 - 6e-3
-X8_ENGINE_SHIPPED = dict(X8_ENGINE_CLS, res="f16x8")
+X8_ENGINE_SHIPPED = dict(X8_ENGINE_CLS, res="f16x8", a_qkv="f16x8w")
+# (a_qkv: since the round's second half NO block of the QKV projection sweeps the A-side term for every row — MEMVUL_QKV_ASIDE's default is "none"; the special rows take it
+# from their row term in all three blocks.  scripts/r06_qkv_model.py: q / none / qkv within 7 % of each other (mean rms) over 4 diffuse + 4 sink draws)
 
 KNOBS = ("w_qkv", "w_o", "w_1", "w_2", "a_qkv", "a_ffn1", "qkv", "p", "ctx", "h", "res")
 # (round 6) "q", "k", "v": the storage format of one of the three alone; each follows "qkv" unless given

@@ -131,8 +131,8 @@ def test_cls_row_aside_form(gu, golden_dir, name, qkv_aside):
     GEMMs, added to those rows' accumulators (gemm_pp.h GemmArgs::cls_corr) — because only that row reaches the pooler un-averaged
     (oracle/precision_model.py knob `cls_fix`; tests/test_precision_model.py::test_cls_row_aside_is_priced_by_the_model).  With the term missing or
     misplaced the logits would sit at the weight-side-only level (2.7e-3, profiles/r04_a2_*): the contract bound below is the functional test.
-    `qkv_aside` = "q": the Q block of the QKV projection keeps its A-side term for every row (the default mask), "none": no block does (then the
-    QKV projection takes a row term too)."""
+    `qkv_aside` = "q": the Q block of the QKV projection keeps its A-side term for every row (the default of rounds 4 - 6a), "none": no block does (the default
+    since: the special rows take the term from the QKV projection's row term in all three blocks)."""
     import make_golden
 
     g = np.load(os.path.join(golden_dir, f"{name}.npz"))
@@ -198,7 +198,7 @@ def test_attention_sinks_on_the_delimiter_tokens_hold_the_contract(gu, golden_di
 
 def test_concentration_monitor_tells_ordinary_token_sinks_from_delimiter_sinks(gu, golden_dir):
     """mv_attention_concentration (round 6): the special rows cover attention sinks on [CLS] / [SEP]; a head whose [CLS] row concentrates on an ORDINARY token is
-    outside the measured envelope of the default form (profiles/r06_k_sink_envelope.txt: 0.8 - 2.7e-3) — so the attention kernel keeps the largest collision mass
+    outside the measured envelope of the default form (profiles/r06_n_sink_envelope.txt: 0.8 - 2.7e-3) — so the attention kernel keeps the largest collision mass
     sum_{j >= 2} p[CLS row][j]^2 it has seen and counts the (sequence, head, layer) items above 0.25, and the Python wrapper warns once.  A [SEP] sink (80 % of
     every row's mass) must NOT trip it, the same sink on a token in the middle of the sequence must, the diffuse model reads ~1 / (effective keys)."""
     import sys
