@@ -201,6 +201,11 @@ def test_documented_switch_defaults_match_the_library_source():
     assert n and int(n.group(1)) == 128
     hdr = open(os.path.join(ROOT, "include", "memvul_hip.h")).read()
     assert "MEMVUL_CLS_ASIDE          1 (default) | 0" in hdr and "MEMVUL_CLS_ASIDE_MIN_LEN  1 .. 512 (default 128)" in hdr
+    q = re.search(r"int qkv_aside_mask = (\d+);", src)  # 0 = "none" (round 6), 1 = "q" (rounds 4 - 6a)
+    assert q and int(q.group(1)) == 0 and 'MEMVUL_QKV_ASIDE          a subset of "qkv", "" or "none" (default "none")' in hdr
+    for doc in ("INTEGRATION.md", "DESIGN.md"):
+        text = " ".join(open(os.path.join(ROOT, doc)).read().split())
+        assert "default `none`" in text or "default is `none`" in text, doc
     # the development knobs are NOT product switches: the header names none of them as read by this library (engine.hip reads them under MEMVUL_DEV_SWITCHES only)
     from memvul_amd import binding
     block = src[src.index("#ifdef MEMVUL_DEV_SWITCHES"):src.index("#endif", src.index("#ifdef MEMVUL_DEV_SWITCHES"))]
