@@ -58,6 +58,7 @@ def main():
     refs = np.load(mk6.OUT)
     cases = sorted(k[:-3] for k in refs.files if k.endswith("_lg"))
     rows = []
+    pooled = {}  # the default form's signed per-logit errors, pooled over the draws with the sink on a delimiter token / on an ordinary token
     by_cfg = {}
     for t in cases:
         m = re.match(r"(\w+)_(\w+)_(\d+)_(\d+)$", t)
@@ -79,6 +80,8 @@ def main():
             rec[form] = float(np.abs(got - lg).max())
             if form == "default":
                 rec["x8_saturated"] = sat
+                rec["rms"] = float(np.sqrt(((got - lg).astype(np.float64) ** 2).mean()))
+                pooled.setdefault("ordinary" if token == "mid" else "delimiter", []).append((got - lg).ravel().astype(np.float64))
         rows.append(rec)
         print("%s seed %d: mass %.2f/%.2f eff keys %.1f/%.1f max|logit| %.2f | %s" % (
             cfg, seed, rec["stat"][0], rec["stat"][2], rec["stat"][1], rec["stat"][3], rec["max_abs_logit"],
@@ -91,8 +94,16 @@ def main():
             if v:
                 line.append("%s median %.2e max %.2e (%d)" % (form, float(np.median(v)), max(v), len(v)))
         print("  ".join(line))
+    summary = {}
+    for kind, v in sorted(pooled.items()):
+        pe = np.concatenate(v)
+        rms = float(np.sqrt((pe ** 2).mean()))
+        qs = {q: float(np.quantile(np.abs(pe), q)) for q in (0.5, 0.9, 0.99, 0.999)}
+        summary[kind] = dict(pooled_logits=len(pe), rms=rms, abs_quantiles=qs, max=float(np.abs(pe).max()))
+        print("default form, sink on a %s token, all %d logits pooled: rms %.2e  |err| p50 %.2e  p90 %.2e  p99 %.2e  p99.9 %.2e  max %.2e  (1e-3 = %.1f rms)"
+              % (kind, len(pe), rms, qs[0.5], qs[0.9], qs[0.99], qs[0.999], summary[kind]["max"], 1e-3 / rms))
     if args.json:
-        json.dump(rows, open(args.json, "w"), indent=1)
+        json.dump(rows + [dict(pooled=summary)], open(args.json, "w"), indent=1)
 
 
 if __name__ == "__main__":
