@@ -134,7 +134,7 @@ struct Work {
   half_t *c16 = nullptr, *cctx = nullptr, *ch16 = nullptr;
   float *lnstats = nullptr, *lnpart = nullptr;  // the two vstats buffers [T][3][2] of the virtual LayerNorm (layer input / mid-layer;
                                                 // each residual GEMM reads one, writes the other)
-  half_t* xlo = nullptr;                        // MV_F16: lo plane of the two-plane raw stream (PP_RESLN3).  MV_F16X8 does not touch it: the stream's low part is the lo8 plane of x8 (+ st_lo)
+  half_t* xlo = nullptr;                        // MV_F16: lo plane of the two-plane raw stream (PP_RESLN3), allocated by mv_finalize_weights.  MV_F16X8 has none: the stream's low part is the lo8 plane of x8 (+ st_lo)
   uint8_t *x8 = nullptr, *ctx8 = nullptr, *h8 = nullptr;  // MV_F16X8: [lo8 | hi8] planes of the raw stream [T][1536], the attention
                                                           // context [T][1536] and the GELU output [T][6144]
   half_t* cls_lo = nullptr;   // MV_F16X8, special rows (rows 0, 1 of every sequence: its [CLS] and [SEP] token): 2^11 x the low parts of those rows of the NEXT GEMM's A operand,
@@ -576,7 +576,7 @@ int encode_dev(mv_handle* h, const int32_t* d_ids, const int32_t* d_lens, int B,
       auto tail_rc = [&]() -> int {
         hipLaunchKernelGGL(cls_gather_kernel, dim3((B + 3) / 4), dim3(256), 0, h->w->stream, h->w->xres, h->w->x16, Sp, B,
                            big ? st_in : (const float*)nullptr, pend_g, pend_b, h->w->c32, h->w->c16, big ? 1 : 0,
-                           big ? h->w->xlo : (const half_t*)nullptr, big ? 1 : 0, c.ln_eps, special ? (const half_t*)h->w->st_lo : (const half_t*)nullptr);
+                           (big && !x8) ? h->w->xlo : (const half_t*)nullptr, big ? 1 : 0, c.ln_eps, special ? (const half_t*)h->w->st_lo : (const half_t*)nullptr);
         if (int rc = launch_check(h, "cls_gather")) return rc;
         if (x8) {
           // MV_F16X8: the B [CLS] rows in full fp32 on the fp32-input matrix cores (their operand rounding would reach the
@@ -1030,7 +1030,6 @@ int mv_create(int device, const mv_config* cfg, mv_handle** out) try {
     A(dev_alloc(h, &h->w->h16, T * MV_INTER));
     A(dev_alloc(h, &h->w->lnstats, T * 6));
     A(dev_alloc(h, &h->w->lnpart, T * 6));
-    A(dev_alloc(h, &h->w->xlo, T * MV_HIDDEN));
     A(dev_alloc(h, &h->w->c32, Bp * MV_HIDDEN));
     A(dev_alloc(h, &h->w->cq, Bp * MV_HIDDEN));
     A(dev_alloc(h, &h->w->c16, Bp * MV_HIDDEN));
@@ -1252,6 +1251,16 @@ int mv_finalize_weights(mv_handle* h, int compute_dtype) try {
   NEED("_projector.weight", 2, 3 * (int64_t)h->P);
   if ((rc = upload_f32(h, &h->Wm, t->data.data(), 2 * 3 * (int64_t)h->P))) return rc;
 #undef NEED
+  if (!precise) {  // MV_F16: the lo fp16 plane of the two-plane raw stream (MV_F16X8 keeps the stream's low part in the lo8 plane of x8 + st_lo: gemm.h GemmArgs::out16b)
+    for (int wi = 0; wi < h->n_alloc; ++wi) {
+      Work* keep = h->w;
+      h->w = &h->work[wi];
+      rc = dev_alloc(h, &h->work[wi].xlo, h->cap_tokens * MV_HIDDEN);
+      if (rc == MV_OK && hipStreamSynchronize(h->w->stream) != hipSuccess) rc = MV_ERR_HIP;
+      h->w = keep;
+      if (rc != MV_OK) return rc;
+    }
+  }
   if (precise) {  // fp8 planes [lo8 | hi8] of the three activations that are GEMM A operands
     if (h->gemm_tile == 128) return fail(h, MV_ERR_STATE, "MV_F16X8 runs on the persistent GEMM path: MEMVUL_GEMM_TILE=128 excludes it");
     for (int wi = 0; wi < h->n_alloc; ++wi) {

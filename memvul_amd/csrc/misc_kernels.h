@@ -238,7 +238,7 @@ __global__ __launch_bounds__(256) void cls_gather_kernel(const float* __restrict
   for (int i = 0; i < 3; ++i) {
     const int c = 4 * lane + 256 * i;
     float4 y;
-    if (xlo) {  // two-plane raw stream: r = hi + lo
+    if (xlo || sp_lo) {  // raw stream as hi + a low part (MV_F16: the lo plane; MV_F16X8: the [CLS] row's compact low part)
       const half4_t hh = *(const half4_t*)(x16 + t * MV_HIDDEN + c), ll = *(const half4_t*)(lo_row + c);
       y.x = __builtin_fmaf((float)ll[0], lo_scale, (float)hh[0]); y.y = __builtin_fmaf((float)ll[1], lo_scale, (float)hh[1]);
       y.z = __builtin_fmaf((float)ll[2], lo_scale, (float)hh[2]); y.w = __builtin_fmaf((float)ll[3], lo_scale, (float)hh[3]);

@@ -11,7 +11,7 @@
 #   errdist      24-draw trained-like error distribution (scripts/r05_error_distribution.py)
 #   envelope     matcher-norm / outlier envelope (scripts/r05_precision_envelope.py)        lengths  sequence-length axis (scripts/r05_length_envelope.py)
 #   sink[:args]  attention-concentration axis (scripts/r06_sink_envelope.py; args e.g. "--only sep_all_80")
-#   configs      other configurations (scripts/gpu_configs.sh)      e2e  the drop-in end to end (scripts/e2e_dropin_probe.py)
+#   configs      other configurations (scripts/gpu_configs.sh)      e2e[:args]  the drop-in end to end (scripts/r06_e2e_dropin.py [n] [record workers])
 #   cmd:<shell>  anything else
 set -u
 TAG=${1:?tag}; shift

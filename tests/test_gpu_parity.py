@@ -90,8 +90,8 @@ def test_trained_like_logits(gu, golden_dir, name, gemm_tile):
     eng.anchor_reset()
 
 
-PRECISE_TRAINED_LIKE_REGRESSION_BOUND = 5.5e-4  # the shipped default on the trained-like goldens measures 3.6 / 5.0e-4 ([CLS]-row form; both terms in every row:
-                                                 # 4.2 / 3.7e-4): a bound tight enough to catch erosion of the margin to the 1e-3 contract, not the contract itself
+PRECISE_TRAINED_LIKE_REGRESSION_BOUND = 5.5e-4  # the shipped default on the trained-like goldens measures 4.5 / 3.5e-4 (round 6; rounds 5 - 6a: 3.6 - 4.0 / 3.5 - 5.0e-4; both
+                                                 # terms in every row: 4.2 / 3.7e-4): a bound tight enough to catch erosion of the margin to the 1e-3 contract, not the contract itself
 
 
 @pytest.mark.parametrize("name", ["l12_trained_s256", "l12_trained_ragged", "l12_base_ragged", "l12_base_s256", "l2_peaky_full", "l2_ragged"])
@@ -158,7 +158,7 @@ def test_cls_row_aside_form(gu, golden_dir, name, qkv_aside):
     eng.anchor_reset(); ref.anchor_reset()
 
 
-SINK_BOUND = 6e-4  # delimiter sinks on the shipped default: measured 2.1 .. 4.9e-4 over the committed draws (profiles/r06_*_sink_envelope.txt); the contract is LOGIT_TOL
+SINK_BOUND = 6e-4  # delimiter sinks on the shipped default: measured 1.9 .. 4.2e-4 on the five committed draws below (1.7 .. 8.9e-4 over all 36: profiles/r06_n_sink_envelope.txt); the contract is LOGIT_TOL
 
 
 @pytest.mark.parametrize("case", ["sep_all_80_3001", "sep_all_95_3001", "sep_cls_80_3002", "cls_all_80_3001", "sep_all_50_3003"])
