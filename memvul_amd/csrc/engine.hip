@@ -181,6 +181,7 @@ struct mv_handle {
 
   // resident corpus
   int32_t *c_ids = nullptr, *c_lens = nullptr;
+  std::vector<int32_t> c_lens_host;  // the lengths as uploaded (encode_dev's min_len of each pass)
   int64_t c_n = 0;
   int c_S = 0;
   float* c_best = nullptr;
@@ -463,6 +464,13 @@ int launch_attention(mv_handle* h, const int32_t* d_lens, int B, int Sp, bool x8
   return launch_check(h, "attention");
 }
 
+// the shortest sequence of a pass, from the host copy of its lengths
+inline int pass_min_len(const int32_t* lens, int n) {
+  int m = INT32_MAX;
+  for (int i = 0; i < n; ++i) m = lens[i] < m ? lens[i] : m;
+  return n > 0 ? m : 0;
+}
+
 // ---- encoder: ids (device) -> u (device, [B][512]); stops after n_layers (<0: all) ------------
 // Two paths, chosen by the size of the pass (pp_selected):
 //   * bench scale: the persistent GEMMs on the two-plane raw stream with the virtual LayerNorm (gemm_pp.h), five launches per
@@ -470,8 +478,8 @@ int launch_attention(mv_handle* h, const int32_t* d_lens, int B, int Sp, bool x8
 //   * small passes: one-tile-per-workgroup GEMMs (gemm.h) on an fp32 stream with explicit LayerNorm kernels.
 // The last layer is pruned to the [CLS] rows when the pooler follows (cls_prune); `full` (debug taps) disables that and
 // leaves the normalised fp32 stream of the last layer run in xres.
-int encode_dev(mv_handle* h, const int32_t* d_ids, const int32_t* d_lens, int B, int S_in, int n_layers, float* u_out,
-               bool full = false, int pitch = 0) {
+int encode_dev(mv_handle* h, const int32_t* d_ids, const int32_t* d_lens, int min_len, int B, int S_in, int n_layers, float* u_out,
+               bool full = false, int pitch = 0) {  // min_len: the shortest sequence of the pass as the HOST knows it (pass_min_len; 0 = unknown)
   if (pitch <= 0) pitch = S_in;  // ints between the rows of d_ids
   const mv_config& c = h->cfg;
   const int Sp = padded_len(S_in);
@@ -489,9 +497,13 @@ int encode_dev(mv_handle* h, const int32_t* d_ids, const int32_t* d_lens, int B,
   // lo8 plane (context, GELU output), one skinny fp16 GEMM [B x K] x [K x N], and the launch adds the result to those rows' accumulators
   // (gemm_pp.h GemmArgs::cls_corr).  Passes of padded length 256 / 512: a 256-row tile then belongs to ONE sequence, so the form of a sequence
   // depends on its own length alone (cls_tile_flags_kernel: sequences shorter than cls_min_len keep the both-terms form, tile by tile) and a row's
-  // result stays independent of the batch it travels in.
-  const bool cls_as = big && x8 && h->cls_aside && (Sp == 256 || Sp == 512);
-  if (cls_as) {
+  // result stays independent of the batch it travels in.  Passes of padded length 192 / 384 (a tile there spans two sequences, a per-tile rule would mix the
+  // forms inside a sequence): the form for the WHOLE pass when its shortest sequence has cls_min_len tokens — what a length-sorted sweep hands over by
+  // construction (ModelMemory.sweep / Engine.bucketed_sweep: a pass at 192 holds 129 .. 192 tokens, at 384 257 .. 384) — else the both-terms form for the whole pass.
+  const bool one_seq_tiles = Sp == 256 || Sp == 512;
+  const bool whole_pass = (Sp == 192 || Sp == 384) && min_len >= h->cls_min_len;
+  const bool cls_as = big && x8 && h->cls_aside && (one_seq_tiles || whole_pass);
+  if (cls_as && one_seq_tiles) {
     const int ntile = (int)(Mpad / 256);
     hipLaunchKernelGGL(cls_tile_flags_kernel, dim3((unsigned)((ntile + 255) / 256)), dim3(256), 0, h->w->stream, d_lens, B, Sp, h->cls_min_len, ntile,
                        h->w->tile_both);
@@ -549,7 +561,7 @@ int encode_dev(mv_handle* h, const int32_t* d_ids, const int32_t* d_lens, int B,
     const bool last = (l == n_layers - 1);
     GemmArgs g{};
     g.M = (int)Mpad; g.Mreal = (int)M; g.S = Sp; g.ln_eps = c.ln_eps; g.x8_sat = h->x8_sat;
-    g.tile_both = cls_as ? h->w->tile_both : nullptr;
+    g.tile_both = (cls_as && one_seq_tiles) ? h->w->tile_both : nullptr;  // (whole_pass: no tile is short)
     g.q = h->w->q; g.k = h->w->k; g.vt = h->w->vt;
     const half_t* wqkv = big ? w.wqkv_f : w.wqkv;
     const float* bqkv = big ? w.bqkv_f : w.bqkv;
@@ -1311,7 +1323,7 @@ int mv_anchor_append(mv_handle* h, const int32_t* ids, const int32_t* lens, int 
     const int nb = (n - off < rows) ? (n - off) : rows;
     HIPCHK(h, hipMemcpyAsync(h->w->d_ids, ids + (size_t)off * S, (size_t)nb * S * 4, hipMemcpyHostToDevice, h->w->stream));
     HIPCHK(h, hipMemcpyAsync(h->w->d_lens, lens + off, (size_t)nb * 4, hipMemcpyHostToDevice, h->w->stream));
-    if (int rc = encode_dev(h, h->w->d_ids, h->w->d_lens, nb, S, -1, h->anchors + (size_t)(h->n_anchors + off) * h->P)) return rc;
+    if (int rc = encode_dev(h, h->w->d_ids, h->w->d_lens, pass_min_len(lens + off, nb), nb, S, -1, h->anchors + (size_t)(h->n_anchors + off) * h->P)) return rc;
     HIPCHK(h, hipStreamSynchronize(h->w->stream));
   }
   h->n_anchors += n;
@@ -1351,7 +1363,7 @@ int mv_encode(mv_handle* h, const int32_t* ids, const int32_t* lens, int B, int 
     const int nb = (B - off < rows) ? (B - off) : rows;
     HIPCHK(h, hipMemcpyAsync(h->w->d_ids, ids + (size_t)off * S, (size_t)nb * S * 4, hipMemcpyHostToDevice, h->w->stream));
     HIPCHK(h, hipMemcpyAsync(h->w->d_lens, lens + off, (size_t)nb * 4, hipMemcpyHostToDevice, h->w->stream));
-    if (int rc = encode_dev(h, h->w->d_ids, h->w->d_lens, nb, S, -1, h->w->u)) return rc;
+    if (int rc = encode_dev(h, h->w->d_ids, h->w->d_lens, pass_min_len(lens + off, nb), nb, S, -1, h->w->u)) return rc;
     if (embed) HIPCHK(h, hipMemcpyAsync(embed + (size_t)off * h->P, h->w->u, (size_t)nb * h->P * 4, hipMemcpyDeviceToHost, h->w->stream));
     HIPCHK(h, hipStreamSynchronize(h->w->stream));
   }
@@ -1372,7 +1384,7 @@ int mv_forward(mv_handle* h, const int32_t* ids, const int32_t* lens, int B, int
     const int nb = (B - off < rows) ? (B - off) : rows;
     HIPCHK(h, hipMemcpyAsync(h->w->d_ids, ids + (size_t)off * S, (size_t)nb * S * 4, hipMemcpyHostToDevice, h->w->stream));
     HIPCHK(h, hipMemcpyAsync(h->w->d_lens, lens + off, (size_t)nb * 4, hipMemcpyHostToDevice, h->w->stream));
-    if (int rc = encode_dev(h, h->w->d_ids, h->w->d_lens, nb, S, -1, h->w->u)) return rc;
+    if (int rc = encode_dev(h, h->w->d_ids, h->w->d_lens, pass_min_len(lens + off, nb), nb, S, -1, h->w->u)) return rc;
     // only the outputs the caller asked for leave the kernel (the best anchor always does)
     if (int rc = match_dev(h, h->w->u, nb, logits ? h->w->logits : nullptr, probs ? h->w->probs : nullptr, nullptr, 1, h->w->best,
                            h->w->best_idx)) return rc;
@@ -1437,6 +1449,7 @@ int mv_corpus_upload(mv_handle* h, const int32_t* ids, const int32_t* lens, int6
   HIPCHK(h, hipMemcpyAsync(h->c_ids, ids, (size_t)n * S * 4, hipMemcpyHostToDevice, h->w->stream));
   HIPCHK(h, hipMemcpyAsync(h->c_lens, lens, (size_t)n * 4, hipMemcpyHostToDevice, h->w->stream));
   HIPCHK(h, hipStreamSynchronize(h->w->stream));
+  h->c_lens_host.assign(lens, lens + n);
   h->c_n = n;
   h->c_S = S;
   return MV_OK;
@@ -1480,7 +1493,7 @@ int mv_corpus_run_len(mv_handle* h, int64_t first, int64_t count, int batch, int
       if (h->rr == 1) h->dual_pending = true;
       h->rr ^= 1;
     }
-    rc = encode_dev(h, h->c_ids + (size_t)off * h->c_S, h->c_lens + off, nb, S_use, -1, h->w->u, false, h->c_S);
+    rc = encode_dev(h, h->c_ids + (size_t)off * h->c_S, h->c_lens + off, pass_min_len(h->c_lens_host.data() + off, nb), nb, S_use, -1, h->w->u, false, h->c_S);
     if (rc != MV_OK) break;
     float* ps = keep_probs ? h->c_psame + (size_t)off * G : nullptr;  // P(same) [nb, G] only when the caller keeps it
     rc = match_dev(h, h->w->u, nb, nullptr, nullptr, ps, 1, h->c_best + (size_t)off * 2, h->c_idx + off);
@@ -1693,7 +1706,7 @@ int mv_debug_encode(mv_handle* h, const int32_t* ids, const int32_t* lens, int B
   HIPCHK(h, hipSetDevice(h->device));
   HIPCHK(h, hipMemcpyAsync(h->w->d_ids, ids, (size_t)B * S * 4, hipMemcpyHostToDevice, h->w->stream));
   HIPCHK(h, hipMemcpyAsync(h->w->d_lens, lens, (size_t)B * 4, hipMemcpyHostToDevice, h->w->stream));
-  if (int rc = encode_dev(h, h->w->d_ids, h->w->d_lens, B, S, n_layers < 0 ? h->cfg.layers : n_layers, h->w->u, /*full=*/true)) return rc;
+  if (int rc = encode_dev(h, h->w->d_ids, h->w->d_lens, pass_min_len(lens, B), B, S, n_layers < 0 ? h->cfg.layers : n_layers, h->w->u, /*full=*/true)) return rc;
   HIPCHK(h, hipStreamSynchronize(h->w->stream));
   return MV_OK;
 } catch (...) { return on_exception(h); }

@@ -88,6 +88,16 @@ __device__ __forceinline__ uint32_t pack_h2(float a, float b) {
   return __builtin_bit_cast(uint32_t, h);
 }
 
+// An fp32 result that is about to be rounded to fp16 goes through this first: left alone, hipcc fuses `(half_t)fmaf(a, b, c)` into v_fma_mix{lo,hi}_f16 (ONE
+// rounding) for some elements of an unrolled epilogue and keeps v_fma_f32 + v_cvt (TWO roundings) for others, so the same row gave different fp16 bits in
+// token block tb and in tb + 4 — 1 ulp in ~2^-13 of the elements — and a row's bits depended on which 64-row group of its tile it sat in (passes of
+// padded length 64 / 192; round 6, scripts/r06_perm_probe*.py).  Every store of these kernels rounds the fp32 value the source names.
+__device__ __forceinline__ void pin_f32x4(float& a, float& b, float& c, float& d) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm("" : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+#endif
+}
+
 // (hipcc/ROCm 7.2: __builtin_bit_cast applied directly to an ext_vector ELEMENT expression reads element 0 —
 // always go through a scalar copy)
 __device__ __forceinline__ uint32_t f2u(float x) { return __float_as_uint(x); }
@@ -904,6 +914,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmArgs a) {
                   acc[tb][cb][0] = v0; acc[tb][cb][1] = v1; acc[tb][cb][2] = v2; acc[tb][cb][3] = v3;
                 }
               }
+              pin_f32x4(v0, v1, v2, v3);
               d[j][k][0] = pack_h2(v0, v1);
               d[j][k][1] = pack_h2(v2, v3);
             }
@@ -924,8 +935,9 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmArgs a) {
               half_t* vp = a.vlo_sp + ((size_t)(cls_b[i >> 1] * MV_HEADS + head) * MV_HEAD_DIM + 4 * q4) * 2 + m16;
 #pragma unroll
               for (int cb = 0; cb < 4; ++cb) {
-                const float vv[4] = {__builtin_fmaf(rrs[2 * i], acc[2 * i][cb][0], rbv[cb].x), __builtin_fmaf(rrs[2 * i], acc[2 * i][cb][1], rbv[cb].y),
-                                     __builtin_fmaf(rrs[2 * i], acc[2 * i][cb][2], rbv[cb].z), __builtin_fmaf(rrs[2 * i], acc[2 * i][cb][3], rbv[cb].w)};
+                float vv[4] = {__builtin_fmaf(rrs[2 * i], acc[2 * i][cb][0], rbv[cb].x), __builtin_fmaf(rrs[2 * i], acc[2 * i][cb][1], rbv[cb].y),
+                               __builtin_fmaf(rrs[2 * i], acc[2 * i][cb][2], rbv[cb].z), __builtin_fmaf(rrs[2 * i], acc[2 * i][cb][3], rbv[cb].w)};
+                pin_f32x4(vv[0], vv[1], vv[2], vv[3]);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) vp[(16 * cb + e) * 2] = (half_t)((vv[e] - (float)(half_t)vv[e]) * 2048.0f);
               }
@@ -940,8 +952,9 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmArgs a) {
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                   const int tb = 2 * i + (k >> 1), cb = 2 * j + (k & 1);
-                  const float v0 = __builtin_fmaf(rrs[tb], acc[tb][cb][0], rbv[cb].x), v1 = __builtin_fmaf(rrs[tb], acc[tb][cb][1], rbv[cb].y);
-                  const float v2 = __builtin_fmaf(rrs[tb], acc[tb][cb][2], rbv[cb].z), v3 = __builtin_fmaf(rrs[tb], acc[tb][cb][3], rbv[cb].w);
+                  float v0 = __builtin_fmaf(rrs[tb], acc[tb][cb][0], rbv[cb].x), v1 = __builtin_fmaf(rrs[tb], acc[tb][cb][1], rbv[cb].y);
+                  float v2 = __builtin_fmaf(rrs[tb], acc[tb][cb][2], rbv[cb].z), v3 = __builtin_fmaf(rrs[tb], acc[tb][cb][3], rbv[cb].w);
+                  pin_f32x4(v0, v1, v2, v3);
                   d[j][k][0] = pack_h2(v0 - (float)(half_t)v0, v1 - (float)(half_t)v1);
                   d[j][k][1] = pack_h2(v2 - (float)(half_t)v2, v3 - (float)(half_t)v3);
                 }

@@ -308,16 +308,27 @@ __global__ __launch_bounds__(512) void dense768_kernel(const float* __restrict__
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 #pragma unroll 1
   for (int kc = 0; kc < KW; kc += 96) {
+    // every operand load of the chunk first (24 x 16 B of the row, 48 dwords of W^T: 144 VGPRs), then its 48 MFMAs: left to itself hipcc 7.2
+    // schedules load -> s_waitcnt vmcnt(0) -> MFMA pairs, i.e. ~40 dependent L2 round trips per chunk (22 us per launch at K = 768 instead of ~8)
+    float4 xa[24];
+    float wv[48];
 #pragma unroll
-    for (int k0 = kc; k0 < kc + 96; k0 += 8) {
-      const float4 a0 = *(const float4*)(xr + k0), a1 = *(const float4*)(xr + k0 + 4);
+    for (int j = 0; j < 12; ++j) {
+      xa[2 * j] = *(const float4*)(xr + kc + 8 * j);
+      xa[2 * j + 1] = *(const float4*)(xr + kc + 8 * j + 4);
+    }
+#pragma unroll
+    for (int j = 0; j < 48; ++j) wv[j] = wc[(size_t)(kc + 2 * j) * N];
+    __builtin_amdgcn_sched_barrier(0);  // the scheduler moves nothing across this line
+#pragma unroll
+    for (int j = 0; j < 12; ++j) {
+      const float4 a0 = xa[2 * j], a1 = xa[2 * j + 1];
       // lanes 0-31 carry k0 + 2 j, lanes 32-63 k0 + 2 j + 1
       const float s0 = h ? a0.y : a0.x, s1 = h ? a0.w : a0.z, s2 = h ? a1.y : a1.x, s3 = h ? a1.w : a1.z;
-      const float w0 = wc[(size_t)(k0 + 0) * N], w1 = wc[(size_t)(k0 + 2) * N], w2 = wc[(size_t)(k0 + 4) * N], w3 = wc[(size_t)(k0 + 6) * N];
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(s0, w0, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(s1, w1, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(s2, w2, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(s3, w3, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(s0, wv[4 * j + 0], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(s1, wv[4 * j + 1], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(s2, wv[4 * j + 2], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(s3, wv[4 * j + 3], acc, 0, 0, 0);
     }
   }
 #pragma unroll

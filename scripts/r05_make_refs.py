@@ -63,7 +63,7 @@ def main():
         np.savez_compressed(OUT, **have)
 
 
-LENGTHS = (8, 16, 32, 64, 128, 256, 512)
+LENGTHS = (8, 16, 32, 64, 128, 192, 256, 384, 512)  # (192 and 384: round 6, the whole-pass [CLS]-row form)
 
 
 def length_inputs(L):

@@ -90,8 +90,10 @@ def test_trained_like_logits(gu, golden_dir, name, gemm_tile):
     eng.anchor_reset()
 
 
-PRECISE_TRAINED_LIKE_REGRESSION_BOUND = 5.5e-4  # the shipped default on the trained-like goldens measures 4.5 / 3.5e-4 (round 6; rounds 5 - 6a: 3.6 - 4.0 / 3.5 - 5.0e-4; both
-                                                 # terms in every row: 4.2 / 3.7e-4): a bound tight enough to catch erosion of the margin to the 1e-3 contract, not the contract itself
+PRECISE_TRAINED_LIKE_REGRESSION_BOUND = 6.2e-4  # the shipped default on the trained-like goldens measures 5.75 / 3.5e-4 (round 6, after every fp16 store of the GEMM epilogues
+                                                 # rounds the fp32 value it names: gemm_pp.h pin_f32x4; before that re-draw of the roundings 4.5 / 3.5e-4, rounds 5 - 6a 3.6 - 4.0 /
+                                                 # 3.5 - 5.0e-4 — ONE golden is one draw: the 24-draw distribution did not move, median 3.40 -> 3.38e-4, pooled rms 1.32 -> 1.28e-4,
+                                                 # profiles/r06_*_error_distribution.txt): a bound that catches erosion of the margin to the 1e-3 contract, not the contract itself
 
 
 @pytest.mark.parametrize("name", ["l12_trained_s256", "l12_trained_ragged", "l12_base_ragged", "l12_base_s256", "l2_peaky_full", "l2_ragged"])
@@ -267,16 +269,65 @@ def test_cls_row_aside_is_decided_per_sequence(gu, golden_dir):
 
 
 def test_cls_row_aside_leaves_other_pass_shapes_alone(gu):
-    """The form acts on passes of padded length 256 and 512 only (a 256-row tile then belongs to one sequence): 64- and 320-token passes (Sp = 64 / 384) give
-    the same bits with and without the switch, a 256-token one does not."""
+    """The form acts on passes of padded length 256 / 512 (a 256-row tile belongs to one sequence: decided per sequence) and 192 / 384 (decided for the whole
+    pass, next test): a 64-token pass (Sp = 64) gives the same bits with and without the switch, 256- and 320-token ones do not."""
     dk, wk = dict(layers=2), dict(qk_scale=2.0, match_scale=29.0, trained_like=True)
     dims, w = gu.weights_for(dk, wk)
-    for S, same in ((64, True), (320, True), (256, False)):
+    for S, same in ((64, True), (320, False), (256, False)):
         ids, lens = synth.make_ids(4, S, dims.vocab_size, seed=5 + S)
         a = gu.engine_for(dk, wk, compute_dtype="precise", env={"MEMVUL_CLS_ASIDE": "1"}).encode(ids, lens)
         b = gu.engine_for(dk, wk, compute_dtype="precise", env={"MEMVUL_CLS_ASIDE": "0"}).encode(ids, lens)
         assert np.array_equal(a, b) == same, S
         assert float(np.abs(a - b).max()) < 1e-3
+
+
+@pytest.mark.parametrize("compute", ["precise", "f16"])
+@pytest.mark.parametrize("S", [64, 192])
+def test_row_bits_do_not_depend_on_the_64_row_group_a_sequence_starts_in(gu, S, compute):
+    """Padded lengths 64 / 192: consecutive sequences start in different 64-row groups of a 256-row tile, i.e. in token blocks tb and tb + 4 of a wave —
+    two copies of the unrolled epilogue code.  Until round 6 hipcc fused `(half_t)fmaf(..)` into v_fma_mix*_f16 (one rounding) in some of those copies and
+    not in others (two roundings): 1 ulp in ~2^-13 of the Q / K / V elements, so a row's bits depended on its position in the pass (gemm_pp.h pin_f32x4).
+    Eight copies of one sequence must give one embedding, bit for bit."""
+    dk, wk = dict(layers=2, vocab_size=2048), dict(qk_scale=2.0, match_scale=29.0, trained_like=True)
+    dims, w = gu.weights_for(dk, wk)
+    eng = gu.engine_for(dk, wk, compute_dtype=compute, max_tokens=16384, max_batch=32, max_anchors=8)
+    ids1, _ = synth.make_ids(1, S, dims.vocab_size, seed=3 + S)
+    u = eng.encode(np.repeat(ids1, 8, axis=0).astype(np.int32), np.full((8,), S, np.int32))
+    assert all(np.array_equal(u[i], u[0]) for i in range(1, 8))
+    ids, lens = synth.make_ids(7, S, dims.vocab_size, seed=11 + S, ragged=True, min_len=S // 2)
+    ids = (ids * (np.arange(S)[None, :] < lens[:, None])).astype(np.int32)
+    a = eng.encode(ids, lens)
+    perm = np.random.default_rng(S).permutation(7)
+    assert np.array_equal(eng.encode(ids[perm], lens[perm]), a[perm])
+
+
+@pytest.mark.parametrize("S", [192, 320, 384])
+def test_cls_row_form_at_padded_lengths_192_and_384_is_decided_for_the_whole_pass(gu, S):
+    """Sp = 192 / 384: a 256-row tile spans two sequences, so the form is taken by the WHOLE pass when its shortest sequence has MEMVUL_CLS_ASIDE_MIN_LEN (128)
+    tokens (engine.hip encode_dev: what a length-sorted sweep hands over by construction) and by none of it otherwise.  All-long pass: the [CLS]-row form's bits
+    (not the both-terms form's), independent of the order of the batch, within the contract of the oracle; one short batch-mate: the both-terms form bit for bit."""
+    dk, wk = dict(layers=2, vocab_size=2048), dict(qk_scale=2.0, match_scale=29.0, trained_like=True)
+    dims, w = gu.weights_for(dk, wk)
+    kw = dict(compute_dtype="precise", max_tokens=16384, max_batch=32, max_anchors=8)
+    on = gu.engine_for(dk, wk, env={"MEMVUL_CLS_ASIDE": "1"}, **kw)
+    off = gu.engine_for(dk, wk, env={"MEMVUL_CLS_ASIDE": "0"}, **kw)
+    B = 7  # an odd batch: the last tile of the pass is partly padding
+    ids, lens = synth.make_ids(B, S, dims.vocab_size, seed=11 + S, ragged=True, min_len=max(130, S - 60))
+    ids = (ids * (np.arange(S)[None, :] < lens[:, None])).astype(np.int32)
+    assert int(lens.min()) >= 128 and (S + 63) // 64 * 64 in (192, 320, 384)  # (320 pads to 384)
+    a, b = on.encode(ids, lens), off.encode(ids, lens)
+    assert all(not np.array_equal(a[i], b[i]) for i in range(B))
+    assert float(np.abs(a - b).max()) < 5e-4
+    perm = np.random.default_rng(S).permutation(B)
+    assert np.array_equal(on.encode(ids[perm], lens[perm]), a[perm])  # which tile a row lands in does not matter
+    u_ref = orc.instance_forward(w, ids.astype(np.int64), synth.mask_from_lens(lens, S))
+    ea, eb = float(np.abs(a - u_ref).max()), float(np.abs(b - u_ref).max())
+    gu.record("cls_row_whole_pass", S=S, u_err=ea, u_err_both_terms=eb)
+    assert ea < 2e-4  # (embeddings; the logit contract at these lengths: test_precise_mode_holds_1e3_in_the_trained_like_regime's ragged goldens)
+    lens2 = lens.copy(); lens2[3] = 40
+    ids2 = (ids * (np.arange(S)[None, :] < lens2[:, None])).astype(np.int32)
+    ids2[3, 39] = ids[3, lens[3] - 1]  # its [SEP]
+    assert np.array_equal(on.encode(ids2, lens2), off.encode(ids2, lens2))
 
 
 def test_short_sequences_carry_v_and_p_as_two_planes(gu, golden_dir):
