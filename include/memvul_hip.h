@@ -80,7 +80,8 @@ typedef struct mv_config {
  *   MEMVUL_CLS_ASIDE          1 (default) | 0.  MV_F16X8: 1 = the [CLS]-row form (every GEMM sweeps the weight-side correction term, the A-side term is
  *                             restored for the [CLS] row of each sequence alone: only that row reaches the pooler, model_memory.py:99); 0 = both first-order
  *                             terms in every row (rounds 3-4: -13 % issue reports/s, same trained-like logit error on diffuse attention).
- *   MEMVUL_CLS_ASIDE_MIN_LEN  1 .. 512 (default 128): sequences shorter than this keep the both-terms form (few keys to average over).
+ *   MEMVUL_CLS_ASIDE_MIN_LEN  1 .. 512 (default 128): sequences shorter than this keep the both-terms form (few keys to average over) — decided per sequence in
+ *                             passes of padded length 256 / 512, for the whole pass (by its shortest sequence) at 192 / 384; shorter passes always keep it.
  *   MEMVUL_QKV_ASIDE          a subset of "qkv", "" or "none" (default "none"): the blocks of the QKV projection that sweep the A-side term for EVERY row (the special
  *                             rows get it in every block either way; "q" = the default of rounds 4 - 6a: -2.7 % issue reports/s, 3 % less logit error).
  *   MEMVUL_CLS_PRUNE          1 (default) | 0: after the last layer's K / V projection only the [CLS] rows are processed.
