@@ -141,6 +141,12 @@ int mv_anchor_set(mv_handle* h, const float* v, int G);
  * Returns after the results are in host memory. */
 int mv_forward(mv_handle* h, const int32_t* ids, const int32_t* lens, int B, int S,
                float* logits, float* probs, float* best, int32_t* best_idx, float* embed);
+/* mv_forward on a batch whose rows the caller has ordered by length and cut into groups (binding.Engine.forward_by_length: the reference's pad-to-longest
+ * batch of UNSORTED issue reports, predict_memory.py:97-101, scored without its padding): group g = rows [group_end[g - 1], group_end[g]) is one pass at
+ * group_width[g] <= S tokens per row (every row of it at most that long), the groups run back to back, one synchronisation.  ids [B][S], outputs as
+ * mv_forward's, in the order of the rows handed over.  B <= max_batch, B * S <= max_tokens. */
+int mv_forward_groups(mv_handle* h, const int32_t* ids, const int32_t* lens, int B, int S, int n_groups, const int32_t* group_end,
+                      const int32_t* group_width, float* logits, float* probs, float* best, int32_t* best_idx, float* embed);
 /* Encoder only (ModelMemory._instance_forward, model_memory.py:90-103): embed fp32 [B,512]. */
 int mv_encode(mv_handle* h, const int32_t* ids, const int32_t* lens, int B, int S, float* embed);
 /* Matcher only on host embeddings u fp32 [B,512] against the resident bank (model_memory.py:135-147). */
@@ -243,6 +249,15 @@ int mv_test_gemm_pp(mv_handle* h, int x8, int M, int N, int K, const float* A, c
                     uint8_t* out8, int iters, float* ms);
 /* The host-side e4m3 encoder used for the MV_F16X8 weight planes (needs no GPU, h may be NULL elsewhere): out[i] = OCP e4m3fn bits of in[i]. */
 int mv_test_e4m3(const float* in, uint8_t* out, int64_t n);
+
+/* Host only, no GPU work, callable from any thread: the JSON line of one batch's records — replaces json.dumps(make_output_human_readable(...))
+ * (model_memory.py:169-191 -> predict_memory.py:111), whose cost is CPython's repr() of B x G doubles.
+ *   out = "[" + ", ".join(prefix_i + piece_0 + repr(p[i][0]) + ... + piece_{cols-1} + repr(p[i][cols-1]) + row_suffix for i in rows) + "]"
+ * prefixes / pieces: the strings back to back, *_off[k] .. *_off[k + 1] the bytes of string k (rows + 1 / cols + 1 offsets); p: double [rows][cols];
+ * every double is printed exactly as Python's repr(float) prints it.  MV_ERR_CAPACITY: `cap` too small; MV_ERR_INVALID: a non-finite value (json.dumps
+ * spells those NaN / Infinity: the caller formats such a batch itself). */
+int mv_format_records(const char* prefixes, const int64_t* prefix_off, int64_t rows, const char* pieces, const int64_t* piece_off, int64_t cols,
+                      const char* row_suffix, const double* p, char* out, int64_t cap, int64_t* written);
 
 #ifdef __cplusplus
 }

@@ -51,9 +51,9 @@ NUM_KERNEL_CLASSES = 14
 ABI_SYMBOLS = [
     "mv_create", "mv_destroy", "mv_last_error", "mv_sync", "mv_load_tensor", "mv_finalize_weights",
     "mv_anchor_reset", "mv_anchor_append", "mv_anchor_count", "mv_anchor_get", "mv_anchor_set",
-    "mv_forward", "mv_encode", "mv_match", "mv_topk", "mv_corpus_upload", "mv_corpus_run", "mv_corpus_run_len",
+    "mv_forward", "mv_forward_groups", "mv_encode", "mv_match", "mv_topk", "mv_corpus_upload", "mv_corpus_run", "mv_corpus_run_len",
     "mv_corpus_results", "mv_x8_saturation", "mv_attention_concentration", "mv_set_streams", "mv_profile_enable", "mv_profile_select", "mv_profile_read", "mv_kernel_class_name",
-    "mv_debug_encode", "mv_debug_read", "mv_test_gemm", "mv_test_gemm_pp", "mv_test_e4m3", "mv_comm_prepare", "mv_comm_unique_id", "mv_comm_init", "mv_comm_allgather",
+    "mv_debug_encode", "mv_debug_read", "mv_test_gemm", "mv_test_gemm_pp", "mv_test_e4m3", "mv_format_records", "mv_comm_prepare", "mv_comm_unique_id", "mv_comm_init", "mv_comm_allgather",
     "mv_comm_destroy", "mv_comm_info", "mv_device_count",
 ]
 
@@ -102,6 +102,7 @@ def load_library(path: Optional[str] = None, dev: bool = False):
         "mv_anchor_get": (C.c_int, [vp, vp]),
         "mv_anchor_set": (C.c_int, [vp, vp, C.c_int]),
         "mv_forward": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, vp, vp, vp, vp, vp]),
+        "mv_forward_groups": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, vp]),
         "mv_encode": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, vp]),
         "mv_match": (C.c_int, [vp, vp, C.c_int, vp, vp, vp, vp]),
         "mv_topk": (C.c_int, [vp, vp, C.c_int, C.c_int, vp, vp]),
@@ -121,6 +122,7 @@ def load_library(path: Optional[str] = None, dev: bool = False):
         "mv_test_gemm": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, C.c_int, P(C.c_float)]),
         "mv_test_gemm_pp": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, C.c_int, P(C.c_float)]),
         "mv_test_e4m3": (C.c_int, [vp, vp, C.c_int64]),
+        "mv_format_records": (C.c_int, [vp, vp, C.c_int64, vp, vp, C.c_int64, C.c_char_p, vp, vp, C.c_int64, P(C.c_int64)]),
         "mv_comm_prepare": (C.c_int, [vp]),
         "mv_comm_unique_id": (C.c_int, [vp, vp, C.c_int]),
         "mv_comm_init": (C.c_int, [vp, C.c_int, C.c_int, vp, C.c_int]),
@@ -286,6 +288,69 @@ class Engine:
                                          _ptr(idx), _ptr(embed)), "mv_forward")
         self._check_saturation()
         return {"logits": logits, "probs": probs, "best": best, "best_idx": idx, "embed": embed}
+
+    # tokens below which one pad-to-longest pass is kept as it is (a pass of a few thousand tokens leaves most of the 256 persistent workgroups idle)
+    BY_LENGTH_MIN_TOKENS = 16384
+
+    def forward_by_length(self, ids: np.ndarray, lens: np.ndarray, want_logits=True, want_probs=True, want_embed=False, min_tokens: Optional[int] = None):
+        """``forward`` on a pad-to-longest batch of UNSORTED issue reports (the reference's collation, predict_memory.py:97-101) without paying for the
+        padding: the rows are grouped by the padded length of their OWN token count (64 .. 256 in steps of 64, 384, 512: engine.hip padded_len), every
+        group is one ``mv_forward`` at its own length, and the results go back to the rows' places.  A group of fewer than ``min_tokens`` tokens travels
+        with the next longer one (a pass that small leaves most of the chip idle).  Same per-row arithmetic as ``forward`` at a different padded length
+        (what Engine.bucketed_sweep does to a resident corpus); a batch whose rows share one padded length is ONE call, bit for bit ``forward``."""
+        ids, lens = _as(ids, np.int32), _as(lens, np.int32)
+        B, S = ids.shape
+        if min_tokens is None:
+            min_tokens = self.BY_LENGTH_MIN_TOKENS
+        pl = np.where(lens <= 256, (np.maximum(lens, 1) + 63) // 64 * 64, (lens + 127) // 128 * 128).astype(np.int64)
+        top = int(pl.max()) if B else 0
+        if B == 0 or B * S < 2 * min_tokens:
+            return self.forward(ids, lens, want_logits, want_probs, want_embed)
+        if int(pl.min()) == top:  # one group: one call, at the group's own length
+            return self.forward(np.ascontiguousarray(ids[:, :top]) if top < S else ids, lens, want_logits, want_probs, want_embed)
+        # ONE gather into length order, the groups are then row slices of it and every pass writes its results straight into its slice of the
+        # length-ordered outputs (no per-group fancy indexing: that was 8 ms of the scorer thread's 15 ms per 512-report batch), ONE gather back
+        G = self.n_anchors
+        order = np.argsort(pl, kind="stable")
+        spl = pl[order]
+        ids_s, lens_s = ids[order], lens[order]
+        bufs = {"logits": np.empty((B, G, 2), np.float32) if want_logits else None, "probs": np.empty((B, G, 2), np.float32) if want_probs else None,
+                "best": np.empty((B, 2), np.float32), "best_idx": np.empty((B,), np.int32), "embed": np.empty((B, self.P), np.float32) if want_embed else None}
+        cuts = np.flatnonzero(np.diff(spl)) + 1  # group boundaries in the length order
+        ends, widths, start = [], [], 0
+        for end in list(cuts) + [B]:
+            width = int(spl[end - 1])
+            if end < B and (end - start) * width < min_tokens:
+                continue  # too small a pass: these rows travel with the next longer group
+            ends.append(int(end)); widths.append(min(S, width))
+            start = end
+        groups = getattr(self, "_forward_groups", None)  # (a stand-in engine of the tests has only `forward`)
+        if groups is not None and groups(ids_s, lens_s, ends, widths, bufs):
+            pass  # ONE library call (mv_forward_groups): the passes back to back on the stream, one synchronisation, the GIL released once per batch
+        else:
+            start = 0
+            for end, width in zip(ends, widths):
+                sub = self.forward(np.ascontiguousarray(ids_s[start:end, :width]), lens_s[start:end], want_logits, want_probs, want_embed)
+                for k, v in sub.items():
+                    if v is not None and bufs.get(k) is not None:
+                        bufs[k][start:end] = v
+                start = end
+        inv = np.empty(B, np.int64)
+        inv[order] = np.arange(B)
+        return {k: (v[inv] if v is not None else None) for k, v in bufs.items()}
+
+    def _forward_groups(self, ids: np.ndarray, lens: np.ndarray, ends, widths, out: Dict[str, Optional[np.ndarray]]) -> bool:
+        """mv_forward_groups into the caller's arrays (rows in length order); False = the batch does not fit one upload (max_batch / max_tokens): the caller
+        walks the groups with ``forward``."""
+        B, S = ids.shape
+        ge, gw = np.asarray(ends, np.int32), np.asarray(widths, np.int32)
+        rc = self._lib.mv_forward_groups(self._h, _ptr(ids), _ptr(lens), B, S, len(ge), _ptr(ge), _ptr(gw), _ptr(out.get("logits")), _ptr(out.get("probs")),
+                                         _ptr(out["best"]), _ptr(out["best_idx"]), _ptr(out.get("embed")))
+        if rc == -5:  # MV_ERR_CAPACITY (checked before any GPU work)
+            return False
+        self._check(rc, "mv_forward_groups")
+        self._check_saturation()
+        return True
 
     def encode(self, ids: np.ndarray, lens: np.ndarray) -> np.ndarray:
         ids, lens = _as(ids, np.int32), _as(lens, np.int32)

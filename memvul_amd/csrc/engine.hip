@@ -6,6 +6,7 @@
 #include <rccl/rccl.h>  // types and prototypes only: librccl.so is opened at run time (mv_comm_init), never linked
 #include <unistd.h>
 
+#include <charconv>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -1399,6 +1400,50 @@ int mv_forward(mv_handle* h, const int32_t* ids, const int32_t* lens, int B, int
   return MV_OK;
 } catch (...) { return on_exception(h); }
 
+// mv_forward over a batch whose rows are ordered by length and cut into groups: group g = rows [group_end[g - 1], group_end[g]) runs as ONE pass at
+// group_width[g] tokens per row (the rows' ids are read in place from the [B][S] upload: pitch S), all groups back to back on the handle's stream, one
+// synchronisation at the end (binding.Engine.forward_by_length: a pad-to-longest batch of unsorted reports without its padding, one library call per batch).
+int mv_forward_groups(mv_handle* h, const int32_t* ids, const int32_t* lens, int B, int S, int n_groups, const int32_t* group_end,
+                      const int32_t* group_width, float* logits, float* probs, float* best, int32_t* best_idx, float* embed) try {
+  if (int rc = check_ready(h)) return rc;
+  if (!ids || !lens || !group_end || !group_width || B <= 0 || S <= 0 || S > h->cfg.max_pos || n_groups <= 0)
+    return fail(h, MV_ERR_INVALID, "mv_forward_groups: bad argument");
+  if (h->n_anchors <= 0) return fail(h, MV_ERR_STATE, "anchor bank is empty (call mv_anchor_append / mv_anchor_set first)");
+  if (B > h->cfg.max_batch || (int64_t)B * S > h->cap_tokens) return fail(h, MV_ERR_CAPACITY, "mv_forward_groups: the batch exceeds mv_config.max_batch / max_tokens");
+  int prev = 0;
+  for (int g = 0; g < n_groups; ++g) {
+    const int nb = group_end[g] - prev, w = group_width[g];
+    if (nb <= 0 || w <= 0 || w > S) return fail(h, MV_ERR_INVALID, "mv_forward_groups: groups must be non-empty, in order, at most S tokens wide");
+    if (nb > max_rows_for(h, w)) return fail(h, MV_ERR_CAPACITY, "mv_forward_groups: a group exceeds one pass (mv_config.max_tokens)");
+    for (int i = prev; i < group_end[g]; ++i)
+      if (lens[i] > w) return fail(h, MV_ERR_INVALID, "mv_forward_groups: a row is longer than its group's width");
+    prev = group_end[g];
+  }
+  if (prev != B) return fail(h, MV_ERR_INVALID, "mv_forward_groups: the groups must cover the batch");
+  if (int rc = check_ids(h, ids, (int64_t)B * S, "mv_forward_groups")) return rc;
+  HIPCHK(h, hipSetDevice(h->device));
+  const int G = h->n_anchors;
+  HIPCHK(h, hipMemcpyAsync(h->w->d_ids, ids, (size_t)B * S * 4, hipMemcpyHostToDevice, h->w->stream));
+  HIPCHK(h, hipMemcpyAsync(h->w->d_lens, lens, (size_t)B * 4, hipMemcpyHostToDevice, h->w->stream));
+  prev = 0;
+  for (int g = 0; g < n_groups; ++g) {
+    const int nb = group_end[g] - prev;
+    float* u = h->w->u + (size_t)prev * h->P;
+    if (int rc = encode_dev(h, h->w->d_ids + (size_t)prev * S, h->w->d_lens + prev, pass_min_len(lens + prev, nb), nb, group_width[g], -1, u, false, S)) return rc;
+    if (int rc = match_dev(h, u, nb, logits ? h->w->logits + (size_t)prev * G * 2 : nullptr, probs ? h->w->probs + (size_t)prev * G * 2 : nullptr, nullptr, 1,
+                           h->w->best + (size_t)prev * 2, h->w->best_idx + prev)) return rc;
+    prev = group_end[g];
+  }
+  const size_t bg = (size_t)B * G;
+  if (logits) HIPCHK(h, hipMemcpyAsync(logits, h->w->logits, bg * 8, hipMemcpyDeviceToHost, h->w->stream));
+  if (probs) HIPCHK(h, hipMemcpyAsync(probs, h->w->probs, bg * 8, hipMemcpyDeviceToHost, h->w->stream));
+  if (best) HIPCHK(h, hipMemcpyAsync(best, h->w->best, (size_t)B * 8, hipMemcpyDeviceToHost, h->w->stream));
+  if (best_idx) HIPCHK(h, hipMemcpyAsync(best_idx, h->w->best_idx, (size_t)B * 4, hipMemcpyDeviceToHost, h->w->stream));
+  if (embed) HIPCHK(h, hipMemcpyAsync(embed, h->w->u, (size_t)B * h->P * 4, hipMemcpyDeviceToHost, h->w->stream));
+  HIPCHK(h, hipStreamSynchronize(h->w->stream));
+  return MV_OK;
+} catch (...) { return on_exception(h); }
+
 int mv_match(mv_handle* h, const float* u, int B, float* logits, float* probs, float* best, int32_t* best_idx) try {
   if (int rc = check_ready(h)) return rc;
   if (!u || B <= 0) return fail(h, MV_ERR_INVALID, "mv_match: bad argument");
@@ -1861,6 +1906,91 @@ int mv_test_gemm_pp(mv_handle* h, int x8, int M, int N, int K, const float* A, c
 int mv_test_e4m3(const float* in, uint8_t* out, int64_t n) try {
   if (!in || !out || n < 0) return MV_ERR_INVALID;
   for (int64_t i = 0; i < n; ++i) out[i] = f32_to_e4m3_bits(in[i]);
+  return MV_OK;
+} catch (...) { return on_exception(nullptr); }
+
+// ---- JSON-lines records of one batch (host only) --------------------------------------------------------------------------------------
+// Python's repr(float) — what json.dumps prints for every probability of make_output_human_readable's records (model_memory.py:169-191 ->
+// predict_memory.py:111) — restated: the shortest digit string that round-trips the double (std::to_chars, scientific) laid out by CPython's rule
+// (PyOS_double_to_string 'r': exponent form when the decimal exponent is < -4 or >= 16, at least two exponent digits, ".0" after a whole number).
+// 0.65 us per double in CPython, ~40 ns here; pinned to repr() on millions of values by tests/test_host_logic.py.
+static inline char* py_repr_double(char* o, double v) {
+  if (v == 0.0) {
+    if (std::signbit(v)) *o++ = '-';
+    *o++ = '0'; *o++ = '.'; *o++ = '0';
+    return o;
+  }
+  char b[40];
+  const auto r = std::to_chars(b, b + sizeof b, v, std::chars_format::scientific);  // [-]d[.ddd]e[+-]XX
+  const char* p = b;
+  if (*p == '-') *o++ = *p++;
+  char dig[24];
+  int nd = 0;
+  dig[nd++] = *p++;
+  if (*p == '.') {
+    ++p;
+    while (*p != 'e') dig[nd++] = *p++;
+  }
+  ++p;  // 'e'
+  const bool eneg = *p == '-';
+  ++p;
+  int e = 0;
+  while (p < r.ptr) e = e * 10 + (*p++ - '0');
+  if (eneg) e = -e;
+  if (e < -4 || e >= 16) {
+    *o++ = dig[0];
+    if (nd > 1) {
+      *o++ = '.';
+      for (int i = 1; i < nd; ++i) *o++ = dig[i];
+    }
+    *o++ = 'e';
+    *o++ = e < 0 ? '-' : '+';
+    const int ae = e < 0 ? -e : e;
+    if (ae >= 100) *o++ = (char)('0' + ae / 100);
+    *o++ = (char)('0' + (ae / 10) % 10);
+    *o++ = (char)('0' + ae % 10);
+  } else if (e < 0) {
+    *o++ = '0'; *o++ = '.';
+    for (int i = 0; i < -e - 1; ++i) *o++ = '0';
+    for (int i = 0; i < nd; ++i) *o++ = dig[i];
+  } else {
+    for (int i = 0; i <= e; ++i) *o++ = i < nd ? dig[i] : '0';
+    *o++ = '.';
+    if (nd > e + 1) for (int i = e + 1; i < nd; ++i) *o++ = dig[i];
+    else *o++ = '0';
+  }
+  return o;
+}
+
+// out = "[" + ", ".join(prefix_i + piece_0 + repr(p[i][0]) + piece_1 + repr(p[i][1]) + ... + row_suffix) + "]"
+int mv_format_records(const char* prefixes, const int64_t* prefix_off, int64_t rows, const char* pieces, const int64_t* piece_off, int64_t cols,
+                      const char* row_suffix, const double* p, char* out, int64_t cap, int64_t* written) try {
+  if (!prefixes || !prefix_off || !pieces || !piece_off || !row_suffix || !p || !out || !written || rows < 0 || cols < 0) return MV_ERR_INVALID;
+  const int64_t nsuf = (int64_t)std::strlen(row_suffix);
+  const int64_t piece_bytes = piece_off[cols] - piece_off[0];
+  char* o = out;
+  char* const end = out + cap;
+  if (end - o < 2) return MV_ERR_CAPACITY;
+  *o++ = '[';
+  for (int64_t i = 0; i < rows; ++i) {
+    const int64_t np_ = prefix_off[i + 1] - prefix_off[i];
+    if (end - o < np_ + piece_bytes + cols * 26 + nsuf + 4) return MV_ERR_CAPACITY;  // (a repr is at most 24 characters)
+    if (i) { *o++ = ','; *o++ = ' '; }
+    std::memcpy(o, prefixes + prefix_off[i], (size_t)np_);
+    o += np_;
+    const double* row = p + i * cols;
+    for (int64_t c = 0; c < cols; ++c) {
+      const int64_t n = piece_off[c + 1] - piece_off[c];
+      std::memcpy(o, pieces + piece_off[c], (size_t)n);
+      o += n;
+      if (!std::isfinite(row[c])) return MV_ERR_INVALID;  // json spells these NaN / Infinity: the caller's Python path does
+      o = py_repr_double(o, row[c]);
+    }
+    std::memcpy(o, row_suffix, (size_t)nsuf);
+    o += nsuf;
+  }
+  *o++ = ']';
+  *written = o - out;
   return MV_OK;
 } catch (...) { return on_exception(nullptr); }
 

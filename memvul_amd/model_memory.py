@@ -232,14 +232,17 @@ class ModelMemory(Model):
     def _ids_lens(sample: Dict[str, Dict[str, Any]]):
         t = sample["tokens"]
         ids = _np(t["token_ids"]).astype(np.int32)
-        mask = _np(t["mask"]).astype(bool)
+        mask = np.asarray(_np(t["mask"]), bool)
         tid = t.get("type_ids")
-        if tid is not None and _np(tid).max() != 0:
+        if tid is not None and _np(tid).any():
             raise ValueError("non-zero token-type ids: the hot path is single-segment (custom_PTM_embedder.py:199-202)")
         lens = mask.sum(1).astype(np.int32)
-        if not np.array_equal(mask, np.arange(mask.shape[1])[None, :] < lens[:, None]):
+        # a prefix mask: the LAST set position of a row is its count - 1 (then every position before it is set too)
+        last = mask.shape[1] - 1 - np.argmax(mask[:, ::-1], axis=1) if mask.shape[1] else np.zeros(len(lens), np.int64)
+        if not np.array_equal(np.where(lens > 0, last, -1), lens.astype(np.int64) - 1):
             raise ValueError("mask must be a prefix mask (pad-to-longest collation)")
-        return ids * mask, lens
+        np.multiply(ids, mask, out=ids)
+        return ids, lens
 
     def _instance_forward(self, sample, use_header: bool = False) -> np.ndarray:
         # (the reference passes self._use_header at every call site, l.112, 133; the engine was created for that choice)
@@ -266,7 +269,8 @@ class ModelMemory(Model):
         if not (metadata and metadata[0]["type"] in ["test", "unlabel"]):
             raise NotImplementedError("the pair-training branch (model_memory.py:149-160) is outside the inference hot path")
         ids, lens = self._ids_lens(sample1)
-        out = self.engine.forward(ids, lens, want_logits=False, want_probs=True)
+        # (rows grouped by their own padded length: a pad-to-longest batch of unsorted reports is mostly padding — Engine.forward_by_length)
+        out = self.engine.forward_by_length(ids, lens, want_logits=False, want_probs=True)
         output_dict["probs"] = out["probs"]           # [B,G,2]; the reference stores p.tolist()
         output_dict["best_anchor"] = out["best_idx"]  # extra (not in the reference): g* per issue report
         probs = out["best"]                           # [B,2] = p[b, g*]

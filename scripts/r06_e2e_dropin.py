@@ -127,6 +127,11 @@ def main():
         undo.append((mm.ModelMemory, "sweep_arrays", st.wrap(mm.ModelMemory, "sweep_arrays", "engine: sweep_arrays (upload + bucketed sweep + download)")))
         undo.append((mm.ModelMemory, "forward_on_instances", st.wrap(mm.ModelMemory, "forward_on_instances", "anchor bank (forward_on_instances x 1)")))
         undo.append((mvdata, "collate", st.wrap(mvdata, "collate", "collate (pad-to-longest, Instances -> arrays)")))
+        import memvul_amd.binding as mb
+        import memvul_amd.records as mr
+        undo.append((mb.Engine, "forward_by_length", st.wrap(mb.Engine, "forward_by_length", "scorer thread: engine.forward_by_length (sort + upload + passes + download)")))
+        undo.append((mm.ModelMemory, "__call__", st.wrap(mm.ModelMemory, "__call__", "scorer thread: model(**batch) in all")))
+        undo.append((mr.RecordWriter, "submit", st.wrap(mr.RecordWriter, "submit", "writer: RecordWriter.submit (format + write)")))
         undo.append((pm, "load_archive", st.wrap(pm, "load_archive", "load_archive (weights -> engine)")))
         undo.append((json, "dumps", st.wrap(json, "dumps", "json.dumps of the records")))
         t0 = time.perf_counter()

@@ -121,6 +121,12 @@ class OracleEngine:
         logits, p, best, idx = orc.match(u, self.v, self.w[synth.KEY_MATCH_W], self.same_idx)
         return {"logits": logits, "probs": p, "best": best, "best_idx": idx.astype(np.int32), "embed": u}
 
+    # the product's own grouping logic (host code: it only needs forward / n_anchors / P of the engine it runs on)
+    from memvul_amd.binding import Engine as _ProductEngine
+    BY_LENGTH_MIN_TOKENS = _ProductEngine.BY_LENGTH_MIN_TOKENS
+    forward_by_length = _ProductEngine.forward_by_length
+    del _ProductEngine
+
     def bucketed_sweep(self, ids, lens, batch, with_probs=False):
         """binding.Engine.bucketed_sweep on the oracle: per-row results do not depend on the batching."""
         best, idx, ps = [], [], []

@@ -652,6 +652,45 @@ def test_length_bucketed_sweep_matches_padded_sweep(gu, compute):
     eng.anchor_reset()
 
 
+@pytest.mark.parametrize("compute", ["precise", "f16"])
+def test_forward_by_length_matches_the_padded_forward(gu, compute):
+    """Engine.forward_by_length (what ModelMemory.forward calls): the rows of a pad-to-longest batch grouped by their own padded length, one mv_forward per
+    group, results back in place.  Same per-row mathematics as the one padded pass at a different padded length: probabilities agree at the fp16-operand
+    level, decisions wherever the top-2 margin is clear; rows of the longest group ran at the batch's own length in both forms and (MV_F16X8) agree bit for bit."""
+    dk, wk = dict(layers=3, vocab_size=2048), dict(qk_scale=2.0, match_scale=6.0)
+    dims, w = gu.weights_for(dk, wk)
+    eng = gu.engine_for(dk, wk, compute_dtype=compute, max_tokens=128 * 512, max_batch=128, max_anchors=32)
+    ids, lens = synth.make_ids(128, 512, dims.vocab_size, ragged=True, min_len=5)
+    ids = (ids * (np.arange(512)[None, :] < lens[:, None])).astype(np.int32)
+    eng.anchor_set(synth.make_anchor_bank(24))
+    a = eng.forward(ids, lens)
+    b = eng.forward_by_length(ids, lens, min_tokens=4096)
+    eng._forward_groups = None  # the same groups walked from Python, one mv_forward each, instead of ONE mv_forward_groups call: the same bits
+    try:
+        c = eng.forward_by_length(ids, lens, min_tokens=4096)
+    finally:
+        del eng._forward_groups
+    assert all(np.array_equal(b[k], c[k]) for k in ("logits", "probs", "best", "best_idx"))
+    d = float(np.abs(a["probs"] - b["probs"]).max())
+    gu.record("forward_by_length", compute=compute, max_p_diff=d)
+    assert d < 1e-3
+    srt = np.sort(a["probs"][:, :, 0], axis=1)
+    clear = (srt[:, -1] - srt[:, -2]) > 4e-3
+    assert np.array_equal(a["best_idx"][clear], b["best_idx"][clear])
+    longest = lens > 384
+    assert longest.sum() >= 8
+    if compute == "precise":  # (MV_F16 picks its kernel path by the size of the pass: the smaller group runs the small-pass kernels)
+        assert np.array_equal(a["probs"][longest], b["probs"][longest]) and np.array_equal(a["logits"][longest], b["logits"][longest])
+    short = lens <= 64
+    assert short.any() and not np.array_equal(a["probs"][short], b["probs"][short])  # (they did run at another padded length)
+    # mv_forward_groups rejects what it cannot run as handed over (before any GPU work)
+    bufs = {"logits": None, "probs": None, "best": np.empty((128, 2), np.float32), "best_idx": np.empty(128, np.int32), "embed": None}
+    for ends, widths in (([64], [512]), ([128], [64]), ([64, 64], [512, 512]), ([64, 128], [512, 600])):  # not the whole batch / a row longer than its group / empty group / wider than S
+        with pytest.raises(RuntimeError):
+            eng._forward_groups(ids, lens, ends, widths, bufs)
+    eng.anchor_reset()
+
+
 @pytest.mark.parametrize("gemm_tile,compute", PATHS)
 def test_edge_shapes_against_the_oracle(gu, gemm_tile, compute):
     """The smallest and the largest inputs the path accepts: a one-token issue report, one anchor, a batch whose rows

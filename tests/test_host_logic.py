@@ -211,3 +211,91 @@ def test_documented_switch_defaults_match_the_library_source():
     block = src[src.index("#ifdef MEMVUL_DEV_SWITCHES"):src.index("#endif", src.index("#ifdef MEMVUL_DEV_SWITCHES"))]
     for k in binding.DEV_SWITCHES:
         assert src.count('"%s"' % k) == block.count('"%s"' % k) >= 1, k
+
+
+def test_forward_by_length_groups_rows_by_their_own_padded_length():
+    """binding.Engine.forward_by_length (ModelMemory.forward's engine call): a pad-to-longest batch of unsorted issue reports (predict_memory.py:97-101) is scored
+    in one pass per padded length of the rows' OWN token counts; groups too small to fill a pass travel with the next longer one; every row's result lands in
+    its place.  Host logic only: a recording stand-in for the engine."""
+    from memvul_amd.binding import Engine
+
+    class Rec:
+        P, n_anchors = 4, 3
+        BY_LENGTH_MIN_TOKENS = Engine.BY_LENGTH_MIN_TOKENS
+        forward_by_length = Engine.forward_by_length
+
+        def __init__(self):
+            self.calls = []
+
+        def forward(self, ids, lens, want_logits=True, want_probs=True, want_embed=False):
+            assert ids.flags["C_CONTIGUOUS"] and ids.dtype == np.int32 and int(lens.max()) <= ids.shape[1]
+            self.calls.append((ids.shape, lens.copy()))
+            key = ids[:, 0].astype(np.float32)  # a row's "result" = a function of the row alone
+            n = len(lens)
+            return {"logits": None, "probs": np.repeat(key, 6).reshape(n, 3, 2) if want_probs else None, "best": np.stack([key, lens.astype(np.float32)], 1),
+                    "best_idx": lens.astype(np.int32), "embed": None}
+
+    rng = np.random.default_rng(3)
+    B, S = 512, 512
+    lens = rng.integers(5, S + 1, B).astype(np.int32)
+    lens[7] = S
+    ids = np.zeros((B, S), np.int32)
+    ids[:, 0] = np.arange(B)
+    e = Rec()
+    out = e.forward_by_length(ids, lens, want_logits=False)
+    assert out["logits"] is None and out["embed"] is None
+    assert np.array_equal(out["best"][:, 0], np.arange(B)) and np.array_equal(out["best_idx"], lens) and np.array_equal(out["probs"][:, 2, 1], np.arange(B))
+    widths = [c[0][1] for c in e.calls]
+    assert widths == sorted(widths) and set(widths) <= {64, 128, 192, 256, 384, 512} and sum(c[0][0] for c in e.calls) == B
+    for (shape, ls) in e.calls[:-1]:
+        assert shape[0] * shape[1] >= Rec.BY_LENGTH_MIN_TOKENS  # every pass but (possibly) the last is worth a launch
+    for (shape, ls) in e.calls:
+        assert int(ls.max()) > (shape[1] - (64 if shape[1] <= 256 else 128))  # the pass runs at the padded length of its longest row
+    padded_tokens = sum(c[0][0] * c[0][1] for c in e.calls)
+    assert padded_tokens < 0.7 * B * S
+    # a small batch, and a batch of one padded length, stay ONE call (the second at its own width)
+    e = Rec(); e.forward_by_length(ids[:16], lens[:16]); assert len(e.calls) == 1 and e.calls[0][0] == (16, S)
+    e = Rec(); l2 = np.full(B, 200, np.int32); e.forward_by_length(ids, l2); assert len(e.calls) == 1 and e.calls[0][0] == (B, 256)
+    # min_tokens larger than the batch: everything travels together, at the longest row's length
+    e = Rec(); e.forward_by_length(ids, lens, min_tokens=B * S); assert [c[0] for c in e.calls] == [(B, S)]
+
+
+def test_native_record_formatter_prints_what_json_dumps_prints():
+    """records.format_batch through mv_format_records (host-only code of libmemvul_hip.so: CPython's repr(float) restated in C++) gives the bytes of the Python
+    formatter — i.e. of json.dumps(make_output_human_readable(...)) (model_memory.py:169-191 -> predict_memory.py:111; tests/test_plumbing.py pins that one) —
+    on probabilities as the engine returns them (float32 -> double), on doubles of every magnitude (random bit patterns), and on the corner cases of the
+    fixed / exponent switch; a non-finite value falls back to json's spelling."""
+    from memvul_amd import build, records as R
+
+    build.build(verbose=False)
+    lib = R.native_formatter()
+    assert lib is not None
+    rng = np.random.default_rng(17)
+    names = ['CWE-%d "q" \\ é' % i for i in range(37)]
+    cols, fmt, nm = R.record_layout(names)
+    urls = ["https://example.invalid/issues/%d?x=\"%%s\"\n" % i for i in range(300)]
+    labels = ["neg" if i % 3 else "CWE-79" for i in range(300)]
+    logit = rng.standard_normal((300, 37)).astype(np.float32) * 9
+    p = (1.0 / (1.0 + np.exp(-logit))).astype(np.float32)
+    py = R.format_batch(fmt, nm, urls, labels, p.astype(np.float64))
+    assert R.format_batch(fmt, nm, urls, labels, p.astype(np.float64), lib) == py
+    assert json.loads(py)[7]["predict"][names[5]] == float(p[7, 5]) and json.loads(py)[7]["Issue_Url"] == urls[7]
+
+    def one(v):
+        v = np.asarray(v, np.float64).reshape(-1, 1)
+        return R.format_batch_native(lib, ["a"], ["u"] * len(v), ["l"] * len(v), v)
+
+    def ref(v):
+        return "[" + ", ".join('{"Issue_Url": "u", "label": "l", "predict": {"a": %r}}' % float(x) for x in np.atleast_1d(v)) + "]"
+
+    bits = rng.integers(0, 2 ** 63, size=400000, dtype=np.int64).view(np.float64)
+    bits = bits[np.isfinite(bits)]
+    bits[::2] *= -1.0
+    assert one(bits) == ref(bits)
+    near = np.concatenate([10.0 ** np.arange(-8, 20), np.nextafter(10.0 ** np.arange(-8, 20), 0), np.nextafter(10.0 ** np.arange(-8, 20), np.inf),
+                           [0.0, -0.0, 5e-324, 1.7976931348623157e308, 0.1, 1 / 3, 2.5, 9999999999999998.0, 123456789012345678.0, 1.5e-7, 1e22, 2.0 ** -20]])
+    assert one(near) == ref(near)
+    f32 = rng.random(600000).astype(np.float32).astype(np.float64) ** 3
+    assert one(f32) == ref(f32)
+    bad = p.astype(np.float64).copy(); bad[3, 4] = np.nan
+    assert R.format_batch(fmt, nm, urls, labels, bad, lib) == R.format_batch(fmt, nm, urls, labels, bad) and "NaN" in R.format_batch(fmt, nm, urls, labels, bad, lib)
