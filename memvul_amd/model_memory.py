@@ -294,6 +294,15 @@ class ModelMemory(Model):
         own longest member's length, two batches are in flight on the GPU, and token ids / results cross PCIe once."""
         if not instances:
             return []
+        metadata, p_same = self.sweep_scores(instances, batch_size)
+        out = []
+        for s0 in range(0, len(instances), batch_size):
+            out.append(self.make_output_human_readable({"meta": metadata[s0:s0 + batch_size], "p_same": p_same[s0:s0 + batch_size]}))
+        return out
+
+    def sweep_scores(self, instances: List[Instance], batch_size: int = 512):
+        """``sweep`` up to the records: ``(metadata, P(same) [n, G])`` with the metric accumulators updated — what a caller that writes the records itself
+        (predict_memory.evaluate_sweep, through records.RecordWriter: the same bytes without one dict per issue report) needs."""
         batch = collate(instances, self.vocab)
         metadata = batch["metadata"]
         if metadata[0]["type"] not in ["test", "unlabel"]:
@@ -303,10 +312,7 @@ class ModelMemory(Model):
         if batch.get("label") is not None:
             self._counts(best, _np(batch["label"]))
         self._siamese_metric(best, metadata)
-        out = []
-        for s0 in range(0, len(instances), batch_size):
-            out.append(self.make_output_human_readable({"meta": metadata[s0:s0 + batch_size], "p_same": p_same[s0:s0 + batch_size]}))
-        return out
+        return metadata, p_same
 
     def sweep_arrays(self, arrays: Dict[str, Any], first: int = 0, last: Optional[int] = None, batch_size: int = 512,
                      with_probs: bool = False):
