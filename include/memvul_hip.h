@@ -147,6 +147,10 @@ int mv_forward(mv_handle* h, const int32_t* ids, const int32_t* lens, int B, int
  * mv_forward's, in the order of the rows handed over.  B <= max_batch, B * S <= max_tokens. */
 int mv_forward_groups(mv_handle* h, const int32_t* ids, const int32_t* lens, int B, int S, int n_groups, const int32_t* group_end,
                       const int32_t* group_width, float* logits, float* probs, float* best, int32_t* best_idx, float* embed);
+/* All of that in one call for a batch in ANY row order: rows ordered by the padded length of their own token count (64 .. 256 in steps of 64, 384, 512),
+ * groups of fewer than min_tokens padded tokens merged into the next longer one, results in the caller's row order (binding.Engine.forward_by_length). */
+int mv_forward_ragged(mv_handle* h, const int32_t* ids, const int32_t* lens, int B, int S, int min_tokens, float* logits, float* probs, float* best,
+                      int32_t* best_idx, float* embed);
 /* Encoder only (ModelMemory._instance_forward, model_memory.py:90-103): embed fp32 [B,512]. */
 int mv_encode(mv_handle* h, const int32_t* ids, const int32_t* lens, int B, int S, float* embed);
 /* Matcher only on host embeddings u fp32 [B,512] against the resident bank (model_memory.py:135-147). */

@@ -51,7 +51,7 @@ NUM_KERNEL_CLASSES = 14
 ABI_SYMBOLS = [
     "mv_create", "mv_destroy", "mv_last_error", "mv_sync", "mv_load_tensor", "mv_finalize_weights",
     "mv_anchor_reset", "mv_anchor_append", "mv_anchor_count", "mv_anchor_get", "mv_anchor_set",
-    "mv_forward", "mv_forward_groups", "mv_encode", "mv_match", "mv_topk", "mv_corpus_upload", "mv_corpus_run", "mv_corpus_run_len",
+    "mv_forward", "mv_forward_groups", "mv_forward_ragged", "mv_encode", "mv_match", "mv_topk", "mv_corpus_upload", "mv_corpus_run", "mv_corpus_run_len",
     "mv_corpus_results", "mv_x8_saturation", "mv_attention_concentration", "mv_set_streams", "mv_profile_enable", "mv_profile_select", "mv_profile_read", "mv_kernel_class_name",
     "mv_debug_encode", "mv_debug_read", "mv_test_gemm", "mv_test_gemm_pp", "mv_test_e4m3", "mv_format_records", "mv_comm_prepare", "mv_comm_unique_id", "mv_comm_init", "mv_comm_allgather",
     "mv_comm_destroy", "mv_comm_info", "mv_device_count",
@@ -103,6 +103,7 @@ def load_library(path: Optional[str] = None, dev: bool = False):
         "mv_anchor_set": (C.c_int, [vp, vp, C.c_int]),
         "mv_forward": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, vp, vp, vp, vp, vp]),
         "mv_forward_groups": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, vp]),
+        "mv_forward_ragged": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp]),
         "mv_encode": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, vp]),
         "mv_match": (C.c_int, [vp, vp, C.c_int, vp, vp, vp, vp]),
         "mv_topk": (C.c_int, [vp, vp, C.c_int, C.c_int, vp, vp]),
@@ -135,6 +136,13 @@ def load_library(path: Optional[str] = None, dev: bool = False):
         fn = getattr(lib, name)  # AttributeError if the .so does not export a declared symbol
         fn.restype = res
         fn.argtypes = args
+    # the three tiny getters the hot loop calls once per batch, bound a second time WITHOUT releasing the interpreter lock around the call (PyDLL): next to other
+    # Python threads every release costs the scoring thread a wait for the lock that is far longer than these calls (profiles/r06_*_e2e_dropin.txt)
+    quick = C.PyDLL(path)
+    for name in ("mv_anchor_count", "mv_x8_saturation", "mv_attention_concentration"):
+        fn = getattr(quick, name)
+        fn.restype, fn.argtypes = sig[name]
+    lib.quick = quick
     _libs[path] = lib
     return lib
 
@@ -217,7 +225,7 @@ class Engine:
         correction planes since the engine was created / last reset (mv_x8_saturation; synchronises).  Such an element keeps fp16
         accuracy and loses its correction term."""
         n = C.c_int64(0)
-        self._check(self._lib.mv_x8_saturation(self._h, C.byref(n), int(bool(reset))), "mv_x8_saturation")
+        self._check(self._lib.quick.mv_x8_saturation(self._h, C.byref(n), int(bool(reset))), "mv_x8_saturation")
         return int(n.value)
 
     def attention_concentration(self, reset: bool = False):
@@ -225,7 +233,7 @@ class Engine:
         head, layer) processed so far, the number of them above 0.25 — more than half of a head's [CLS]-row attention on one token that is neither [CLS] nor
         [SEP]: the regime outside the measured envelope of the default form (include/memvul_hip.h) — and the number looked at."""
         m, n, t = C.c_float(0), C.c_int64(0), C.c_int64(0)
-        self._check(self._lib.mv_attention_concentration(self._h, C.byref(m), C.byref(n), C.byref(t), int(bool(reset))), "mv_attention_concentration")
+        self._check(self._lib.quick.mv_attention_concentration(self._h, C.byref(m), C.byref(n), C.byref(t), int(bool(reset))), "mv_attention_concentration")
         return float(m.value), int(n.value), int(t.value)
 
     def _check_saturation(self):
@@ -258,7 +266,7 @@ class Engine:
 
     @property
     def n_anchors(self) -> int:
-        return int(self._lib.mv_anchor_count(self._h))
+        return int(self._lib.quick.mv_anchor_count(self._h))
 
     def anchor_get(self) -> np.ndarray:
         out = np.empty((self.n_anchors, self.P), np.float32)
@@ -302,10 +310,17 @@ class Engine:
         B, S = ids.shape
         if min_tokens is None:
             min_tokens = self.BY_LENGTH_MIN_TOKENS
-        pl = np.where(lens <= 256, (np.maximum(lens, 1) + 63) // 64 * 64, (lens + 127) // 128 * 128).astype(np.int64)
-        top = int(pl.max()) if B else 0
         if B == 0 or B * S < 2 * min_tokens:
             return self.forward(ids, lens, want_logits, want_probs, want_embed)
+        ragged = getattr(self, "_forward_ragged", None)  # (a stand-in engine of the tests has only `forward`)
+        if ragged is not None:
+            # everything below inside the library (mv_forward_ragged): ONE release of the interpreter lock per batch
+            out = {"logits": np.empty((B, self.n_anchors, 2), np.float32) if want_logits else None, "probs": np.empty((B, self.n_anchors, 2), np.float32) if want_probs else None,
+                   "best": np.empty((B, 2), np.float32), "best_idx": np.empty((B,), np.int32), "embed": np.empty((B, self.P), np.float32) if want_embed else None}
+            if ragged(ids, lens, min_tokens, out):
+                return out
+        pl = np.where(lens <= 256, (np.maximum(lens, 1) + 63) // 64 * 64, (lens + 127) // 128 * 128).astype(np.int64)
+        top = int(pl.max()) if B else 0
         if int(pl.min()) == top:  # one group: one call, at the group's own length
             return self.forward(np.ascontiguousarray(ids[:, :top]) if top < S else ids, lens, want_logits, want_probs, want_embed)
         # ONE gather into length order, the groups are then row slices of it and every pass writes its results straight into its slice of the
@@ -338,6 +353,17 @@ class Engine:
         inv = np.empty(B, np.int64)
         inv[order] = np.arange(B)
         return {k: (v[inv] if v is not None else None) for k, v in bufs.items()}
+
+    def _forward_ragged(self, ids: np.ndarray, lens: np.ndarray, min_tokens: int, out: Dict[str, Optional[np.ndarray]]) -> bool:
+        """mv_forward_ragged into the caller's arrays; False = the batch does not fit one upload (the caller walks the groups itself)."""
+        B, S = ids.shape
+        rc = self._lib.mv_forward_ragged(self._h, _ptr(ids), _ptr(lens), B, S, int(min_tokens), _ptr(out.get("logits")), _ptr(out.get("probs")),
+                                         _ptr(out["best"]), _ptr(out["best_idx"]), _ptr(out.get("embed")))
+        if rc == -5:  # MV_ERR_CAPACITY (checked before any GPU work)
+            return False
+        self._check(rc, "mv_forward_ragged")
+        self._check_saturation()
+        return True
 
     def _forward_groups(self, ids: np.ndarray, lens: np.ndarray, ends, widths, out: Dict[str, Optional[np.ndarray]]) -> bool:
         """mv_forward_groups into the caller's arrays (rows in length order); False = the batch does not fit one upload (max_batch / max_tokens): the caller

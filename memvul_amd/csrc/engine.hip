@@ -6,6 +6,7 @@
 #include <rccl/rccl.h>  // types and prototypes only: librccl.so is opened at run time (mv_comm_init), never linked
 #include <unistd.h>
 
+#include <algorithm>
 #include <charconv>
 #include <chrono>
 #include <cmath>
@@ -183,6 +184,10 @@ struct mv_handle {
   // resident corpus
   int32_t *c_ids = nullptr, *c_lens = nullptr;
   std::vector<int32_t> c_lens_host;  // the lengths as uploaded (encode_dev's min_len of each pass)
+  struct {  // mv_forward_ragged: the batch in length order and its results before they go back to the caller's row order
+    std::vector<int32_t> ids, lens, idx;
+    std::vector<float> logits, probs, best, embed;
+  } ragged;
   int64_t c_n = 0;
   int c_S = 0;
   float* c_best = nullptr;
@@ -1441,6 +1446,59 @@ int mv_forward_groups(mv_handle* h, const int32_t* ids, const int32_t* lens, int
   if (best_idx) HIPCHK(h, hipMemcpyAsync(best_idx, h->w->best_idx, (size_t)B * 4, hipMemcpyDeviceToHost, h->w->stream));
   if (embed) HIPCHK(h, hipMemcpyAsync(embed, h->w->u, (size_t)B * h->P * 4, hipMemcpyDeviceToHost, h->w->stream));
   HIPCHK(h, hipStreamSynchronize(h->w->stream));
+  return MV_OK;
+} catch (...) { return on_exception(h); }
+
+// mv_forward on a pad-to-longest batch of UNSORTED rows, all of binding.Engine.forward_by_length inside ONE call: the rows ordered (stably) by the padded length of
+// their own token count, cut into groups (a group of fewer than min_tokens padded tokens travels with the next longer one), gathered on the host, scored by
+// mv_forward_groups, and the results put back in the caller's row order.  One call = one release of the caller's interpreter lock per batch: next to two other
+// Python threads every release cost the scoring thread ~10 ms of waiting (profiles/r06_*_e2e_dropin.txt).
+int mv_forward_ragged(mv_handle* h, const int32_t* ids, const int32_t* lens, int B, int S, int min_tokens, float* logits, float* probs, float* best,
+                      int32_t* best_idx, float* embed) try {
+  if (int rc = check_ready(h)) return rc;
+  if (!ids || !lens || B <= 0 || S <= 0 || S > h->cfg.max_pos || !best || !best_idx) return fail(h, MV_ERR_INVALID, "mv_forward_ragged: bad argument");
+  if (B > h->cfg.max_batch || (int64_t)B * S > h->cap_tokens) return fail(h, MV_ERR_CAPACITY, "mv_forward_ragged: the batch exceeds mv_config.max_batch / max_tokens");
+  const int G = h->n_anchors;
+  std::vector<int> pl(B), order(B);
+  for (int i = 0; i < B; ++i) {
+    if (lens[i] > S) return fail(h, MV_ERR_INVALID, "mv_forward_ragged: a row is longer than S");
+    pl[i] = padded_len(lens[i] < 1 ? 1 : lens[i]);
+    order[i] = i;
+  }
+  std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return pl[a] < pl[b]; });
+  std::vector<int32_t> ends, widths;
+  int start = 0;
+  for (int end = 1; end <= B; ++end) {
+    if (end < B && pl[order[end]] == pl[order[end - 1]]) continue;  // inside a run of one padded length
+    const int width = pl[order[end - 1]];
+    if (end < B && (int64_t)(end - start) * width < min_tokens) continue;  // too small a pass: these rows travel with the next longer group
+    ends.push_back(end);
+    widths.push_back(width < S ? width : S);
+    start = end;
+  }
+  auto& st = h->ragged;
+  st.ids.resize((size_t)B * S);
+  st.lens.resize(B);
+  for (int i = 0; i < B; ++i) {
+    std::memcpy(st.ids.data() + (size_t)i * S, ids + (size_t)order[i] * S, (size_t)S * 4);
+    st.lens[i] = lens[order[i]];
+  }
+  if (logits) st.logits.resize((size_t)B * G * 2);
+  if (probs) st.probs.resize((size_t)B * G * 2);
+  st.best.resize((size_t)B * 2);
+  st.idx.resize(B);
+  if (embed) st.embed.resize((size_t)B * h->P);
+  if (int rc = mv_forward_groups(h, st.ids.data(), st.lens.data(), B, S, (int)ends.size(), ends.data(), widths.data(), logits ? st.logits.data() : nullptr,
+                                 probs ? st.probs.data() : nullptr, st.best.data(), st.idx.data(), embed ? st.embed.data() : nullptr)) return rc;
+  const size_t g2 = (size_t)G * 2;
+  for (int i = 0; i < B; ++i) {
+    const size_t o = (size_t)order[i];
+    if (logits) std::memcpy(logits + o * g2, st.logits.data() + (size_t)i * g2, g2 * 4);
+    if (probs) std::memcpy(probs + o * g2, st.probs.data() + (size_t)i * g2, g2 * 4);
+    best[o * 2] = st.best[(size_t)i * 2]; best[o * 2 + 1] = st.best[(size_t)i * 2 + 1];
+    best_idx[o] = st.idx[i];
+    if (embed) std::memcpy(embed + o * h->P, st.embed.data() + (size_t)i * h->P, (size_t)h->P * 4);
+  }
   return MV_OK;
 } catch (...) { return on_exception(h); }
 

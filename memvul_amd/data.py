@@ -69,6 +69,8 @@ def collate(instances: List[Instance], vocab=None) -> Dict[str, Any]:
             ids = np.zeros((B, L), np.int64)
             typ = np.zeros((B, L), np.int64)
             mask = np.zeros((B, L), bool)
+            lens = np.zeros(B, np.int32)
+            single = True
             for b, ins in enumerate(instances):
                 toks = ins.fields[name].tokens
                 n = len(toks)
@@ -77,9 +79,15 @@ def collate(instances: List[Instance], vocab=None) -> Dict[str, Any]:
                     ids[b, :n] = row
                 else:
                     ids[b, :n] = [t.text_id for t in toks]
-                    typ[b, :n] = [t.type_id or 0 for t in toks]
+                    tt = [t.type_id or 0 for t in toks]
+                    typ[b, :n] = tt
+                    single = single and not any(tt)
                 mask[b, :n] = True
-            out[name] = {"tokens": {"token_ids": ids, "mask": mask, "type_ids": typ}}
+                lens[b] = n
+            # "_collated": what this function knows by construction (a prefix mask of these lengths, zero padding, single segment or not) — ModelMemory._ids_lens
+            # takes it (with the int32 copy of the ids the engine wants) instead of re-deriving it from the arrays on the scoring thread (ten numpy passes over [B, L], each a GIL hand-over: 11 ms per batch of
+            # 512 next to two other Python threads, profiles/r06_*_e2e_dropin.txt)
+            out[name] = {"tokens": {"token_ids": ids, "mask": mask, "type_ids": typ, "_collated": (ids.astype(np.int32), lens, single)}}
         elif isinstance(f0, LabelField):
             if vocab is None:
                 raise ValueError("a Vocabulary is needed to index LabelFields (DataLoader.index_with)")

@@ -231,6 +231,12 @@ class ModelMemory(Model):
     @staticmethod
     def _ids_lens(sample: Dict[str, Dict[str, Any]]):
         t = sample["tokens"]
+        known = t.get("_collated")
+        if known is not None:  # memvul_amd.data.collate: lengths, prefix mask, zero padding and the segment check by construction
+            ids32, lens, single = known
+            if not single:
+                raise ValueError("non-zero token-type ids: the hot path is single-segment (custom_PTM_embedder.py:199-202)")
+            return ids32, lens
         ids = _np(t["token_ids"]).astype(np.int32)
         mask = np.asarray(_np(t["mask"]), bool)
         tid = t.get("type_ids")

@@ -96,6 +96,8 @@ class Stage:
 
 
 def main():
+    if os.environ.get("MEMVUL_PROBE_SWITCH_INTERVAL"):  # A/B of the interpreter's thread switch interval (default 5 ms)
+        sys.setswitchinterval(float(os.environ["MEMVUL_PROBE_SWITCH_INTERVAL"]))
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 40000
     import plumbing_util as pu
     from memvul_amd import data as mvdata
@@ -115,7 +117,10 @@ def main():
     results = {}
     os.environ["MEMVUL_RECORD_WORKERS"] = sys.argv[2] if len(sys.argv) > 2 else "0"
     print("MEMVUL_RECORD_WORKERS = %s (processes formatting the JSON records; 0 = in the driver process)" % os.environ["MEMVUL_RECORD_WORKERS"])
+    only = sys.argv[3].split(",") if len(sys.argv) > 3 else None
     for form, kw in (("arrays", dict(sweep="arrays")), ("sweep", dict(sweep=True)), ("instances", dict(sweep=False))):
+        if only and form not in only:
+            continue
         st = Stage()
         import memvul_amd.reader_memory as rm
         import memvul_amd.model_memory as mm
@@ -132,6 +137,21 @@ def main():
         undo.append((mb.Engine, "forward_by_length", st.wrap(mb.Engine, "forward_by_length", "scorer thread: engine.forward_by_length (sort + upload + passes + download)")))
         undo.append((mm.ModelMemory, "__call__", st.wrap(mm.ModelMemory, "__call__", "scorer thread: model(**batch) in all")))
         undo.append((mr.RecordWriter, "submit", st.wrap(mr.RecordWriter, "submit", "writer: RecordWriter.submit (format + write)")))
+        import memvul_amd.custom_metric as cmm
+        undo.append((cmm.SiameseMeasureV1, "__call__", st.wrap(cmm.SiameseMeasureV1, "__call__", "scorer thread: _siamese_metric")))
+        undo.append((mm._ClassificationCounts, "__call__", st.wrap(mm._ClassificationCounts, "__call__", "scorer thread: _counts")))
+        _il = mm.ModelMemory.__dict__["_ids_lens"].__func__
+        acc_il = st.t
+
+        def _il_timed(sample, _f=_il):
+            t0 = time.perf_counter()
+            try:
+                return _f(sample)
+            finally:
+                acc_il["scorer thread: _ids_lens"] = acc_il.get("scorer thread: _ids_lens", 0.0) + time.perf_counter() - t0
+
+        mm.ModelMemory._ids_lens = staticmethod(_il_timed)
+        undo.append((mm.ModelMemory, "_ids_lens", staticmethod(_il)))
         undo.append((pm, "load_archive", st.wrap(pm, "load_archive", "load_archive (weights -> engine)")))
         undo.append((json, "dumps", st.wrap(json, "dumps", "json.dumps of the records")))
         t0 = time.perf_counter()

@@ -665,12 +665,19 @@ def test_forward_by_length_matches_the_padded_forward(gu, compute):
     eng.anchor_set(synth.make_anchor_bank(24))
     a = eng.forward(ids, lens)
     b = eng.forward_by_length(ids, lens, min_tokens=4096)
-    eng._forward_groups = None  # the same groups walked from Python, one mv_forward each, instead of ONE mv_forward_groups call: the same bits
+    # b came from ONE mv_forward_ragged call; the same grouping done in Python around mv_forward_groups, and around one mv_forward per group: the same bits
+    eng._forward_ragged = None
     try:
         c = eng.forward_by_length(ids, lens, min_tokens=4096)
+        eng._forward_groups = None
+        d2 = eng.forward_by_length(ids, lens, min_tokens=4096)
     finally:
-        del eng._forward_groups
-    assert all(np.array_equal(b[k], c[k]) for k in ("logits", "probs", "best", "best_idx"))
+        del eng._forward_ragged
+        if "_forward_groups" in eng.__dict__:
+            del eng._forward_groups
+    assert all(np.array_equal(b[k], c[k]) and np.array_equal(b[k], d2[k]) for k in ("logits", "probs", "best", "best_idx"))
+    e1 = eng.forward_by_length(ids, lens, want_logits=False, want_embed=True, min_tokens=4096)
+    assert e1["logits"] is None and np.array_equal(e1["probs"], b["probs"]) and np.array_equal(e1["embed"], eng.forward_by_length(ids, lens, want_embed=True, min_tokens=4096)["embed"])
     d = float(np.abs(a["probs"] - b["probs"]).max())
     gu.record("forward_by_length", compute=compute, max_p_diff=d)
     assert d < 1e-3
