@@ -151,6 +151,13 @@ int mv_forward_groups(mv_handle* h, const int32_t* ids, const int32_t* lens, int
  * groups of fewer than min_tokens padded tokens merged into the next longer one, results in the caller's row order (binding.Engine.forward_by_length). */
 int mv_forward_ragged(mv_handle* h, const int32_t* ids, const int32_t* lens, int B, int S, int min_tokens, float* logits, float* probs, float* best,
                       int32_t* best_idx, float* embed);
+/* mv_forward_ragged in two halves: `begin` enqueues the batch (upload, passes, download into pinned staging) on the stream of the next workspace set and returns a
+ * ticket without waiting; `end` waits for it and fills the caller's arrays (those of the outputs `begin` was asked for; best / best_idx always).  One batch per
+ * workspace set (MEMVUL_STREAMS, 2 by default) may be in flight; collect tickets in the order they were issued.  predict_memory.evaluate hands over batch k + 1
+ * before it collects batch k, so the GPU does not wait for the host between batches (the reference's loop is serial: predict_memory.py:103-110). */
+int mv_forward_ragged_begin(mv_handle* h, const int32_t* ids, const int32_t* lens, int B, int S, int min_tokens, int want_logits, int want_probs, int want_embed,
+                            int* ticket);
+int mv_forward_ragged_end(mv_handle* h, int ticket, float* logits, float* probs, float* best, int32_t* best_idx, float* embed);
 /* Encoder only (ModelMemory._instance_forward, model_memory.py:90-103): embed fp32 [B,512]. */
 int mv_encode(mv_handle* h, const int32_t* ids, const int32_t* lens, int B, int S, float* embed);
 /* Matcher only on host embeddings u fp32 [B,512] against the resident bank (model_memory.py:135-147). */

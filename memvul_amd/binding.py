@@ -51,7 +51,7 @@ NUM_KERNEL_CLASSES = 14
 ABI_SYMBOLS = [
     "mv_create", "mv_destroy", "mv_last_error", "mv_sync", "mv_load_tensor", "mv_finalize_weights",
     "mv_anchor_reset", "mv_anchor_append", "mv_anchor_count", "mv_anchor_get", "mv_anchor_set",
-    "mv_forward", "mv_forward_groups", "mv_forward_ragged", "mv_encode", "mv_match", "mv_topk", "mv_corpus_upload", "mv_corpus_run", "mv_corpus_run_len",
+    "mv_forward", "mv_forward_groups", "mv_forward_ragged", "mv_forward_ragged_begin", "mv_forward_ragged_end", "mv_encode", "mv_match", "mv_topk", "mv_corpus_upload", "mv_corpus_run", "mv_corpus_run_len",
     "mv_corpus_results", "mv_x8_saturation", "mv_attention_concentration", "mv_set_streams", "mv_profile_enable", "mv_profile_select", "mv_profile_read", "mv_kernel_class_name",
     "mv_debug_encode", "mv_debug_read", "mv_test_gemm", "mv_test_gemm_pp", "mv_test_e4m3", "mv_format_records", "mv_comm_prepare", "mv_comm_unique_id", "mv_comm_init", "mv_comm_allgather",
     "mv_comm_destroy", "mv_comm_info", "mv_device_count",
@@ -104,6 +104,8 @@ def load_library(path: Optional[str] = None, dev: bool = False):
         "mv_forward": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, vp, vp, vp, vp, vp]),
         "mv_forward_groups": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, vp]),
         "mv_forward_ragged": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp]),
+        "mv_forward_ragged_begin": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, P(C.c_int)]),
+        "mv_forward_ragged_end": (C.c_int, [vp, C.c_int, vp, vp, vp, vp, vp]),
         "mv_encode": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, vp]),
         "mv_match": (C.c_int, [vp, vp, C.c_int, vp, vp, vp, vp]),
         "mv_topk": (C.c_int, [vp, vp, C.c_int, C.c_int, vp, vp]),
@@ -175,6 +177,7 @@ class Engine:
             raise RuntimeError(f"mv_create failed ({rc}): {msg.decode() if msg else ''}")
         self._h = h
         self.device = device
+        self._tickets = []  # forward_by_length_begin: batches in flight, oldest first
 
     # -- plumbing
     def _check(self, rc: int, what: str):
@@ -353,6 +356,38 @@ class Engine:
         inv = np.empty(B, np.int64)
         inv[order] = np.arange(B)
         return {k: (v[inv] if v is not None else None) for k, v in bufs.items()}
+
+    def forward_by_length_begin(self, ids: np.ndarray, lens: np.ndarray, want_logits=True, want_probs=True, want_embed=False, min_tokens: Optional[int] = None):
+        """``forward_by_length`` handed over without waiting for it (mv_forward_ragged_begin): returns a ticket for ``forward_by_length_end``.  One batch per
+        workspace set may be in flight (two by default); collect in the order of the calls.  A batch the asynchronous entry cannot take (too small to be
+        worth grouping, too large for one upload, every workspace set busy) is scored at once and its ticket holds the results."""
+        ids, lens = _as(ids, np.int32), _as(lens, np.int32)
+        B, S = ids.shape
+        mt = self.BY_LENGTH_MIN_TOKENS if min_tokens is None else min_tokens
+        if B > 0 and B * S >= 2 * mt and len(self._tickets) < 2:
+            t = C.c_int(-1)
+            rc = self._lib.mv_forward_ragged_begin(self._h, _ptr(ids), _ptr(lens), B, S, int(mt), int(want_logits), int(want_probs), int(want_embed), C.byref(t))
+            if rc == 0:
+                self._tickets.append(t.value)
+                return ("pending", t.value, B, bool(want_logits), bool(want_probs), bool(want_embed))
+            if rc != -5:  # (MV_ERR_CAPACITY: below)
+                self._check(rc, "mv_forward_ragged_begin")
+        return ("done", self.forward_by_length(ids, lens, want_logits, want_probs, want_embed, min_tokens))
+
+    def forward_by_length_end(self, ticket):
+        if ticket[0] == "done":
+            return ticket[1]
+        _, t, B, want_logits, want_probs, want_embed = ticket
+        if not self._tickets or self._tickets[0] != t:
+            raise RuntimeError("forward_by_length_end: tickets are collected in the order they were issued")
+        G = self.n_anchors
+        out = {"logits": np.empty((B, G, 2), np.float32) if want_logits else None, "probs": np.empty((B, G, 2), np.float32) if want_probs else None,
+               "best": np.empty((B, 2), np.float32), "best_idx": np.empty((B,), np.int32), "embed": np.empty((B, self.P), np.float32) if want_embed else None}
+        self._tickets.pop(0)
+        self._check(self._lib.mv_forward_ragged_end(self._h, t, _ptr(out["logits"]), _ptr(out["probs"]), _ptr(out["best"]), _ptr(out["best_idx"]), _ptr(out["embed"])),
+                    "mv_forward_ragged_end")
+        self._check_saturation()
+        return out
 
     def _forward_ragged(self, ids: np.ndarray, lens: np.ndarray, min_tokens: int, out: Dict[str, Optional[np.ndarray]]) -> bool:
         """mv_forward_ragged into the caller's arrays; False = the batch does not fit one upload (the caller walks the groups itself)."""

@@ -188,6 +188,16 @@ struct mv_handle {
     std::vector<int32_t> ids, lens, idx;
     std::vector<float> logits, probs, best, embed;
   } ragged;
+  struct RaggedSlot {  // mv_forward_ragged_begin / _end: one batch in flight per workspace set, its staging in PINNED host memory (the copies really are asynchronous)
+    bool busy = false;
+    int B = 0, G = 0;
+    bool logits = false, probs = false, embed = false;
+    std::vector<int> order;
+    int32_t *ids = nullptr, *lens = nullptr, *idx = nullptr;   // [cap_tokens], [max_batch], [max_batch]
+    float *lg = nullptr, *pr = nullptr, *best = nullptr, *emb = nullptr;  // [max_batch][max_anchors][2] x 2, [max_batch][2], [max_batch][P]
+  } rslot[2];
+  int rnext = 0;
+  std::vector<void*> pinned;
   int64_t c_n = 0;
   int c_S = 0;
   float* c_best = nullptr;
@@ -1095,6 +1105,7 @@ void mv_destroy(mv_handle* h) {
   for (auto& r : h->recs) { hipEventDestroy(r.e0); hipEventDestroy(r.e1); }
   for (auto e : h->free_events) hipEventDestroy(e);
   for (void* p : h->allocs) hipFree(p);
+  for (void* p : h->pinned) hipHostFree(p);
   for (auto& wk : h->work)
     if (wk.stream) hipStreamDestroy(wk.stream);
   delete h;
@@ -1498,6 +1509,122 @@ int mv_forward_ragged(mv_handle* h, const int32_t* ids, const int32_t* lens, int
     best[o * 2] = st.best[(size_t)i * 2]; best[o * 2 + 1] = st.best[(size_t)i * 2 + 1];
     best_idx[o] = st.idx[i];
     if (embed) std::memcpy(embed + o * h->P, st.embed.data() + (size_t)i * h->P, (size_t)h->P * 4);
+  }
+  return MV_OK;
+} catch (...) { return on_exception(h); }
+
+// mv_forward_ragged in two halves, so that the caller can hand over batch k + 1 BEFORE it collects batch k: `begin` orders and groups the rows, gathers them into
+// pinned memory, enqueues upload + passes + download on the stream of the next workspace set and returns a ticket without waiting; `end` waits for that stream and puts
+// the results into the caller's arrays in the caller's row order.  At most one batch per workspace set (MEMVUL_STREAMS: 2) is in flight; tickets are collected in
+// the order they were issued.  The GPU then never waits for the caller's Python between two batches (predict_memory.evaluate).
+static int ragged_plan(mv_handle* h, const int32_t* lens, int B, int S, int min_tokens, std::vector<int>& order, std::vector<int32_t>& ends, std::vector<int32_t>& widths) {
+  std::vector<int> pl(B);
+  order.resize(B);
+  for (int i = 0; i < B; ++i) {
+    if (lens[i] > S) return fail(h, MV_ERR_INVALID, "mv_forward_ragged: a row is longer than S");
+    pl[i] = padded_len(lens[i] < 1 ? 1 : lens[i]);
+    order[i] = i;
+  }
+  std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return pl[a] < pl[b]; });
+  int start = 0;
+  for (int end = 1; end <= B; ++end) {
+    if (end < B && pl[order[end]] == pl[order[end - 1]]) continue;  // inside a run of one padded length
+    const int width = pl[order[end - 1]];
+    if (end < B && (int64_t)(end - start) * width < min_tokens) continue;  // too small a pass: these rows travel with the next longer group
+    if (end - start > max_rows_for(h, width < S ? width : S)) return fail(h, MV_ERR_CAPACITY, "mv_forward_ragged: a group exceeds one pass (mv_config.max_tokens)");
+    ends.push_back(end);
+    widths.push_back(width < S ? width : S);
+    start = end;
+  }
+  return MV_OK;
+}
+
+int mv_forward_ragged_begin(mv_handle* h, const int32_t* ids, const int32_t* lens, int B, int S, int min_tokens, int want_logits, int want_probs, int want_embed,
+                            int* ticket) try {
+  if (int rc = check_ready(h)) return rc;
+  if (!ids || !lens || !ticket || B <= 0 || S <= 0 || S > h->cfg.max_pos) return fail(h, MV_ERR_INVALID, "mv_forward_ragged_begin: bad argument");
+  if (h->n_anchors <= 0) return fail(h, MV_ERR_STATE, "anchor bank is empty (call mv_anchor_append / mv_anchor_set first)");
+  if (B > h->cfg.max_batch || (int64_t)B * S > h->cap_tokens) return fail(h, MV_ERR_CAPACITY, "mv_forward_ragged_begin: the batch exceeds mv_config.max_batch / max_tokens");
+  const int slot = h->rnext % (h->n_alloc < 2 ? 1 : 2);
+  auto& rs = h->rslot[slot];
+  if (rs.busy) return fail(h, MV_ERR_STATE, "mv_forward_ragged_begin: the workspace set's previous batch has not been collected (mv_forward_ragged_end)");
+  std::vector<int32_t> ends, widths;
+  if (int rc = ragged_plan(h, lens, B, S, min_tokens, rs.order, ends, widths)) return rc;
+  if (int rc = check_ids(h, ids, (int64_t)B * S, "mv_forward_ragged_begin")) return rc;
+  HIPCHK(h, hipSetDevice(h->device));
+  const int G = h->n_anchors;
+  if (!rs.ids) {  // pinned staging of this slot, once
+    const size_t mb = (size_t)h->cfg.max_batch, bg2 = mb * (size_t)h->cfg.max_anchors * 2;
+    auto pin = [&](void** p, size_t bytes) -> int {
+      if (hipHostMalloc(p, bytes, hipHostMallocDefault) != hipSuccess) return fail(h, MV_ERR_NOMEM, "hipHostMalloc failed (mv_forward_ragged_begin)");
+      h->pinned.push_back(*p);
+      return MV_OK;
+    };
+    int rc = pin((void**)&rs.ids, (size_t)h->cap_tokens * 4);
+    if (!rc) rc = pin((void**)&rs.lens, mb * 4);
+    if (!rc) rc = pin((void**)&rs.idx, mb * 4);
+    if (!rc) rc = pin((void**)&rs.lg, bg2 * 4);
+    if (!rc) rc = pin((void**)&rs.pr, bg2 * 4);
+    if (!rc) rc = pin((void**)&rs.best, mb * 2 * 4);
+    if (!rc) rc = pin((void**)&rs.emb, mb * (size_t)h->P * 4);
+    if (rc) { rs.ids = nullptr; return rc; }
+  }
+  for (int i = 0; i < B; ++i) {
+    std::memcpy(rs.ids + (size_t)i * S, ids + (size_t)rs.order[i] * S, (size_t)S * 4);
+    rs.lens[i] = lens[rs.order[i]];
+  }
+  Work* keep = h->w;
+  h->w = &h->work[slot];
+  auto run = [&]() -> int {
+    HIPCHK(h, hipMemcpyAsync(h->w->d_ids, rs.ids, (size_t)B * S * 4, hipMemcpyHostToDevice, h->w->stream));
+    HIPCHK(h, hipMemcpyAsync(h->w->d_lens, rs.lens, (size_t)B * 4, hipMemcpyHostToDevice, h->w->stream));
+    int prev = 0;
+    for (size_t g = 0; g < ends.size(); ++g) {
+      const int nb = ends[g] - prev;
+      float* u = h->w->u + (size_t)prev * h->P;
+      if (int rc = encode_dev(h, h->w->d_ids + (size_t)prev * S, h->w->d_lens + prev, pass_min_len(rs.lens + prev, nb), nb, widths[g], -1, u, false, S)) return rc;
+      if (int rc = match_dev(h, u, nb, want_logits ? h->w->logits + (size_t)prev * G * 2 : nullptr, want_probs ? h->w->probs + (size_t)prev * G * 2 : nullptr, nullptr, 1,
+                             h->w->best + (size_t)prev * 2, h->w->best_idx + prev)) return rc;
+      prev = ends[g];
+    }
+    const size_t bg = (size_t)B * G;
+    if (want_logits) HIPCHK(h, hipMemcpyAsync(rs.lg, h->w->logits, bg * 8, hipMemcpyDeviceToHost, h->w->stream));
+    if (want_probs) HIPCHK(h, hipMemcpyAsync(rs.pr, h->w->probs, bg * 8, hipMemcpyDeviceToHost, h->w->stream));
+    HIPCHK(h, hipMemcpyAsync(rs.best, h->w->best, (size_t)B * 8, hipMemcpyDeviceToHost, h->w->stream));
+    HIPCHK(h, hipMemcpyAsync(rs.idx, h->w->best_idx, (size_t)B * 4, hipMemcpyDeviceToHost, h->w->stream));
+    if (want_embed) HIPCHK(h, hipMemcpyAsync(rs.emb, h->w->u, (size_t)B * h->P * 4, hipMemcpyDeviceToHost, h->w->stream));
+    return MV_OK;
+  };
+  const int rc = run();
+  h->w = keep;
+  if (rc != MV_OK) {
+    hipStreamSynchronize(h->work[slot].stream);
+    return rc;
+  }
+  rs.busy = true; rs.B = B; rs.G = G;
+  rs.logits = want_logits != 0; rs.probs = want_probs != 0; rs.embed = want_embed != 0;
+  *ticket = slot;
+  h->rnext += 1;
+  return MV_OK;
+} catch (...) { return on_exception(h); }
+
+int mv_forward_ragged_end(mv_handle* h, int ticket, float* logits, float* probs, float* best, int32_t* best_idx, float* embed) try {
+  if (!h || ticket < 0 || ticket > 1 || !h->rslot[ticket].busy) return fail(h, MV_ERR_STATE, "mv_forward_ragged_end: no batch in flight under this ticket");
+  auto& rs = h->rslot[ticket];
+  HIPCHK(h, hipSetDevice(h->device));
+  const hipError_t e = hipStreamSynchronize(h->work[ticket].stream);
+  rs.busy = false;
+  if (e != hipSuccess) return fail(h, MV_ERR_HIP, std::string("mv_forward_ragged_end: ") + hipGetErrorString(e));
+  if (!best || !best_idx || (rs.logits && !logits) || (rs.probs && !probs) || (rs.embed && !embed))
+    return fail(h, MV_ERR_INVALID, "mv_forward_ragged_end: an output the batch was started with is missing");
+  const size_t g2 = (size_t)rs.G * 2;
+  for (int i = 0; i < rs.B; ++i) {
+    const size_t o = (size_t)rs.order[i];
+    if (rs.logits) std::memcpy(logits + o * g2, rs.lg + (size_t)i * g2, g2 * 4);
+    if (rs.probs) std::memcpy(probs + o * g2, rs.pr + (size_t)i * g2, g2 * 4);
+    best[o * 2] = rs.best[(size_t)i * 2]; best[o * 2 + 1] = rs.best[(size_t)i * 2 + 1];
+    best_idx[o] = rs.idx[i];
+    if (rs.embed) std::memcpy(embed + o * h->P, rs.emb + (size_t)i * h->P, (size_t)h->P * 4);
   }
   return MV_OK;
 } catch (...) { return on_exception(h); }
