@@ -287,6 +287,28 @@ class ModelMemory(Model):
 
     __call__ = forward
 
+    def forward_begin(self, sample1=None, sample2=None, label=None, metadata: List[Dict[str, Any]] = None):
+        """``forward`` in two halves for a caller that overlaps batches (predict_memory.evaluate): the engine takes the batch here without waiting for it
+        (Engine.forward_by_length_begin) ..."""
+        if not (metadata and metadata[0]["type"] in ["test", "unlabel"]) or not hasattr(self.engine, "forward_by_length_begin"):
+            return ("done", self.forward(sample1, sample2, label, metadata))
+        ids, lens = self._ids_lens(sample1)
+        return ("pending", self.engine.forward_by_length_begin(ids, lens, want_logits=False, want_probs=True), label, metadata)
+
+    def forward_end(self, pending) -> Dict[str, Any]:
+        """... and is collected here, where the metric accumulators are updated: ``forward_end(forward_begin(**batch))`` is ``forward(**batch)`` (model_memory.py:118-167),
+        and batches collected in the order they were begun update the metrics in the reference's order."""
+        if pending[0] == "done":
+            return pending[1]
+        _, ticket, label, metadata = pending
+        out = self.engine.forward_by_length_end(ticket)
+        output_dict: Dict[str, Any] = {"meta": metadata, "probs": out["probs"], "best_anchor": out["best_idx"]}
+        probs = out["best"]
+        if label is not None:
+            self._counts(probs, _np(label))
+        self._siamese_metric(probs, metadata)
+        return output_dict
+
     def forward_on_instances(self, instances: List[Instance]) -> List[Dict[str, Any]]:
         """AllenNLP ``Model.forward_on_instances``: collate (pad to the longest of the chunk) + forward."""
         batch = collate(instances, self.vocab)

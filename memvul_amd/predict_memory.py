@@ -65,6 +65,11 @@ def evaluate(model, data_loader, cuda_device: int = -1, batch_weight_key: str = 
             put(q_in, None)
 
     def scorer():
+        # a model with forward_begin / forward_end (ModelMemory): batch k + 1 is handed to the engine BEFORE batch k is collected, so the GPU does not wait for
+        # this thread's Python — or for the interpreter lock it shares with the two others — between batches; collected in order: the same calls in the same
+        # order on the metric accumulators.  Any other model: model(**batch), as AllenNLP's evaluate calls it.
+        two_halves = hasattr(model, "forward_begin") and hasattr(model, "forward_end")
+        pending = None
         try:
             while not stop.is_set():
                 try:
@@ -73,13 +78,30 @@ def evaluate(model, data_loader, cuda_device: int = -1, batch_weight_key: str = 
                     continue
                 if batch is None:
                     break
-                out = model(**batch)
+                if two_halves:
+                    nxt = model.forward_begin(**batch)
+                    out = model.forward_end(pending) if pending is not None else None
+                    pending = nxt
+                    if out is None:
+                        continue
+                else:
+                    out = model(**batch)
+                if predictions_output_file:
+                    put(q_out, out)
+            if pending is not None and not stop.is_set():
+                last, pending = pending, None
+                out = model.forward_end(last)
                 if predictions_output_file:
                     put(q_out, out)
         except BaseException as e:
             err.append(e)
             stop.set()
         finally:
+            if pending is not None:  # an error on the way: leave no batch in flight inside the engine
+                try:
+                    model.forward_end(pending)
+                except BaseException:
+                    pass
             put(q_out, None)
 
     th = [threading.Thread(target=collator, name="memvul-collate", daemon=True), threading.Thread(target=scorer, name="memvul-score", daemon=True)]

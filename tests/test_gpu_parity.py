@@ -690,6 +690,18 @@ def test_forward_by_length_matches_the_padded_forward(gu, compute):
         assert np.array_equal(a["probs"][longest], b["probs"][longest]) and np.array_equal(a["logits"][longest], b["logits"][longest])
     short = lens <= 64
     assert short.any() and not np.array_equal(a["probs"][short], b["probs"][short])  # (they did run at another padded length)
+    # the two halves (mv_forward_ragged_begin / _end): two batches in flight on the two workspace sets, collected in order, the bits of the one-call form
+    t1 = eng.forward_by_length_begin(ids, lens, min_tokens=4096)
+    t2 = eng.forward_by_length_begin(ids[::-1].copy(), lens[::-1].copy(), want_logits=False, min_tokens=4096)
+    assert t1[0] == "pending" and t2[0] == "pending"
+    t3 = eng.forward_by_length_begin(ids[:16], lens[:16])  # too small to be worth grouping: scored at once, next to the two in flight
+    assert t3[0] == "done"
+    with pytest.raises(RuntimeError):
+        eng.forward_by_length_end(t2)  # out of order
+    r1, r2, r3 = eng.forward_by_length_end(t1), eng.forward_by_length_end(t2), eng.forward_by_length_end(t3)
+    assert all(np.array_equal(r1[k], b[k]) for k in ("logits", "probs", "best", "best_idx"))
+    assert r2["logits"] is None and np.array_equal(r2["probs"], b["probs"][::-1]) and np.array_equal(r2["best_idx"], b["best_idx"][::-1])
+    assert np.array_equal(r3["probs"], eng.forward(ids[:16], lens[:16])["probs"])
     # mv_forward_groups rejects what it cannot run as handed over (before any GPU work)
     bufs = {"logits": None, "probs": None, "best": np.empty((128, 2), np.float32), "best_idx": np.empty(128, np.int32), "embed": None}
     for ends, widths in (([64], [512]), ([128], [64]), ([64, 64], [512, 512]), ([64, 128], [512, 600])):  # not the whole batch / a row longer than its group / empty group / wider than S
