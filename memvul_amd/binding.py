@@ -386,7 +386,8 @@ class Engine:
         self._tickets.pop(0)
         self._check(self._lib.mv_forward_ragged_end(self._h, t, _ptr(out["logits"]), _ptr(out["probs"]), _ptr(out["best"]), _ptr(out["best_idx"]), _ptr(out["embed"])),
                     "mv_forward_ragged_end")
-        self._check_saturation()
+        if not self._tickets:  # (the counters are read after a synchronisation of EVERY stream: with the next batch in flight that would wait for it — holding the lock)
+            self._check_saturation()
         return out
 
     def _forward_ragged(self, ids: np.ndarray, lens: np.ndarray, min_tokens: int, out: Dict[str, Optional[np.ndarray]]) -> bool:
