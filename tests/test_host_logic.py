@@ -299,3 +299,59 @@ def test_native_record_formatter_prints_what_json_dumps_prints():
     assert one(f32) == ref(f32)
     bad = p.astype(np.float64).copy(); bad[3, 4] = np.nan
     assert R.format_batch(fmt, nm, urls, labels, bad, lib) == R.format_batch(fmt, nm, urls, labels, bad) and "NaN" in R.format_batch(fmt, nm, urls, labels, bad, lib)
+
+
+def test_evaluate_keeps_one_batch_in_flight_and_collects_in_order(tmp_path):
+    """predict_memory.evaluate with a model that scores in two halves (ModelMemory.forward_begin / forward_end): batch k + 1 is begun BEFORE batch k is
+    collected, every batch is collected exactly once and in order (the metric accumulators see the reference's order, predict_memory.py:103-110), the records
+    come out in order, and an error in either half surfaces on the caller's thread with nothing left in flight.  Host logic only: a recording stand-in."""
+    from memvul_amd.predict_memory import evaluate
+
+    class Model:
+        _same_idx = 0
+        _golden_labels = ["CWE-1", "CWE-2"]
+
+        def __init__(self, fail_at=None):
+            self.log, self.in_flight, self.max_in_flight, self.fail_at = [], 0, 0, fail_at
+
+        def eval(self):
+            pass
+
+        def forward_begin(self, sample1=None, label=None, metadata=None):
+            k = metadata[0]["k"]
+            if self.fail_at == ("begin", k):
+                raise ValueError("begin %d" % k)
+            self.log.append(("begin", k))
+            self.in_flight += 1
+            self.max_in_flight = max(self.max_in_flight, self.in_flight)
+            return (k, metadata)
+
+        def forward_end(self, pending):
+            k, metadata = pending
+            self.in_flight -= 1
+            self.log.append(("end", k))
+            if self.fail_at == ("end", k):
+                raise ValueError("end %d" % k)
+            p = np.full((len(metadata), 2, 2), 0.25 + 0.01 * k, np.float32)
+            return {"meta": metadata, "probs": p}
+
+        def get_metrics(self, reset=False):
+            return {"n_end": sum(1 for e in self.log if e[0] == "end")}
+
+    def loader(n):
+        for k in range(n):
+            yield {"sample1": None, "label": None,
+                   "metadata": [{"type": "unlabel", "k": k, "instance": ({"Issue_Url": "u%d_%d" % (k, i), "label": "neg"},)} for i in range(3)]}
+
+    m = Model()
+    out = str(tmp_path / "pred.json")
+    assert evaluate(m, loader(5), predictions_output_file=out) == {"n_end": 5}
+    assert [e for e in m.log if e[0] == "end"] == [("end", k) for k in range(5)] and m.max_in_flight == 2 and m.in_flight == 0
+    assert m.log.index(("begin", 1)) < m.log.index(("end", 0)) and m.log.index(("begin", 4)) < m.log.index(("end", 3))
+    lines = [json.loads(l) for l in open(out)]
+    assert [r[0]["Issue_Url"] for r in lines] == ["u%d_0" % k for k in range(5)] and lines[3][1]["predict"]["CWE-2"] == float(np.float32(0.28))
+    for fail_at in (("begin", 2), ("end", 2), ("end", 4)):
+        m = Model(fail_at)
+        with pytest.raises(ValueError):
+            evaluate(m, loader(5), predictions_output_file=out)
+        assert m.in_flight == 0  # whatever was begun has been collected
