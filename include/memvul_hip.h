@@ -154,7 +154,9 @@ int mv_forward_ragged(mv_handle* h, const int32_t* ids, const int32_t* lens, int
 /* mv_forward_ragged in two halves: `begin` enqueues the batch (upload, passes, download into pinned staging) on the stream of the next workspace set and returns a
  * ticket without waiting; `end` waits for it and fills the caller's arrays (those of the outputs `begin` was asked for; best / best_idx always).  One batch per
  * workspace set (MEMVUL_STREAMS, 2 by default) may be in flight; collect tickets in the order they were issued.  predict_memory.evaluate hands over batch k + 1
- * before it collects batch k, so the GPU does not wait for the host between batches (the reference's loop is serial: predict_memory.py:103-110). */
+ * before it collects batch k, so the GPU does not wait for the host between batches (the reference's loop is serial: predict_memory.py:103-110).  The batches
+ * use the workspace sets of the resident sweep (mv_corpus_run): collect every ticket before starting one, and the other way round; like the rest of a handle's
+ * entry points these two are not thread-safe. */
 int mv_forward_ragged_begin(mv_handle* h, const int32_t* ids, const int32_t* lens, int B, int S, int min_tokens, int want_logits, int want_probs, int want_embed,
                             int* ticket);
 int mv_forward_ragged_end(mv_handle* h, int ticket, float* logits, float* probs, float* best, int32_t* best_idx, float* embed);
