@@ -182,8 +182,17 @@ class ReaderMemory(DatasetReader):
         all_data.reverse()
         n_total = len(all_data)
 
-        def make(first):
-            part = all_data[first:first + chunk]
+        # chunk boundaries: the first chunks are small and double (chunk / 8, / 4, / 2, then chunk) — the scorer waits for the FIRST chunk's tokenisation only,
+        # so a 16 k-sample first chunk cost the array form a second of idle GPU per file; every chunk stays a multiple of chunk / 8 (= of the batch size when
+        # chunk is 32 batches: evaluate_arrays writes one JSON line per batch_size samples)
+        bounds, step = [0], (chunk // 8 if chunk % 8 == 0 and chunk >= 8 else chunk)
+        while bounds[-1] < n_total:
+            bounds.append(min(n_total, bounds[-1] + step))
+            step = min(chunk, step * 2)
+
+        def make(i):
+            first = bounds[i]
+            part = all_data[first:bounds[i + 1]]
             ids, lens = self._tokenizer.batch_ids([self._text_of(s) for s in part])
             return {"type": type_, "ids": ids, "lens": lens, "same": np.fromiter((s[self._target] == "pos" for s in part), dtype=bool, count=len(part)),
                     "labels": [s["CWE_ID"] if s[self._target] == "pos" else s[self._target] for s in part],
@@ -191,9 +200,9 @@ class ReaderMemory(DatasetReader):
 
         with ThreadPoolExecutor(1) as ex:
             fut = ex.submit(make, 0) if n_total else None
-            for first in range(0, n_total, chunk):
+            for i in range(len(bounds) - 1):
                 cur = fut.result()
-                fut = ex.submit(make, first + chunk) if first + chunk < n_total else None
+                fut = ex.submit(make, i + 1) if i + 2 < len(bounds) else None
                 yield cur
 
     def _stream(self, samples, type_):
