@@ -133,6 +133,25 @@ class PretrainedTransformerTokenizer(Tokenizer):
         inside); the hashing stand-in can fan out over ``workers`` forked processes."""
         import numpy as np
 
+        bt = getattr(self._hf, "backend_tokenizer", None) if self._hf is not None else None
+        if bt is not None and len(texts):
+            # the Rust tokenizer itself, not the transformers wrapper around it: the wrapper turns every encoding into dicts of Python lists under the interpreter
+            # lock (1.3 s of a 1.8 s call for 8 k reports; the same ids: tests/test_plumbing.py) — here the ids go from the encodings into ONE flat int32 array and from
+            # there into the padded matrix, no Python object per token or per text
+            import itertools
+
+            if self._max_length is not None:
+                bt.enable_truncation(max_length=self._max_length)  # (longest_first, right, stride 0: what truncation=True asks of the wrapper)
+            else:
+                bt.no_truncation()
+            bt.no_padding()
+            encs = bt.encode_batch(list(texts), add_special_tokens=self._add_special)
+            lens = np.fromiter((len(e) for e in encs), dtype=np.int32, count=len(encs))
+            flat = np.fromiter(itertools.chain.from_iterable(e.ids for e in encs), dtype=np.int32, count=int(lens.sum()))
+            L = int(lens.max())
+            ids = np.zeros((len(encs), L), np.int32)
+            ids[np.arange(L)[None, :] < lens[:, None]] = flat
+            return ids, lens
         if self._hf is not None:
             rows = self._hf(list(texts), add_special_tokens=self._add_special, truncation=self._max_length is not None,
                             max_length=self._max_length, return_attention_mask=False, return_token_type_ids=False)["input_ids"]
